@@ -1,0 +1,208 @@
+/*
+ * vidil_hip.h — C ABI of libvidil_hip.so, the MI355X (gfx950) kernels behind
+ * VidIL's frame-encoding hot path.
+ *
+ * The reference is pure Python on PyTorch (no FFI of its own); every entry
+ * point below replaces the torch/cuDNN/cuBLAS op sequence that one reference
+ * function issues.  The "replaces" line cites that function as file:line under
+ * the reference tree (MikeWangWZHL/VidIL).
+ *
+ * Conventions
+ *   - every function returns 0 on success, a negative VIDIL_E* code on error;
+ *     vidil_last_error() returns a static, thread-local message for the last
+ *     failure on the calling thread.
+ *   - all pointers are DEVICE pointers unless the name ends in _host.
+ *   - `stream` is a hipStream_t passed as void* (torch.cuda.current_stream()
+ *     .cuda_stream on the Python side).  Nothing here allocates, frees or
+ *     synchronises; workspaces are caller-owned.
+ *   - "f16" = IEEE half (the MFMA input type), "f32" = float.  Accumulation,
+ *     LayerNorm statistics, softmax and the residual stream are f32.
+ *   - head_dim is 64 everywhere on this path (ViT-B/L, MED/BERT, CLIP B/32 and
+ *     L/14 towers all use 64).
+ */
+#ifndef VIDIL_HIP_H
+#define VIDIL_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define VIDIL_OK 0
+#define VIDIL_EINVAL (-1)   /* bad argument (shape, alignment, null pointer)  */
+#define VIDIL_ELAUNCH (-2)  /* hipLaunchKernel / hipFuncSetAttribute failed   */
+#define VIDIL_EUNSUP (-3)   /* shape outside what the kernels were built for  */
+
+const char* vidil_last_error(void);
+/* ABI version of this header; bumped on any signature change. */
+int vidil_abi_version(void);
+/* Number of symbols a loader must find; used by the not-gpu load test. */
+int vidil_num_entry_points(void);
+
+/* ------------------------------------------------------------------------ */
+/* GEMM  C[M,N] = A[M,K] · W[N,K]^T  (+bias) with a fused epilogue.           */
+/* A and W are f16 row-major with K contiguous (torch nn.Linear layout).      */
+/* K must be a multiple of 64.  M, N arbitrary (>0).                          */
+/* ------------------------------------------------------------------------ */
+enum {
+  VIDIL_EPI_F16 = 0,   /* out f16 [M,ldo]   = act(acc + bias)                              */
+  VIDIL_EPI_F32 = 1,   /* out f32 [M,ldo]   = act(acc + bias) + resid (resid may alias out)*/
+  VIDIL_EPI_HEADS = 2, /* scatter into per-head Q / K / V^T buffers (see below)            */
+  VIDIL_EPI_PATCH = 3  /* out f32 row (m + m/tpi + 1) = acc + bias + pos[(m%tpi)+1]        */
+};
+enum { VIDIL_ACT_NONE = 0, VIDIL_ACT_GELU_ERF = 1, VIDIL_ACT_QUICK_GELU = 2 };
+
+typedef struct vidil_gemm_args {
+  const void* A;      /* f16 [M,K]                                             */
+  const void* W;      /* f16 [N,K]                                             */
+  const float* bias;  /* f32 [N] or NULL                                       */
+  int32_t M, N, K;
+  int32_t epi;        /* VIDIL_EPI_*                                           */
+  int32_t act;        /* VIDIL_ACT_* (EPI_F16 / EPI_F32 only)                  */
+  void* out;          /* EPI_F16: f16, EPI_F32/PATCH: f32, row stride ldo      */
+  int32_t ldo;
+  const float* resid; /* EPI_F32: f32 [M,ldo] added after act, or NULL         */
+  /* EPI_HEADS: column n -> part = part0 + n/(H*64), h = (n%(H*64))/64, d=n%64;
+   * row m -> b = m/T, t = m%T.
+   *   part 0: Q [b][h][t][64]            f16, value * q_scale, row capacity Tq_cap
+   *   part 1: K [b][h][t_off+t][64]      f16, row capacity Tk_cap
+   *   part 2: VT[b][h][d][t_off+t]       f16, row stride NP (multiple of 8)     */
+  void* q;
+  void* k;
+  void* vt;
+  int32_t T, H, part0, t_off, Tq_cap, Tk_cap, NP;
+  float q_scale;
+  /* EPI_PATCH */
+  const float* pos;   /* f32 [(tpi+1), N]                                      */
+  int32_t tpi;        /* patches per image                                     */
+} vidil_gemm_args;
+
+/* replaces: nn.Linear calls of models/vit.py:35-41,72,84; models/med.py:153-171,
+ * 236,301,314,512,534; timm PatchEmbed conv (models/vit.py:144-145,182) as an
+ * im2col-free GEMM; HF CLIP q/k/v/out/fc1/fc2/projection Linears. */
+int vidil_gemm_f16(const vidil_gemm_args* args, void* stream);
+
+/* ------------------------------------------------------------------------ */
+/* LayerNorm over the last dim.  x f32 rows of length D at stride x_stride    */
+/* (elements); writes f16 and/or f32 outputs (either may be NULL), dense.     */
+/* D must be a multiple of 64 and <= 1024... (768, 512, 1024 on this path)    */
+/* replaces: nn.LayerNorm at models/vit.py:108-109,192 (eps 1e-6),            */
+/* models/med.py:92,238,316,514 (eps 1e-12), HF CLIP layer norms (eps 1e-5).  */
+/* ------------------------------------------------------------------------ */
+int vidil_layernorm(const float* x, int64_t x_stride, const float* gamma,
+                    const float* beta, float eps, int32_t M, int32_t D,
+                    void* out_f16, float* out_f32, void* stream);
+
+/* ------------------------------------------------------------------------ */
+/* Attention for short sequences (Nk <= 288): softmax(Q K^T [+mask]) V.       */
+/* Q  f16 [Bq][H][Tq_cap][64] (already scaled by 1/sqrt(64)),                 */
+/* K  f16 [Bk][H][Tk_cap][64], VT f16 [Bk][H][64][NP]; Bk = Bq / kv_group.    */
+/* Keys >= kv_len[b] (or >= Nk when kv_len==NULL) are excluded; causal!=0     */
+/* additionally excludes key > q + causal_off.                                */
+/* out f16 row (b*Nq + q), column h*64+d, row stride ldo.                     */
+/* replaces: models/vit.py:75-83; models/med.py:178-220 (self, cross, cached);*/
+/* HF CLIPAttention.                                                          */
+/* ------------------------------------------------------------------------ */
+int vidil_attention(const void* q, const void* k, const void* vt, void* out,
+                    const int32_t* kv_len, int32_t Bq, int32_t H, int32_t Nq,
+                    int32_t Nk, int32_t Tq_cap, int32_t Tk_cap, int32_t NP,
+                    int32_t kv_group, int32_t causal, int32_t causal_off,
+                    int32_t ldo, void* stream);
+
+/* ------------------------------------------------------------------------ */
+/* Frame -> patch rows (im2col for stride==kernel conv), fused with dtype     */
+/* conversion.  out f16 [B*(S/ps)^2, 3*ps*ps], column = c*ps*ps + py*ps + px  */
+/* (the flattening of a conv weight [N,3,ps,ps]).                             */
+/* replaces: timm PatchEmbed / HF CLIPVisionEmbeddings conv input read.       */
+/* ------------------------------------------------------------------------ */
+int vidil_patchify_f32(const float* img /*[B,3,S,S]*/, void* out, int32_t B,
+                       int32_t S, int32_t ps, void* stream);
+/* uint8 HWC frames, fused (x/255 - mean[c]) / std[c]:                        */
+/* replaces run_video_CapFilt.py:128-137 (ToTensor+Normalize) and HF          */
+/* CLIPImageProcessor rescale+normalize for frames already at S x S.          */
+int vidil_patchify_u8(const uint8_t* img /*[B,S,S,3]*/, void* out, int32_t B,
+                      int32_t S, int32_t ps, const float* mean3_host,
+                      const float* std3_host, void* stream);
+/* x[b*T + 0, :] = cls[:] + pos[0, :]   (models/vit.py:184-187)               */
+int vidil_set_cls_row(float* x, const float* cls, const float* pos0, int32_t B,
+                      int32_t T, int32_t D, void* stream);
+
+/* ------------------------------------------------------------------------ */
+/* Token embedding: out[m,:] = word[ids[m],:] + pos[pos_off + m%T,:]  (f32)   */
+/* replaces models/med.py:85-91 and HF CLIPTextEmbeddings.                    */
+/* ------------------------------------------------------------------------ */
+int vidil_embed_tokens(const int32_t* ids, const float* word, const float* pos,
+                       float* out, int32_t M, int32_t T, int32_t pos_off,
+                       int32_t D, int32_t vocab, void* stream);
+
+/* out[i,:] = x[idx[i],:]   (f32 rows of length D)                            */
+int vidil_gather_rows_f32(const float* x, const int32_t* idx, float* out,
+                          int32_t n, int32_t D, void* stream);
+/* x[i,:] /= ||x[i,:]||_2   (in place, f32)   HF CLIP embeds normalisation    */
+int vidil_l2_normalize_rows(float* x, int32_t n, int32_t D, void* stream);
+
+/* ------------------------------------------------------------------------ */
+/* Beam-search step on device (HF transformers 4.15 semantics, the version    */
+/* models/med.py:7-8 names; call site models/blip.py:154-161).                */
+/* ------------------------------------------------------------------------ */
+/* per image b (rows b*nb .. b*nb+nb-1 of logits [R,V]):                      */
+/*   lp = log_softmax(logits[row]);  if ban_token>=0: lp[ban_token] = -inf;   */
+/*   cand = lp + beam_scores[row];  top (2*nb) over nb*V, sorted descending,  */
+/*   ties -> lower flat index first.                                          */
+/* out_scores f32 [B, 2nb], out_index i32 [B, 2nb] (flat index beam*V+tok).   */
+int vidil_logsoftmax_topk(const float* logits, const float* beam_scores,
+                          int32_t B, int32_t nb, int32_t V, int32_t ban_token,
+                          float* out_scores, int32_t* out_index, void* stream);
+
+typedef struct vidil_beam_state {
+  int32_t* seqs;        /* [B*nb, max_len] token ids (current beams)          */
+  int32_t* seqs_next;   /* [B*nb, max_len] scratch, swapped by the caller     */
+  float* beam_scores;   /* [B*nb]                                             */
+  int32_t* beam_idx;    /* [B*nb] out: global source row of each new beam     */
+  int32_t* next_tok;    /* [B*nb] out: token appended to each new beam        */
+  int32_t* done;        /* [B]                                                */
+  int32_t* n_hyp;       /* [B]                                                */
+  double* hyp_score;    /* [B, nb]  (Python-float arithmetic in the reference) */
+  int32_t* hyp_len;     /* [B, nb]                                            */
+  int32_t* hyp_tok;     /* [B, nb, max_len]                                   */
+  double* worst;        /* [B]  worst kept hypothesis score (init 1e9)        */
+  int32_t* n_done;      /* [1]  number of finished images after this step     */
+} vidil_beam_state;
+
+/* BeamSearchScorer.process: walk the 2*nb candidates, bank EOS hypotheses,   */
+/* fill the next beams, update done flags; then append tokens into seqs_next. */
+int vidil_beam_update(const vidil_beam_state* st, const float* cand_scores,
+                      const int32_t* cand_index, int32_t B, int32_t nb,
+                      int32_t V, int32_t cur_len, int32_t max_len,
+                      int32_t eos_id, int32_t pad_id, void* stream);
+/* BeamSearchScorer.finalize: out_tokens i32 [B,max_len] = best hypothesis,    */
+/* then eos_id if it fits, then pad_id; out_len i32 [B] (EOS not counted).    */
+int vidil_beam_finalize(const vidil_beam_state* st, int32_t B, int32_t nb,
+                        int32_t cur_len, int32_t max_len, int32_t eos_id,
+                        int32_t pad_id, int32_t* out_tokens, int32_t* out_len,
+                        float* out_score, void* stream);
+/* KV-cache reorder (models/med.py:951-955): for every layer l, row s:        */
+/* dst[l][s] = src[l][beam_idx[s]]; a row is row_halfs f16 values.            */
+int vidil_kv_reorder(const void* src, void* dst, const int32_t* beam_idx,
+                     int32_t L, int32_t rows, int64_t row_halfs, void* stream);
+
+/* ------------------------------------------------------------------------ */
+/* Ontology scan + per-frame top-k (run_visual_tokenization.py:276,298-308).  */
+/* img f32 [NF,D] ; txt f32 [NCpad,D] where each category c occupies rows     */
+/* seg_start[c] .. seg_start[c]+seg_len[c]-1 and seg_start[c] % 32 == 0.      */
+/* scores are exact f32: s = fma(a[k],b[k],s) for k = 0..D-1 in order.        */
+/* out_index i32 [NF,ncat,topk] = class index WITHIN the category, ordered by */
+/* (score desc, index asc); out_score f32 same shape.                         */
+/* partial: caller workspace, vidil_scan_topk_ws_bytes() bytes.               */
+/* ------------------------------------------------------------------------ */
+int64_t vidil_scan_topk_ws_bytes(int32_t NF, int32_t NCpad, int32_t topk);
+int vidil_scan_topk(const float* img, const float* txt, int32_t NF, int32_t D,
+                    int32_t ncat, const int32_t* seg_start_host,
+                    const int32_t* seg_len_host, int32_t topk, void* partial,
+                    int32_t* out_index, float* out_score, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* VIDIL_HIP_H */

@@ -1,0 +1,316 @@
+"""Per-kernel numerics on the GPU: every HIP kernel against a plain PyTorch fp32
+reference of the same op (tolerances reflect f16 MFMA inputs with f32 accumulate),
+and the integer/index kernels bit-exactly against the oracle."""
+import ctypes
+import math
+import os
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+DEV = "cuda"
+
+
+def _k():
+    from vidil_amd import kernels
+    return kernels
+
+
+def _rand(*shape, scale=1.0, seed=0, dtype=torch.float32):
+    g = torch.Generator(device="cpu").manual_seed(seed)
+    return (torch.randn(*shape, generator=g) * scale).to(dtype)
+
+
+# ------------------------------------------------------------------------------- GEMM
+@pytest.mark.parametrize("M,N,K", [(197 * 4, 768, 768), (1000, 2304, 768), (300, 3072, 768),
+                                   (513, 768, 3072), (72, 30524, 768), (7, 2, 768), (128, 512, 512)])
+def test_gemm_f16_f32_out(M, N, K):
+    k = _k()
+    a = _rand(M, K, seed=1).half()
+    w = _rand(N, K, scale=0.05, seed=2).half()
+    bias = _rand(N, seed=3)
+    ref = a.float() @ w.float().t() + bias
+    out16 = k.gemm(a.to(DEV), w.to(DEV), bias.to(DEV), out_dtype=torch.float16)
+    out32 = k.gemm(a.to(DEV), w.to(DEV), bias.to(DEV), out_dtype=torch.float32)
+    torch.cuda.synchronize()
+    # f32 accumulate of exact f16 products: only summation-order error
+    assert torch.allclose(out32.cpu(), ref, rtol=1e-4, atol=1e-3)
+    assert torch.allclose(out16.float().cpu(), ref, rtol=2e-3, atol=2e-3)
+
+
+def test_gemm_transpose_detecting():
+    """A = I with an asymmetric W catches a row/col swap in the C layout."""
+    k = _k()
+    M = N = K = 128
+    a = torch.eye(M, K).half()
+    w = (torch.arange(N * K).reshape(N, K) % 97).float().half()
+    out = k.gemm(a.to(DEV), w.to(DEV), None, out_dtype=torch.float32).cpu()
+    assert torch.equal(out, w.float().t())
+
+
+@pytest.mark.parametrize("act", ["gelu", "quick"])
+def test_gemm_activation_and_residual(act):
+    k = _k()
+    M, N, K = 394, 3072, 768
+    a = _rand(M, K, seed=4).half()
+    w = _rand(N, K, scale=0.05, seed=5).half()
+    bias = _rand(N, seed=6)
+    pre = a.float() @ w.float().t() + bias
+    if act == "gelu":
+        ref = torch.nn.functional.gelu(pre)
+        code = k.ACT_GELU_ERF
+    else:
+        ref = pre * torch.sigmoid(1.702 * pre)
+        code = k.ACT_QUICK_GELU
+    out = k.gemm(a.to(DEV), w.to(DEV), bias.to(DEV), act=code, out_dtype=torch.float16)
+    assert torch.allclose(out.float().cpu(), ref, rtol=2e-3, atol=2e-3)
+    # residual, in place
+    x = _rand(M, N, seed=7)
+    xd = x.to(DEV).clone()
+    k.gemm(a.to(DEV), w.to(DEV), bias.to(DEV), out=xd, resid=xd)
+    assert torch.allclose(xd.cpu(), x + pre, rtol=1e-4, atol=1e-3)
+
+
+def test_gemm_heads_epilogue():
+    k = _k()
+    B, T, H = 3, 197, 12
+    M, K, N = B * T, 768, 3 * H * 64
+    NP = 200
+    a = _rand(M, K, seed=8).half()
+    w = _rand(N, K, scale=0.05, seed=9).half()
+    bias = _rand(N, seed=10)
+    ref = (a.float() @ w.float().t() + bias).view(B, T, 3, H, 64)
+    q = torch.zeros(B, H, T, 64, dtype=torch.float16, device=DEV)
+    kk = torch.zeros(B, H, T, 64, dtype=torch.float16, device=DEV)
+    vt = torch.zeros(B, H, 64, NP, dtype=torch.float16, device=DEV)
+    k.gemm(a.to(DEV), w.to(DEV), bias.to(DEV),
+           heads=dict(q=q, k=kk, vt=vt, T=T, H=H, part0=0, t_off=0, Tq_cap=T, Tk_cap=T, NP=NP, q_scale=0.125))
+    tol = dict(rtol=2e-3, atol=2e-3)
+    assert torch.allclose(q.float().cpu(), ref[:, :, 0].permute(0, 2, 1, 3) * 0.125, **tol)
+    assert torch.allclose(kk.float().cpu(), ref[:, :, 1].permute(0, 2, 1, 3), **tol)
+    assert torch.allclose(vt.float().cpu()[..., :T], ref[:, :, 2].permute(0, 2, 3, 1), **tol)
+    assert torch.all(vt[..., T:] == 0)
+    # KV-cache append: parts 1,2 only, at an offset
+    Tc = 24
+    kc = torch.zeros(B, H, Tc, 64, dtype=torch.float16, device=DEV)
+    vc = torch.zeros(B, H, 64, Tc, dtype=torch.float16, device=DEV)
+    a1 = _rand(B, K, seed=11).half()
+    w_kv = w[H * 64:]
+    k.gemm(a1.to(DEV), w_kv.to(DEV).contiguous(), bias[H * 64:].to(DEV).contiguous(),
+           heads=dict(k=kc, vt=vc, T=1, H=H, part0=1, t_off=5, Tk_cap=Tc, NP=Tc))
+    r1 = (a1.float() @ w_kv.float().t() + bias[H * 64:]).view(B, 2, H, 64)
+    assert torch.allclose(kc[:, :, 5].float().cpu(), r1[:, 0], **tol)
+    assert torch.allclose(vc[:, :, :, 5].float().cpu(), r1[:, 1], **tol)
+    assert torch.all(kc[:, :, :5] == 0) and torch.all(kc[:, :, 6:] == 0)
+
+
+def test_gemm_patch_epilogue():
+    k = _k()
+    B, tpi, N, K = 5, 196, 768, 768
+    a = _rand(B * tpi, K, seed=12).half()
+    w = _rand(N, K, scale=0.05, seed=13).half()
+    bias = _rand(N, seed=14)
+    pos = _rand(tpi + 1, N, seed=15)
+    out = torch.full((B * (tpi + 1), N), -7.0, dtype=torch.float32, device=DEV)
+    k.gemm(a.to(DEV), w.to(DEV), bias.to(DEV), patch=dict(out=out, pos=pos.to(DEV), tpi=tpi))
+    ref = (a.float() @ w.float().t() + bias).view(B, tpi, N) + pos[1:]
+    o = out.cpu().view(B, tpi + 1, N)
+    assert torch.allclose(o[:, 1:], ref, rtol=1e-4, atol=1e-3)
+    assert torch.all(o[:, 0] == -7.0)
+
+
+def test_gemm_rejects_bad_k():
+    k = _k()
+    a = torch.zeros(8, 100, dtype=torch.float16, device=DEV)
+    w = torch.zeros(8, 100, dtype=torch.float16, device=DEV)
+    with pytest.raises(k.VidilHipError):
+        k.gemm(a, w)
+
+
+# -------------------------------------------------------------------------- LayerNorm
+@pytest.mark.parametrize("D,eps", [(768, 1e-6), (768, 1e-12), (512, 1e-5), (1024, 1e-6)])
+def test_layernorm(D, eps):
+    k = _k()
+    M = 333
+    x = _rand(M, D, scale=3.0, seed=20) + 0.5
+    g = _rand(D, seed=21) * 0.1 + 1.0
+    b = _rand(D, seed=22) * 0.1
+    ref = torch.nn.functional.layer_norm(x, (D,), g, b, eps)
+    o16 = torch.empty(M, D, dtype=torch.float16, device=DEV)
+    o32 = torch.empty(M, D, dtype=torch.float32, device=DEV)
+    k.layernorm(x.to(DEV), g.to(DEV), b.to(DEV), eps, out16=o16, out32=o32)
+    assert torch.allclose(o32.cpu(), ref, rtol=1e-5, atol=1e-5)
+    assert torch.allclose(o16.float().cpu(), ref, rtol=1e-3, atol=1e-3)
+    # strided rows (CLS gather): every 5th row
+    o = torch.empty(M // 5, D, dtype=torch.float32, device=DEV)
+    k.layernorm(x.to(DEV), g.to(DEV), b.to(DEV), eps, M=M // 5, D=D, x_stride=5 * D, out32=o)
+    assert torch.allclose(o.cpu(), ref[::5][: M // 5], rtol=1e-5, atol=1e-5)
+
+
+# --------------------------------------------------------------------------- attention
+def _attn_ref(q, kk, v, kv_len=None, causal=False, causal_off=0, kv_group=1):
+    # q [Bq,H,Nq,64] (pre-scaled), kk/v [Bk,H,Nk,64]
+    Bq, H, Nq, _ = q.shape
+    kk = kk.repeat_interleave(kv_group, 0)
+    v = v.repeat_interleave(kv_group, 0)
+    s = q @ kk.transpose(-1, -2)
+    Nk = kk.shape[2]
+    keys = torch.arange(Nk)
+    mask = torch.zeros(Bq, 1, Nq, Nk, dtype=torch.bool)
+    if kv_len is not None:
+        mask |= keys[None, None, None, :] >= kv_len[:, None, None, None]
+    if causal:
+        mask |= keys[None, None, None, :] > (torch.arange(Nq)[None, None, :, None] + causal_off)
+    s = s.masked_fill(mask, float("-inf"))
+    return (torch.softmax(s, -1) @ v).permute(0, 2, 1, 3).reshape(Bq, Nq, H * 64)
+
+
+@pytest.mark.parametrize("Bq,H,Nq,Nk,kv_group,causal,use_len", [
+    (3, 12, 197, 197, 1, False, False),    # ViT
+    (4, 12, 50, 50, 1, False, False),      # CLIP vision
+    (5, 8, 77, 77, 1, True, False),        # CLIP text (causal)
+    (6, 12, 35, 35, 1, False, True),       # ITM self (pad mask)
+    (6, 12, 35, 197, 3, False, False),     # ITM cross, 3 captions per frame
+    (6, 12, 1, 9, 1, False, False),        # decode self, cache of 9
+    (2, 12, 3, 197, 1, False, False),      # decode cross, 3 beams as query rows
+    (2, 16, 257, 257, 1, False, False),    # CLIP-L/14
+    (2, 12, 4, 4, 1, True, False),         # decoder prefill
+])
+def test_attention(Bq, H, Nq, Nk, kv_group, causal, use_len):
+    k = _k()
+    Bk = Bq // kv_group
+    NP = (Nk + 7) // 8 * 8
+    q = _rand(Bq, H, Nq, 64, seed=30).half()
+    kk = _rand(Bk, H, Nk, 64, seed=31).half()
+    v = _rand(Bk, H, Nk, 64, seed=32).half()
+    kv_len = None
+    if use_len:
+        kv_len = torch.tensor([(7 * i) % Nk + 1 for i in range(Bq)], dtype=torch.int32)
+    ref = _attn_ref(q.float() * 0.125, kk.float(), v.float(), kv_len, causal, 0, kv_group)
+    vt = torch.zeros(Bk, H, 64, NP, dtype=torch.float16)
+    vt[..., :Nk] = v.transpose(-1, -2)
+    vt[..., Nk:] = float("nan")  # padding must never leak
+    out = torch.zeros(Bq * Nq, H * 64, dtype=torch.float16, device=DEV)
+    k.attention((q * 0.125).half().to(DEV), kk.to(DEV), vt.to(DEV), out, Bq=Bq, H=H, Nq=Nq, Nk=Nk, Tq_cap=Nq,
+                Tk_cap=Nk, NP=NP, kv_group=kv_group, causal=causal, kv_len=None if kv_len is None else kv_len.to(DEV))
+    got = out.float().cpu().view(Bq, Nq, H * 64)
+    assert torch.isfinite(got).all()
+    ref = _attn_ref((q * 0.125).half().float(), kk.float(), v.float(), kv_len, causal, 0, kv_group)
+    assert torch.allclose(got, ref, rtol=3e-3, atol=3e-3), (got - ref).abs().max()
+
+
+# ----------------------------------------------------------------------- patch / embed
+def test_patchify_f32_and_u8():
+    k = _k()
+    B, S, ps = 3, 224, 16
+    img = _rand(B, 3, S, S, seed=40)
+    out = k.patchify_f32(img.to(DEV), ps).float().cpu()
+    ref = torch.nn.functional.unfold(img, kernel_size=ps, stride=ps).transpose(1, 2).reshape(B * 196, 3 * ps * ps)
+    assert torch.allclose(out, ref, rtol=1e-3, atol=1e-3)
+    mean = (0.48145466, 0.4578275, 0.40821073)
+    std = (0.26862954, 0.26130258, 0.27577711)
+    rng = np.random.default_rng(1000)
+    u8 = torch.from_numpy(rng.integers(0, 256, size=(B, S, S, 3), dtype=np.uint8))
+    for p in (16, 32):
+        out8 = k.patchify_u8(u8.to(DEV), p, mean, std).float().cpu()
+        x = (u8.permute(0, 3, 1, 2).float() / 255.0 - torch.tensor(mean).view(1, 3, 1, 1)) / torch.tensor(std).view(1, 3, 1, 1)
+        G = S // p
+        ref8 = torch.nn.functional.unfold(x, kernel_size=p, stride=p).transpose(1, 2).reshape(B * G * G, 3 * p * p)
+        assert torch.allclose(out8, ref8, rtol=1e-3, atol=2e-3)
+
+
+def test_cls_embed_gather_l2():
+    k = _k()
+    B, T, D = 4, 197, 768
+    x = torch.zeros(B * T, D, device=DEV)
+    cls, pos0 = _rand(D, seed=41), _rand(D, seed=42)
+    k.set_cls_row(x, cls.to(DEV), pos0.to(DEV), B, T, D)
+    xc = x.cpu().view(B, T, D)
+    assert torch.equal(xc[:, 0], (cls + pos0).expand(B, D)) and torch.all(xc[:, 1:] == 0)
+    V = 1000
+    word, pos = _rand(V, D, seed=43), _rand(512, D, seed=44)
+    ids = torch.randint(0, V, (6, 5), dtype=torch.int32)
+    out = torch.empty(30, D, device=DEV)
+    k.embed_tokens(ids.to(DEV), word.to(DEV), pos.to(DEV), out, T=5, pos_off=3)
+    ref = word[ids.long()] + pos[3:8][None]
+    assert torch.equal(out.cpu().view(6, 5, D), ref)
+    idx = torch.tensor([5, 0, 29, 7], dtype=torch.int32)
+    g = k.gather_rows(out, idx.to(DEV)).cpu()
+    assert torch.equal(g, ref.view(30, D)[idx.long()])
+    e = _rand(9, 512, seed=45)
+    n = k.l2_normalize_rows(e.to(DEV).clone()).cpu()
+    assert torch.allclose(n, e / e.norm(dim=-1, keepdim=True), rtol=1e-6, atol=1e-7)
+
+
+# ------------------------------------------------------------------------- beam kernels
+def _topk_ref(logits, beam_scores, B, nb, ban):
+    lp = torch.log_softmax(logits.double(), -1).float()  # compare at f32 precision below
+    lp = torch.log_softmax(logits, -1)
+    if ban >= 0:
+        lp[:, ban] = float("-inf")
+    c = (lp + beam_scores[:, None]).view(B, -1)
+    return torch.topk(c, 2 * nb, dim=1, largest=True, sorted=True)
+
+
+@pytest.mark.parametrize("nb,V,ban", [(3, 30524, 102), (3, 30524, -1), (1, 777, -1), (4, 5000, 3)])
+def test_logsoftmax_topk(nb, V, ban):
+    k = _k()
+    B = 5
+    logits = _rand(B * nb, V, scale=2.0, seed=50)
+    bs = torch.tensor([0.0, -1e9, -1e9, -1e9][:nb] * B)
+    bs[nb:] = -_rand(B * nb - nb, seed=51).abs() * 3
+    rs, ri = _topk_ref(logits, bs, B, nb, ban)
+    s, i = k.logsoftmax_topk(logits.to(DEV), bs.to(DEV), B, nb, ban)
+    assert torch.equal(i.cpu().long(), ri)
+    assert torch.allclose(s.cpu(), rs, rtol=1e-5, atol=1e-5)
+
+
+def test_kv_reorder():
+    k = _k()
+    L, rows, rh = 3, 10, 64 * 12
+    src = _rand(L, rows, rh, seed=52).half().to(DEV)
+    dst = torch.zeros_like(src)
+    idx = torch.tensor([3, 3, 0, 9, 1, 1, 1, 8, 2, 0], dtype=torch.int32)
+    k.kv_reorder(src, dst, idx.to(DEV), L, rows)
+    assert torch.equal(dst.cpu(), src.cpu()[:, idx.long()])
+
+
+# ------------------------------------------------------------------------ ontology scan
+def _scan_oracle():
+    here = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    lib = ctypes.CDLL(os.path.join(here, "oracle", "_build", "libscan_ref.so"))
+    lib.vidil_ref_scan_topk.restype = None
+    return lib
+
+
+def test_scan_topk_bit_exact_vs_oracle():
+    k = _k()
+    NF, D, topk = 45, 512, 5
+    seg_len = [1999, 700, 365, 33]
+    seg_start, n = [], 0
+    for L in seg_len:
+        seg_start.append(n)
+        n += (L + 31) // 32 * 32
+    txt = _rand(n, D, seed=60)
+    txt = txt / txt.norm(dim=-1, keepdim=True)
+    # duplicate rows => exact ties, resolved towards the lower index
+    txt[seg_start[2] + 40] = txt[seg_start[2] + 7]
+    txt[seg_start[2] + 41] = txt[seg_start[2] + 7]
+    img = _rand(NF, D, seed=61)
+    img = img / img.norm(dim=-1, keepdim=True)
+    img[3] = txt[seg_start[2] + 7]  # frame 3 scores the duplicated class highest
+    oi, os_ = k.scan_topk(img.to(DEV), txt.to(DEV), seg_start, seg_len, topk)
+    lib = _scan_oracle()
+    ri = np.zeros((NF, 4, topk), np.int32)
+    rs = np.zeros((NF, 4, topk), np.float32)
+    imgc, txtc = np.ascontiguousarray(img.numpy()), np.ascontiguousarray(txt.numpy())
+    ss = (ctypes.c_int32 * 4)(*seg_start)
+    sl = (ctypes.c_int32 * 4)(*seg_len)
+    lib.vidil_ref_scan_topk(imgc.ctypes.data_as(ctypes.c_void_p), txtc.ctypes.data_as(ctypes.c_void_p), NF, D, 4, ss, sl,
+                            topk, ri.ctypes.data_as(ctypes.c_void_p), rs.ctypes.data_as(ctypes.c_void_p))
+    assert np.array_equal(oi.cpu().numpy(), ri)
+    assert np.array_equal(os_.cpu().numpy().view(np.uint32), rs.view(np.uint32))  # bit-exact scores
+    assert list(ri[3, 2, :3]) == [7, 40, 41]

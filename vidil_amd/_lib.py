@@ -1,0 +1,98 @@
+"""ctypes binding of libvidil_hip.so (the C ABI declared in include/vidil_hip.h).
+
+The product path has no CPU fallback: if the shared library is missing this
+module raises at first use, loudly.  Build it with
+``python -c "import __graft_entry__ as g; g.build()"`` or ``make -C vidil_amd/csrc``.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "csrc", "libvidil_hip.so")
+
+EPI_F16, EPI_F32, EPI_HEADS, EPI_PATCH = 0, 1, 2, 3
+ACT_NONE, ACT_GELU_ERF, ACT_QUICK_GELU = 0, 1, 2
+
+
+class GemmArgs(C.Structure):
+    """Mirror of ``vidil_gemm_args`` (include/vidil_hip.h)."""
+
+    _fields_ = [
+        ("A", C.c_void_p), ("W", C.c_void_p), ("bias", C.c_void_p),
+        ("M", C.c_int32), ("N", C.c_int32), ("K", C.c_int32),
+        ("epi", C.c_int32), ("act", C.c_int32),
+        ("out", C.c_void_p), ("ldo", C.c_int32),
+        ("resid", C.c_void_p),
+        ("q", C.c_void_p), ("k", C.c_void_p), ("vt", C.c_void_p),
+        ("T", C.c_int32), ("H", C.c_int32), ("part0", C.c_int32), ("t_off", C.c_int32),
+        ("Tq_cap", C.c_int32), ("Tk_cap", C.c_int32), ("NP", C.c_int32),
+        ("q_scale", C.c_float),
+        ("pos", C.c_void_p), ("tpi", C.c_int32),
+    ]
+
+
+class BeamState(C.Structure):
+    """Mirror of ``vidil_beam_state``."""
+
+    _fields_ = [(n, C.c_void_p) for n in (
+        "seqs", "seqs_next", "beam_scores", "beam_idx", "next_tok", "done", "n_hyp",
+        "hyp_score", "hyp_len", "hyp_tok", "worst", "n_done")]
+
+
+_i32, _i64, _f32, _p = C.c_int32, C.c_int64, C.c_float, C.c_void_p
+
+# name -> (restype, argtypes); the order/types restate include/vidil_hip.h.
+SIGNATURES = {
+    "vidil_last_error": (C.c_char_p, []),
+    "vidil_abi_version": (_i32, []),
+    "vidil_num_entry_points": (_i32, []),
+    "vidil_gemm_f16": (_i32, [C.POINTER(GemmArgs), _p]),
+    "vidil_layernorm": (_i32, [_p, _i64, _p, _p, _f32, _i32, _i32, _p, _p, _p]),
+    "vidil_attention": (_i32, [_p, _p, _p, _p, _p] + [_i32] * 11 + [_p]),
+    "vidil_patchify_f32": (_i32, [_p, _p, _i32, _i32, _i32, _p]),
+    "vidil_patchify_u8": (_i32, [_p, _p, _i32, _i32, _i32, C.POINTER(_f32), C.POINTER(_f32), _p]),
+    "vidil_set_cls_row": (_i32, [_p, _p, _p, _i32, _i32, _i32, _p]),
+    "vidil_embed_tokens": (_i32, [_p, _p, _p, _p, _i32, _i32, _i32, _i32, _i32, _p]),
+    "vidil_gather_rows_f32": (_i32, [_p, _p, _p, _i32, _i32, _p]),
+    "vidil_l2_normalize_rows": (_i32, [_p, _i32, _i32, _p]),
+    "vidil_logsoftmax_topk": (_i32, [_p, _p, _i32, _i32, _i32, _i32, _p, _p, _p]),
+    "vidil_beam_update": (_i32, [C.POINTER(BeamState), _p, _p] + [_i32] * 7 + [_p]),
+    "vidil_beam_finalize": (_i32, [C.POINTER(BeamState)] + [_i32] * 6 + [_p, _p, _p, _p]),
+    "vidil_kv_reorder": (_i32, [_p, _p, _p, _i32, _i32, _i64, _p]),
+    "vidil_scan_topk_ws_bytes": (_i64, [_i32, _i32, _i32]),
+    "vidil_scan_topk": (_i32, [_p, _p, _i32, _i32, _i32, C.POINTER(_i32), C.POINTER(_i32), _i32, _p, _p, _p, _p]),
+}
+
+_lib = None
+
+
+class VidilHipError(RuntimeError):
+    pass
+
+
+def load():
+    """Load (once) and return the ctypes library with typed entry points."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise VidilHipError(
+            f"{LIB_PATH} is missing: the HIP extension is not built. There is no CPU "
+            "fallback for the product path. Run `make -C vidil_amd/csrc` or "
+            "`python -c 'import __graft_entry__ as g; g.build()'`.")
+    lib = C.CDLL(LIB_PATH)
+    for name, (res, args) in SIGNATURES.items():
+        fn = getattr(lib, name)  # AttributeError if the symbol is not exported
+        fn.restype = res
+        fn.argtypes = args
+    _lib = lib
+    return lib
+
+
+def check(rc: int, what: str = "") -> None:
+    """Map a non-zero return code to an exception carrying vidil_last_error()."""
+    if rc != 0:
+        msg = load().vidil_last_error().decode("utf-8", "replace")
+        raise VidilHipError(f"{what or 'vidil'} failed (rc={rc}): {msg}")

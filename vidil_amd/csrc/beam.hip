@@ -1,0 +1,300 @@
+// beam.hip — device-side beam search bookkeeping so a whole caption batch
+// decodes without a host round trip per step.  Semantics follow HF
+// transformers 4.15 (generation_utils.beam_search + BeamSearchScorer +
+// MinLengthLogitsProcessor), the version models/med.py:7-8 of the reference
+// names; the reference call site is models/blip.py:154-161.
+//
+//   logsoftmax_topk : one workgroup per image; log-softmax of its nb rows,
+//                     optional EOS ban, + beam score, sorted top-2nb over
+//                     nb*V candidates (ties -> lower flat index).
+//   beam_update     : one thread per image; BeamSearchScorer.process + the
+//                     input_ids gather/append.
+//   beam_finalize   : one thread per image; BeamSearchScorer.finalize.
+//   kv_reorder      : BertLMHeadModel._reorder_cache (models/med.py:951-955).
+#include <math.h>
+#include "common.h"
+
+namespace {
+
+constexpr int MAXC = 8;   // 2*nb candidates, nb <= 4
+constexpr int MAXNB = 4;
+constexpr int MAXLEN = 64;
+
+struct Cand {
+  float s;
+  int i;
+};
+__device__ __forceinline__ bool better(float s1, int i1, float s2, int i2) {
+  return s1 > s2 || (s1 == s2 && i1 < i2);
+}
+__device__ __forceinline__ Cand wave_best(Cand c) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) {
+    const float s = __shfl_xor(c.s, o, 64);
+    const int i = __shfl_xor(c.i, o, 64);
+    if (better(s, i, c.s, c.i)) { c.s = s; c.i = i; }
+  }
+  return c;
+}
+
+__device__ float block_reduce_max(float v, float* red) {
+  v = wave_max(v);
+  __syncthreads();
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = v;
+  __syncthreads();
+  return fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
+}
+__device__ float block_reduce_sum(float v, float* red) {
+  v = wave_sum(v);
+  __syncthreads();
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = v;
+  __syncthreads();
+  return (red[0] + red[1]) + (red[2] + red[3]);
+}
+
+template <int NB>
+__global__ __launch_bounds__(256) void lsm_topk_kernel(const float* __restrict__ logits,
+                                                       const float* __restrict__ beam_scores, int V, int ban,
+                                                       float* __restrict__ out_s, int* __restrict__ out_i) {
+  constexpr int K = 2 * NB;
+  __shared__ float red[4];
+  __shared__ float ls[256 * K];
+  __shared__ int li[256 * K];
+  __shared__ Cand wbest[4];
+  const int b = blockIdx.x, tid = threadIdx.x;
+
+  float ts[K];
+  int ti[K];
+#pragma unroll
+  for (int j = 0; j < K; ++j) { ts[j] = -INFINITY; ti[j] = 0x7fffffff; }
+
+  for (int beam = 0; beam < NB; ++beam) {
+    const float* row = logits + ((size_t)b * NB + beam) * V;
+    float m = -INFINITY;
+    for (int i = tid; i < V; i += 256) m = fmaxf(m, row[i]);
+    m = block_reduce_max(m, red);
+    float sum = 0.f;
+    for (int i = tid; i < V; i += 256) sum += expf(row[i] - m);
+    sum = block_reduce_sum(sum, red);
+    const float lse = logf(sum);
+    const float bs = beam_scores[b * NB + beam];
+    for (int i = tid; i < V; i += 256) {
+      float lp = (row[i] - m) - lse;
+      if (i == ban) lp = -INFINITY;
+      const float c = lp + bs;
+      const int flat = beam * V + i;
+      if (better(c, flat, ts[K - 1], ti[K - 1])) {
+        ts[K - 1] = c; ti[K - 1] = flat;
+#pragma unroll
+        for (int j = K - 1; j > 0; --j) {
+          if (better(ts[j], ti[j], ts[j - 1], ti[j - 1])) {
+            const float s = ts[j]; ts[j] = ts[j - 1]; ts[j - 1] = s;
+            const int x = ti[j]; ti[j] = ti[j - 1]; ti[j - 1] = x;
+          }
+        }
+      }
+    }
+  }
+#pragma unroll
+  for (int j = 0; j < K; ++j) { ls[tid * K + j] = ts[j]; li[tid * K + j] = ti[j]; }
+  __syncthreads();
+  int head = 0;
+  for (int round = 0; round < K; ++round) {
+    Cand c;
+    c.s = head < K ? ls[tid * K + head] : -INFINITY;
+    c.i = head < K ? li[tid * K + head] : 0x7fffffff;
+    c = wave_best(c);
+    if ((tid & 63) == 0) wbest[tid >> 6] = c;
+    __syncthreads();
+    Cand g = wbest[0];
+#pragma unroll
+    for (int w = 1; w < 4; ++w)
+      if (better(wbest[w].s, wbest[w].i, g.s, g.i)) g = wbest[w];
+    if (head < K && li[tid * K + head] == g.i) ++head;  // flat indices are unique
+    if (tid == 0) { out_s[b * K + round] = g.s; out_i[b * K + round] = g.i; }
+    __syncthreads();
+  }
+}
+
+// ---- BeamHypotheses.add (double arithmetic: the reference does this on Python floats)
+__device__ void hyp_add(const vidil_beam_state& st, int b, int nb, int max_len, const int32_t* toks, int len,
+                        double sum_logprobs) {
+  const double score = sum_logprobs / (double)len;
+  int n = st.n_hyp[b];
+  double* hs = st.hyp_score + (size_t)b * nb;
+  int32_t* hl = st.hyp_len + (size_t)b * nb;
+  int32_t* ht = st.hyp_tok + (size_t)b * nb * max_len;
+  if (n < nb) {
+    hs[n] = score; hl[n] = len;
+    for (int t = 0; t < len; ++t) ht[(size_t)n * max_len + t] = toks[t];
+    st.n_hyp[b] = n + 1;
+    st.worst[b] = fmin(score, st.worst[b]);
+    return;
+  }
+  if (!(score > st.worst[b])) return;
+  // list is full: the new one is appended, then the lowest (score, position) is deleted.
+  int lo = 0;
+  for (int j = 1; j < nb; ++j)
+    if (hs[j] < hs[lo]) lo = j;
+  // (the appended entry has score > worst == hs[lo], so it is never the one deleted)
+  for (int j = lo; j + 1 < nb; ++j) {
+    hs[j] = hs[j + 1]; hl[j] = hl[j + 1];
+    for (int t = 0; t < hl[j]; ++t) ht[(size_t)j * max_len + t] = ht[(size_t)(j + 1) * max_len + t];
+  }
+  hs[nb - 1] = score; hl[nb - 1] = len;
+  for (int t = 0; t < len; ++t) ht[(size_t)(nb - 1) * max_len + t] = toks[t];
+  double w = hs[0];
+  for (int j = 1; j < nb; ++j) w = fmin(w, hs[j]);
+  st.worst[b] = w;
+}
+
+__global__ void beam_update_kernel(const vidil_beam_state st, const float* __restrict__ cand_s,
+                                   const int32_t* __restrict__ cand_i, int B, int nb, int V, int cur_len, int max_len,
+                                   int eos_id, int pad_id) {
+  const int b = blockIdx.x * blockDim.x + threadIdx.x;
+  if (b >= B) return;
+  const int K = 2 * nb;
+  float ns[MAXNB];
+  int nt[MAXNB], nsrc[MAXNB];
+  if (st.done[b]) {
+    for (int j = 0; j < nb; ++j) { ns[j] = 0.f; nt[j] = pad_id; nsrc[j] = b * nb + j; }
+  } else {
+    int slot = 0;
+    for (int rank = 0; rank < K && slot < nb; ++rank) {
+      const int flat = cand_i[b * K + rank];
+      const float sc = cand_s[b * K + rank];
+      const int beam = flat / V, tok = flat - beam * V;
+      const int src = b * nb + beam;
+      if (tok == eos_id) {
+        if (rank >= nb) continue;
+        hyp_add(st, b, nb, max_len, st.seqs + (size_t)src * max_len, cur_len, (double)sc);
+      } else {
+        ns[slot] = sc; nt[slot] = tok; nsrc[slot] = src; ++slot;
+      }
+    }
+    for (; slot < nb; ++slot) { ns[slot] = -1e9f; nt[slot] = pad_id; nsrc[slot] = b * nb; }  // unreachable
+    if (st.n_hyp[b] >= nb) {
+      const double cur_score = (double)cand_s[b * K] / (double)cur_len;
+      if (st.worst[b] >= cur_score) st.done[b] = 1;
+    }
+  }
+  for (int j = 0; j < nb; ++j) {
+    const int row = b * nb + j;
+    st.beam_scores[row] = ns[j];
+    st.beam_idx[row] = nsrc[j];
+    st.next_tok[row] = nt[j];
+    const int32_t* src = st.seqs + (size_t)nsrc[j] * max_len;
+    int32_t* dst = st.seqs_next + (size_t)row * max_len;
+    for (int t = 0; t < cur_len; ++t) dst[t] = src[t];
+    dst[cur_len] = nt[j];
+  }
+  if (st.done[b] && st.n_done != nullptr) atomicAdd(st.n_done, 1);
+}
+
+__global__ void beam_finalize_kernel(const vidil_beam_state st, int B, int nb, int cur_len, int max_len, int eos_id,
+                                     int pad_id, int32_t* __restrict__ out_tok, int32_t* __restrict__ out_len,
+                                     float* __restrict__ out_score) {
+  const int b = blockIdx.x * blockDim.x + threadIdx.x;
+  if (b >= B) return;
+  if (!st.done[b]) {
+    for (int j = 0; j < nb; ++j) {
+      const int row = b * nb + j;
+      hyp_add(st, b, nb, max_len, st.seqs + (size_t)row * max_len, cur_len, (double)st.beam_scores[row]);
+    }
+  }
+  // sorted(beams, key=score).pop(): the highest score, the LAST one among equals
+  const int n = st.n_hyp[b];
+  const double* hs = st.hyp_score + (size_t)b * nb;
+  int best = 0;
+  for (int j = 1; j < n; ++j)
+    if (hs[j] >= hs[best]) best = j;
+  const int len = st.hyp_len[(size_t)b * nb + best];
+  const int32_t* ht = st.hyp_tok + ((size_t)b * nb + best) * max_len;
+  for (int t = 0; t < max_len; ++t) out_tok[(size_t)b * max_len + t] = t < len ? ht[t] : pad_id;
+  if (len < max_len) out_tok[(size_t)b * max_len + len] = eos_id;
+  out_len[b] = len;
+  out_score[b] = (float)hs[best];
+}
+
+__global__ __launch_bounds__(256) void kv_reorder_kernel(const uint4* __restrict__ src, uint4* __restrict__ dst,
+                                                         const int32_t* __restrict__ beam_idx, int rows,
+                                                         int64_t row_vec) {
+  const int s = blockIdx.x, l = blockIdx.y;
+  const int from = beam_idx[s];
+  const uint4* a = src + ((size_t)l * rows + from) * row_vec;
+  uint4* d = dst + ((size_t)l * rows + s) * row_vec;
+  for (int64_t i = threadIdx.x; i < row_vec; i += 256) d[i] = a[i];
+}
+
+}  // namespace
+
+extern "C" int vidil_logsoftmax_topk(const float* logits, const float* beam_scores, int32_t B, int32_t nb, int32_t V,
+                                     int32_t ban_token, float* out_scores, int32_t* out_index, void* stream) {
+  VIDIL_REQUIRE(logits && beam_scores && out_scores && out_index, "logsoftmax_topk: null pointer");
+  VIDIL_REQUIRE(B > 0 && V > 0, "logsoftmax_topk: bad shape");
+  VIDIL_REQUIRE((long)nb * V < 0x7fffffffL, "logsoftmax_topk: nb*V overflows int32");
+  hipStream_t s = (hipStream_t)stream;
+  switch (nb) {
+    case 1: hipLaunchKernelGGL(lsm_topk_kernel<1>, dim3(B), dim3(256), 0, s, logits, beam_scores, V, ban_token, out_scores, out_index); break;
+    case 2: hipLaunchKernelGGL(lsm_topk_kernel<2>, dim3(B), dim3(256), 0, s, logits, beam_scores, V, ban_token, out_scores, out_index); break;
+    case 3: hipLaunchKernelGGL(lsm_topk_kernel<3>, dim3(B), dim3(256), 0, s, logits, beam_scores, V, ban_token, out_scores, out_index); break;
+    case 4: hipLaunchKernelGGL(lsm_topk_kernel<4>, dim3(B), dim3(256), 0, s, logits, beam_scores, V, ban_token, out_scores, out_index); break;
+    default:
+      vidil_set_error("logsoftmax_topk: num_beams=%d not supported (1..4)", nb);
+      return VIDIL_EUNSUP;
+  }
+  VIDIL_CHECK_LAUNCH("logsoftmax_topk");
+  return VIDIL_OK;
+}
+
+static int check_state(const vidil_beam_state* st, int nb, int max_len, const char* who) {
+  VIDIL_REQUIRE(st != nullptr, "%s: null state", who);
+  VIDIL_REQUIRE(st->seqs && st->seqs_next && st->beam_scores && st->beam_idx && st->next_tok && st->done && st->n_hyp &&
+                    st->hyp_score && st->hyp_len && st->hyp_tok && st->worst,
+                "%s: null pointer in state", who);
+  VIDIL_REQUIRE(nb >= 1 && nb <= MAXNB, "%s: num_beams=%d not supported (1..4)", who, nb);
+  VIDIL_REQUIRE(max_len >= 2 && max_len <= MAXLEN, "%s: max_len=%d not supported (2..64)", who, max_len);
+  return VIDIL_OK;
+}
+
+extern "C" int vidil_beam_update(const vidil_beam_state* st, const float* cand_scores, const int32_t* cand_index,
+                                 int32_t B, int32_t nb, int32_t V, int32_t cur_len, int32_t max_len, int32_t eos_id,
+                                 int32_t pad_id, void* stream) {
+  int rc = check_state(st, nb, max_len, "beam_update");
+  if (rc) return rc;
+  VIDIL_REQUIRE(cand_scores && cand_index && B > 0 && V > 0, "beam_update: bad args");
+  VIDIL_REQUIRE(cur_len >= 1 && cur_len < max_len, "beam_update: cur_len=%d must be in [1,max_len)", cur_len);
+  hipStream_t s = (hipStream_t)stream;
+  if (st->n_done != nullptr) {
+    hipError_t e = hipMemsetAsync(st->n_done, 0, sizeof(int32_t), s);
+    if (e != hipSuccess) { vidil_set_error("beam_update: memset failed: %s", hipGetErrorString(e)); return VIDIL_ELAUNCH; }
+  }
+  hipLaunchKernelGGL(beam_update_kernel, dim3((B + 63) / 64), dim3(64), 0, s, *st, cand_scores, cand_index, B, nb, V,
+                     cur_len, max_len, eos_id, pad_id);
+  VIDIL_CHECK_LAUNCH("beam_update");
+  return VIDIL_OK;
+}
+
+extern "C" int vidil_beam_finalize(const vidil_beam_state* st, int32_t B, int32_t nb, int32_t cur_len, int32_t max_len,
+                                   int32_t eos_id, int32_t pad_id, int32_t* out_tokens, int32_t* out_len,
+                                   float* out_score, void* stream) {
+  int rc = check_state(st, nb, max_len, "beam_finalize");
+  if (rc) return rc;
+  VIDIL_REQUIRE(out_tokens && out_len && out_score && B > 0, "beam_finalize: bad args");
+  VIDIL_REQUIRE(cur_len >= 1 && cur_len <= max_len, "beam_finalize: cur_len=%d", cur_len);
+  hipLaunchKernelGGL(beam_finalize_kernel, dim3((B + 63) / 64), dim3(64), 0, (hipStream_t)stream, *st, B, nb, cur_len,
+                     max_len, eos_id, pad_id, out_tokens, out_len, out_score);
+  VIDIL_CHECK_LAUNCH("beam_finalize");
+  return VIDIL_OK;
+}
+
+extern "C" int vidil_kv_reorder(const void* src, void* dst, const int32_t* beam_idx, int32_t L, int32_t rows,
+                                int64_t row_halfs, void* stream) {
+  VIDIL_REQUIRE(src && dst && beam_idx && src != dst, "kv_reorder: bad pointers (src must differ from dst)");
+  VIDIL_REQUIRE(L > 0 && rows > 0 && row_halfs > 0 && row_halfs % 8 == 0, "kv_reorder: row_halfs must be a multiple of 8");
+  VIDIL_REQUIRE(L <= 65535, "kv_reorder: too many layers");
+  hipLaunchKernelGGL(kv_reorder_kernel, dim3(rows, L), dim3(256), 0, (hipStream_t)stream, (const uint4*)src, (uint4*)dst,
+                     beam_idx, rows, row_halfs / 8);
+  VIDIL_CHECK_LAUNCH("kv_reorder");
+  return VIDIL_OK;
+}

@@ -1,0 +1,279 @@
+// gemm.hip — f16 MFMA GEMM  C[M,N] = A[M,K] · W[N,K]^T with fused epilogues.
+//
+// gfx950 design:
+//   * 256-thread workgroup = 4 waves in a 2x2 grid; block tile BM x BN (128 or
+//     64 each), K-step 64; every wave owns (BM/2)x(BN/2) as 32x32 MFMA tiles
+//     (v_mfma_f32_32x32x16_f16, f32 accumulate).
+//   * A and W tiles go HBM -> LDS with global_load_lds_dwordx4 (16 B / lane,
+//     no VGPR round trip), two LDS stages, one barrier per K-step.
+//   * LDS rows are 128 B (64 halfs); the 16-B slot index is XOR-swizzled with
+//     (row>>1)&7 on the SOURCE address (the LDS-DMA destination is lane
+//     linear) and on the ds_read_b128 side, which makes the fragment reads
+//     conflict free for the b128 lane groups.
+//   * blockIdx is remapped so consecutive logical tiles (which share an A row
+//     panel) run on one XCD and hit its private L2.
+//   * epilogues: bias / GELU / residual / per-head Q-K-V^T scatter / patch
+//     row remap + positional embedding, all on the f32 accumulators.
+#include "common.h"
+
+namespace {
+
+constexpr int BK = 64;
+
+template <int BM, int BN, int EPI, int ACT>
+__global__ __launch_bounds__(256) void gemm_kernel(const vidil_gemm_args p) {
+  constexpr int TM = BM / 64;  // 32x32 tiles per wave along M
+  constexpr int TN = BN / 64;
+  constexpr int A_BYTES = BM * BK * 2;
+  constexpr int STAGE_BYTES = (BM + BN) * BK * 2;
+  constexpr int LA = BM * 8 / 256;  // 16-B chunks per thread per stage (A)
+  constexpr int LB = BN * 8 / 256;
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wm = wave >> 1, wn = wave & 1;
+  const int hi = lane >> 5;
+  const int l31 = lane & 31;
+
+  const int M = p.M, N = p.N, K = p.K;
+  const int tiles_n = (N + BN - 1) / BN;
+  const int tiles_m = (M + BM - 1) / BM;
+  // XCD-aware bijective remap of the block index (8 XCDs, block b -> XCD b%8).
+  int logical;
+  {
+    const int nblk = tiles_m * tiles_n;
+    const int bid = blockIdx.x;
+    const int xcd = bid & 7, q = nblk >> 3, r = nblk & 7;
+    logical = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (bid >> 3);
+  }
+  const int tile_m = logical / tiles_n;
+  const int tile_n = logical - tile_m * tiles_n;
+  const int m0 = tile_m * BM, n0 = tile_n * BN;
+
+  const f16* __restrict__ A = (const f16*)p.A;
+  const f16* __restrict__ W = (const f16*)p.W;
+
+  // per-thread source pointers for the staging loads (K offset added per step)
+  const f16* ga[LA];
+  const f16* gb[LB];
+#pragma unroll
+  for (int i = 0; i < LA; ++i) {
+    const int q = i * 256 + tid;
+    const int r = q >> 3, s = q & 7;
+    const int c = s ^ ((r >> 1) & 7);
+    int row = m0 + r;
+    row = row < M ? row : M - 1;
+    ga[i] = A + (size_t)row * K + c * 8;
+  }
+#pragma unroll
+  for (int i = 0; i < LB; ++i) {
+    const int q = i * 256 + tid;
+    const int r = q >> 3, s = q & 7;
+    const int c = s ^ ((r >> 1) & 7);
+    int row = n0 + r;
+    row = row < N ? row : N - 1;
+    gb[i] = W + (size_t)row * K + c * 8;
+  }
+
+  auto stage = [&](int kt, int buf) {
+    char* la = smem + buf * STAGE_BYTES;
+    char* lb = la + A_BYTES;
+#pragma unroll
+    for (int i = 0; i < LA; ++i) {
+      __builtin_amdgcn_global_load_lds(
+          (const __attribute__((address_space(1))) void*)(ga[i] + kt * BK),
+          (__attribute__((address_space(3))) void*)(la + (i * 256 + wave * 64) * 16), 16, 0, 0);
+    }
+#pragma unroll
+    for (int i = 0; i < LB; ++i) {
+      __builtin_amdgcn_global_load_lds(
+          (const __attribute__((address_space(1))) void*)(gb[i] + kt * BK),
+          (__attribute__((address_space(3))) void*)(lb + (i * 256 + wave * 64) * 16), 16, 0, 0);
+    }
+  };
+
+  f32x16 acc[TM][TN];
+#pragma unroll
+  for (int i = 0; i < TM; ++i)
+#pragma unroll
+    for (int j = 0; j < TN; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+  const int sw = (lane >> 1) & 7;  // ((row>>1)&7) with row = 32*x + (lane&31)
+  const int a_row_off = (wm * (BM / 2) + l31) * 128;
+  const int b_row_off = (wn * (BN / 2) + l31) * 128;
+
+  const int nk = K / BK;
+  stage(0, 0);
+  __syncthreads();
+  for (int kt = 0; kt < nk; ++kt) {
+    const int cur = kt & 1;
+    if (kt + 1 < nk) stage(kt + 1, cur ^ 1);
+    const char* la = smem + cur * STAGE_BYTES;
+    const char* lb = la + A_BYTES;
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks) {
+      const int slot = ((ks * 2 + hi) ^ sw) * 16;
+      f16x8 af[TM], bf[TN];
+#pragma unroll
+      for (int i = 0; i < TM; ++i) af[i] = *(const f16x8*)(la + a_row_off + i * 32 * 128 + slot);
+#pragma unroll
+      for (int j = 0; j < TN; ++j) bf[j] = *(const f16x8*)(lb + b_row_off + j * 32 * 128 + slot);
+#pragma unroll
+      for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(af[i], bf[j], acc[i][j], 0, 0, 0);
+    }
+    __syncthreads();
+  }
+
+  // ---------------------------------------------------------------- epilogue
+  // acc[i][j][r] : row = m0 + wm*BM/2 + i*32 + (r&3) + 8*(r>>2) + 4*hi
+  //                col = n0 + wn*BN/2 + j*32 + (lane&31)
+#pragma unroll
+  for (int j = 0; j < TN; ++j) {
+    const int col = n0 + wn * (BN / 2) + j * 32 + l31;
+    const bool col_ok = col < N;
+    const float bias = (p.bias != nullptr && col_ok) ? p.bias[col] : 0.f;
+    // EPI_HEADS column decomposition
+    int part = 0, hcol = 0;
+    if constexpr (EPI == VIDIL_EPI_HEADS) {
+      const int hd = p.H * 64;
+      part = p.part0 + col / hd;
+      hcol = col % hd;  // h*64 + d
+    }
+#pragma unroll
+    for (int i = 0; i < TM; ++i) {
+#pragma unroll
+      for (int rq = 0; rq < 4; ++rq) {
+        const int row_base = m0 + wm * (BM / 2) + i * 32 + 8 * rq + 4 * hi;
+        int b = 0, t = 0;
+        if constexpr (EPI == VIDIL_EPI_HEADS) {
+          b = row_base / p.T;
+          t = row_base - b * p.T;
+        } else if constexpr (EPI == VIDIL_EPI_PATCH) {
+          b = row_base / p.tpi;
+          t = row_base - b * p.tpi;
+        }
+#pragma unroll
+        for (int rr = 0; rr < 4; ++rr) {
+          const int row = row_base + rr;
+          float v = acc[i][j][rq * 4 + rr] + bias;
+          if constexpr (ACT == VIDIL_ACT_GELU_ERF) v = gelu_erf(v);
+          if constexpr (ACT == VIDIL_ACT_QUICK_GELU) v = quick_gelu(v);
+          const bool ok = col_ok && row < M;
+          if constexpr (EPI == VIDIL_EPI_F16) {
+            if (ok) ((f16*)p.out)[(size_t)row * p.ldo + col] = (f16)v;
+          } else if constexpr (EPI == VIDIL_EPI_F32) {
+            if (ok) {
+              const size_t o = (size_t)row * p.ldo + col;
+              if (p.resid != nullptr) v += p.resid[o];
+              ((float*)p.out)[o] = v;
+            }
+          } else if constexpr (EPI == VIDIL_EPI_HEADS) {
+            if (ok) {
+              const int h = hcol >> 6, d = hcol & 63;
+              const size_t bh = (size_t)b * p.H + h;
+              if (part == 0) {
+                ((f16*)p.q)[(bh * p.Tq_cap + t) * 64 + d] = (f16)(v * p.q_scale);
+              } else if (part == 1) {
+                ((f16*)p.k)[(bh * p.Tk_cap + p.t_off + t) * 64 + d] = (f16)v;
+              } else {
+                ((f16*)p.vt)[(bh * 64 + d) * (size_t)p.NP + p.t_off + t] = (f16)v;
+              }
+            }
+            if (++t == p.T) { t = 0; ++b; }
+          } else {  // EPI_PATCH
+            if (ok) {
+              const size_t orow = (size_t)row + b + 1;
+              ((float*)p.out)[orow * p.ldo + col] = v + p.pos[(size_t)(t + 1) * N + col];
+            }
+            if (++t == p.tpi) { t = 0; ++b; }
+          }
+        }
+      }
+    }
+  }
+}
+
+template <int BM, int BN, int EPI, int ACT>
+int launch(const vidil_gemm_args& a, hipStream_t s) {
+  constexpr int smem = 2 * (BM + BN) * BK * 2;
+  static bool attr_set = false;
+  auto kern = gemm_kernel<BM, BN, EPI, ACT>;
+  if (!attr_set) {
+    hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, smem);
+    if (e != hipSuccess) {
+      vidil_set_error("gemm: hipFuncSetAttribute failed: %s", hipGetErrorString(e));
+      return VIDIL_ELAUNCH;
+    }
+    attr_set = true;
+  }
+  const int tiles = ((a.M + BM - 1) / BM) * ((a.N + BN - 1) / BN);
+  hipLaunchKernelGGL(kern, dim3(tiles), dim3(256), smem, s, a);
+  VIDIL_CHECK_LAUNCH("gemm");
+  return VIDIL_OK;
+}
+
+template <int EPI, int ACT>
+int pick_tile(const vidil_gemm_args& a, hipStream_t s) {
+  // Fill 256 CUs (2 workgroups each at 128x128): shrink the tile when the
+  // grid would otherwise be too small (decode-step GEMMs with M of a few
+  // hundred rows).
+  const long t128 = (long)((a.M + 127) / 128) * ((a.N + 127) / 128);
+  if (t128 >= 384 || a.M > 4096) return launch<128, 128, EPI, ACT>(a, s);
+  const long t64n = (long)((a.M + 127) / 128) * ((a.N + 63) / 64);
+  if (t64n >= 256 && a.M >= 128) return launch<128, 64, EPI, ACT>(a, s);
+  return launch<64, 64, EPI, ACT>(a, s);
+}
+
+}  // namespace
+
+extern "C" int vidil_gemm_f16(const vidil_gemm_args* args, void* stream) {
+  VIDIL_REQUIRE(args != nullptr, "gemm: null args");
+  const vidil_gemm_args& a = *args;
+  VIDIL_REQUIRE(a.A && a.W, "gemm: null operand");
+  VIDIL_REQUIRE(a.M > 0 && a.N > 0 && a.K > 0, "gemm: bad shape M=%d N=%d K=%d", a.M, a.N, a.K);
+  VIDIL_REQUIRE(a.K % BK == 0, "gemm: K=%d must be a multiple of %d", a.K, BK);
+  VIDIL_REQUIRE(((uintptr_t)a.A & 15) == 0 && ((uintptr_t)a.W & 15) == 0, "gemm: operands must be 16-B aligned");
+  hipStream_t s = (hipStream_t)stream;
+  switch (a.epi) {
+    case VIDIL_EPI_F16:
+      VIDIL_REQUIRE(a.out && a.ldo >= a.N, "gemm/f16: bad out/ldo");
+      if (a.act == VIDIL_ACT_NONE) return pick_tile<VIDIL_EPI_F16, VIDIL_ACT_NONE>(a, s);
+      if (a.act == VIDIL_ACT_GELU_ERF) return pick_tile<VIDIL_EPI_F16, VIDIL_ACT_GELU_ERF>(a, s);
+      if (a.act == VIDIL_ACT_QUICK_GELU) return pick_tile<VIDIL_EPI_F16, VIDIL_ACT_QUICK_GELU>(a, s);
+      break;
+    case VIDIL_EPI_F32:
+      VIDIL_REQUIRE(a.out && a.ldo >= a.N, "gemm/f32: bad out/ldo");
+      if (a.act == VIDIL_ACT_NONE) return pick_tile<VIDIL_EPI_F32, VIDIL_ACT_NONE>(a, s);
+      if (a.act == VIDIL_ACT_GELU_ERF) return pick_tile<VIDIL_EPI_F32, VIDIL_ACT_GELU_ERF>(a, s);
+      if (a.act == VIDIL_ACT_QUICK_GELU) return pick_tile<VIDIL_EPI_F32, VIDIL_ACT_QUICK_GELU>(a, s);
+      break;
+    case VIDIL_EPI_HEADS: {
+      VIDIL_REQUIRE(a.act == VIDIL_ACT_NONE, "gemm/heads: no activation");
+      VIDIL_REQUIRE(a.H > 0 && a.T > 0 && a.N % (a.H * 64) == 0, "gemm/heads: N=%d not a multiple of H*64 (H=%d)", a.N, a.H);
+      const int nparts = a.N / (a.H * 64);
+      VIDIL_REQUIRE(a.part0 >= 0 && a.part0 + nparts <= 3, "gemm/heads: part0=%d with %d parts", a.part0, nparts);
+      for (int part = a.part0; part < a.part0 + nparts; ++part) {
+        if (part == 0) VIDIL_REQUIRE(a.q && a.Tq_cap >= a.T, "gemm/heads: bad q / Tq_cap");
+        if (part == 1) VIDIL_REQUIRE(a.k && a.Tk_cap >= a.t_off + a.T, "gemm/heads: bad k / Tk_cap");
+        if (part == 2) VIDIL_REQUIRE(a.vt && a.NP >= a.t_off + a.T, "gemm/heads: bad vt / NP");
+      }
+      VIDIL_REQUIRE(a.M % a.T == 0, "gemm/heads: M=%d not a multiple of T=%d", a.M, a.T);
+      return pick_tile<VIDIL_EPI_HEADS, VIDIL_ACT_NONE>(a, s);
+    }
+    case VIDIL_EPI_PATCH:
+      VIDIL_REQUIRE(a.act == VIDIL_ACT_NONE, "gemm/patch: no activation");
+      VIDIL_REQUIRE(a.out && a.pos && a.tpi > 0 && a.M % a.tpi == 0 && a.ldo >= a.N, "gemm/patch: bad args");
+      return pick_tile<VIDIL_EPI_PATCH, VIDIL_ACT_NONE>(a, s);
+    default:
+      break;
+  }
+  vidil_set_error("gemm: unsupported epi=%d act=%d", a.epi, a.act);
+  return VIDIL_EUNSUP;
+}

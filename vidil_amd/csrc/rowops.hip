@@ -1,0 +1,239 @@
+// rowops.hip — HBM-bound row kernels: LayerNorm, patch extraction (im2col for
+// stride==kernel conv, fused with uint8 -> normalised f16), CLS row, token
+// embedding, row gather, L2 normalisation.  All are one wave per row (or per
+// patch), 16-B vector accesses, f32 statistics.
+#include "common.h"
+
+namespace {
+
+// One wave per row; D/64 elements per lane, processed as float4 where D%256==0
+// is not required: lane handles elements lane*4 + 256*i (+0..3).
+template <int VPL>  // float4 vectors per lane: D = 256*VPL
+__global__ __launch_bounds__(256) void layernorm_kernel(const float* __restrict__ x, int64_t x_stride,
+                                                        const float* __restrict__ gamma,
+                                                        const float* __restrict__ beta, float eps, int M,
+                                                        f16* __restrict__ out16, float* __restrict__ out32) {
+  constexpr int D = 256 * VPL;
+  const int lane = threadIdx.x & 63;
+  const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (row >= M) return;
+  const float* xr = x + (size_t)row * x_stride;
+  f32x4 v[VPL];
+  float s = 0.f;
+#pragma unroll
+  for (int i = 0; i < VPL; ++i) {
+    v[i] = *(const f32x4*)(xr + i * 256 + lane * 4);
+    s += (v[i][0] + v[i][1]) + (v[i][2] + v[i][3]);
+  }
+  const float mean = wave_sum(s) * (1.0f / D);
+  float ss = 0.f;
+#pragma unroll
+  for (int i = 0; i < VPL; ++i) {
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      const float d = v[i][e] - mean;
+      ss += d * d;
+    }
+  }
+  const float var = wave_sum(ss) * (1.0f / D);
+  const float rstd = 1.0f / sqrtf(var + eps);
+#pragma unroll
+  for (int i = 0; i < VPL; ++i) {
+    const int c = i * 256 + lane * 4;
+    const f32x4 g = *(const f32x4*)(gamma + c);
+    const f32x4 b = *(const f32x4*)(beta + c);
+    f32x4 y;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) y[e] = (v[i][e] - mean) * rstd * g[e] + b[e];
+    if (out32 != nullptr) *(f32x4*)(out32 + (size_t)row * D + c) = y;
+    if (out16 != nullptr) *(f16x4*)(out16 + (size_t)row * D + c) = f16x4{(f16)y[0], (f16)y[1], (f16)y[2], (f16)y[3]};
+  }
+}
+
+// out[(b*P + py*G + px), c*ps*ps + y*ps + x] = img[b, c, py*ps + y, px*ps + x]
+// one thread = 8 consecutive x of one (patch, c, y) line.
+__global__ __launch_bounds__(256) void patchify_f32_kernel(const float* __restrict__ img, f16* __restrict__ out,
+                                                           int B, int S, int ps) {
+  const int G = S / ps;
+  const int xch = ps / 8;                      // 8-pixel chunks per patch line
+  const size_t total = (size_t)B * G * G * 3 * ps * xch;
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+    size_t r = i;
+    const int xc = r % xch; r /= xch;
+    const int y = r % ps; r /= ps;
+    const int c = r % 3; r /= 3;
+    const int px = r % G; r /= G;
+    const int py = r % G; r /= G;
+    const int b = (int)r;
+    const float* src = img + (((size_t)b * 3 + c) * S + (py * ps + y)) * S + px * ps + xc * 8;
+    const f32x4 a0 = *(const f32x4*)(src), a1 = *(const f32x4*)(src + 4);
+    f16x8 o = {(f16)a0[0], (f16)a0[1], (f16)a0[2], (f16)a0[3], (f16)a1[0], (f16)a1[1], (f16)a1[2], (f16)a1[3]};
+    f16* dst = out + ((size_t)(b * G + py) * G + px) * (3 * ps * ps) + (c * ps + y) * ps + xc * 8;
+    *(f16x8*)dst = o;
+  }
+}
+
+struct Norm3 { float scale[3]; float shift[3]; };  // y = x*scale + shift
+
+// uint8 HWC -> normalised f16 patch rows.  One thread = 8 consecutive pixels
+// (24 B read, three 16-B stores to the three channel planes of the patch row).
+__global__ __launch_bounds__(256) void patchify_u8_kernel(const uint8_t* __restrict__ img, f16* __restrict__ out,
+                                                          int B, int S, int ps, Norm3 nm) {
+  const int G = S / ps;
+  const int xch = ps / 8;
+  const size_t total = (size_t)B * G * G * ps * xch;
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+    size_t r = i;
+    const int xc = r % xch; r /= xch;
+    const int px = r % G; r /= G;       // px before y: consecutive threads walk a frame row
+    const int y = r % ps; r /= ps;
+    const int py = r % G; r /= G;
+    const int b = (int)r;
+    const uint8_t* src = img + (((size_t)b * S + (py * ps + y)) * S + px * ps + xc * 8) * 3;
+    // 24 bytes, 8-B aligned (pixel index multiple of 8)
+    const uint2 w0 = *(const uint2*)(src), w1 = *(const uint2*)(src + 8), w2 = *(const uint2*)(src + 16);
+    uint8_t bytes[24];
+    *(uint2*)(bytes) = w0; *(uint2*)(bytes + 8) = w1; *(uint2*)(bytes + 16) = w2;
+    f16* dst = out + ((size_t)(b * G + py) * G + px) * (3 * ps * ps) + y * ps + xc * 8;
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+      f16x8 o;
+#pragma unroll
+      for (int e = 0; e < 8; ++e) o[e] = (f16)((float)bytes[e * 3 + c] * nm.scale[c] + nm.shift[c]);
+      *(f16x8*)(dst + c * ps * ps) = o;
+    }
+  }
+}
+
+__global__ void set_cls_kernel(float* __restrict__ x, const float* __restrict__ cls, const float* __restrict__ pos0,
+                               int B, int T, int D) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= B * D) return;
+  const int b = i / D, d = i - b * D;
+  x[(size_t)b * T * D + d] = cls[d] + pos0[d];
+}
+
+__global__ __launch_bounds__(256) void embed_tokens_kernel(const int32_t* __restrict__ ids, const float* __restrict__ word,
+                                                          const float* __restrict__ pos, float* __restrict__ out,
+                                                          int M, int T, int pos_off, int D, int vocab) {
+  const int lane = threadIdx.x & 63;
+  const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (row >= M) return;
+  int id = ids[row];
+  id = id < 0 ? 0 : (id >= vocab ? vocab - 1 : id);
+  const float* w = word + (size_t)id * D;
+  const float* pe = pos + (size_t)(pos_off + row % T) * D;
+  for (int c = lane * 4; c < D; c += 256) {
+    const f32x4 a = *(const f32x4*)(w + c), b = *(const f32x4*)(pe + c);
+    *(f32x4*)(out + (size_t)row * D + c) = a + b;
+  }
+}
+
+__global__ __launch_bounds__(256) void gather_rows_kernel(const float* __restrict__ x, const int32_t* __restrict__ idx,
+                                                          float* __restrict__ out, int n, int D) {
+  const int lane = threadIdx.x & 63;
+  const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (row >= n) return;
+  const float* src = x + (size_t)idx[row] * D;
+  for (int c = lane * 4; c < D; c += 256) *(f32x4*)(out + (size_t)row * D + c) = *(const f32x4*)(src + c);
+}
+
+__global__ __launch_bounds__(256) void l2norm_kernel(float* __restrict__ x, int n, int D) {
+  const int lane = threadIdx.x & 63;
+  const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (row >= n) return;
+  float* xr = x + (size_t)row * D;
+  float ss = 0.f;
+  for (int c = lane * 4; c < D; c += 256) {
+    const f32x4 a = *(const f32x4*)(xr + c);
+    ss += a[0] * a[0] + a[1] * a[1] + a[2] * a[2] + a[3] * a[3];
+  }
+  const float nrm = sqrtf(wave_sum(ss));
+  for (int c = lane * 4; c < D; c += 256) {
+    f32x4 a = *(const f32x4*)(xr + c);
+    a[0] /= nrm; a[1] /= nrm; a[2] /= nrm; a[3] /= nrm;
+    *(f32x4*)(xr + c) = a;
+  }
+}
+
+inline int grid_for(size_t total, int block) {
+  size_t g = (total + block - 1) / block;
+  return (int)(g > 256 * 16 ? 256 * 16 : (g == 0 ? 1 : g));
+}
+
+}  // namespace
+
+extern "C" int vidil_layernorm(const float* x, int64_t x_stride, const float* gamma, const float* beta, float eps,
+                               int32_t M, int32_t D, void* out_f16, float* out_f32, void* stream) {
+  VIDIL_REQUIRE(x && gamma && beta && (out_f16 || out_f32), "layernorm: null pointer");
+  VIDIL_REQUIRE(M > 0, "layernorm: M=%d", M);
+  VIDIL_REQUIRE(x_stride % 4 == 0, "layernorm: x_stride must be a multiple of 4");
+  hipStream_t s = (hipStream_t)stream;
+  dim3 grid((M + 3) / 4), block(256);
+  switch (D) {
+    case 256: hipLaunchKernelGGL(layernorm_kernel<1>, grid, block, 0, s, x, x_stride, gamma, beta, eps, M, (f16*)out_f16, out_f32); break;
+    case 512: hipLaunchKernelGGL(layernorm_kernel<2>, grid, block, 0, s, x, x_stride, gamma, beta, eps, M, (f16*)out_f16, out_f32); break;
+    case 768: hipLaunchKernelGGL(layernorm_kernel<3>, grid, block, 0, s, x, x_stride, gamma, beta, eps, M, (f16*)out_f16, out_f32); break;
+    case 1024: hipLaunchKernelGGL(layernorm_kernel<4>, grid, block, 0, s, x, x_stride, gamma, beta, eps, M, (f16*)out_f16, out_f32); break;
+    case 1280: hipLaunchKernelGGL(layernorm_kernel<5>, grid, block, 0, s, x, x_stride, gamma, beta, eps, M, (f16*)out_f16, out_f32); break;
+    default:
+      vidil_set_error("layernorm: D=%d not supported (256/512/768/1024/1280)", D);
+      return VIDIL_EUNSUP;
+  }
+  VIDIL_CHECK_LAUNCH("layernorm");
+  return VIDIL_OK;
+}
+
+extern "C" int vidil_patchify_f32(const float* img, void* out, int32_t B, int32_t S, int32_t ps, void* stream) {
+  VIDIL_REQUIRE(img && out && B > 0, "patchify_f32: bad args");
+  VIDIL_REQUIRE(ps % 8 == 0 && S % ps == 0, "patchify_f32: S=%d ps=%d (ps%%8==0, S%%ps==0 required)", S, ps);
+  const size_t total = (size_t)B * (S / ps) * (S / ps) * 3 * ps * (ps / 8);
+  hipLaunchKernelGGL(patchify_f32_kernel, dim3(grid_for(total, 256)), dim3(256), 0, (hipStream_t)stream, img, (f16*)out, B, S, ps);
+  VIDIL_CHECK_LAUNCH("patchify_f32");
+  return VIDIL_OK;
+}
+
+extern "C" int vidil_patchify_u8(const uint8_t* img, void* out, int32_t B, int32_t S, int32_t ps,
+                                 const float* mean3_host, const float* std3_host, void* stream) {
+  VIDIL_REQUIRE(img && out && mean3_host && std3_host && B > 0, "patchify_u8: bad args");
+  VIDIL_REQUIRE(ps % 8 == 0 && S % ps == 0, "patchify_u8: S=%d ps=%d (ps%%8==0, S%%ps==0 required)", S, ps);
+  Norm3 nm;
+  for (int c = 0; c < 3; ++c) {
+    // (x/255 - mean)/std  ==  x * (1/(255*std)) - mean/std ; evaluated in f32 on device
+    nm.scale[c] = 1.0f / (255.0f * std3_host[c]);
+    nm.shift[c] = -mean3_host[c] / std3_host[c];
+  }
+  const size_t total = (size_t)B * (S / ps) * (S / ps) * ps * (ps / 8);
+  hipLaunchKernelGGL(patchify_u8_kernel, dim3(grid_for(total, 256)), dim3(256), 0, (hipStream_t)stream, img, (f16*)out, B, S, ps, nm);
+  VIDIL_CHECK_LAUNCH("patchify_u8");
+  return VIDIL_OK;
+}
+
+extern "C" int vidil_set_cls_row(float* x, const float* cls, const float* pos0, int32_t B, int32_t T, int32_t D, void* stream) {
+  VIDIL_REQUIRE(x && cls && pos0 && B > 0 && T > 0 && D > 0, "set_cls_row: bad args");
+  hipLaunchKernelGGL(set_cls_kernel, dim3((B * D + 255) / 256), dim3(256), 0, (hipStream_t)stream, x, cls, pos0, B, T, D);
+  VIDIL_CHECK_LAUNCH("set_cls_row");
+  return VIDIL_OK;
+}
+
+extern "C" int vidil_embed_tokens(const int32_t* ids, const float* word, const float* pos, float* out, int32_t M,
+                                  int32_t T, int32_t pos_off, int32_t D, int32_t vocab, void* stream) {
+  VIDIL_REQUIRE(ids && word && pos && out && M > 0 && T > 0 && D % 4 == 0 && vocab > 0, "embed_tokens: bad args");
+  hipLaunchKernelGGL(embed_tokens_kernel, dim3((M + 3) / 4), dim3(256), 0, (hipStream_t)stream, ids, word, pos, out, M, T, pos_off, D, vocab);
+  VIDIL_CHECK_LAUNCH("embed_tokens");
+  return VIDIL_OK;
+}
+
+extern "C" int vidil_gather_rows_f32(const float* x, const int32_t* idx, float* out, int32_t n, int32_t D, void* stream) {
+  VIDIL_REQUIRE(x && idx && out && n > 0 && D % 4 == 0, "gather_rows: bad args");
+  hipLaunchKernelGGL(gather_rows_kernel, dim3((n + 3) / 4), dim3(256), 0, (hipStream_t)stream, x, idx, out, n, D);
+  VIDIL_CHECK_LAUNCH("gather_rows");
+  return VIDIL_OK;
+}
+
+extern "C" int vidil_l2_normalize_rows(float* x, int32_t n, int32_t D, void* stream) {
+  VIDIL_REQUIRE(x && n > 0 && D % 4 == 0, "l2_normalize_rows: bad args");
+  hipLaunchKernelGGL(l2norm_kernel, dim3((n + 3) / 4), dim3(256), 0, (hipStream_t)stream, x, n, D);
+  VIDIL_CHECK_LAUNCH("l2_normalize_rows");
+  return VIDIL_OK;
+}

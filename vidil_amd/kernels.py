@@ -1,0 +1,278 @@
+"""Thin tensor -> raw-pointer wrappers over the C ABI (include/vidil_hip.h).
+
+torch is used here only for device memory and the current HIP stream; every
+arithmetic op on the hot path is one of the HIP kernels behind these calls.
+All functions raise ``VidilHipError`` on a non-zero return code.
+"""
+from __future__ import annotations
+
+import ctypes as C
+
+import torch
+
+from . import _lib
+from ._lib import (ACT_GELU_ERF, ACT_NONE, ACT_QUICK_GELU, EPI_F16, EPI_F32, EPI_HEADS,
+                   EPI_PATCH, BeamState, GemmArgs, VidilHipError, check)
+
+__all__ = [
+    "gemm", "layernorm", "attention", "patchify_f32", "patchify_u8", "set_cls_row",
+    "embed_tokens", "gather_rows", "l2_normalize_rows", "logsoftmax_topk", "BeamBuffers",
+    "beam_update", "beam_finalize", "kv_reorder", "scan_topk", "scan_topk_ws_bytes",
+    "ACT_NONE", "ACT_GELU_ERF", "ACT_QUICK_GELU", "VidilHipError",
+]
+
+
+def _stream() -> int:
+    return torch.cuda.current_stream().cuda_stream
+
+
+def _ptr(t, dtype=None, name="tensor"):
+    if t is None:
+        return None
+    if not t.is_cuda:
+        raise VidilHipError(f"{name}: expected a CUDA/HIP tensor, got {t.device} (no CPU fallback)")
+    if dtype is not None and t.dtype != dtype:
+        raise VidilHipError(f"{name}: expected dtype {dtype}, got {t.dtype}")
+    if not t.is_contiguous():
+        raise VidilHipError(f"{name}: tensor must be contiguous")
+    return t.data_ptr()
+
+
+# --------------------------------------------------------------------------- GEMM
+def gemm(a, w, bias=None, *, out=None, out_dtype=torch.float16, act=ACT_NONE, resid=None,
+         heads=None, patch=None):
+    """C = A · W^T with a fused epilogue.
+
+    a [M,K] f16, w [N,K] f16, bias f32 [N] or None.
+      * default: returns/fills ``out`` [M,N] (f16 or f32 by ``out_dtype``); f32 may add ``resid``.
+      * heads=dict(q=,k=,vt=,T=,H=,part0=,t_off=,Tq_cap=,Tk_cap=,NP=,q_scale=): per-head scatter.
+      * patch=dict(out=,pos=,tpi=): patch-embedding epilogue (row remap + pos embed).
+    """
+    lib = _lib.load()
+    M, K = a.shape
+    N = w.shape[0]
+    if w.shape[1] != K:
+        raise VidilHipError(f"gemm: A is [{M},{K}] but W is {tuple(w.shape)}")
+    g = GemmArgs()
+    g.A = _ptr(a, torch.float16, "gemm.A")
+    g.W = _ptr(w, torch.float16, "gemm.W")
+    g.bias = _ptr(bias, torch.float32, "gemm.bias")
+    g.M, g.N, g.K = M, N, K
+    g.act = act
+    ret = None
+    if heads is not None:
+        g.epi = EPI_HEADS
+        g.q = _ptr(heads.get("q"), torch.float16, "gemm.q")
+        g.k = _ptr(heads.get("k"), torch.float16, "gemm.k")
+        g.vt = _ptr(heads.get("vt"), torch.float16, "gemm.vt")
+        g.T, g.H = heads["T"], heads["H"]
+        g.part0 = heads.get("part0", 0)
+        g.t_off = heads.get("t_off", 0)
+        g.Tq_cap = heads.get("Tq_cap", heads["T"])
+        g.Tk_cap = heads.get("Tk_cap", heads["T"])
+        g.NP = heads.get("NP", 0)
+        g.q_scale = heads.get("q_scale", 1.0)
+    elif patch is not None:
+        g.epi = EPI_PATCH
+        ret = patch["out"]
+        g.out = _ptr(ret, torch.float32, "gemm.patch.out")
+        g.ldo = ret.shape[-1]
+        g.pos = _ptr(patch["pos"], torch.float32, "gemm.patch.pos")
+        g.tpi = patch["tpi"]
+    else:
+        if out is None:
+            out = torch.empty((M, N), dtype=out_dtype, device=a.device)
+        ret = out
+        g.epi = EPI_F16 if out.dtype == torch.float16 else EPI_F32
+        g.out = _ptr(out, None, "gemm.out")
+        g.ldo = out.shape[-1]
+        if resid is not None:
+            if out.dtype != torch.float32:
+                raise VidilHipError("gemm: resid needs an f32 output")
+            g.resid = _ptr(resid, torch.float32, "gemm.resid")
+    check(lib.vidil_gemm_f16(C.byref(g), _stream()), "gemm")
+    return ret
+
+
+# ---------------------------------------------------------------------- row kernels
+def layernorm(x, gamma, beta, eps, *, M=None, D=None, x_stride=None, out16=None, out32=None):
+    """LayerNorm rows of f32 ``x``.  Rows are ``x_stride`` elements apart (default dense)."""
+    lib = _lib.load()
+    D = D if D is not None else x.shape[-1]
+    M = M if M is not None else x.numel() // D
+    x_stride = x_stride if x_stride is not None else D
+    check(lib.vidil_layernorm(_ptr(x, torch.float32, "ln.x"), x_stride, _ptr(gamma, torch.float32, "ln.gamma"),
+                              _ptr(beta, torch.float32, "ln.beta"), float(eps), M, D,
+                              _ptr(out16, torch.float16, "ln.out16"), _ptr(out32, torch.float32, "ln.out32"),
+                              _stream()), "layernorm")
+
+
+def attention(q, k, vt, out, *, Bq, H, Nq, Nk, Tq_cap, Tk_cap, NP, kv_group=1, causal=False,
+              causal_off=0, kv_len=None, ldo=None):
+    lib = _lib.load()
+    ldo = ldo if ldo is not None else H * 64
+    check(lib.vidil_attention(_ptr(q, torch.float16, "attn.q"), _ptr(k, torch.float16, "attn.k"),
+                              _ptr(vt, torch.float16, "attn.vt"), _ptr(out, torch.float16, "attn.out"),
+                              _ptr(kv_len, torch.int32, "attn.kv_len"), Bq, H, Nq, Nk, Tq_cap, Tk_cap, NP,
+                              kv_group, int(bool(causal)), causal_off, ldo, _stream()), "attention")
+    return out
+
+
+def patchify_f32(img, ps, out=None):
+    lib = _lib.load()
+    B, Cc, S, S2 = img.shape
+    if Cc != 3 or S != S2:
+        raise VidilHipError(f"patchify_f32: expected [B,3,S,S], got {tuple(img.shape)}")
+    G = S // ps
+    if out is None:
+        out = torch.empty((B * G * G, 3 * ps * ps), dtype=torch.float16, device=img.device)
+    check(lib.vidil_patchify_f32(_ptr(img, torch.float32, "patchify.img"), _ptr(out, torch.float16, "patchify.out"),
+                                 B, S, ps, _stream()), "patchify_f32")
+    return out
+
+
+def patchify_u8(img, ps, mean, std, out=None):
+    lib = _lib.load()
+    B, S, S2, Cc = img.shape
+    if Cc != 3 or S != S2:
+        raise VidilHipError(f"patchify_u8: expected [B,S,S,3], got {tuple(img.shape)}")
+    G = S // ps
+    if out is None:
+        out = torch.empty((B * G * G, 3 * ps * ps), dtype=torch.float16, device=img.device)
+    m3 = (C.c_float * 3)(*[float(v) for v in mean])
+    s3 = (C.c_float * 3)(*[float(v) for v in std])
+    check(lib.vidil_patchify_u8(_ptr(img, torch.uint8, "patchify.img"), _ptr(out, torch.float16, "patchify.out"),
+                                B, S, ps, m3, s3, _stream()), "patchify_u8")
+    return out
+
+
+def set_cls_row(x, cls, pos0, B, T, D):
+    check(_lib.load().vidil_set_cls_row(_ptr(x, torch.float32), _ptr(cls, torch.float32), _ptr(pos0, torch.float32),
+                                        B, T, D, _stream()), "set_cls_row")
+
+
+def embed_tokens(ids, word, pos, out, *, T, pos_off=0):
+    M = ids.numel()
+    D = word.shape[1]
+    check(_lib.load().vidil_embed_tokens(_ptr(ids, torch.int32, "embed.ids"), _ptr(word, torch.float32),
+                                         _ptr(pos, torch.float32), _ptr(out, torch.float32), M, T, pos_off, D,
+                                         word.shape[0], _stream()), "embed_tokens")
+    return out
+
+
+def gather_rows(x, idx, out=None):
+    n, D = idx.numel(), x.shape[-1]
+    if out is None:
+        out = torch.empty((n, D), dtype=torch.float32, device=x.device)
+    check(_lib.load().vidil_gather_rows_f32(_ptr(x, torch.float32), _ptr(idx, torch.int32), _ptr(out, torch.float32),
+                                            n, D, _stream()), "gather_rows")
+    return out
+
+
+def l2_normalize_rows(x):
+    n, D = x.shape
+    check(_lib.load().vidil_l2_normalize_rows(_ptr(x, torch.float32), n, D, _stream()), "l2_normalize_rows")
+    return x
+
+
+# ------------------------------------------------------------------------ beam search
+def logsoftmax_topk(logits, beam_scores, B, nb, ban_token=-1, out_scores=None, out_index=None):
+    V = logits.shape[-1]
+    dev = logits.device
+    if out_scores is None:
+        out_scores = torch.empty((B, 2 * nb), dtype=torch.float32, device=dev)
+    if out_index is None:
+        out_index = torch.empty((B, 2 * nb), dtype=torch.int32, device=dev)
+    check(_lib.load().vidil_logsoftmax_topk(_ptr(logits, torch.float32, "topk.logits"),
+                                            _ptr(beam_scores, torch.float32, "topk.beam_scores"), B, nb, V,
+                                            ban_token, _ptr(out_scores, torch.float32), _ptr(out_index, torch.int32),
+                                            _stream()), "logsoftmax_topk")
+    return out_scores, out_index
+
+
+class BeamBuffers:
+    """Device-resident beam-search state for ``B`` images x ``nb`` beams."""
+
+    def __init__(self, B, nb, max_len, device):
+        self.B, self.nb, self.max_len = B, nb, max_len
+        i32 = dict(dtype=torch.int32, device=device)
+        self.seqs = torch.zeros((B * nb, max_len), **i32)
+        self.seqs_next = torch.zeros((B * nb, max_len), **i32)
+        self.beam_scores = torch.zeros((B * nb,), dtype=torch.float32, device=device)
+        self.beam_idx = torch.zeros((B * nb,), **i32)
+        self.next_tok = torch.zeros((B * nb,), **i32)
+        self.done = torch.zeros((B,), **i32)
+        self.n_hyp = torch.zeros((B,), **i32)
+        self.hyp_score = torch.zeros((B, nb), dtype=torch.float64, device=device)
+        self.hyp_len = torch.zeros((B, nb), **i32)
+        self.hyp_tok = torch.zeros((B, nb, max_len), **i32)
+        self.worst = torch.full((B,), 1e9, dtype=torch.float64, device=device)
+        self.n_done = torch.zeros((1,), **i32)
+
+    def reset(self, prompt_ids):
+        """prompt_ids: int32 [B, P]; beams of an image start identical, scores [0,-1e9,...]."""
+        B, nb = self.B, self.nb
+        P = prompt_ids.shape[1]
+        self.seqs.zero_()
+        self.seqs[:, :P] = prompt_ids.repeat_interleave(nb, dim=0)
+        bs = torch.full((B, nb), -1e9, dtype=torch.float32, device=self.seqs.device)
+        bs[:, 0] = 0.0
+        self.beam_scores.copy_(bs.view(-1))
+        self.done.zero_(); self.n_hyp.zero_(); self.worst.fill_(1e9); self.n_done.zero_()
+
+    def struct(self):
+        s = BeamState()
+        for name, _ in BeamState._fields_:
+            setattr(s, name, getattr(self, name).data_ptr())
+        return s
+
+    def swap(self):
+        self.seqs, self.seqs_next = self.seqs_next, self.seqs
+
+
+def beam_update(bufs: BeamBuffers, cand_scores, cand_index, V, cur_len, eos_id, pad_id):
+    st = bufs.struct()
+    check(_lib.load().vidil_beam_update(C.byref(st), _ptr(cand_scores, torch.float32), _ptr(cand_index, torch.int32),
+                                        bufs.B, bufs.nb, V, cur_len, bufs.max_len, eos_id, pad_id, _stream()),
+          "beam_update")
+    bufs.swap()
+
+
+def beam_finalize(bufs: BeamBuffers, cur_len, eos_id, pad_id):
+    dev = bufs.seqs.device
+    out_tok = torch.empty((bufs.B, bufs.max_len), dtype=torch.int32, device=dev)
+    out_len = torch.empty((bufs.B,), dtype=torch.int32, device=dev)
+    out_score = torch.empty((bufs.B,), dtype=torch.float32, device=dev)
+    st = bufs.struct()
+    check(_lib.load().vidil_beam_finalize(C.byref(st), bufs.B, bufs.nb, cur_len, bufs.max_len, eos_id, pad_id,
+                                          _ptr(out_tok), _ptr(out_len), _ptr(out_score), _stream()), "beam_finalize")
+    return out_tok, out_len, out_score
+
+
+def kv_reorder(src, dst, beam_idx, L, rows):
+    row_halfs = src.numel() // (L * rows)
+    check(_lib.load().vidil_kv_reorder(_ptr(src, torch.float16), _ptr(dst, torch.float16),
+                                       _ptr(beam_idx, torch.int32), L, rows, row_halfs, _stream()), "kv_reorder")
+
+
+# ------------------------------------------------------------------------- ontology scan
+def scan_topk_ws_bytes(NF, NCpad, topk):
+    return int(_lib.load().vidil_scan_topk_ws_bytes(NF, NCpad, topk))
+
+
+def scan_topk(img, txt, seg_start, seg_len, topk, workspace=None):
+    """img f32 [NF,D]; txt f32 [NCpad,D]; seg_start/seg_len: python lists per category."""
+    NF, D = img.shape
+    ncat = len(seg_start)
+    dev = img.device
+    need = scan_topk_ws_bytes(NF, txt.shape[0], topk)
+    if workspace is None or workspace.numel() < need:
+        workspace = torch.empty((need,), dtype=torch.uint8, device=dev)
+    out_i = torch.empty((NF, ncat, topk), dtype=torch.int32, device=dev)
+    out_s = torch.empty((NF, ncat, topk), dtype=torch.float32, device=dev)
+    ss = (C.c_int32 * ncat)(*seg_start)
+    sl = (C.c_int32 * ncat)(*seg_len)
+    check(_lib.load().vidil_scan_topk(_ptr(img, torch.float32, "scan.img"), _ptr(txt, torch.float32, "scan.txt"), NF, D,
+                                      ncat, ss, sl, topk, _ptr(workspace), _ptr(out_i), _ptr(out_s), _stream()),
+          "scan_topk")
+    return out_i, out_s
