@@ -54,10 +54,11 @@ enum {
 enum { VIDIL_ACT_NONE = 0, VIDIL_ACT_GELU_ERF = 1, VIDIL_ACT_QUICK_GELU = 2 };
 
 typedef struct vidil_gemm_args {
-  const void* A;      /* f16 [M,K]                                             */
+  const void* A;      /* f16 [M,K], row stride lda                             */
   const void* W;      /* f16 [N,K]                                             */
   const float* bias;  /* f32 [N] or NULL                                       */
   int32_t M, N, K;
+  int32_t lda;        /* A row stride in elements; 0 = K; multiple of 8        */
   int32_t epi;        /* VIDIL_EPI_*                                           */
   int32_t act;        /* VIDIL_ACT_* (EPI_F16 / EPI_F32 only)                  */
   void* out;          /* EPI_F16: f16, EPI_F32/PATCH: f32, row stride ldo      */
@@ -97,7 +98,8 @@ int vidil_layernorm(const float* x, int64_t x_stride, const float* gamma,
 /* ------------------------------------------------------------------------ */
 /* Attention for short sequences (Nk <= 288): softmax(Q K^T [+mask]) V.       */
 /* Q  f16 [Bq][H][Tq_cap][64] (already scaled by 1/sqrt(64)),                 */
-/* K  f16 [Bk][H][Tk_cap][64], VT f16 [Bk][H][64][NP]; Bk = Bq / kv_group.    */
+/* K  f16 [Bk][H][Tk_cap][64], VT f16 [Bk][H][64][NP]; query batch b reads     */
+/* key/value batch kv_index[b] (or b / kv_group when kv_index == NULL).       */
 /* Keys >= kv_len[b] (or >= Nk when kv_len==NULL) are excluded; causal!=0     */
 /* additionally excludes key > q + causal_off.                                */
 /* out f16 row (b*Nq + q), column h*64+d, row stride ldo.                     */
@@ -105,7 +107,8 @@ int vidil_layernorm(const float* x, int64_t x_stride, const float* gamma,
 /* HF CLIPAttention.                                                          */
 /* ------------------------------------------------------------------------ */
 int vidil_attention(const void* q, const void* k, const void* vt, void* out,
-                    const int32_t* kv_len, int32_t Bq, int32_t H, int32_t Nq,
+                    const int32_t* kv_len, const int32_t* kv_index, int32_t Bq,
+                    int32_t H, int32_t Nq,
                     int32_t Nk, int32_t Tq_cap, int32_t Tk_cap, int32_t NP,
                     int32_t kv_group, int32_t causal, int32_t causal_off,
                     int32_t ldo, void* stream);

@@ -1,0 +1,145 @@
+"""oracle/beam_ref.py — TEST INFRASTRUCTURE.  Restatement of the beam search the
+reference gets from HuggingFace ``transformers`` (call site models/blip.py:154-161:
+``text_decoder.generate(num_beams=3, max_length=20, min_length=5, eos=[SEP],
+pad=[PAD], repetition_penalty=1.0)``).
+
+PARITY UNPINNED against executable reference code: the algorithm lives in the
+third-party ``transformers`` (unpinned in docker/requirements.txt:9;
+models/med.py:7-8 names v4.15.0), which is absent from /root/reference and not
+installable here; the installed 5.15 normalises hypothesis scores by generated
+length instead (a different ranking rule).  This file restates the published
+v4.15.0 algorithm — ``generation_utils.GenerationMixin.beam_search``,
+``generation_beam_search.BeamSearchScorer/BeamHypotheses`` and
+``generation_logits_process.MinLengthLogitsProcessor`` — with
+length_penalty=1.0, early_stopping=False, num_beam_groups=1,
+num_return_sequences=1.  It is pinned by the known-answer tests in
+tests/test_beam_ref.py.
+"""
+from __future__ import annotations
+
+import numpy as np
+import torch
+
+
+class BeamHypotheses:
+    """transformers 4.15 generation_beam_search.BeamHypotheses."""
+
+    def __init__(self, num_beams, length_penalty=1.0, early_stopping=False):
+        self.num_beams = num_beams
+        self.length_penalty = length_penalty
+        self.early_stopping = early_stopping
+        self.beams = []            # list of (score, token list), insertion ordered
+        self.worst_score = 1e9
+
+    def __len__(self):
+        return len(self.beams)
+
+    def add(self, hyp, sum_logprobs):
+        score = sum_logprobs / (len(hyp) ** self.length_penalty)
+        if len(self) < self.num_beams or score > self.worst_score:
+            self.beams.append((score, list(hyp)))
+            if len(self) > self.num_beams:
+                ranked = sorted((s, idx) for idx, (s, _) in enumerate(self.beams))
+                del self.beams[ranked[0][1]]
+                self.worst_score = ranked[1][0]
+            else:
+                self.worst_score = min(score, self.worst_score)
+
+    def is_done(self, best_sum_logprobs, cur_len):
+        if len(self) < self.num_beams:
+            return False
+        if self.early_stopping:
+            return True
+        return self.worst_score >= best_sum_logprobs / cur_len ** self.length_penalty
+
+
+def log_softmax_rows(logits):
+    """f32 log-softmax as torch computes it (x - max - log(sum(exp(x - max))))."""
+    return torch.log_softmax(torch.as_tensor(logits, dtype=torch.float32), dim=-1).numpy()
+
+
+def beam_search(step_fn, prompt_ids, *, num_beams=3, max_length=20, min_length=5, eos_token_id=102,
+                pad_token_id=0, trace=None):
+    """Run beam search.
+
+    step_fn(input_ids[np.int64, rows x cur_len], beam_idx or None) -> logits[rows, V] (f32) for
+    the LAST position.  ``beam_idx`` (np.int64[rows]) is the row gather applied to
+    the sequences since the previous call (the caller reorders its KV cache with
+    it, models/med.py:951-955); None on the first call.
+
+    Returns (sequences: list of np.int64 arrays incl. prompt and a trailing EOS
+    when shorter than max_length, scores: list of float).
+    """
+    prompt_ids = np.asarray(prompt_ids, dtype=np.int64)
+    B = prompt_ids.shape[0]
+    nb = num_beams
+    input_ids = np.repeat(prompt_ids, nb, axis=0)            # _expand_inputs_for_generation
+    beam_scores = np.zeros((B, nb), dtype=np.float32)
+    beam_scores[:, 1:] = -1e9
+    beam_scores = beam_scores.reshape(-1)
+    hyps = [BeamHypotheses(nb) for _ in range(B)]
+    done = [False] * B
+    beam_idx = None
+    cur_len = input_ids.shape[1]
+    while True:
+        logits = np.asarray(step_fn(input_ids, beam_idx), dtype=np.float32)
+        V = logits.shape[-1]
+        scores = log_softmax_rows(logits)
+        if cur_len < min_length:                               # MinLengthLogitsProcessor
+            scores[:, eos_token_id] = -np.inf
+        scores = scores + beam_scores[:, None]
+        flat = torch.from_numpy(scores.reshape(B, nb * V))
+        top_s, top_i = torch.topk(flat, 2 * nb, dim=1, largest=True, sorted=True)
+        top_s, top_i = top_s.numpy(), top_i.numpy()
+        if trace is not None:
+            trace.append(dict(cur_len=cur_len, logits=logits.copy(), cand_scores=top_s.copy(), cand_index=top_i.copy()))
+        next_indices = top_i // V
+        next_tokens = top_i % V
+        # ---- BeamSearchScorer.process
+        nbs = np.zeros((B, nb), dtype=np.float32)
+        nbt = np.zeros((B, nb), dtype=np.int64)
+        nbi = np.zeros((B, nb), dtype=np.int64)
+        for b in range(B):
+            if done[b]:
+                nbs[b, :] = 0
+                nbt[b, :] = pad_token_id
+                nbi[b, :] = 0
+                continue
+            slot = 0
+            for rank in range(2 * nb):
+                tok, sc, idx = int(next_tokens[b, rank]), float(top_s[b, rank]), int(next_indices[b, rank])
+                row = b * nb + idx
+                if tok == eos_token_id:
+                    if rank >= nb:
+                        continue
+                    hyps[b].add(input_ids[row].tolist(), sc)
+                else:
+                    nbs[b, slot], nbt[b, slot], nbi[b, slot] = sc, tok, row
+                    slot += 1
+                if slot == nb:
+                    break
+            assert slot == nb
+            done[b] = done[b] or hyps[b].is_done(float(top_s[b].max()), cur_len)
+        beam_scores = nbs.reshape(-1)
+        beam_idx = nbi.reshape(-1)
+        input_ids = np.concatenate([input_ids[beam_idx], nbt.reshape(-1, 1)], axis=1)
+        cur_len += 1
+        if all(done) or input_ids.shape[1] >= max_length:
+            break
+    # ---- BeamSearchScorer.finalize
+    for b in range(B):
+        if done[b]:
+            continue
+        for j in range(nb):
+            row = b * nb + j
+            hyps[b].add(input_ids[row].tolist(), float(beam_scores[row]))
+    seqs, best_scores = [], []
+    for b in range(B):
+        ranked = sorted(hyps[b].beams, key=lambda x: x[0])
+        s, toks = ranked.pop()
+        toks = list(toks)
+        if len(toks) < max_length:
+            toks.append(eos_token_id)
+        seqs.append(np.asarray(toks, dtype=np.int64))
+        best_scores.append(s)
+    return seqs, best_scores

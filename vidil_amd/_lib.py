@@ -21,7 +21,7 @@ class GemmArgs(C.Structure):
 
     _fields_ = [
         ("A", C.c_void_p), ("W", C.c_void_p), ("bias", C.c_void_p),
-        ("M", C.c_int32), ("N", C.c_int32), ("K", C.c_int32),
+        ("M", C.c_int32), ("N", C.c_int32), ("K", C.c_int32), ("lda", C.c_int32),
         ("epi", C.c_int32), ("act", C.c_int32),
         ("out", C.c_void_p), ("ldo", C.c_int32),
         ("resid", C.c_void_p),
@@ -50,7 +50,7 @@ SIGNATURES = {
     "vidil_num_entry_points": (_i32, []),
     "vidil_gemm_f16": (_i32, [C.POINTER(GemmArgs), _p]),
     "vidil_layernorm": (_i32, [_p, _i64, _p, _p, _f32, _i32, _i32, _p, _p, _p]),
-    "vidil_attention": (_i32, [_p, _p, _p, _p, _p] + [_i32] * 11 + [_p]),
+    "vidil_attention": (_i32, [_p, _p, _p, _p, _p, _p] + [_i32] * 11 + [_p]),
     "vidil_patchify_f32": (_i32, [_p, _p, _i32, _i32, _i32, _p]),
     "vidil_patchify_u8": (_i32, [_p, _p, _i32, _i32, _i32, C.POINTER(_f32), C.POINTER(_f32), _p]),
     "vidil_set_cls_row": (_i32, [_p, _p, _p, _i32, _i32, _i32, _p]),

@@ -1,0 +1,94 @@
+"""BLIP image-text-matching filter on the HIP kernels — drop-in for the reference's
+``models/blip_itm.py`` on the hot path (``blip_itm(...)``, ``BLIP_ITM.forward(image,
+caption, match_head='itm') -> [F,2]`` raw logits).
+
+``itm_pairs`` is the de-duplicated schedule CapFilt uses: the filter ViT and the
+per-layer cross-attention K/V run ONCE per frame, and every (frame, caption) pair of
+a batch of videos goes through the text encoder in one pass — the reference instead
+re-runs the whole ViT once per caption (run_video_CapFilt.py:110-112 ->
+models/blip_itm.py:43).
+"""
+from __future__ import annotations
+
+import torch
+import torch.nn as nn
+
+from . import kernels as K
+from .blip import create_vit, load_checkpoint, resolve_med_config
+from .med import BertConfig, BertModel
+from .packing import PackedCache, require_cuda, v32, w16
+from .tokenizer import init_tokenizer
+
+ITM_MAX_LENGTH = 35  # models/blip_itm.py:46
+
+
+class BLIP_ITM(PackedCache, nn.Module):
+    def __init__(self, med_config="configs/med_config.json", image_size=384, vit="base", vit_grad_ckpt=False,
+                 vit_ckpt_layer=0, embed_dim=256, tokenizer=None):
+        super().__init__()
+        self.visual_encoder, vision_width = create_vit(vit, image_size, vit_grad_ckpt, vit_ckpt_layer)
+        self.tokenizer = tokenizer if tokenizer is not None else init_tokenizer()
+        cfg = BertConfig.from_json_file(resolve_med_config(med_config))
+        cfg.encoder_width = vision_width
+        self.text_encoder = BertModel(config=cfg, add_pooling_layer=False)
+        text_width = cfg.hidden_size
+        self.vision_proj = nn.Linear(vision_width, embed_dim)   # 'itc' head: kept for checkpoint keys only
+        self.text_proj = nn.Linear(text_width, embed_dim)
+        self.itm_head = nn.Linear(text_width, 2)
+
+    def _pack(self):
+        return dict(itm_w=w16(self.itm_head.weight), itm_b=v32(self.itm_head.bias))
+
+    def parameters_for_fingerprint(self):
+        return [self.itm_head.weight, self.itm_head.bias]
+
+    # ------------------------------------------------------------------ tokenisation
+    def tokenize(self, captions):
+        """models/blip_itm.py:46-47: padding='max_length', truncation, max_length=35; first id stays [CLS]."""
+        enc = self.tokenizer(captions, padding="max_length", truncation=True, max_length=ITM_MAX_LENGTH,
+                             return_tensors="pt")
+        ids = enc.input_ids.to(torch.int32)
+        lens = enc.attention_mask.sum(dim=1).to(torch.int32)
+        return ids, lens
+
+    # ------------------------------------------------------------------ de-duplicated schedule
+    @torch.no_grad()
+    def itm_pairs(self, enc16, n_images, ids, lens, image_index):
+        """enc16 f16 [n_images*Te, width]; ids i32 [P,35]; lens i32 [P]; image_index i32 [P].
+        Returns f32 [P,2] raw ITM logits."""
+        require_cuda(enc16, "BLIP_ITM")
+        te = self.text_encoder
+        dev = enc16.device
+        Te = enc16.shape[0] // n_images
+        cross = te.project_cross_kv(enc16, n_images, Te)
+        ids = ids.to(dev).contiguous()
+        lens = lens.to(dev).contiguous()
+        image_index = image_index.to(dev).to(torch.int32).contiguous()
+        P, T = ids.shape
+        C = te.config.hidden_size
+        _, h16 = te.encode(ids, lens, cross, image_index)
+        # itm_head on token 0 of every pair: the GEMM reads rows p*T of h16 (strided A operand)
+        p = self.packed()
+        out = torch.empty((P, 2), dtype=torch.float32, device=dev)
+        K.gemm(h16.view(-1), p["itm_w"], p["itm_b"], out=out, M=P, lda=T * C)
+        return out
+
+    @torch.no_grad()
+    def forward(self, image, caption, match_head="itm"):
+        """Reference call shape (models/blip_itm.py:41-58): F images, F captions -> [F,2]."""
+        if match_head != "itm":
+            raise NotImplementedError("match_head='itc' is not on the hot path")
+        require_cuda(image, "BLIP_ITM.forward")
+        F = image.shape[0]
+        _, y16 = self.visual_encoder.forward_both(image)
+        ids, lens = self.tokenize(list(caption))
+        return self.itm_pairs(y16, F, ids, lens, torch.arange(F, dtype=torch.int32))
+
+
+def blip_itm(pretrained="", **kwargs):
+    """Reference: models/blip_itm.py:70-75."""
+    model = BLIP_ITM(**kwargs)
+    if pretrained:
+        model, msg = load_checkpoint(model, pretrained)
+        assert len(msg.missing_keys) == 0
+    return model

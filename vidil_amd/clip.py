@@ -1,0 +1,284 @@
+"""CLIP towers on the HIP kernels — stand-in for the HuggingFace ``CLIPModel`` /
+``CLIPProcessor`` objects the reference drives in run_visual_tokenization.py
+(:83-96 text embeddings, :135-143 image embeddings, :347-350 construction).
+
+Same parameter names as HF's ``CLIPModel.state_dict()`` (so ``openai/clip-vit-*``
+weights load with ``load_state_dict``), same outputs (``.image_embeds`` /
+``.text_embeds``, unit-norm), plus ``encode_image`` / ``encode_text``.  Unlike the
+reference's call pattern, ``model(**inputs)`` runs only the tower whose inputs are
+given (the reference feeds a dummy image to text batches and 'hello world' to image
+batches, run_visual_tokenization.py:90-91,138-141).
+"""
+from __future__ import annotations
+
+from types import SimpleNamespace
+
+import torch
+import torch.nn as nn
+
+from . import kernels as K
+from .packing import PackedCache, require_cuda, v32, w16
+
+CLIP_MEAN = (0.48145466, 0.4578275, 0.40821073)
+CLIP_STD = (0.26862954, 0.26130258, 0.27577711)
+
+
+class CLIPVisionConfig:
+    def __init__(self, hidden_size=768, intermediate_size=3072, num_hidden_layers=12, num_attention_heads=12,
+                 image_size=224, patch_size=32, layer_norm_eps=1e-5, **_):
+        self.__dict__.update(locals()); self.__dict__.pop("self"); self.__dict__.pop("_", None)
+
+
+class CLIPTextConfig:
+    def __init__(self, vocab_size=49408, hidden_size=512, intermediate_size=2048, num_hidden_layers=12,
+                 num_attention_heads=8, max_position_embeddings=77, layer_norm_eps=1e-5, eos_token_id=49407,
+                 bos_token_id=49406, pad_token_id=1, **_):
+        self.__dict__.update(locals()); self.__dict__.pop("self"); self.__dict__.pop("_", None)
+
+
+class CLIPConfig:
+    """Defaults = openai/clip-vit-base-patch32; ``CLIPConfig.vit_l14()`` = the reference YAMLs' default model."""
+
+    def __init__(self, vision=None, text=None, projection_dim=512):
+        self.vision_config = vision or CLIPVisionConfig()
+        self.text_config = text or CLIPTextConfig()
+        self.projection_dim = projection_dim
+
+    @classmethod
+    def vit_l14(cls):
+        return cls(CLIPVisionConfig(hidden_size=1024, intermediate_size=4096, num_hidden_layers=24,
+                                    num_attention_heads=16, patch_size=14),
+                   CLIPTextConfig(hidden_size=768, intermediate_size=3072, num_attention_heads=12), 768)
+
+
+# ---- parameter holders with HF's names --------------------------------------------------
+class _Attn(nn.Module):
+    def __init__(self, d):
+        super().__init__()
+        self.k_proj = nn.Linear(d, d)
+        self.v_proj = nn.Linear(d, d)
+        self.q_proj = nn.Linear(d, d)
+        self.out_proj = nn.Linear(d, d)
+
+
+class _MLP(nn.Module):
+    def __init__(self, d, inter):
+        super().__init__()
+        self.fc1 = nn.Linear(d, inter)
+        self.fc2 = nn.Linear(inter, d)
+
+
+class _Layer(nn.Module):
+    def __init__(self, d, inter, eps):
+        super().__init__()
+        self.self_attn = _Attn(d)
+        self.layer_norm1 = nn.LayerNorm(d, eps=eps)
+        self.mlp = _MLP(d, inter)
+        self.layer_norm2 = nn.LayerNorm(d, eps=eps)
+
+
+class _Encoder(nn.Module):
+    def __init__(self, cfg):
+        super().__init__()
+        self.layers = nn.ModuleList([_Layer(cfg.hidden_size, cfg.intermediate_size, cfg.layer_norm_eps)
+                                     for _ in range(cfg.num_hidden_layers)])
+
+
+class _VisionEmbeddings(nn.Module):
+    def __init__(self, cfg):
+        super().__init__()
+        self.class_embedding = nn.Parameter(torch.randn(cfg.hidden_size))
+        self.patch_embedding = nn.Conv2d(3, cfg.hidden_size, kernel_size=cfg.patch_size, stride=cfg.patch_size, bias=False)
+        n = (cfg.image_size // cfg.patch_size) ** 2 + 1
+        self.position_embedding = nn.Embedding(n, cfg.hidden_size)
+
+
+class _VisionModel(nn.Module):
+    def __init__(self, cfg):
+        super().__init__()
+        self.embeddings = _VisionEmbeddings(cfg)
+        self.pre_layrnorm = nn.LayerNorm(cfg.hidden_size, eps=cfg.layer_norm_eps)   # (sic) HF's spelling
+        self.encoder = _Encoder(cfg)
+        self.post_layernorm = nn.LayerNorm(cfg.hidden_size, eps=cfg.layer_norm_eps)
+
+
+class _TextEmbeddings(nn.Module):
+    def __init__(self, cfg):
+        super().__init__()
+        self.token_embedding = nn.Embedding(cfg.vocab_size, cfg.hidden_size)
+        self.position_embedding = nn.Embedding(cfg.max_position_embeddings, cfg.hidden_size)
+
+
+class _TextModel(nn.Module):
+    def __init__(self, cfg):
+        super().__init__()
+        self.embeddings = _TextEmbeddings(cfg)
+        self.encoder = _Encoder(cfg)
+        self.final_layer_norm = nn.LayerNorm(cfg.hidden_size, eps=cfg.layer_norm_eps)
+
+
+def _pack_layers(encoder):
+    out = []
+    for l in encoder.layers:
+        a = l.self_attn
+        out.append(dict(
+            n1g=v32(l.layer_norm1.weight), n1b=v32(l.layer_norm1.bias),
+            qkv_w=w16(a.q_proj.weight, a.k_proj.weight, a.v_proj.weight),
+            qkv_b=v32(a.q_proj.bias, a.k_proj.bias, a.v_proj.bias),
+            o_w=w16(a.out_proj.weight), o_b=v32(a.out_proj.bias),
+            n2g=v32(l.layer_norm2.weight), n2b=v32(l.layer_norm2.bias),
+            fc1_w=w16(l.mlp.fc1.weight), fc1_b=v32(l.mlp.fc1.bias),
+            fc2_w=w16(l.mlp.fc2.weight), fc2_b=v32(l.mlp.fc2.bias)))
+    return out
+
+
+def _run_layers(layers, x, B, T, H, eps, *, causal=False, kv_len=None):
+    """Pre-LN CLIP encoder layers on the f32 residual stream x [B*T, D] (in place)."""
+    dev = x.device
+    M, D = x.shape
+    NP = (T + 7) // 8 * 8
+    xn = torch.empty((M, D), dtype=torch.float16, device=dev)
+    q = torch.empty((B, H, T, 64), dtype=torch.float16, device=dev)
+    k = torch.empty((B, H, T, 64), dtype=torch.float16, device=dev)
+    vt = torch.empty((B, H, 64, NP), dtype=torch.float16, device=dev)
+    o = torch.empty((M, D), dtype=torch.float16, device=dev)
+    hid = torch.empty((M, layers[0]["fc1_w"].shape[0]), dtype=torch.float16, device=dev)
+    heads = dict(q=q, k=k, vt=vt, T=T, H=H, part0=0, t_off=0, Tq_cap=T, Tk_cap=T, NP=NP, q_scale=0.125)
+    for l in layers:
+        K.layernorm(x, l["n1g"], l["n1b"], eps, out16=xn)
+        K.gemm(xn, l["qkv_w"], l["qkv_b"], heads=heads)
+        K.attention(q, k, vt, o, Bq=B, H=H, Nq=T, Nk=T, Tq_cap=T, Tk_cap=T, NP=NP, causal=causal, kv_len=kv_len)
+        K.gemm(o, l["o_w"], l["o_b"], out=x, resid=x)
+        K.layernorm(x, l["n2g"], l["n2b"], eps, out16=xn)
+        K.gemm(xn, l["fc1_w"], l["fc1_b"], out=hid, act=K.ACT_QUICK_GELU)
+        K.gemm(hid, l["fc2_w"], l["fc2_b"], out=x, resid=x)
+    return x
+
+
+class CLIPModel(PackedCache, nn.Module):
+    def __init__(self, config: CLIPConfig = None):
+        super().__init__()
+        self.config = config or CLIPConfig()
+        vc, tc = self.config.vision_config, self.config.text_config
+        for c in (vc, tc):
+            if c.hidden_size // c.num_attention_heads != 64:
+                raise ValueError("vidil_amd CLIP kernels are built for head_dim 64")
+        self.text_model = _TextModel(tc)
+        self.vision_model = _VisionModel(vc)
+        self.visual_projection = nn.Linear(vc.hidden_size, self.config.projection_dim, bias=False)
+        self.text_projection = nn.Linear(tc.hidden_size, self.config.projection_dim, bias=False)
+        self.logit_scale = nn.Parameter(torch.tensor(2.6592))
+        self.apply(self._init)
+
+    @staticmethod
+    def _init(m):
+        if isinstance(m, (nn.Linear, nn.Embedding)):
+            nn.init.normal_(m.weight, std=0.02)
+            if isinstance(m, nn.Linear) and m.bias is not None:
+                nn.init.zeros_(m.bias)
+
+    def _pack(self):
+        vm, tm = self.vision_model, self.text_model
+        D = self.config.vision_config.hidden_size
+        return dict(
+            pe_w=w16(vm.embeddings.patch_embedding.weight.reshape(D, -1)),
+            cls=v32(vm.embeddings.class_embedding), pos=v32(vm.embeddings.position_embedding.weight).view(-1, D),
+            pre_g=v32(vm.pre_layrnorm.weight), pre_b=v32(vm.pre_layrnorm.bias),
+            post_g=v32(vm.post_layernorm.weight), post_b=v32(vm.post_layernorm.bias),
+            vproj=w16(self.visual_projection.weight), vlayers=_pack_layers(vm.encoder),
+            tok=v32(tm.embeddings.token_embedding.weight).view(self.config.text_config.vocab_size, -1),
+            tpos=v32(tm.embeddings.position_embedding.weight).view(self.config.text_config.max_position_embeddings, -1),
+            fin_g=v32(tm.final_layer_norm.weight), fin_b=v32(tm.final_layer_norm.bias),
+            tproj=w16(self.text_projection.weight), tlayers=_pack_layers(tm.encoder))
+
+    # ------------------------------------------------------------------ vision tower
+    def _vision_from_patches(self, patches16, B):
+        p = self.packed()
+        vc = self.config.vision_config
+        D, H = vc.hidden_size, vc.num_attention_heads
+        P = (vc.image_size // vc.patch_size) ** 2
+        T = P + 1
+        dev = patches16.device
+        x = torch.empty((B * T, D), dtype=torch.float32, device=dev)
+        K.gemm(patches16, p["pe_w"], None, patch=dict(out=x, pos=p["pos"], tpi=P))
+        K.set_cls_row(x, p["cls"], p["pos"], B, T, D)
+        K.layernorm(x, p["pre_g"], p["pre_b"], vc.layer_norm_eps, out32=x)
+        _run_layers(p["vlayers"], x, B, T, H, vc.layer_norm_eps)
+        pooled16 = torch.empty((B, D), dtype=torch.float16, device=dev)
+        K.layernorm(x, p["post_g"], p["post_b"], vc.layer_norm_eps, M=B, D=D, x_stride=T * D, out16=pooled16)
+        emb = K.gemm(pooled16, p["vproj"], None, out_dtype=torch.float32)
+        return K.l2_normalize_rows(emb)
+
+    @torch.no_grad()
+    def encode_image(self, pixel_values):
+        """pixel_values f32 [F,3,S,S] (already normalised) -> unit-norm f32 [F,P]."""
+        require_cuda(pixel_values, "CLIPModel.encode_image")
+        ps = self.config.vision_config.patch_size
+        patches = K.patchify_f32(pixel_values.contiguous().float(), ps)
+        return self._vision_from_patches(patches, pixel_values.shape[0])
+
+    @torch.no_grad()
+    def encode_image_u8(self, frames_u8):
+        """uint8 [F,S,S,3] frames already at the model resolution; fused /255 + CLIP normalisation."""
+        require_cuda(frames_u8, "CLIPModel.encode_image_u8")
+        ps = self.config.vision_config.patch_size
+        patches = K.patchify_u8(frames_u8.contiguous(), ps, CLIP_MEAN, CLIP_STD)
+        return self._vision_from_patches(patches, frames_u8.shape[0])
+
+    # ------------------------------------------------------------------ text tower
+    @torch.no_grad()
+    def encode_text(self, input_ids, attention_mask=None):
+        """ids [N,L] (int) -> unit-norm f32 [N,P]; pooled at the first EOS (HF >= 4.31 rule; argmax rule when
+        eos_token_id == 2).  Right padding is harmless under the causal mask, as in HF."""
+        require_cuda(input_ids, "CLIPModel.encode_text")
+        p = self.packed()
+        tc = self.config.text_config
+        D, H = tc.hidden_size, tc.num_attention_heads
+        N, L = input_ids.shape
+        dev = input_ids.device
+        ids32 = input_ids.to(torch.int32).contiguous()
+        x = torch.empty((N * L, D), dtype=torch.float32, device=dev)
+        K.embed_tokens(ids32.view(-1), p["tok"], p["tpos"], x, T=L, pos_off=0)
+        kv_len = None
+        if attention_mask is not None:
+            kv_len = attention_mask.to(dev).sum(dim=1).to(torch.int32).contiguous()
+        _run_layers(p["tlayers"], x, N, L, H, tc.layer_norm_eps, causal=True, kv_len=kv_len)
+        if tc.eos_token_id == 2:
+            pos = ids32.argmax(dim=-1)
+        else:
+            pos = (ids32 == tc.eos_token_id).to(torch.int32).argmax(dim=-1)
+        rows = (torch.arange(N, device=dev) * L + pos).to(torch.int32)
+        sel = K.gather_rows(x, rows)
+        pooled16 = torch.empty((N, D), dtype=torch.float16, device=dev)
+        K.layernorm(sel, p["fin_g"], p["fin_b"], tc.layer_norm_eps, out16=pooled16)
+        emb = K.gemm(pooled16, p["tproj"], None, out_dtype=torch.float32)
+        return K.l2_normalize_rows(emb)
+
+    def forward(self, input_ids=None, pixel_values=None, attention_mask=None, **_):
+        out = SimpleNamespace(image_embeds=None, text_embeds=None)
+        if pixel_values is not None:
+            out.image_embeds = self.encode_image(pixel_values)
+        if input_ids is not None:
+            out.text_embeds = self.encode_text(input_ids, attention_mask)
+        return out
+
+
+class CLIPFrameProcessor:
+    """The image half of HF ``CLIPProcessor`` for frames that are already S x S uint8 (the BASELINE
+    workload): resize / centre-crop are the identity, leaving x/255 and (x-mean)/std, which the
+    ``patchify_u8`` kernel fuses.  Non-S x S input is the 'next' row (GPU bicubic resize)."""
+
+    def __init__(self, size=224):
+        self.size = size
+
+    def __call__(self, images=None, text=None, return_tensors="pt", **_):
+        import numpy as np
+
+        frames = images if isinstance(images, (list, tuple)) else [images]
+        arr = np.stack([np.asarray(f) for f in frames])
+        if arr.shape[1] != self.size or arr.shape[2] != self.size:
+            raise NotImplementedError(f"CLIPFrameProcessor: frames must be {self.size}x{self.size} (got {arr.shape})")
+        x = torch.from_numpy(arr).permute(0, 3, 1, 2).to(torch.float32) / 255.0
+        mean = torch.tensor(CLIP_MEAN).view(1, 3, 1, 1)
+        std = torch.tensor(CLIP_STD).view(1, 3, 1, 1)
+        return {"pixel_values": (x - mean) / std}

@@ -25,6 +25,7 @@ struct AttnP {
   const f16* vt;
   f16* out;
   const int32_t* kv_len;
+  const int32_t* kv_index;
   int Bq, H, Nq, Nk, Tq_cap, Tk_cap, NP, kv_group, causal, causal_off, ldo;
 };
 
@@ -43,7 +44,7 @@ __global__ __launch_bounds__(256) void attn_kernel(const AttnP p) {
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int hi = lane >> 5, l31 = lane & 31;
   const int h = blockIdx.y, bq = blockIdx.z;
-  const int bk = bq / p.kv_group;
+  const int bk = p.kv_index != nullptr ? p.kv_index[bq] : bq / p.kv_group;
   int kvlen = p.Nk;
   if (p.kv_len != nullptr) {
     const int v = p.kv_len[bq];
@@ -205,18 +206,18 @@ int launch(const AttnP& p, hipStream_t s) {
 }  // namespace
 
 extern "C" int vidil_attention(const void* q, const void* k, const void* vt, void* out,
-                               const int32_t* kv_len, int32_t Bq, int32_t H, int32_t Nq,
+                               const int32_t* kv_len, const int32_t* kv_index, int32_t Bq, int32_t H, int32_t Nq,
                                int32_t Nk, int32_t Tq_cap, int32_t Tk_cap, int32_t NP,
                                int32_t kv_group, int32_t causal, int32_t causal_off,
                                int32_t ldo, void* stream) {
   VIDIL_REQUIRE(q && k && vt && out, "attention: null pointer");
   VIDIL_REQUIRE(Bq > 0 && H > 0 && Nq > 0 && Nk > 0, "attention: bad shape Bq=%d H=%d Nq=%d Nk=%d", Bq, H, Nq, Nk);
-  VIDIL_REQUIRE(kv_group > 0 && Bq % kv_group == 0, "attention: Bq=%d not a multiple of kv_group=%d", Bq, kv_group);
+  VIDIL_REQUIRE(kv_group > 0 && (kv_index != nullptr || Bq % kv_group == 0), "attention: Bq=%d not a multiple of kv_group=%d", Bq, kv_group);
   VIDIL_REQUIRE(Tq_cap >= Nq && Tk_cap >= Nk && NP >= Nk, "attention: capacities too small");
   VIDIL_REQUIRE(NP % 8 == 0, "attention: NP=%d must be a multiple of 8", NP);
   VIDIL_REQUIRE(ldo >= H * 64, "attention: ldo=%d < H*64", ldo);
   VIDIL_REQUIRE(H <= 65535 && Bq <= 65535 * 1, "attention: grid too large (H=%d Bq=%d)", H, Bq);
-  AttnP p{(const f16*)q, (const f16*)k, (const f16*)vt, (f16*)out, kv_len, Bq, H, Nq, Nk,
+  AttnP p{(const f16*)q, (const f16*)k, (const f16*)vt, (f16*)out, kv_len, kv_index, Bq, H, Nq, Nk,
           Tq_cap, Tk_cap, NP, kv_group, causal, causal_off, ldo};
   hipStream_t s = (hipStream_t)stream;
   const int nkt = (Nk + 31) / 32;

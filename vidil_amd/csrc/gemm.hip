@@ -38,6 +38,7 @@ __global__ __launch_bounds__(256) void gemm_kernel(const vidil_gemm_args p) {
   const int l31 = lane & 31;
 
   const int M = p.M, N = p.N, K = p.K;
+  const int lda = p.lda > 0 ? p.lda : K;
   const int tiles_n = (N + BN - 1) / BN;
   const int tiles_m = (M + BM - 1) / BM;
   // XCD-aware bijective remap of the block index (8 XCDs, block b -> XCD b%8).
@@ -65,7 +66,7 @@ __global__ __launch_bounds__(256) void gemm_kernel(const vidil_gemm_args p) {
     const int c = s ^ ((r >> 1) & 7);
     int row = m0 + r;
     row = row < M ? row : M - 1;
-    ga[i] = A + (size_t)row * K + c * 8;
+    ga[i] = A + (size_t)row * lda + c * 8;
   }
 #pragma unroll
   for (int i = 0; i < LB; ++i) {
@@ -239,6 +240,7 @@ extern "C" int vidil_gemm_f16(const vidil_gemm_args* args, void* stream) {
   VIDIL_REQUIRE(a.A && a.W, "gemm: null operand");
   VIDIL_REQUIRE(a.M > 0 && a.N > 0 && a.K > 0, "gemm: bad shape M=%d N=%d K=%d", a.M, a.N, a.K);
   VIDIL_REQUIRE(a.K % BK == 0, "gemm: K=%d must be a multiple of %d", a.K, BK);
+  VIDIL_REQUIRE(a.lda == 0 || (a.lda >= a.K && a.lda % 8 == 0), "gemm: lda=%d must be 0 or >= K and a multiple of 8", a.lda);
   VIDIL_REQUIRE(((uintptr_t)a.A & 15) == 0 && ((uintptr_t)a.W & 15) == 0, "gemm: operands must be 16-B aligned");
   hipStream_t s = (hipStream_t)stream;
   switch (a.epi) {

@@ -40,7 +40,7 @@ def _ptr(t, dtype=None, name="tensor"):
 
 # --------------------------------------------------------------------------- GEMM
 def gemm(a, w, bias=None, *, out=None, out_dtype=torch.float16, act=ACT_NONE, resid=None,
-         heads=None, patch=None):
+         heads=None, patch=None, M=None, lda=None):
     """C = A · W^T with a fused epilogue.
 
     a [M,K] f16, w [N,K] f16, bias f32 [N] or None.
@@ -49,15 +49,21 @@ def gemm(a, w, bias=None, *, out=None, out_dtype=torch.float16, act=ACT_NONE, re
       * patch=dict(out=,pos=,tpi=): patch-embedding epilogue (row remap + pos embed).
     """
     lib = _lib.load()
-    M, K = a.shape
+    K_ = w.shape[1]
+    if lda is None:
+        M, Ka = a.shape
+        if Ka != K_:
+            raise VidilHipError(f"gemm: A is {tuple(a.shape)} but W is {tuple(w.shape)}")
+    elif M is None:
+        raise VidilHipError("gemm: strided A (lda) needs an explicit M")
+    K = K_
     N = w.shape[0]
-    if w.shape[1] != K:
-        raise VidilHipError(f"gemm: A is [{M},{K}] but W is {tuple(w.shape)}")
     g = GemmArgs()
     g.A = _ptr(a, torch.float16, "gemm.A")
     g.W = _ptr(w, torch.float16, "gemm.W")
     g.bias = _ptr(bias, torch.float32, "gemm.bias")
     g.M, g.N, g.K = M, N, K
+    g.lda = 0 if lda is None else lda
     g.act = act
     ret = None
     if heads is not None:
@@ -108,12 +114,13 @@ def layernorm(x, gamma, beta, eps, *, M=None, D=None, x_stride=None, out16=None,
 
 
 def attention(q, k, vt, out, *, Bq, H, Nq, Nk, Tq_cap, Tk_cap, NP, kv_group=1, causal=False,
-              causal_off=0, kv_len=None, ldo=None):
+              causal_off=0, kv_len=None, kv_index=None, ldo=None):
     lib = _lib.load()
     ldo = ldo if ldo is not None else H * 64
     check(lib.vidil_attention(_ptr(q, torch.float16, "attn.q"), _ptr(k, torch.float16, "attn.k"),
                               _ptr(vt, torch.float16, "attn.vt"), _ptr(out, torch.float16, "attn.out"),
-                              _ptr(kv_len, torch.int32, "attn.kv_len"), Bq, H, Nq, Nk, Tq_cap, Tk_cap, NP,
+                              _ptr(kv_len, torch.int32, "attn.kv_len"), _ptr(kv_index, torch.int32, "attn.kv_index"),
+                              Bq, H, Nq, Nk, Tq_cap, Tk_cap, NP,
                               kv_group, int(bool(causal)), causal_off, ldo, _stream()), "attention")
     return out
 

@@ -1,0 +1,320 @@
+"""MED (BERT with cross-attention) on the HIP kernels.
+
+Mirror of the parts of the reference's models/med.py that the hot path executes:
+``BertModel`` (ITM text encoder, models/blip_itm.py:31) and ``BertLMHeadModel``
+(caption decoder, models/blip.py:98).  Parameter names are the reference's, so
+BLIP checkpoints load unchanged (``bert.encoder.layer.N.crossattention.self.key.weight`` …).
+
+Schedule differences from the reference (results are the same function):
+  * cross-attention K/V are projected ONCE per image per layer
+    (``project_cross_kv``) instead of on every call for every beam
+    (models/med.py:160-163);
+  * the decoder KV cache is a preallocated [rows, H, max_len, 64] / V^T buffer the
+    GEMM epilogue appends into, instead of ``torch.cat`` per step (:164-168);
+  * q/k/v of self-attention are one fused GEMM.
+"""
+from __future__ import annotations
+
+import json
+
+import torch
+import torch.nn as nn
+
+from . import kernels as K
+from .packing import PackedCache, require_cuda, v32, w16
+
+LN_EPS_DEFAULT = 1e-12
+
+
+class BertConfig:
+    """The fields of configs/med_config.json the hot path reads."""
+
+    def __init__(self, **kw):
+        self.hidden_size = 768
+        self.num_hidden_layers = 12
+        self.num_attention_heads = 12
+        self.intermediate_size = 3072
+        self.hidden_act = "gelu"
+        self.layer_norm_eps = LN_EPS_DEFAULT
+        self.max_position_embeddings = 512
+        self.vocab_size = 30524
+        self.pad_token_id = 0
+        self.type_vocab_size = 2
+        self.initializer_range = 0.02
+        self.encoder_width = 768
+        self.add_cross_attention = True
+        self.hidden_dropout_prob = 0.1
+        self.attention_probs_dropout_prob = 0.1
+        for k, v in kw.items():
+            setattr(self, k, v)
+        if self.hidden_act != "gelu":
+            raise ValueError("only hidden_act='gelu' (erf) is implemented")
+        if self.hidden_size // self.num_attention_heads != 64:
+            raise ValueError("vidil_amd MED kernels are built for head_dim 64")
+
+    @classmethod
+    def from_json_file(cls, path):
+        with open(path) as f:
+            return cls(**json.load(f))
+
+
+# ---- parameter holders (names = reference state_dict keys) -------------------------
+class _SelfAttn(nn.Module):
+    def __init__(self, cfg, cross):
+        super().__init__()
+        kv_in = cfg.encoder_width if cross else cfg.hidden_size
+        self.query = nn.Linear(cfg.hidden_size, cfg.hidden_size)
+        self.key = nn.Linear(kv_in, cfg.hidden_size)
+        self.value = nn.Linear(kv_in, cfg.hidden_size)
+
+
+class _DenseLN(nn.Module):
+    def __init__(self, d_in, d_out, eps):
+        super().__init__()
+        self.dense = nn.Linear(d_in, d_out)
+        self.LayerNorm = nn.LayerNorm(d_out, eps=eps)
+
+
+class _Attention(nn.Module):
+    def __init__(self, cfg, cross=False):
+        super().__init__()
+        self.self = _SelfAttn(cfg, cross)
+        self.output = _DenseLN(cfg.hidden_size, cfg.hidden_size, cfg.layer_norm_eps)
+
+
+class _Intermediate(nn.Module):
+    def __init__(self, cfg):
+        super().__init__()
+        self.dense = nn.Linear(cfg.hidden_size, cfg.intermediate_size)
+
+
+class BertLayer(nn.Module):
+    def __init__(self, cfg, layer_num):
+        super().__init__()
+        self.attention = _Attention(cfg)
+        if cfg.add_cross_attention:
+            self.crossattention = _Attention(cfg, cross=True)
+        self.intermediate = _Intermediate(cfg)
+        self.output = _DenseLN(cfg.intermediate_size, cfg.hidden_size, cfg.layer_norm_eps)
+
+
+class BertEncoder(nn.Module):
+    def __init__(self, cfg):
+        super().__init__()
+        self.layer = nn.ModuleList([BertLayer(cfg, i) for i in range(cfg.num_hidden_layers)])
+
+
+class BertEmbeddings(nn.Module):
+    def __init__(self, cfg):
+        super().__init__()
+        self.word_embeddings = nn.Embedding(cfg.vocab_size, cfg.hidden_size, padding_idx=cfg.pad_token_id)
+        self.position_embeddings = nn.Embedding(cfg.max_position_embeddings, cfg.hidden_size)
+        self.LayerNorm = nn.LayerNorm(cfg.hidden_size, eps=cfg.layer_norm_eps)
+        self.register_buffer("position_ids", torch.arange(cfg.max_position_embeddings).expand((1, -1)))
+
+
+def _init_bert(module, std):
+    """models/med.py:558-568."""
+    if isinstance(module, (nn.Linear, nn.Embedding)):
+        module.weight.data.normal_(mean=0.0, std=std)
+    elif isinstance(module, nn.LayerNorm):
+        module.bias.data.zero_()
+        module.weight.data.fill_(1.0)
+    if isinstance(module, nn.Linear) and module.bias is not None:
+        module.bias.data.zero_()
+
+
+class CrossKV:
+    """Per-image cross-attention keys / values^T of every layer: K [L][B,H,Te,64], VT [L][B,H,64,NP]."""
+
+    def __init__(self, k, vt, B, Te, NP):
+        self.k, self.vt, self.B, self.Te, self.NP = k, vt, B, Te, NP
+
+
+class BertModel(PackedCache, nn.Module):
+    """ITM text encoder / decoder trunk.  ``forward`` is not the generic HF signature: the hot
+    path calls ``encode`` (ITM) or is driven by ``BertLMHeadModel``."""
+
+    def __init__(self, config, add_pooling_layer=False):
+        super().__init__()
+        if add_pooling_layer:
+            raise ValueError("the pooler is not on the hot path (reference builds add_pooling_layer=False)")
+        self.config = config
+        self.embeddings = BertEmbeddings(config)
+        self.encoder = BertEncoder(config)
+        self.apply(lambda m: _init_bert(m, config.initializer_range))
+
+    # ------------------------------------------------------------------ packing
+    def _pack(self):
+        e = self.embeddings
+        p = dict(word=v32(e.word_embeddings.weight).view(self.config.vocab_size, -1),
+                 pos=v32(e.position_embeddings.weight).view(self.config.max_position_embeddings, -1),
+                 emb_g=v32(e.LayerNorm.weight), emb_b=v32(e.LayerNorm.bias), layers=[])
+        for l in self.encoder.layer:
+            a, o = l.attention.self, l.attention.output
+            d = dict(qkv_w=w16(a.query.weight, a.key.weight, a.value.weight),
+                     qkv_b=v32(a.query.bias, a.key.bias, a.value.bias),
+                     ao_w=w16(o.dense.weight), ao_b=v32(o.dense.bias),
+                     ao_g=v32(o.LayerNorm.weight), ao_bt=v32(o.LayerNorm.bias),
+                     i_w=w16(l.intermediate.dense.weight), i_b=v32(l.intermediate.dense.bias),
+                     o_w=w16(l.output.dense.weight), o_b=v32(l.output.dense.bias),
+                     o_g=v32(l.output.LayerNorm.weight), o_bt=v32(l.output.LayerNorm.bias))
+            if hasattr(l, "crossattention"):
+                c, co = l.crossattention.self, l.crossattention.output
+                d.update(cq_w=w16(c.query.weight), cq_b=v32(c.query.bias),
+                         ckv_w=w16(c.key.weight, c.value.weight), ckv_b=v32(c.key.bias, c.value.bias),
+                         co_w=w16(co.dense.weight), co_b=v32(co.dense.bias),
+                         co_g=v32(co.LayerNorm.weight), co_bt=v32(co.LayerNorm.bias))
+            p["layers"].append(d)
+        return p
+
+    # --------------------------------------------------------- cross K/V (once per image)
+    def project_cross_kv(self, enc16, B, Te):
+        """enc16: f16 [B*Te, encoder_width] image tokens.  One fused K|V GEMM per layer."""
+        p = self.packed()
+        H = self.config.num_attention_heads
+        NP = (Te + 7) // 8 * 8
+        L = len(p["layers"])
+        dev = enc16.device
+        k = torch.empty((L, B, H, Te, 64), dtype=torch.float16, device=dev)
+        vt = torch.empty((L, B, H, 64, NP), dtype=torch.float16, device=dev)
+        for i, d in enumerate(p["layers"]):
+            K.gemm(enc16, d["ckv_w"], d["ckv_b"],
+                   heads=dict(k=k[i], vt=vt[i], T=Te, H=H, part0=1, t_off=0, Tk_cap=Te, NP=NP))
+        return CrossKV(k, vt, B, Te, NP)
+
+    # ------------------------------------------------------------------ layers
+    def run_layers(self, h32, h16, *, rows, T, self_k, self_vt, t_off, Tk_cap, NPs, causal, kv_len,
+                   cross: CrossKV, cross_index=None, cross_group=1, ws=None):
+        """Run every layer on the f32/f16 hidden pair (both [rows*T, C], updated in place).
+
+        self_k / self_vt: [L][rows,H,Tk_cap,64] / [L][rows,H,64,NPs] — this call's keys are appended at
+        ``t_off`` and attention runs over t_off+T keys (causal inside the new block when ``causal``).
+        """
+        p = self.packed()
+        cfg = self.config
+        H, C = cfg.num_attention_heads, cfg.hidden_size
+        eps = cfg.layer_norm_eps
+        M = rows * T
+        dev = h32.device
+        if ws is None:
+            ws = {}
+        q = ws.get("q")
+        if q is None or q.shape[0] < rows or q.shape[2] != T:
+            q = torch.empty((rows, H, T, 64), dtype=torch.float16, device=dev)
+            ws["q"] = q
+        o = torch.empty((M, C), dtype=torch.float16, device=dev)
+        tmp = torch.empty((M, C), dtype=torch.float32, device=dev)
+        inter = torch.empty((M, cfg.intermediate_size), dtype=torch.float16, device=dev)
+        Nk = t_off + T
+        for i, d in enumerate(p["layers"]):
+            K.gemm(h16, d["qkv_w"], d["qkv_b"],
+                   heads=dict(q=q, k=self_k[i], vt=self_vt[i], T=T, H=H, part0=0, t_off=t_off, Tq_cap=T,
+                              Tk_cap=Tk_cap, NP=NPs, q_scale=0.125))
+            K.attention(q, self_k[i], self_vt[i], o, Bq=rows, H=H, Nq=T, Nk=Nk, Tq_cap=T, Tk_cap=Tk_cap, NP=NPs,
+                        causal=causal, causal_off=t_off, kv_len=kv_len)
+            K.gemm(o, d["ao_w"], d["ao_b"], out=tmp, resid=h32)
+            K.layernorm(tmp, d["ao_g"], d["ao_bt"], eps, out16=h16, out32=h32)
+            if cross is not None:
+                K.gemm(h16, d["cq_w"], d["cq_b"], heads=dict(q=q, T=T, H=H, part0=0, Tq_cap=T, q_scale=0.125))
+                K.attention(q, cross.k[i], cross.vt[i], o, Bq=rows, H=H, Nq=T, Nk=cross.Te, Tq_cap=T,
+                            Tk_cap=cross.Te, NP=cross.NP, kv_group=cross_group, kv_index=cross_index)
+                K.gemm(o, d["co_w"], d["co_b"], out=tmp, resid=h32)
+                K.layernorm(tmp, d["co_g"], d["co_bt"], eps, out16=h16, out32=h32)
+            K.gemm(h16, d["i_w"], d["i_b"], out=inter, act=K.ACT_GELU_ERF)
+            K.gemm(inter, d["o_w"], d["o_b"], out=tmp, resid=h32)
+            K.layernorm(tmp, d["o_g"], d["o_bt"], eps, out16=h16, out32=h32)
+        return h32, h16
+
+    def embed(self, ids_i32, T, pos_off):
+        """ids int32 [rows*T] -> (h32, h16) after the embedding LayerNorm (models/med.py:71-94)."""
+        p = self.packed()
+        C = self.config.hidden_size
+        M = ids_i32.numel()
+        dev = ids_i32.device
+        raw = torch.empty((M, C), dtype=torch.float32, device=dev)
+        K.embed_tokens(ids_i32, p["word"], p["pos"], raw, T=T, pos_off=pos_off)
+        h32 = torch.empty((M, C), dtype=torch.float32, device=dev)
+        h16 = torch.empty((M, C), dtype=torch.float16, device=dev)
+        K.layernorm(raw, p["emb_g"], p["emb_b"], self.config.layer_norm_eps, out16=h16, out32=h32)
+        return h32, h16
+
+    def encode(self, ids_i32, kv_len_i32, cross: CrossKV, cross_index):
+        """ITM encoder pass (models/blip_itm.py:51-56): ids int32 [P,T] right-padded, kv_len [P] = number of
+        real tokens, pair p attends to image ``cross_index[p]``.  Returns h32 [P*T, C]."""
+        require_cuda(ids_i32, "BertModel.encode")
+        P, T = ids_i32.shape
+        H = self.config.num_attention_heads
+        L = self.config.num_hidden_layers
+        dev = ids_i32.device
+        NPs = (T + 7) // 8 * 8
+        h32, h16 = self.embed(ids_i32.reshape(-1), T, 0)
+        sk = torch.empty((1, P, H, T, 64), dtype=torch.float16, device=dev).expand(L, -1, -1, -1, -1)
+        sv = torch.empty((1, P, H, 64, NPs), dtype=torch.float16, device=dev).expand(L, -1, -1, -1, -1)
+        # (one scratch K / V^T buffer is reused by every layer: the encoder keeps no cache)
+        self.run_layers(h32, h16, rows=P, T=T, self_k=sk, self_vt=sv, t_off=0, Tk_cap=T, NPs=NPs, causal=False,
+                        kv_len=kv_len_i32, cross=cross, cross_index=cross_index)
+        return h32, h16
+
+    def forward(self, *a, **k):
+        raise NotImplementedError("use BertModel.encode / BLIP_ITM on the hot path")
+
+
+class _LMTransform(nn.Module):
+    def __init__(self, cfg):
+        super().__init__()
+        self.dense = nn.Linear(cfg.hidden_size, cfg.hidden_size)
+        self.LayerNorm = nn.LayerNorm(cfg.hidden_size, eps=cfg.layer_norm_eps)
+
+
+class _LMPredictions(nn.Module):
+    def __init__(self, cfg):
+        super().__init__()
+        self.transform = _LMTransform(cfg)
+        self.decoder = nn.Linear(cfg.hidden_size, cfg.vocab_size, bias=False)
+        self.bias = nn.Parameter(torch.zeros(cfg.vocab_size))
+        self.decoder.bias = self.bias  # same aliasing as models/med.py:527-530
+
+
+class _LMHead(nn.Module):
+    def __init__(self, cfg):
+        super().__init__()
+        self.predictions = _LMPredictions(cfg)
+
+
+class BertLMHeadModel(PackedCache, nn.Module):
+    """Caption decoder: ``bert`` trunk + ``cls`` LM head (models/med.py:811-955)."""
+
+    def __init__(self, config):
+        super().__init__()
+        self.config = config
+        self.bert = BertModel(config, add_pooling_layer=False)
+        self.cls = _LMHead(config)
+        self.cls.apply(lambda m: _init_bert(m, config.initializer_range))
+
+    def _pack(self):
+        pr = self.cls.predictions
+        return dict(t_w=w16(pr.transform.dense.weight), t_b=v32(pr.transform.dense.bias),
+                    t_g=v32(pr.transform.LayerNorm.weight), t_bt=v32(pr.transform.LayerNorm.bias),
+                    dec_w=w16(pr.decoder.weight), dec_b=v32(pr.bias))
+
+    def lm_logits(self, h16, rows, T, out=None):
+        """LM head (models/med.py:501-545) on the LAST token of each of ``rows`` sequences of length T:
+        dense -> erf-GELU -> LayerNorm -> decoder(+bias).  h16: f16 [rows*T, C].  Returns f32 [rows, V].
+        (The reference computes logits for all T positions and HF generate() keeps only the last.)"""
+        p = self.packed()
+        cfg = self.config
+        C = cfg.hidden_size
+        dev = h16.device
+        last = h16.view(-1)[(T - 1) * C:]  # row r of the strided view = token T-1 of sequence r
+        t32 = torch.empty((rows, C), dtype=torch.float32, device=dev)
+        K.gemm(last, p["t_w"], p["t_b"], out=t32, act=K.ACT_GELU_ERF, M=rows, lda=T * C)
+        t16 = torch.empty((rows, C), dtype=torch.float16, device=dev)
+        K.layernorm(t32, p["t_g"], p["t_bt"], cfg.layer_norm_eps, out16=t16)
+        if out is None:
+            out = torch.empty((rows, cfg.vocab_size), dtype=torch.float32, device=dev)
+        K.gemm(t16, p["dec_w"], p["dec_b"], out=out)
+        return out
+
+    def forward(self, *a, **k):
+        raise NotImplementedError("use vidil_amd.blip.BLIP_Decoder.generate on the hot path")

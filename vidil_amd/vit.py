@@ -1,0 +1,195 @@
+"""BLIP vision transformer on the HIP kernels.
+
+Mirror of the reference ``VisionTransformer`` (models/vit.py:113-194): same
+constructor arguments, same parameter names (so BLIP ``.pth`` checkpoints load
+unchanged: ``patch_embed.proj.weight``, ``cls_token``, ``pos_embed``,
+``blocks.N.{norm1,attn.qkv,attn.proj,norm2,mlp.fc1,mlp.fc2}``, ``norm``), same
+``forward(x[B,3,S,S]) -> [B,1+P,width]`` fp32 contract.  The arithmetic is:
+
+    patchify (f32->f16 im2col) -> GEMM(+bias+pos, row remap) -> 12 x [
+        LN -> QKV GEMM (per-head Q/K/V^T scatter, q pre-scaled) -> in-register
+        softmax attention -> proj GEMM (+residual, in place) -> LN ->
+        fc1 GEMM (+erf-GELU) -> fc2 GEMM (+residual) ] -> LN
+
+with the residual stream, LayerNorm statistics and softmax in f32 and the MFMA
+operands in f16.
+"""
+from __future__ import annotations
+
+import math
+from functools import partial
+
+import torch
+import torch.nn as nn
+
+from . import kernels as K
+from .packing import PackedCache, require_cuda, v32, w16
+
+
+class PatchEmbed(nn.Module):
+    """Parameter holder matching timm's PatchEmbed (``proj`` = Conv2d k=s=patch)."""
+
+    def __init__(self, img_size=224, patch_size=16, in_chans=3, embed_dim=768):
+        super().__init__()
+        self.img_size = (img_size, img_size)
+        self.patch_size = (patch_size, patch_size)
+        self.grid_size = (img_size // patch_size, img_size // patch_size)
+        self.num_patches = self.grid_size[0] * self.grid_size[1]
+        self.proj = nn.Conv2d(in_chans, embed_dim, kernel_size=patch_size, stride=patch_size)
+
+
+class Mlp(nn.Module):
+    def __init__(self, in_features, hidden_features):
+        super().__init__()
+        self.fc1 = nn.Linear(in_features, hidden_features)
+        self.fc2 = nn.Linear(hidden_features, in_features)
+
+
+class Attention(nn.Module):
+    def __init__(self, dim, num_heads=8, qkv_bias=False):
+        super().__init__()
+        self.num_heads = num_heads
+        self.scale = (dim // num_heads) ** -0.5
+        self.qkv = nn.Linear(dim, dim * 3, bias=qkv_bias)
+        self.proj = nn.Linear(dim, dim)
+
+
+class Block(nn.Module):
+    def __init__(self, dim, num_heads, mlp_ratio=4.0, qkv_bias=False, norm_layer=nn.LayerNorm):
+        super().__init__()
+        self.norm1 = norm_layer(dim)
+        self.attn = Attention(dim, num_heads=num_heads, qkv_bias=qkv_bias)
+        self.norm2 = norm_layer(dim)
+        self.mlp = Mlp(dim, int(dim * mlp_ratio))
+
+
+class VisionTransformer(PackedCache, nn.Module):
+    def __init__(self, img_size=224, patch_size=16, in_chans=3, num_classes=1000, embed_dim=768, depth=12,
+                 num_heads=12, mlp_ratio=4.0, qkv_bias=True, qk_scale=None, representation_size=None,
+                 drop_rate=0.0, attn_drop_rate=0.0, drop_path_rate=0.0, norm_layer=None,
+                 use_grad_checkpointing=False, ckpt_layer=0):
+        super().__init__()
+        if embed_dim // num_heads != 64:
+            raise ValueError("vidil_amd ViT kernels are built for head_dim 64")
+        self.num_features = self.embed_dim = embed_dim
+        self.num_heads = num_heads
+        self.ln_eps = 1e-6  # models/vit.py:142
+        norm_layer = norm_layer or partial(nn.LayerNorm, eps=self.ln_eps)
+        self.patch_embed = PatchEmbed(img_size=img_size, patch_size=patch_size, in_chans=in_chans, embed_dim=embed_dim)
+        num_patches = self.patch_embed.num_patches
+        self.cls_token = nn.Parameter(torch.zeros(1, 1, embed_dim))
+        self.pos_embed = nn.Parameter(torch.zeros(1, num_patches + 1, embed_dim))
+        self.blocks = nn.ModuleList([
+            Block(embed_dim, num_heads, mlp_ratio, qkv_bias, norm_layer) for _ in range(depth)])
+        self.norm = norm_layer(embed_dim)
+        # init rules of models/vit.py:163-174
+        nn.init.trunc_normal_(self.pos_embed, std=0.02)
+        nn.init.trunc_normal_(self.cls_token, std=0.02)
+        self.apply(self._init_weights)
+
+    @staticmethod
+    def _init_weights(m):
+        if isinstance(m, nn.Linear):
+            nn.init.trunc_normal_(m.weight, std=0.02)
+            if m.bias is not None:
+                nn.init.constant_(m.bias, 0)
+        elif isinstance(m, nn.LayerNorm):
+            nn.init.constant_(m.bias, 0)
+            nn.init.constant_(m.weight, 1.0)
+
+    # ------------------------------------------------------------------ packing
+    def _pack(self):
+        D = self.embed_dim
+        pe = self.patch_embed.proj
+        p = dict(
+            pe_w=w16(pe.weight.reshape(D, -1)), pe_b=v32(pe.bias),
+            cls=v32(self.cls_token), pos=v32(self.pos_embed).view(-1, D),
+            norm_g=v32(self.norm.weight), norm_b=v32(self.norm.bias), blocks=[])
+        for b in self.blocks:
+            p["blocks"].append(dict(
+                n1g=v32(b.norm1.weight), n1b=v32(b.norm1.bias),
+                qkv_w=w16(b.attn.qkv.weight), qkv_b=v32(b.attn.qkv.bias),
+                proj_w=w16(b.attn.proj.weight), proj_b=v32(b.attn.proj.bias),
+                n2g=v32(b.norm2.weight), n2b=v32(b.norm2.bias),
+                fc1_w=w16(b.mlp.fc1.weight), fc1_b=v32(b.mlp.fc1.bias),
+                fc2_w=w16(b.mlp.fc2.weight), fc2_b=v32(b.mlp.fc2.bias)))
+        return p
+
+    # ------------------------------------------------------------------ forward
+    def embed_patches(self, patches16, B):
+        """patches16: f16 [B*P, 3*ps*ps] (from patchify_*).  Returns the f32 residual stream [B*T, D]."""
+        p = self.packed()
+        D, P = self.embed_dim, self.patch_embed.num_patches
+        T = P + 1
+        x = torch.empty((B * T, D), dtype=torch.float32, device=patches16.device)
+        K.gemm(patches16, p["pe_w"], p["pe_b"], patch=dict(out=x, pos=p["pos"], tpi=P))
+        K.set_cls_row(x, p["cls"], p["pos"], B, T, D)
+        return x
+
+    def run_blocks(self, x, B, want16=True):
+        """x: f32 [B*T, D] residual stream (modified in place).  Returns (y32, y16) after the final LN."""
+        p = self.packed()
+        D, H = self.embed_dim, self.num_heads
+        T = self.patch_embed.num_patches + 1
+        NP = (T + 7) // 8 * 8
+        dev = x.device
+        M = B * T
+        xn = torch.empty((M, D), dtype=torch.float16, device=dev)
+        q = torch.empty((B, H, T, 64), dtype=torch.float16, device=dev)
+        k = torch.empty((B, H, T, 64), dtype=torch.float16, device=dev)
+        vt = torch.empty((B, H, 64, NP), dtype=torch.float16, device=dev)
+        o = torch.empty((M, D), dtype=torch.float16, device=dev)
+        hid = torch.empty((M, p["blocks"][0]["fc1_w"].shape[0]), dtype=torch.float16, device=dev)
+        heads = dict(q=q, k=k, vt=vt, T=T, H=H, part0=0, t_off=0, Tq_cap=T, Tk_cap=T, NP=NP, q_scale=0.125)
+        for b in p["blocks"]:
+            K.layernorm(x, b["n1g"], b["n1b"], self.ln_eps, out16=xn)
+            K.gemm(xn, b["qkv_w"], b["qkv_b"], heads=heads)
+            K.attention(q, k, vt, o, Bq=B, H=H, Nq=T, Nk=T, Tq_cap=T, Tk_cap=T, NP=NP)
+            K.gemm(o, b["proj_w"], b["proj_b"], out=x, resid=x)
+            K.layernorm(x, b["n2g"], b["n2b"], self.ln_eps, out16=xn)
+            K.gemm(xn, b["fc1_w"], b["fc1_b"], out=hid, act=K.ACT_GELU_ERF)
+            K.gemm(hid, b["fc2_w"], b["fc2_b"], out=x, resid=x)
+        y32 = torch.empty((M, D), dtype=torch.float32, device=dev)
+        y16 = xn if want16 else None
+        K.layernorm(x, p["norm_g"], p["norm_b"], self.ln_eps, out16=y16, out32=y32)
+        return y32, y16
+
+    def forward_both(self, x):
+        """x f32 [B,3,S,S] on the GPU -> (f32 [B,T,D], f16 [B*T,D])."""
+        require_cuda(x, "VisionTransformer.forward")
+        B = x.shape[0]
+        ps = self.patch_embed.patch_size[0]
+        patches = K.patchify_f32(x.contiguous().float(), ps)
+        xr = self.embed_patches(patches, B)
+        y32, y16 = self.run_blocks(xr, B)
+        return y32.view(B, -1, self.embed_dim), y16
+
+    def forward_u8(self, frames_u8, mean, std):
+        """uint8 [B,S,S,3] frames (already S x S) with fused /255 + normalise."""
+        require_cuda(frames_u8, "VisionTransformer.forward_u8")
+        B = frames_u8.shape[0]
+        ps = self.patch_embed.patch_size[0]
+        patches = K.patchify_u8(frames_u8.contiguous(), ps, mean, std)
+        xr = self.embed_patches(patches, B)
+        y32, y16 = self.run_blocks(xr, B)
+        return y32.view(B, -1, self.embed_dim), y16
+
+    def forward(self, x, register_blk=-1):
+        return self.forward_both(x)[0]
+
+
+def interpolate_pos_embed(pos_embed_checkpoint, visual_encoder):
+    """Resize a checkpoint's position grid to this encoder's (reference: models/vit.py:281-305)."""
+    width = pos_embed_checkpoint.shape[-1]
+    num_patches = visual_encoder.patch_embed.num_patches
+    extra = visual_encoder.pos_embed.shape[-2] - num_patches
+    old = int((pos_embed_checkpoint.shape[-2] - extra) ** 0.5)
+    new = int(num_patches ** 0.5)
+    if old == new:
+        return pos_embed_checkpoint
+    keep = pos_embed_checkpoint[:, :extra]
+    grid = pos_embed_checkpoint[:, extra:].reshape(-1, old, old, width).permute(0, 3, 1, 2)
+    grid = torch.nn.functional.interpolate(grid, size=(new, new), mode="bicubic", align_corners=False)
+    grid = grid.permute(0, 2, 3, 1).flatten(1, 2)
+    print("reshape position embedding from %d to %d" % (old ** 2, new ** 2))
+    return torch.cat((keep, grid), dim=1)
