@@ -92,7 +92,8 @@ def beam_search(step_fn, prompt_ids, *, num_beams=3, max_length=20, min_length=5
         top_s, top_i = torch.topk(flat, 2 * nb, dim=1, largest=True, sorted=True)
         top_s, top_i = top_s.numpy(), top_i.numpy()
         if trace is not None:
-            trace.append(dict(cur_len=cur_len, logits=logits.copy(), cand_scores=top_s.copy(), cand_index=top_i.copy()))
+            trace.append(dict(cur_len=cur_len, logits=logits.copy(), cand_scores=top_s.copy(), cand_index=top_i.copy(),
+                              beam_scores=beam_scores.copy()))
         next_indices = top_i // V
         next_tokens = top_i % V
         # ---- BeamSearchScorer.process

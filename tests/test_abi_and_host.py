@@ -1,0 +1,168 @@
+"""CPU-only checks of the drop-in boundary: the C-ABI library loads and exports every symbol
+include/vidil_hip.h declares (no compute calls), the ctypes mirror agrees with the header,
+argument validation fails loudly, and the host-side mirror of the reference interface."""
+import ctypes
+import os
+import re
+
+import numpy as np
+import pytest
+import torch
+
+from common import ROOT
+
+HEADER = os.path.join(ROOT, "include", "vidil_hip.h")
+
+
+def header_functions():
+    src = open(HEADER).read()
+    src = re.sub(r"/\*.*?\*/", "", src, flags=re.S)
+    return sorted(set(re.findall(r"\b(vidil_[a-z0-9_]+)\s*\(", src)))
+
+
+def test_library_exports_every_declared_symbol():
+    from vidil_amd import _lib
+
+    lib = _lib.load()
+    names = header_functions()
+    assert len(names) >= 18
+    for n in names:
+        assert hasattr(lib, n), f"{n} declared in include/vidil_hip.h but not exported"
+    assert set(names) == set(_lib.SIGNATURES), set(names) ^ set(_lib.SIGNATURES)
+    assert lib.vidil_num_entry_points() == len(names)
+    assert lib.vidil_abi_version() == 1
+
+
+def test_gemm_args_struct_matches_header_field_order():
+    from vidil_amd._lib import GemmArgs
+
+    src = open(HEADER).read()
+    body = src[src.index("typedef struct vidil_gemm_args"):src.index("} vidil_gemm_args;")]
+    body = re.sub(r"/\*.*?\*/", "", body, flags=re.S)
+    fields = []
+    for decl in body.split("{", 1)[1].split(";"):
+        decl = decl.strip()
+        if not decl:
+            continue
+        for part in decl.split(","):
+            fields.append(re.findall(r"([A-Za-z_0-9]+)\s*$", part.strip())[0])
+    assert fields == [f[0] for f in GemmArgs._fields_]
+
+
+def test_argument_validation_without_a_gpu():
+    """Bad shapes are rejected before any launch, with a message (error convention of the ABI)."""
+    from vidil_amd import _lib
+
+    lib = _lib.load()
+    g = _lib.GemmArgs()
+    assert lib.vidil_gemm_f16(ctypes.byref(g), None) == -1
+    assert b"null operand" in lib.vidil_last_error()
+    g.A, g.W, g.M, g.N, g.K = 16, 16, 8, 8, 100
+    assert lib.vidil_gemm_f16(ctypes.byref(g), None) == -1
+    assert b"multiple of 64" in lib.vidil_last_error()
+    assert lib.vidil_attention(16, 16, 16, 16, None, None, 1, 12, 4, 400, 4, 400, 400, 1, 0, 0, 768, None) == -3
+    assert b"not supported" in lib.vidil_last_error()
+    assert lib.vidil_scan_topk_ws_bytes(128, 42784, 5) > 0
+
+
+def test_product_path_refuses_cpu_tensors():
+    from vidil_amd import kernels as K
+    from vidil_amd.vit import VisionTransformer
+
+    with pytest.raises(K.VidilHipError):
+        K.gemm(torch.zeros(8, 64, dtype=torch.float16), torch.zeros(8, 64, dtype=torch.float16))
+    v = VisionTransformer(img_size=32, patch_size=16, embed_dim=256, depth=1, num_heads=4)
+    with pytest.raises(K.VidilHipError):
+        v(torch.zeros(1, 3, 32, 32))
+
+
+def test_state_dict_names_match_reference_checkpoints():
+    """the key names BLIP .pth files carry."""
+    from vidil_amd.blip import BLIP_Decoder
+    from vidil_amd.blip_itm import BLIP_ITM
+    from vidil_amd.tokenizer import SyntheticBertTokenizer
+
+    tok = SyntheticBertTokenizer()
+    cap = BLIP_Decoder(image_size=224, vit="base", tokenizer=tok)
+    keys = set(cap.state_dict().keys())
+    for k in ["visual_encoder.blocks.0.attn.qkv.weight", "visual_encoder.pos_embed", "visual_encoder.cls_token",
+              "visual_encoder.patch_embed.proj.weight", "text_decoder.bert.encoder.layer.0.crossattention.self.key.weight",
+              "text_decoder.cls.predictions.decoder.weight", "text_decoder.cls.predictions.bias",
+              "text_decoder.bert.embeddings.word_embeddings.weight", "text_decoder.bert.encoder.layer.11.output.LayerNorm.bias"]:
+        assert k in keys, k
+    assert tuple(cap.state_dict()["visual_encoder.blocks.0.attn.qkv.weight"].shape) == (2304, 768)
+    assert tuple(cap.state_dict()["text_decoder.cls.predictions.decoder.weight"].shape) == (30524, 768)
+    assert len([k for k in cap.visual_encoder.state_dict()]) == 150
+    assert cap.prompt_length == 4 and cap.prompt_ids(2, "cpu").tolist() == [[30522, 1037, 3861, 1997]] * 2
+    itm = BLIP_ITM(image_size=224, vit="base", tokenizer=tok)
+    ik = set(itm.state_dict().keys())
+    for k in ["itm_head.weight", "text_encoder.encoder.layer.3.crossattention.output.dense.weight", "vision_proj.weight"]:
+        assert k in ik, k
+    if os.path.isfile("/root/reference/models/med.py"):
+        from oracle import ref_shim
+
+        _, med = ref_shim.load()
+        ref_keys = set("text_decoder." + k for k in med.BertLMHeadModel(ref_shim.med_config()).state_dict().keys())
+        mine = set(k for k in keys if k.startswith("text_decoder."))
+        assert ref_keys == mine, ref_keys ^ mine
+
+
+def test_load_checkpoint_semantics(tmp_path):
+    """models/blip.py:332-354: checkpoint['model'], pos-embed interpolation from a 384 checkpoint, strict=False."""
+    from vidil_amd.blip import BLIP_Decoder, blip_decoder
+    from vidil_amd.tokenizer import SyntheticBertTokenizer
+
+    tok = SyntheticBertTokenizer()
+    src = BLIP_Decoder(image_size=64, vit="base", tokenizer=tok)
+    sd = {k: v.clone() for k, v in src.state_dict().items()}
+    big = torch.randn(1, 1 + 36, 768)          # a checkpoint trained at 96x96 (6x6 grid)
+    sd["visual_encoder.pos_embed"] = big
+    sd["unexpected.key"] = torch.zeros(1)
+    path = os.path.join(tmp_path, "ckpt.pth")
+    torch.save({"model": sd}, path)
+    m = blip_decoder(pretrained=path, image_size=64, vit="base", tokenizer=tok)
+    assert tuple(m.visual_encoder.pos_embed.shape) == (1, 17, 768)
+    from oracle import vit_ref
+
+    assert torch.allclose(m.visual_encoder.pos_embed, vit_ref.interpolate_pos_embed(big, 16), atol=1e-6)
+    assert torch.equal(m.text_decoder.bert.embeddings.word_embeddings.weight, sd["text_decoder.bert.embeddings.word_embeddings.weight"])
+
+
+def test_synthetic_tokenizer_round_trip_and_itm_padding():
+    from vidil_amd.tokenizer import SyntheticBertTokenizer
+
+    tok = SyntheticBertTokenizer()
+    assert tok("a picture of ").input_ids == [101, 1037, 3861, 1997, 102]
+    ids = [30522, 1037, 3861, 1997, 2000, 17, 29999, 102, 0, 0]
+    text = tok.decode(ids, skip_special_tokens=True)
+    assert text == "a picture of w2000 w17 w29999" and text[len("a picture of "):] == "w2000 w17 w29999"
+    enc = tok(["w2000 w17", "w5"], padding="max_length", truncation=True, max_length=35, return_tensors="pt")
+    assert enc.input_ids.shape == (2, 35) and enc.input_ids[0, :4].tolist() == [101, 2000, 17, 102]
+    assert enc.attention_mask.sum(1).tolist() == [4, 3]
+    long = tok(" ".join(f"w{i}" for i in range(1000, 1100)), truncation=True, max_length=35)
+    assert len(long.input_ids) == 35 and long.input_ids[-1] == 102
+
+
+def test_capfilt_host_logic():
+    from vidil_amd import capfilt
+
+    assert capfilt.dedup(["a", "b", "a", "c", "b"]) == ["a", "b", "c"]
+    assert capfilt.keep_caption([0.1, 0.41, 0.2], 0.4, "max_filter") is True
+    assert capfilt.keep_caption([0.1, 0.40, 0.2], 0.4, "max_filter") is False       # strict '>'
+    assert capfilt.keep_caption([0.3, 0.6], 0.4, "avg_filter") is True
+    items = [dict(video_id="v0", text=["x"], unfiltered_text=["x", "y"]), dict(video_id="v1", text=[], unfiltered_text=["z"]),
+             dict(video_id="v2", text=["q"])]
+    f, u = capfilt.collect_outputs(items)
+    assert f == {"v0": ["x"]} and u == {"v0": ["x", "y"], "v1": ["z"]}              # v1 filtered out, v2 never processed
+
+
+def test_balanced_shards_cover_everything_in_order():
+    from vidil_amd import dist as vdist
+
+    for n, w in [(16, 8), (10, 4), (3, 8), (0, 2), (2990, 8)]:
+        bounds = [vdist.shard_bounds(n, w, r) for r in range(w)]
+        assert bounds[0][0] == 0 and bounds[-1][1] == n
+        assert all(bounds[i][1] == bounds[i + 1][0] for i in range(w - 1))
+        sizes = [e - s for s, e in bounds]
+        assert max(sizes) - min(sizes) <= 1
+    assert [e - s for s, e in (vdist.shard_bounds(16, 8, r) for r in range(8))] == [2] * 8

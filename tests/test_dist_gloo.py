@@ -1,0 +1,63 @@
+"""The N>1 path on CPU: world_size-2 Gloo processes shard a video list in balanced contiguous
+blocks, gather their JSON results to rank 0, and the merged files equal the single-process
+output (order included) — the property the 1/2/4/8-GPU runs rely on."""
+import json
+import os
+import socket
+import subprocess
+import sys
+
+from common import ROOT
+
+WORKER = r"""
+import json, os, sys
+sys.path.insert(0, {root!r})
+from vidil_amd import dist as vdist, capfilt, visual_tokenization as vt
+
+rank, world, _ = vdist.init_distributed_mode(backend="gloo")
+videos = [f"video{{i}}" for i in range(11)]
+s, e = vdist.shard_bounds(len(videos))
+items = []
+for v in videos[s:e]:
+    n = int(v[5:])
+    items.append(dict(video_id=v, text=[] if n % 4 == 3 else [f"cap {{n}} é"], unfiltered_text=[f"cap {{n}} é", "x"]))
+f, u = capfilt.collect_outputs(items)
+capfilt.write_outputs({out!r}, f, u)
+toks = {{v: dict(frame_tokens=[dict(objects=["o"])], caption=[], aggregated_tokens=dict(objects=["o"])) for v in videos[s:e]}}
+vt.write_outputs({out!r}, toks)
+t = vdist.max_over_ranks(float(rank + 1))
+assert t == float(world), t
+vdist.barrier()
+"""
+
+
+def _free_port():
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def _run(world, out):
+    port = _free_port()
+    script = WORKER.format(root=ROOT, out=out)
+    procs = []
+    for r in range(world):
+        env = dict(os.environ, RANK=str(r), WORLD_SIZE=str(world), LOCAL_RANK=str(r), MASTER_ADDR="127.0.0.1",
+                   MASTER_PORT=str(port))
+        procs.append(subprocess.Popen([sys.executable, "-c", script], env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT))
+    for p in procs:
+        o, _ = p.communicate(timeout=240)
+        assert p.returncode == 0, o.decode()
+
+
+def test_two_rank_gather_equals_single_process(tmp_path):
+    out1, out2 = str(tmp_path / "w1"), str(tmp_path / "w2")
+    _run(1, out1)
+    _run(2, out2)
+    for name in ("video_text_CapFilt.json", "video_text_Cap.json", "visual_tokens.json"):
+        a = open(os.path.join(out1, name)).read()
+        b = open(os.path.join(out2, name)).read()
+        assert a == b, name
+    d = json.load(open(os.path.join(out2, "video_text_CapFilt.json")))
+    assert list(d.keys()) == [f"video{i}" for i in range(11) if i % 4 != 3]      # filtered-out videos drop, order kept
+    assert list(json.load(open(os.path.join(out2, "video_text_Cap.json"))).keys()) == [f"video{i}" for i in range(11)]

@@ -1,0 +1,140 @@
+"""CPU tests of the oracle: against the committed golden vectors (generated from the
+reference's own modules by tests/golden/make_golden.py) and, where /root/reference is
+present, against the reference modules run live."""
+import json
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from common import GOLDEN, load_golden
+from oracle import clip_ref, med_ref, ref_shim, tokens_ref, vit_ref
+
+TOL = dict(rtol=1e-5, atol=2e-5)
+
+
+def test_vit_oracle_matches_golden():
+    sd, g = load_golden("vit_small.npz")
+    x = torch.from_numpy(g["x"])
+    with torch.no_grad():
+        y, blocks = vit_ref.vit_forward(sd, x, depth=2, heads=4, return_blocks=True)
+    assert torch.allclose(blocks[1], torch.from_numpy(g["block0"]), **TOL)
+    assert torch.allclose(blocks[2], torch.from_numpy(g["block1"]), **TOL)
+    assert torch.allclose(y, torch.from_numpy(g["y"]), **TOL)
+
+
+def test_decoder_oracle_matches_golden():
+    sd, g = load_golden("med_decoder_small.npz")
+    enc = torch.from_numpy(g["enc"]).repeat_interleave(2, dim=0)
+    kw = dict(layers=2, H=4)
+    with torch.no_grad():
+        l0, cache = med_ref.decoder_logits(sd, torch.from_numpy(g["ids"]), enc, **kw)
+        assert torch.allclose(l0, torch.from_numpy(g["logits0"]), **TOL)
+        assert torch.allclose(cache[1][0], torch.from_numpy(g["k_cache_l1"]), **TOL)
+        past = med_ref.reorder_cache(cache, torch.from_numpy(g["beam_idx"]))
+        l1, cache = med_ref.decoder_logits(sd, torch.from_numpy(g["ids1"]), enc, past, **kw)
+        assert torch.allclose(l1, torch.from_numpy(g["logits1"]), **TOL)
+        l2, _ = med_ref.decoder_logits(sd, torch.from_numpy(g["ids2"]), enc, cache, **kw)
+        assert torch.allclose(l2, torch.from_numpy(g["logits2"]), **TOL)
+
+
+def test_itm_oracle_matches_golden():
+    sd, g = load_golden("med_itm_small.npz")
+    with torch.no_grad():
+        out = med_ref.itm_logits(sd, torch.from_numpy(g["enc"]), torch.from_numpy(g["ids"]), torch.from_numpy(g["mask"]),
+                                 layers=2, H=4)
+    assert torch.allclose(out, torch.from_numpy(g["itm"]), **TOL)
+
+
+def test_clip_oracle_matches_golden():
+    sd, g = load_golden("clip_small.npz")
+    with torch.no_grad():
+        ie = clip_ref.image_embeds(sd, torch.from_numpy(g["pixel_values"]), layers=2, heads=4, patch=32)
+        te = clip_ref.text_embeds(sd, torch.from_numpy(g["input_ids"]), torch.from_numpy(g["attention_mask"]),
+                                  layers=2, heads=4, eos_token_id=999)
+    assert torch.allclose(ie, torch.from_numpy(g["image_embeds"]), rtol=1e-5, atol=1e-6)
+    assert torch.allclose(te, torch.from_numpy(g["text_embeds"]), rtol=1e-5, atol=1e-6)
+
+
+def test_ontology_sizes_golden():
+    sizes = json.load(open(os.path.join(GOLDEN, "ontology_sizes.json")))
+    # SURVEY.md §8 a26 / Appendix B
+    assert {k: v["n"] for k, v in sizes["vg"].items()} == dict(objects=19958, attributes=15026, scenes=365, verbs=7410)
+    assert {k: v["n"] for k, v in sizes["vg_tencent"].items()} == dict(objects=11163, attributes=15157, scenes=365, verbs=7410)
+    assert sizes["vg"]["scenes"]["distinct"] == 314
+
+
+def test_filter_quirk_skips_element_after_a_removal():
+    """run_visual_tokenization.py:383-385 mutates the list it iterates."""
+    out = tokens_ref.filter_ontology(["a", "b"], ["a", "b", "c", "a", "d"], [], [])
+    # python: i=0 'a' removed -> list [b,c,a,d]; i=1 'c'; i=2 'a' in objects -> remove first 'a' -> [b,c,d]; stop
+    ref = ["a", "b", "c", "a", "d"]
+    for key in ref:
+        if key in ["a", "b"]:
+            ref.remove(key)
+    assert out["attributes"] == ref == ["b", "c", "d"]
+
+
+def test_aggregate_frame_tokens_tie_order():
+    """run_visual_tokenization.py:173-187: rank-major counting, stable sort by count."""
+    ft = [dict(objects=["x", "y"], attributes=[], scenes=["s", "t"], verbs=["v", "w"]),
+          dict(objects=["y", "x"], attributes=[], scenes=["s", "u"], verbs=["w", "v"])]
+    agg = tokens_ref.aggregate_frame_tokens(ft)
+    assert agg["objects"] == ["x", "y"]          # both count 2; 'x' seen first (rank 0, frame 0)
+    assert agg["attributes"] == []
+    assert agg["scenes"] == ["s", "t"]           # s:2, then t,u at 1 in insertion order -> top-2
+    assert agg["verbs"] == ["v", "w"]
+
+
+def test_reference_shard_bounds_leave_ranks_empty():
+    """run_video_CapFilt.py:237-241 with 16 videos on 8 ranks -> 3,3,3,3,3,1,0,0."""
+    sizes = [max(0, e - s) for s, e in (tokens_ref.shard_bounds(16, 8, r) for r in range(8))]
+    assert sizes == [3, 3, 3, 3, 3, 1, 0, 0]
+
+
+# --------------------------------------------------------------------- live reference (build container only)
+needs_ref = pytest.mark.skipif(not ref_shim.available(), reason="/root/reference not present")
+
+
+@needs_ref
+def test_oracle_vs_reference_full_size_modules():
+    vit_mod, med_mod = ref_shim.load()
+    torch.manual_seed(7)
+    v = vit_mod.VisionTransformer(img_size=224, patch_size=16, embed_dim=768, depth=12, num_heads=12).eval()
+    x = torch.randn(1, 3, 224, 224)
+    sd = {"visual_encoder." + k: t for k, t in v.state_dict().items()}
+    with torch.no_grad():
+        y, y2 = v(x), vit_ref.vit_forward(sd, x)
+    assert torch.allclose(y, y2, **TOL)
+    cfg = ref_shim.med_config()
+    dec = med_mod.BertLMHeadModel(cfg).eval()
+    dsd = {"text_decoder." + k: t for k, t in dec.state_dict().items()}
+    ids = torch.tensor([[30522, 1037, 3861, 1997]])
+    with torch.no_grad():
+        out = dec(ids, attention_mask=torch.ones_like(ids), encoder_hidden_states=y,
+                  encoder_attention_mask=torch.ones(1, 197, dtype=torch.long), return_dict=True, is_decoder=True)
+        lg, _ = med_ref.decoder_logits(dsd, ids, y)
+    assert torch.allclose(out.logits[:, -1], lg, **TOL)
+
+
+@needs_ref
+def test_ontology_filter_replayed_on_reference_files():
+    root = os.path.join(ref_shim.REFERENCE_ROOT, "visual_token_ontology")
+    from vidil_amd.visual_tokenization import load_visual_token_texts
+
+    for name in ("vg", "vg_tencent"):
+        ont = tokens_ref.load_ontology(root, name)
+        mine = load_visual_token_texts(root, name)
+        assert mine == ont                         # product host logic == oracle restatement
+        # literal replay of the reference's loop
+        files = tokens_ref.ONTOLOGY_FILES[name]
+        objs = json.load(open(os.path.join(root, files["objects"])))
+        attrs = json.load(open(os.path.join(root, files["attributes"])))
+        for key in attrs:
+            if key in objs:
+                attrs.remove(key)
+        for key in tokens_ref.OMIT_KEYWORDS:
+            if key in attrs:
+                attrs.remove(key)
+        assert ont["attributes"] == attrs

@@ -9,6 +9,9 @@ from __future__ import annotations
 import ctypes as C
 import os
 
+import torch  # noqa: F401  -- MUST precede the CDLL below: torch ships its own libamdhip64; loading ours
+# first would bind libvidil_hip.so to a second HIP runtime that has no initialised device.
+
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "csrc", "libvidil_hip.so")
 

@@ -83,6 +83,49 @@ class DecodeTrace:
         self.cand_index = []
 
 
+class DecoderSession:
+    """Device-resident decoding state of R = B*nb sequences over B images: per-image cross K/V (projected
+    once), double-buffered self-attention KV cache, and the two forward entry points the beam loop needs."""
+
+    def __init__(self, text_decoder, enc16, B, nb, max_length):
+        self.dec, self.bert = text_decoder, text_decoder.bert
+        cfg = text_decoder.config
+        dev = enc16.device
+        self.B, self.nb, self.R = B, nb, B * nb
+        self.H, self.L = cfg.num_attention_heads, cfg.num_hidden_layers
+        Te = enc16.shape[0] // B
+        self.cross = self.bert.project_cross_kv(enc16, B, Te)
+        self.Tcap = max_length
+        self.NPs = (max_length + 7) // 8 * 8
+        self.kc = [torch.empty((self.L, self.R, self.H, self.Tcap, 64), dtype=torch.float16, device=dev) for _ in range(2)]
+        self.vc = [torch.empty((self.L, self.R, self.H, 64, self.NPs), dtype=torch.float16, device=dev) for _ in range(2)]
+        self.cur = 0
+        self.ws_prefill, self.ws_step = {}, {}
+        self.logits = None
+
+    def prefill(self, ids_i32, P):
+        """ids_i32: int32 [R*P] prompt tokens of every row.  Returns last-position logits f32 [R,V]."""
+        h32, h16 = self.bert.embed(ids_i32, P, 0)
+        self.bert.run_layers(h32, h16, rows=self.R, T=P, self_k=self.kc[self.cur], self_vt=self.vc[self.cur], t_off=0,
+                             Tk_cap=self.Tcap, NPs=self.NPs, causal=True, kv_len=None, cross=self.cross,
+                             cross_group=self.nb, ws=self.ws_prefill)
+        self.logits = self.dec.lm_logits(h16, self.R, P)
+        return self.logits
+
+    def step(self, next_tok_i32, beam_idx_i32, past_len):
+        """Reorder the KV cache rows by ``beam_idx`` (models/med.py:951-955), then one cached forward of the
+        single new token at position ``past_len``.  Returns logits f32 [R,V]."""
+        K.kv_reorder(self.kc[self.cur], self.kc[self.cur ^ 1], beam_idx_i32, self.L, self.R)
+        K.kv_reorder(self.vc[self.cur], self.vc[self.cur ^ 1], beam_idx_i32, self.L, self.R)
+        self.cur ^= 1
+        h32, h16 = self.bert.embed(next_tok_i32, 1, past_len)
+        self.bert.run_layers(h32, h16, rows=self.R, T=1, self_k=self.kc[self.cur], self_vt=self.vc[self.cur],
+                             t_off=past_len, Tk_cap=self.Tcap, NPs=self.NPs, causal=False, kv_len=None,
+                             cross=self.cross, cross_group=self.nb, ws=self.ws_step)
+        self.logits = self.dec.lm_logits(h16, self.R, 1, out=self.logits)
+        return self.logits
+
+
 class BLIP_Decoder(nn.Module):
     def __init__(self, med_config="configs/med_config.json", image_size=384, vit="base", vit_grad_ckpt=False,
                  vit_ckpt_layer=0, prompt="a picture of ", tokenizer=None):
@@ -114,28 +157,16 @@ class BLIP_Decoder(nn.Module):
         tok = self.tokenizer
         eos, pad = tok.sep_token_id, tok.pad_token_id
         dev = enc16.device
-        nb, R = num_beams, B * num_beams
-        H, L, V = cfg.num_attention_heads, cfg.num_hidden_layers, cfg.vocab_size
-        Te = enc16.shape[0] // B
-        cross = bert.project_cross_kv(enc16, B, Te)
-        Tcap = max_length
-        NPs = (Tcap + 7) // 8 * 8
-        kc = [torch.empty((L, R, H, Tcap, 64), dtype=torch.float16, device=dev) for _ in range(2)]
-        vc = [torch.empty((L, R, H, 64, NPs), dtype=torch.float16, device=dev) for _ in range(2)]
+        nb = num_beams
+        V = cfg.vocab_size
+        sess = DecoderSession(dec, enc16, B, nb, max_length)
         bufs = K.BeamBuffers(B, nb, max_length, dev)
         prompt = self.prompt_ids(B, dev)
         P = prompt.shape[1]
         bufs.reset(prompt)
-        cur = 0
-        ws = {}
         # ---- prefill over the prompt (all beams of an image start identical)
-        ids = bufs.seqs[:, :P].contiguous().view(-1)
-        h32, h16 = bert.embed(ids, P, 0)
-        bert.run_layers(h32, h16, rows=R, T=P, self_k=kc[cur], self_vt=vc[cur], t_off=0, Tk_cap=Tcap, NPs=NPs,
-                        causal=True, kv_len=None, cross=cross, cross_group=nb, ws=ws)
-        logits = dec.lm_logits(h16, R, P)
+        logits = sess.prefill(bufs.seqs[:, :P].contiguous().view(-1), P)
         cur_len = P
-        ws1 = {}
         while True:
             ban = eos if cur_len < min_length else -1
             cs, ci = K.logsoftmax_topk(logits, bufs.beam_scores, B, nb, ban)
@@ -149,13 +180,7 @@ class BLIP_Decoder(nn.Module):
                 break
             if check_done_every and (cur_len % check_done_every == 0) and int(bufs.n_done.item()) == B:
                 break
-            K.kv_reorder(kc[cur], kc[cur ^ 1], bufs.beam_idx, L, R)
-            K.kv_reorder(vc[cur], vc[cur ^ 1], bufs.beam_idx, L, R)
-            cur ^= 1
-            h32, h16 = bert.embed(bufs.next_tok, 1, cur_len - 1)
-            bert.run_layers(h32, h16, rows=R, T=1, self_k=kc[cur], self_vt=vc[cur], t_off=cur_len - 1, Tk_cap=Tcap,
-                            NPs=NPs, causal=False, kv_len=None, cross=cross, cross_group=nb, ws=ws1)
-            logits = dec.lm_logits(h16, R, 1, out=logits)
+            logits = sess.step(bufs.next_tok, bufs.beam_idx, cur_len - 1)
         out_tok, out_len, _ = K.beam_finalize(bufs, cur_len, eos, pad)
         return out_tok, out_len
 

@@ -1,0 +1,207 @@
+"""Frame captioning + CapFilt filtering driver — the hot loop of the reference's
+run_video_CapFilt.py (:93-126 helpers, :139-204 ``CapFilt``, :206-291 ``main``).
+
+``caption_frames`` / ``filter_captions`` keep the reference's per-video call shapes.
+``CapFiltEngine`` is the batched, de-duplicated schedule the throughput path uses:
+many videos per launch, ViT once per frame per model, cross-attention K/V once per
+frame, all (frame, caption) pairs of the batch through the ITM encoder in one pass,
+one device->host copy per batch.  Frame decoding/sampling (decord) stays outside:
+the engine takes already-sampled uint8 frames (parity is defined on given frames).
+"""
+from __future__ import annotations
+
+import json
+import os
+
+import numpy as np
+import torch
+
+from . import dist as vdist
+from .blip import CLIP_MEAN, CLIP_STD, blip_decoder
+from .blip_itm import blip_itm
+
+
+@torch.no_grad()
+def caption_frames(captioner, images, mode="beam"):
+    """run_video_CapFilt.py:93-105."""
+    if mode == "beam":
+        return captioner.generate(images, sample=False, num_beams=3, max_length=20, min_length=5)
+    return captioner.generate(images, sample=True, top_p=0.9, max_length=20, min_length=5)
+
+
+def keep_caption(itm_score, threshold, mode="max_filter"):
+    """run_video_CapFilt.py:116-123 on the per-frame match probabilities of one caption."""
+    s = np.asarray(itm_score, dtype=np.float32)
+    prob = np.sum(s) / len(s) if mode == "avg_filter" else np.max(s)
+    return bool(prob > threshold)
+
+
+@torch.no_grad()
+def filter_captions(filterer, images, texts, threshold, mode="max_filter"):
+    """run_video_CapFilt.py:107-126, reference call shape (one filterer call per caption)."""
+    kept = []
+    for t in texts:
+        itm_output = filterer(images, [t for _ in range(images.size()[0])], match_head="itm")
+        itm_score = torch.nn.functional.softmax(itm_output, dim=1)[:, 1].detach().cpu().numpy()
+        if keep_caption(itm_score, threshold, mode):
+            kept.append(t)
+    return kept
+
+
+def dedup(captions):
+    """run_video_CapFilt.py:185-188."""
+    out = []
+    for c in captions:
+        if c not in out:
+            out.append(c)
+    return out
+
+
+def split_sentences(texts, do_sentence_tokenization=True):
+    """run_video_CapFilt.py:166-175.  spaCy when installed; otherwise newline/period splitting."""
+    if not texts:
+        return []
+    if not do_sentence_tokenization:
+        return [t.replace("\n", ". ").strip() for t in texts]
+    try:
+        import spacy
+
+        nlp = split_sentences.__dict__.get("_nlp")
+        if nlp is None:
+            nlp = spacy.load("en_core_web_sm", disable=["ner", "tagger", "lemmatizer"])
+            split_sentences._nlp = nlp
+        out = []
+        for t in texts:
+            for sent in nlp(t.replace("\n", ". ")).sents:
+                if len(sent.text) > 3:
+                    out.append(sent.text.strip())
+        return out
+    except ImportError:
+        out = []
+        for t in texts:
+            for s in t.replace("\n", ". ").split(". "):
+                if len(s) > 3:
+                    out.append(s.strip())
+        return out
+
+
+class CapFiltEngine:
+    """Batched CapFilt over already-sampled frames.
+
+    config keys (configs/pipeline_config/*.yaml of the reference): caption, filter,
+    filter_generated_only, keep_original_caption, threshold, filter_mode, generation_mode,
+    do_sentence_tokenization, image_size, vit, caption_model_ckpt, filterer_model_ckpt.
+    """
+
+    def __init__(self, config, device, captioner=None, filterer=None):
+        self.config = config
+        self.device = torch.device(device)
+        S, vit = config.get("image_size", 224), config.get("vit", "base")
+        if captioner is None:
+            captioner = blip_decoder(pretrained=config.get("caption_model_ckpt", ""), image_size=S, vit=vit)
+        if filterer is None:
+            filterer = blip_itm(pretrained=config.get("filterer_model_ckpt", ""), image_size=S, vit=vit)
+        self.captioner = captioner.eval().to(self.device)
+        self.filterer = filterer.eval().to(self.device)
+        self.last_stats = {}
+        self.last_frame_captions = []
+
+    @torch.no_grad()
+    def process(self, items, frames_u8):
+        """items: list of dicts {'video_id', 'text': [original captions]}; frames_u8: uint8 [Nv,F,S,S,3]
+        device tensor.  Fills item['text'] / item['unfiltered_text'] like run_video_CapFilt.py:166-204."""
+        cfg = self.config
+        Nv, F = frames_u8.shape[0], frames_u8.shape[1]
+        flat = frames_u8.reshape(Nv * F, *frames_u8.shape[2:])
+        generated = [[] for _ in range(Nv)]
+        if cfg.get("caption", True):
+            if cfg.get("generation_mode", "beam") != "beam":
+                raise NotImplementedError("generation_mode != 'beam' is not built yet")
+            _, y16 = self.captioner.visual_encoder.forward_u8(flat, CLIP_MEAN, CLIP_STD)
+            out_tok, _ = self.captioner.generate_ids(y16, Nv * F, num_beams=3, max_length=20, min_length=5)
+            caps = self.captioner.decode_captions(out_tok)
+            self.last_frame_captions = caps
+            generated = [dedup(caps[v * F:(v + 1) * F]) for v in range(Nv)]
+        # candidate lists per video, reference branches at :177-195
+        to_filter = []
+        for v, item in enumerate(items):
+            orig = split_sentences(item.get("text", []), cfg.get("do_sentence_tokenization", True))
+            if not cfg.get("caption", True):
+                cand = orig
+                item["unfiltered_text"] = cand
+                gen = []
+            else:
+                gen = generated[v]
+                if cfg.get("keep_original_caption", False):
+                    cand = orig + gen
+                else:
+                    item["text"] = []
+                    cand = gen
+                item["unfiltered_text"] = cand
+            if cfg.get("filter", True):
+                to_filter.append(gen if cfg.get("filter_generated_only", True) else cand)
+            else:
+                item["text"] = cand
+                to_filter.append(None)
+        n_pairs = 0
+        if cfg.get("filter", True):
+            kept = self._filter_batch(flat, Nv, F, to_filter)
+            for v, item in enumerate(items):
+                if cfg.get("filter_generated_only", True):
+                    item["text"] = list(item.get("text", [])) + kept[v]
+                else:
+                    item["text"] = kept[v]
+            n_pairs = sum(len(c) for c in to_filter) * F
+        self.last_stats = dict(videos=Nv, frames=Nv * F, unique_captions=sum(len(g) for g in generated), itm_pairs=n_pairs)
+        return items
+
+    def _filter_batch(self, flat_u8, Nv, F, caps_per_video):
+        cfg = self.config
+        flt = self.filterer
+        _, y16 = flt.visual_encoder.forward_u8(flat_u8, CLIP_MEAN, CLIP_STD)
+        all_caps, cap_video = [], []
+        for v, caps in enumerate(caps_per_video):
+            for c in caps:
+                all_caps.append(c)
+                cap_video.append(v)
+        kept = [[] for _ in range(Nv)]
+        if not all_caps:
+            return kept
+        ids, lens = flt.tokenize(all_caps)
+        # pair order: caption-major, frame-minor (the reference's loop order, :110-112)
+        cap_idx = torch.arange(len(all_caps)).repeat_interleave(F)
+        img_idx = (torch.tensor(cap_video) * F).repeat_interleave(F) + torch.arange(F).repeat(len(all_caps))
+        logits = flt.itm_pairs(y16, Nv * F, ids[cap_idx], lens[cap_idx], img_idx.to(torch.int32))
+        prob = torch.nn.functional.softmax(logits, dim=1)[:, 1].detach().cpu().numpy().reshape(len(all_caps), F)
+        for i, c in enumerate(all_caps):
+            if keep_caption(prob[i], cfg.get("threshold", 0.4), cfg.get("filter_mode", "max_filter")):
+                kept[cap_video[i]].append(c)
+        return kept
+
+
+def collect_outputs(items):
+    """run_video_CapFilt.py:250-259: (filtered, unfiltered) dicts; videos with no kept caption drop out of the first."""
+    filtered, unfiltered = {}, {}
+    for item in items:
+        if "unfiltered_text" not in item:
+            continue
+        unfiltered[item["video_id"]] = item["unfiltered_text"]
+        if item["text"] != []:
+            filtered[item["video_id"]] = item["text"]
+    return filtered, unfiltered
+
+
+def write_outputs(output_dir, filtered, unfiltered):
+    """Gather every rank's dicts to rank 0 and write video_text_CapFilt.json / video_text_Cap.json
+    (run_video_CapFilt.py:261-291; the tmp-file merge becomes one gather of JSON bytes)."""
+    parts = vdist.gather_json([filtered, unfiltered])
+    if parts is None:
+        return None
+    f_all = vdist.merge_rank_dicts([p[0] for p in parts])
+    u_all = vdist.merge_rank_dicts([p[1] for p in parts])
+    os.makedirs(output_dir, exist_ok=True)
+    with open(os.path.join(output_dir, "video_text_CapFilt.json"), "w") as out:
+        json.dump(f_all, out, indent=4)
+    with open(os.path.join(output_dir, "video_text_Cap.json"), "w") as out:
+        json.dump(u_all, out, indent=4)
+    return f_all, u_all

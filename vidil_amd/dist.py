@@ -1,0 +1,132 @@
+"""One-process-per-GPU plumbing for the two drivers.
+
+Mirror of the slice of the reference's utils.py the hot path uses
+(utils.py:214-281: ``init_distributed_mode``, rank helpers, print muting), with two
+deliberate differences:
+  * work is split in BALANCED contiguous blocks (the reference's ``len//world + 1``
+    steps leave ranks empty and crash them, run_visual_tokenization.py:265,427-431);
+    contiguity is kept so rank-order concatenation reproduces single-process order;
+  * per-rank results are gathered to rank 0 as UTF-8 JSON bytes over the process
+    group (RCCL over xGMI with backend 'nccl', Gloo on CPU) instead of tmp files on a
+    shared filesystem + barrier (run_video_CapFilt.py:249-291).  This is the only
+    collective on the path: the videos shard with no data-path exchange.
+"""
+from __future__ import annotations
+
+import datetime
+import json
+import os
+
+import torch
+import torch.distributed as dist
+
+
+def is_dist_avail_and_initialized():
+    return dist.is_available() and dist.is_initialized()
+
+
+def get_world_size():
+    return dist.get_world_size() if is_dist_avail_and_initialized() else 1
+
+
+def get_rank():
+    return dist.get_rank() if is_dist_avail_and_initialized() else 0
+
+
+def is_main_process():
+    return get_rank() == 0
+
+
+def setup_for_distributed(is_master):
+    """utils.py:214-226: mute print on non-master ranks (force=True overrides)."""
+    import builtins
+
+    builtin_print = builtins.print
+
+    def print(*args, **kwargs):  # noqa: A001
+        force = kwargs.pop("force", False)
+        if is_master or force:
+            builtin_print(*args, **kwargs)
+
+    builtins.print = print
+
+
+def init_distributed_mode(args=None, backend=None, mute=False):
+    """env:// rendezvous (RANK / WORLD_SIZE / LOCAL_RANK / MASTER_*).  Returns (rank, world, local_rank)."""
+    if "RANK" not in os.environ or "WORLD_SIZE" not in os.environ:
+        if args is not None:
+            args.distributed = False
+        return 0, 1, 0
+    rank, world, local = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"]), int(os.environ.get("LOCAL_RANK", 0))
+    if backend is None:
+        backend = "nccl" if torch.cuda.is_available() else "gloo"
+    if backend == "nccl":
+        torch.cuda.set_device(local)
+    if not dist.is_initialized():
+        dist.init_process_group(backend=backend, init_method="env://", world_size=world, rank=rank,
+                                timeout=datetime.timedelta(seconds=7200))
+    barrier()
+    if args is not None:
+        args.rank, args.world_size, args.gpu, args.distributed = rank, world, local, True
+    if mute:
+        setup_for_distributed(rank == 0)
+    return rank, world, local
+
+
+def barrier():
+    if is_dist_avail_and_initialized():
+        if dist.get_backend() == "nccl":
+            dist.barrier(device_ids=[torch.cuda.current_device()])
+        else:
+            dist.barrier()
+
+
+def shard_bounds(n, world=None, rank=None):
+    """Balanced contiguous block [start, end) of ``n`` items for ``rank``."""
+    world = get_world_size() if world is None else world
+    rank = get_rank() if rank is None else rank
+    base, rem = divmod(n, world)
+    start = rank * base + min(rank, rem)
+    return start, start + base + (1 if rank < rem else 0)
+
+
+def _comm_device():
+    if is_dist_avail_and_initialized() and dist.get_backend() == "nccl":
+        return torch.device("cuda", torch.cuda.current_device())
+    return torch.device("cpu")
+
+
+def gather_json(obj):
+    """Gather one JSON-serialisable object per rank; rank 0 gets the list in rank order, others None."""
+    if not is_dist_avail_and_initialized():
+        return [obj]
+    dev = _comm_device()
+    payload = torch.frombuffer(bytearray(json.dumps(obj).encode("utf-8")), dtype=torch.uint8).to(dev)
+    world = dist.get_world_size()
+    size = torch.tensor([payload.numel()], dtype=torch.int64, device=dev)
+    sizes = [torch.zeros(1, dtype=torch.int64, device=dev) for _ in range(world)]
+    dist.all_gather(sizes, size)
+    mx = int(max(int(s.item()) for s in sizes))
+    buf = torch.zeros(mx, dtype=torch.uint8, device=dev)
+    buf[: payload.numel()] = payload
+    bufs = [torch.zeros(mx, dtype=torch.uint8, device=dev) for _ in range(world)]
+    dist.all_gather(bufs, buf)
+    if dist.get_rank() != 0:
+        return None
+    return [json.loads(bytes(b[: int(s.item())].cpu().tolist()).decode("utf-8")) for b, s in zip(bufs, sizes)]
+
+
+def merge_rank_dicts(parts):
+    """dict.update in rank order, as run_video_CapFilt.py:272-283 / run_visual_tokenization.py:454-457."""
+    out = {}
+    for p in parts:
+        out.update(p)
+    return out
+
+
+def max_over_ranks(value: float) -> float:
+    if not is_dist_avail_and_initialized():
+        return value
+    t = torch.tensor([value], dtype=torch.float64, device=_comm_device())
+    dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    return float(t.item())

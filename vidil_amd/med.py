@@ -216,9 +216,17 @@ class BertModel(PackedCache, nn.Module):
             K.gemm(o, d["ao_w"], d["ao_b"], out=tmp, resid=h32)
             K.layernorm(tmp, d["ao_g"], d["ao_bt"], eps, out16=h16, out32=h32)
             if cross is not None:
-                K.gemm(h16, d["cq_w"], d["cq_b"], heads=dict(q=q, T=T, H=H, part0=0, Tq_cap=T, q_scale=0.125))
-                K.attention(q, cross.k[i], cross.vt[i], o, Bq=rows, H=H, Nq=T, Nk=cross.Te, Tq_cap=T,
-                            Tk_cap=cross.Te, NP=cross.NP, kv_group=cross_group, kv_index=cross_index)
+                if T == 1 and cross_index is None and cross_group > 1:
+                    # decode step: the cross_group beams of an image become the query rows of ONE
+                    # attention batch, so the image's K/V are staged once, not once per beam.
+                    G = cross_group
+                    K.gemm(h16, d["cq_w"], d["cq_b"], heads=dict(q=q, T=G, H=H, part0=0, Tq_cap=G, q_scale=0.125))
+                    K.attention(q, cross.k[i], cross.vt[i], o, Bq=rows // G, H=H, Nq=G, Nk=cross.Te, Tq_cap=G,
+                                Tk_cap=cross.Te, NP=cross.NP)
+                else:
+                    K.gemm(h16, d["cq_w"], d["cq_b"], heads=dict(q=q, T=T, H=H, part0=0, Tq_cap=T, q_scale=0.125))
+                    K.attention(q, cross.k[i], cross.vt[i], o, Bq=rows, H=H, Nq=T, Nk=cross.Te, Tq_cap=T,
+                                Tk_cap=cross.Te, NP=cross.NP, kv_group=cross_group, kv_index=cross_index)
                 K.gemm(o, d["co_w"], d["co_b"], out=tmp, resid=h32)
                 K.layernorm(tmp, d["co_g"], d["co_bt"], eps, out16=h16, out32=h32)
             K.gemm(h16, d["i_w"], d["i_b"], out=inter, act=K.ACT_GELU_ERF)

@@ -1,0 +1,172 @@
+"""CLIP visual tokenization driver — the hot loop of the reference's
+run_visual_tokenization.py with ``--encoder_version clip`` (:161-314 ``predict_video``,
+:318-463 ``main``): ontology load/filter, one-off text embeddings, per-frame image
+embeddings, ontology cosine scan, per-frame top-k per category, per-video frequency
+aggregation.
+
+The score matrix is never materialised: ``scan_topk`` fuses the f32 scan with the
+per-category top-k on the device and only [frames, 4, topk] indices come back (the
+reference copies the full [frames x 42,759] matrix to the host and argsorts every
+row, :298-306).
+"""
+from __future__ import annotations
+
+import json
+import os
+from collections import defaultdict
+
+import numpy as np
+import torch
+
+from . import dist as vdist
+from . import kernels as K
+
+CATEGORIES = ("objects", "attributes", "scenes", "verbs")
+
+# run_visual_tokenization.py:471-472
+OMIT_KEYWORDS = ['media player', 'video', 'playing video', 'audio', 'sound', 'taking video', 'water mark',
+                 'water marked', 'watermark', 'watermarks', 'for sale in', 'sold from', 'stock', 'sold on',
+                 'by viewers', 'are provided by', 'are posted on', 'for more', 'tag with', 'stream from',
+                 'viewed from', 'showing video of', 'are on at', 'shuttlecock', 'shutter', 'shutter is white',
+                 'shutters have bones', 'tape is looped', 'bliss wants you', 'thumbnail', 'technique']
+
+_ONTOLOGY_FILES = {
+    "vg": ("vg/openimage_classes_all_cleaned_fictional_characters.json",
+           "vg/vg_original_attributes_synsets_keys_cleaned_remove_similar0.9.json",
+           "vg/place365_ontology.json",
+           "vg/vg_srl_selected_object_synsets_keys_remove_similar0.9.json"),
+    "vg_tencent": ("vg_tencent/tencent_ml_images_objects.json",
+                   "vg_tencent/vg_original_attributes_synsets_keys_cleaned_remove_similar0.9.json",
+                   "vg/place365_ontology.json",
+                   "vg_tencent/vg_srl_selected_object_synsets_keys_remove_similar0.9.json"),
+}
+
+
+def get_prefix_prompt_functions(version):
+    """run_visual_tokenization.py:56-80."""
+    if version == "v0":
+        fn = lambda x: x  # noqa: E731
+    elif version == "v1":
+        fn = lambda x: f"A photo of {x}"  # noqa: E731
+    else:
+        raise ValueError(f"unknown prompt version {version}")
+    return {k: fn for k in CATEGORIES}
+
+
+def load_visual_token_texts(ontology_root, ontology="vg"):
+    """run_visual_tokenization.py:369-406, including the reference's filter quirk: attributes that are
+    also objects are removed from the list WHILE it is iterated, so the element after each removal is
+    never examined.  Class order defines the index space of the visual tokens, so it is reproduced."""
+    if ontology not in _ONTOLOGY_FILES:
+        raise ValueError(f"ontology '{ontology}' has no branch in the reference (vg, vg_tencent)")
+    lists = [json.load(open(os.path.join(ontology_root, f))) for f in _ONTOLOGY_FILES[ontology]]
+    objects, attributes, scenes, verbs = lists
+    if isinstance(verbs, dict):
+        verbs = list(verbs.keys())
+    object_set = set(objects)
+    i = 0
+    while i < len(attributes):
+        if attributes[i] in object_set:
+            attributes.remove(attributes[i])
+        i += 1
+    for key in OMIT_KEYWORDS:
+        for lst in (objects, attributes, scenes, verbs):
+            if key in lst:
+                lst.remove(key)
+    return {"objects": objects, "attributes": attributes, "scenes": scenes, "verbs": verbs}
+
+
+def aggregate_frame_tokens(frame_tokens):
+    """run_visual_tokenization.py:173-187."""
+    keys = frame_tokens[0].keys()
+    aggregated = {key: [] for key in keys}
+    topk = len(frame_tokens[0]["objects"])
+    for key in keys:
+        if frame_tokens[0][key] == []:
+            continue
+        count = defaultdict(int)
+        for j in range(topk):
+            for fr in frame_tokens:
+                count[fr[key][j]] += 1
+        ranked = sorted(count.items(), key=lambda x: x[1], reverse=True)
+        aggregated[key] = [t for t, _ in ranked[:topk]]
+    return aggregated
+
+
+class OntologyIndex:
+    """Device-resident class-text embeddings of the four categories, packed for ``scan_topk``:
+    one f32 matrix, each category starting at a multiple of 32 rows (zero rows in between)."""
+
+    def __init__(self, embeds_by_cat, device):
+        self.seg_start, self.seg_len = [], []
+        n = 0
+        for key in CATEGORIES:
+            e = embeds_by_cat[key]
+            self.seg_start.append(n)
+            self.seg_len.append(e.shape[0])
+            n += (e.shape[0] + 31) // 32 * 32
+        D = embeds_by_cat[CATEGORIES[0]].shape[1]
+        self.matrix = torch.zeros((n, D), dtype=torch.float32, device=device)
+        for key, s in zip(CATEGORIES, self.seg_start):
+            e = embeds_by_cat[key]
+            self.matrix[s:s + e.shape[0]] = e.to(device=device, dtype=torch.float32)
+        self.workspace = None
+
+
+@torch.no_grad()
+def get_text_embeddings_clip(model, tokenize, texts, device, batch=512):
+    """run_visual_tokenization.py:83-96: batches of 512 texts through the text tower (only)."""
+    out = []
+    for i in range(0, len(texts), batch):
+        enc = tokenize(texts[i:i + batch])
+        out.append(model.encode_text(enc["input_ids"].to(device), enc.get("attention_mask")))
+    return torch.cat(out, dim=0)
+
+
+class VisualTokenizer:
+    def __init__(self, config, model, visual_token_texts, text_embeds_by_cat, device):
+        self.config = config
+        self.device = torch.device(device)
+        self.model = model.eval().to(self.device)
+        self.texts = visual_token_texts
+        self.index = OntologyIndex(text_embeds_by_cat, self.device)
+        self.topk = config.get("topk_visualize", 5)
+
+    @torch.no_grad()
+    def frame_topk(self, frames_u8):
+        """uint8 [NF,S,S,3] -> (i32 [NF,4,topk] class indices within each category, f32 scores), on device."""
+        emb = self.model.encode_image_u8(frames_u8)
+        need = K.scan_topk_ws_bytes(emb.shape[0], self.index.matrix.shape[0], self.topk)
+        if self.index.workspace is None or self.index.workspace.numel() < need:
+            self.index.workspace = torch.empty((need,), dtype=torch.uint8, device=self.device)
+        return K.scan_topk(emb, self.index.matrix, self.index.seg_start, self.index.seg_len, self.topk,
+                           workspace=self.index.workspace)
+
+    @torch.no_grad()
+    def process(self, video_ids, frames_u8, captions):
+        """frames_u8 uint8 [Nv,F,S,S,3] on the device.  Returns {video_id: {frame_tokens, caption,
+        aggregated_tokens}} (the schema visual_token_generation/prompts.py reads)."""
+        Nv, F = frames_u8.shape[0], frames_u8.shape[1]
+        idx, _ = self.frame_topk(frames_u8.reshape(Nv * F, *frames_u8.shape[2:]))
+        idx = idx.cpu().numpy().reshape(Nv, F, len(CATEGORIES), self.topk)
+        out = {}
+        for v, vid in enumerate(video_ids):
+            frame_tokens = []
+            for f in range(F):
+                frame_tokens.append({key: [self.texts[key][int(ii)] for ii in idx[v, f, c] if ii >= 0]
+                                     for c, key in enumerate(CATEGORIES)})
+            out[vid] = {"frame_tokens": frame_tokens, "caption": captions[v],
+                        "aggregated_tokens": aggregate_frame_tokens(frame_tokens)}
+        return out
+
+
+def write_outputs(output_dir, videoid_2_visual_tokens):
+    """run_visual_tokenization.py:447-463 with the tmp-file merge replaced by a gather of JSON bytes."""
+    parts = vdist.gather_json(videoid_2_visual_tokens)
+    if parts is None:
+        return None
+    merged = vdist.merge_rank_dicts(parts)
+    os.makedirs(output_dir, exist_ok=True)
+    with open(os.path.join(output_dir, "visual_tokens.json"), "w") as out:
+        json.dump(merged, out, indent=4)
+    return merged
