@@ -98,17 +98,26 @@ int vidil_layernorm(const float* x, int64_t x_stride, const float* gamma,
 /* ------------------------------------------------------------------------ */
 /* Attention for short sequences (Nk <= 288): softmax(Q K^T [+mask]) V.       */
 /* Q  f16 [Bq][H][Tq_cap][64] (already scaled by 1/sqrt(64)),                 */
-/* K  f16 [Bk][H][Tk_cap][64], VT f16 [Bk][H][64][NP]; query batch b reads     */
-/* key/value batch kv_index[b] (or b / kv_group when kv_index == NULL).       */
+/* K  f16 [Bk][H][Tk_cap][64], VT f16 [Bk][H][64][NP].                         */
+/* Which key/value batch a query batch b reads — three forms, all of which let */
+/* every query that shares a K/V (the captions of a frame, the beams of an     */
+/* image) be served by ONE staging of that K/V:                               */
+/*   group_start != NULL : kv batch j serves query batches                    */
+/*                         group_start[j] .. group_start[j+1]-1 (n_kv batches, */
+/*                         at most max_group query batches each);             */
+/*   kv_index != NULL    : query batch b reads kv batch kv_index[b];           */
+/*   otherwise           : kv batch j serves query batches j*kv_group ..      */
+/*                         (j+1)*kv_group-1.                                  */
 /* Keys >= kv_len[b] (or >= Nk when kv_len==NULL) are excluded; causal!=0     */
 /* additionally excludes key > q + causal_off.                                */
-/* out f16 row (b*Nq + q), column h*64+d, row stride ldo.                     */
+/* out f16 row (b*Nq + q), column h*64+d, row stride ldo (multiple of 8).     */
 /* replaces: models/vit.py:75-83; models/med.py:178-220 (self, cross, cached);*/
 /* HF CLIPAttention.                                                          */
 /* ------------------------------------------------------------------------ */
 int vidil_attention(const void* q, const void* k, const void* vt, void* out,
-                    const int32_t* kv_len, const int32_t* kv_index, int32_t Bq,
-                    int32_t H, int32_t Nq,
+                    const int32_t* kv_len, const int32_t* kv_index,
+                    const int32_t* group_start, int32_t n_kv, int32_t max_group,
+                    int32_t Bq, int32_t H, int32_t Nq,
                     int32_t Nk, int32_t Tq_cap, int32_t Tk_cap, int32_t NP,
                     int32_t kv_group, int32_t causal, int32_t causal_off,
                     int32_t ldo, void* stream);

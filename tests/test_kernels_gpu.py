@@ -122,6 +122,111 @@ def test_gemm_patch_epilogue():
     assert torch.all(o[:, 0] == -7.0)
 
 
+# ---- the 256x256 8-wave kernel (large problems): same contracts, reference computed on the GPU in fp32 ----
+def _ref_mm(a, w, bias):
+    return (a.to(DEV).float() @ w.to(DEV).float().t() + bias.to(DEV)).cpu()
+
+
+@pytest.mark.parametrize("M,N,K", [(197 * 128 + 37, 768, 768), (197 * 64, 3072, 768), (197 * 96 + 5, 768, 3072),
+                                   (1536, 30524, 768), (50 * 512, 768, 768)])
+def test_gemm256_f16_and_f32(M, N, K):
+    k = _k()
+    a = _rand(M, K, seed=70).half()
+    w = _rand(N, K, scale=0.05, seed=71).half()
+    bias = _rand(N, seed=72)
+    ref = _ref_mm(a, w, bias)
+    o32 = k.gemm(a.to(DEV), w.to(DEV), bias.to(DEV), out_dtype=torch.float32).cpu()
+    assert torch.allclose(o32, ref, rtol=1e-4, atol=2e-3), (o32 - ref).abs().max()
+    if N % 8 == 0:
+        o16 = k.gemm(a.to(DEV), w.to(DEV), bias.to(DEV), out_dtype=torch.float16).float().cpu()
+        assert torch.allclose(o16, ref, rtol=2e-3, atol=3e-3)
+    # identical to the small-tile kernel bit for bit (same k order per output element)
+    os.environ["VIDIL_GEMM256_TEST"] = "1"
+    sub = slice(0, 300)
+    o_small = k.gemm(a[sub].to(DEV).contiguous(), w.to(DEV), bias.to(DEV), out_dtype=torch.float32).cpu()
+    assert torch.equal(o_small, o32[sub])
+
+
+def test_gemm256_transpose_detecting_and_tails():
+    k = _k()
+    M, N, K = 256 * 170 + 3, 320, 256        # 171 x 2 tiles; last row tile has 3 rows, last column tile 64 columns
+    a = torch.zeros(M, K)
+    a[torch.arange(M), torch.arange(M) % K] = 1.0
+    w = ((torch.arange(N * K).reshape(N, K) * 7) % 113).float()
+    out = k.gemm(a.half().to(DEV), w.half().to(DEV), None, out_dtype=torch.float32).cpu()
+    ref = w.t()[torch.arange(M) % K]
+    assert torch.equal(out, ref)
+
+
+@pytest.mark.parametrize("act", ["gelu", "quick", "none"])
+def test_gemm256_activation_residual(act):
+    k = _k()
+    M, N, K = 197 * 100, 3072 if act != "none" else 768, 768
+    a = _rand(M, K, seed=73).half()
+    w = _rand(N, K, scale=0.05, seed=74).half()
+    bias = _rand(N, seed=75)
+    pre = _ref_mm(a, w, bias)
+    if act == "none":
+        x = _rand(M, N, seed=76)
+        xd = x.to(DEV).clone()
+        k.gemm(a.to(DEV), w.to(DEV), bias.to(DEV), out=xd, resid=xd)
+        assert torch.allclose(xd.cpu(), x + pre, rtol=1e-4, atol=2e-3)
+        return
+    ref = torch.nn.functional.gelu(pre) if act == "gelu" else pre * torch.sigmoid(1.702 * pre)
+    code = k.ACT_GELU_ERF if act == "gelu" else k.ACT_QUICK_GELU
+    out = k.gemm(a.to(DEV), w.to(DEV), bias.to(DEV), act=code, out_dtype=torch.float16)
+    assert torch.allclose(out.float().cpu(), ref, rtol=2e-3, atol=3e-3)
+    # the small-tile kernel (picked for few rows) must agree BIT FOR BIT: results may not depend on batch size
+    small = k.gemm(a[:197 * 3].to(DEV).contiguous(), w.to(DEV), bias.to(DEV), act=code, out_dtype=torch.float16)
+    assert torch.equal(small.cpu(), out[:197 * 3].cpu())
+
+
+def test_gemm256_heads_and_patch_epilogues():
+    k = _k()
+    B, T, H = 128, 197, 12
+    M, K, N = B * T, 768, 3 * H * 64
+    NP = 200
+    a = _rand(M, K, seed=77).half()
+    w = _rand(N, K, scale=0.05, seed=78).half()
+    bias = _rand(N, seed=79)
+    ref = _ref_mm(a, w, bias).view(B, T, 3, H, 64)
+    q = torch.zeros(B, H, T, 64, dtype=torch.float16, device=DEV)
+    kk = torch.zeros(B, H, T, 64, dtype=torch.float16, device=DEV)
+    vt = torch.zeros(B, H, 64, NP, dtype=torch.float16, device=DEV)
+    k.gemm(a.to(DEV), w.to(DEV), bias.to(DEV),
+           heads=dict(q=q, k=kk, vt=vt, T=T, H=H, part0=0, t_off=0, Tq_cap=T, Tk_cap=T, NP=NP, q_scale=0.125))
+    tol = dict(rtol=2e-3, atol=3e-3)
+    assert torch.allclose(q.float().cpu(), ref[:, :, 0].permute(0, 2, 1, 3) * 0.125, **tol)
+    assert torch.allclose(kk.float().cpu(), ref[:, :, 1].permute(0, 2, 1, 3), **tol)
+    assert torch.allclose(vt.float().cpu()[..., :T], ref[:, :, 2].permute(0, 2, 3, 1), **tol)
+    assert torch.all(vt[..., T:] == 0)
+    # bit-identical to the small-tile kernel on a 2-frame batch
+    q2 = torch.zeros(2, H, T, 64, dtype=torch.float16, device=DEV)
+    k2 = torch.zeros(2, H, T, 64, dtype=torch.float16, device=DEV)
+    v2 = torch.zeros(2, H, 64, NP, dtype=torch.float16, device=DEV)
+    k.gemm(a[:2 * T].to(DEV).contiguous(), w.to(DEV), bias.to(DEV),
+           heads=dict(q=q2, k=k2, vt=v2, T=T, H=H, part0=0, t_off=0, Tq_cap=T, Tk_cap=T, NP=NP, q_scale=0.125))
+    assert torch.equal(q2, q[:2]) and torch.equal(k2, kk[:2]) and torch.equal(v2, vt[:2])
+    # cross K|V projection (parts 1,2 only)
+    w2, b2 = w[H * 64:].contiguous(), bias[H * 64:].contiguous()
+    kk.zero_(); vt.zero_()
+    k.gemm(a.to(DEV), w2.to(DEV), b2.to(DEV), heads=dict(k=kk, vt=vt, T=T, H=H, part0=1, Tk_cap=T, NP=NP))
+    assert torch.allclose(kk.float().cpu(), ref[:, :, 1].permute(0, 2, 1, 3), **tol)
+    assert torch.allclose(vt.float().cpu()[..., :T], ref[:, :, 2].permute(0, 2, 3, 1), **tol)
+    # patch epilogue
+    tpi = 196
+    ap = _rand(B * tpi, K, seed=80).half()
+    wp = _rand(768, K, scale=0.05, seed=81).half()
+    bp = _rand(768, seed=82)
+    pos = _rand(tpi + 1, 768, seed=83)
+    out = torch.full((B * (tpi + 1), 768), -7.0, dtype=torch.float32, device=DEV)
+    k.gemm(ap.to(DEV), wp.to(DEV), bp.to(DEV), patch=dict(out=out, pos=pos.to(DEV), tpi=tpi))
+    refp = _ref_mm(ap, wp, bp).view(B, tpi, 768) + pos[1:]
+    o = out.cpu().view(B, tpi + 1, 768)
+    assert torch.allclose(o[:, 1:], refp, rtol=1e-4, atol=2e-3)
+    assert torch.all(o[:, 0] == -7.0)
+
+
 def test_gemm_rejects_bad_k():
     k = _k()
     a = torch.zeros(8, 100, dtype=torch.float16, device=DEV)
@@ -199,6 +304,37 @@ def test_attention(Bq, H, Nq, Nk, kv_group, causal, use_len):
     got = out.float().cpu().view(Bq, Nq, H * 64)
     assert torch.isfinite(got).all()
     ref = _attn_ref((q * 0.125).half().float(), kk.float(), v.float(), kv_len, causal, 0, kv_group)
+    assert torch.allclose(got, ref, rtol=3e-3, atol=3e-3), (got - ref).abs().max()
+
+
+@pytest.mark.parametrize("Nq,Nk,counts,use_len", [
+    (35, 197, [3, 0, 8, 1, 5], False),     # ITM cross: captions per frame vary, one frame has none (LDS kernel, 4/8 waves)
+    (1, 197, [3, 3, 3, 3], False),         # decode cross via the table form (direct kernel)
+    (35, 35, [1, 1, 1], True),             # degenerate groups == plain batches, with key lengths
+    (4, 197, [9, 2], False),               # 36 rows -> LDS kernel, 8 rows -> same launch
+])
+def test_attention_grouped_by_prefix_table(Nq, Nk, counts, use_len):
+    """Query batches that share a key/value batch (captions of a frame, beams of an image)."""
+    k = _k()
+    H = 12
+    n_kv = len(counts)
+    Bq = sum(counts)
+    NP = (Nk + 7) // 8 * 8
+    q = (_rand(Bq, H, Nq, 64, seed=33) * 0.125).half()
+    kk = _rand(n_kv, H, Nk, 64, seed=34).half()
+    v = _rand(n_kv, H, Nk, 64, seed=35).half()
+    gs = torch.zeros(n_kv + 1, dtype=torch.int32)
+    gs[1:] = torch.cumsum(torch.tensor(counts), 0)
+    kv_of = torch.repeat_interleave(torch.arange(n_kv), torch.tensor(counts))
+    kv_len = torch.tensor([(5 * i) % Nk + 1 for i in range(Bq)], dtype=torch.int32) if use_len else None
+    ref = _attn_ref(q.float(), kk.float()[kv_of], v.float()[kv_of], kv_len)
+    vt = torch.full((n_kv, H, 64, NP), float("nan"), dtype=torch.float16)
+    vt[..., :Nk] = v.transpose(-1, -2)
+    out = torch.full((Bq * Nq, H * 64), 7.0, dtype=torch.float16, device=DEV)
+    k.attention(q.to(DEV), kk.to(DEV), vt.to(DEV), out, Bq=Bq, H=H, Nq=Nq, Nk=Nk, Tq_cap=Nq, Tk_cap=Nk, NP=NP,
+                group_start=gs.to(DEV), max_group=max(counts), kv_len=None if kv_len is None else kv_len.to(DEV))
+    got = out.float().cpu().view(Bq, Nq, H * 64)
+    assert torch.isfinite(got).all()
     assert torch.allclose(got, ref, rtol=3e-3, atol=3e-3), (got - ref).abs().max()
 
 

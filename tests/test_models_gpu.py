@@ -204,7 +204,8 @@ def test_full_vit_and_caption_logits_and_beam_tokens_vs_oracle(full_models):
         assert np.abs(cs.cpu().numpy() - oc).max() < 1e-2
         for b in range(B):
             if np.min(oc[b][:-1] - oc[b][1:]) > 1e-2:
-                assert np.array_equal(ci[b].cpu().numpy(), otrace[s]["cand_index"][b]), (s, b)
+                # (the identity of the LAST candidate depends on its gap to the unseen 7th one: compare the first 5)
+                assert np.array_equal(ci[b].cpu().numpy()[:-1], otrace[s]["cand_index"][b][:-1]), (s, b)
                 n_decisive += 1
     assert n_decisive >= 10, n_decisive
 

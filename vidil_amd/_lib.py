@@ -53,7 +53,7 @@ SIGNATURES = {
     "vidil_num_entry_points": (_i32, []),
     "vidil_gemm_f16": (_i32, [C.POINTER(GemmArgs), _p]),
     "vidil_layernorm": (_i32, [_p, _i64, _p, _p, _f32, _i32, _i32, _p, _p, _p]),
-    "vidil_attention": (_i32, [_p, _p, _p, _p, _p, _p] + [_i32] * 11 + [_p]),
+    "vidil_attention": (_i32, [_p, _p, _p, _p, _p, _p, _p] + [_i32] * 13 + [_p]),
     "vidil_patchify_f32": (_i32, [_p, _p, _i32, _i32, _i32, _p]),
     "vidil_patchify_u8": (_i32, [_p, _p, _i32, _i32, _i32, C.POINTER(_f32), C.POINTER(_f32), _p]),
     "vidil_set_cls_row": (_i32, [_p, _p, _p, _i32, _i32, _i32, _p]),

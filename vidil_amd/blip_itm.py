@@ -53,9 +53,11 @@ class BLIP_ITM(PackedCache, nn.Module):
 
     # ------------------------------------------------------------------ de-duplicated schedule
     @torch.no_grad()
-    def itm_pairs(self, enc16, n_images, ids, lens, image_index):
-        """enc16 f16 [n_images*Te, width]; ids i32 [P,35]; lens i32 [P]; image_index i32 [P].
-        Returns f32 [P,2] raw ITM logits."""
+    def itm_pairs(self, enc16, n_images, ids, lens, image_index=None, group_start=None, max_group=0):
+        """enc16 f16 [n_images*Te, width]; ids i32 [P,35]; lens i32 [P].  Either image_index i32 [P] (pair ->
+        image, any order) or, for IMAGE-MAJOR pair order, group_start i32 [n_images+1] (pairs of image j are
+        group_start[j] .. group_start[j+1]-1, at most max_group of them), which lets one fetch of an image's
+        cross K/V serve all its captions.  Returns f32 [P,2] raw ITM logits."""
         require_cuda(enc16, "BLIP_ITM")
         te = self.text_encoder
         dev = enc16.device
@@ -63,10 +65,14 @@ class BLIP_ITM(PackedCache, nn.Module):
         cross = te.project_cross_kv(enc16, n_images, Te)
         ids = ids.to(dev).contiguous()
         lens = lens.to(dev).contiguous()
-        image_index = image_index.to(dev).to(torch.int32).contiguous()
+        if group_start is not None:
+            group_start = group_start.to(dev).to(torch.int32).contiguous()
+        else:
+            image_index = image_index.to(dev).to(torch.int32).contiguous()
         P, T = ids.shape
         C = te.config.hidden_size
-        _, h16 = te.encode(ids, lens, cross, image_index)
+        _, h16 = te.encode(ids, lens, cross, cross_index=image_index, cross_groups=group_start,
+                           cross_max_group=max_group)
         # itm_head on token 0 of every pair: the GEMM reads rows p*T of h16 (strided A operand)
         p = self.packed()
         out = torch.empty((P, 2), dtype=torch.float32, device=dev)

@@ -168,14 +168,34 @@ class CapFiltEngine:
         if not all_caps:
             return kept
         ids, lens = flt.tokenize(all_caps)
-        # pair order: caption-major, frame-minor (the reference's loop order, :110-112)
-        cap_idx = torch.arange(len(all_caps)).repeat_interleave(F)
-        img_idx = (torch.tensor(cap_video) * F).repeat_interleave(F) + torch.arange(F).repeat(len(all_caps))
-        logits = flt.itm_pairs(y16, Nv * F, ids[cap_idx], lens[cap_idx], img_idx.to(torch.int32))
-        prob = torch.nn.functional.softmax(logits, dim=1)[:, 1].detach().cpu().numpy().reshape(len(all_caps), F)
-        for i, c in enumerate(all_caps):
-            if keep_caption(prob[i], cfg.get("threshold", 0.4), cfg.get("filter_mode", "max_filter")):
-                kept[cap_video[i]].append(c)
+        # pair order: IMAGE-major (video, frame, caption) so the captions of a frame are consecutive and share
+        # one fetch of that frame's cross K/V; the reference's loop is caption-major (:110-112) but every
+        # (frame, caption) score is independent of the order.
+        cap_first, n = [], 0
+        for caps in caps_per_video:
+            cap_first.append(n)
+            n += len(caps)
+        pair_cap, counts = [], []
+        for v, caps in enumerate(caps_per_video):
+            block = list(range(cap_first[v], cap_first[v] + len(caps)))
+            for _ in range(F):
+                pair_cap.extend(block)
+                counts.append(len(caps))
+        pair_cap = torch.tensor(pair_cap, dtype=torch.long)
+        group_start = torch.zeros(Nv * F + 1, dtype=torch.int32)
+        group_start[1:] = torch.cumsum(torch.tensor(counts, dtype=torch.int32), 0)
+        logits = flt.itm_pairs(y16, Nv * F, ids[pair_cap], lens[pair_cap], group_start=group_start,
+                               max_group=max(counts))
+        prob = torch.nn.functional.softmax(logits, dim=1)[:, 1].detach().cpu().numpy()
+        gs = group_start.numpy()
+        for v, caps in enumerate(caps_per_video):
+            if not caps:
+                continue
+            # rows of this video: F consecutive blocks of len(caps) pairs -> [F, C] -> per caption over frames
+            pv = prob[gs[v * F]: gs[v * F] + F * len(caps)].reshape(F, len(caps))
+            for ci, c in enumerate(caps):
+                if keep_caption(pv[:, ci], cfg.get("threshold", 0.4), cfg.get("filter_mode", "max_filter")):
+                    kept[v].append(c)
         return kept
 
 

@@ -1,20 +1,32 @@
 // attention.hip — softmax(Q K^T) V for the short sequences on this path
 // (ViT 197 keys, CLIP 50/77/257, MED text 1..35 queries over <=20 cached or 197
-// image keys).  One workgroup = (128 query rows, one head, one query batch);
-// each wave owns 32 query rows.
+// image keys).
 //
-// gfx950 design:
-//   * K ([keys][64], rows padded to 144 B) and V^T ([64][keys], row stride
-//     keys+4 halfs) of the head are staged once in LDS; both strides are chosen
-//     so the ds_read_b128 / ds_read_b64 fragment reads are bank-conflict free.
-//   * scores are computed TRANSPOSED (S^T = K·Q^T, v_mfma_f32_32x32x16_f16) so
-//     a lane holds every score of its own query row: the whole softmax is
-//     in-register (one cross-half shuffle per reduction), no online rescale is
-//     needed because all keys (<=288) fit in registers.
-//   * the P registers feed the P·V MFMA A-operand directly; the key order
-//     inside a 16-key MFMA step is the order the S^T layout leaves them in
-//     ({0-3,8-11} / {4-7,12-15} per half-wave) and the V^T fragment reads use
-//     the same order, so no permute is needed.
+// Work unit = (key/value batch j, head h): all query batches that read j's K/V
+// (uniform groups of `kv_group` consecutive query batches, or an explicit prefix
+// table `group_start`) are flattened into "virtual rows" v = (qb - first)*Nq + t,
+// so an image's K/V are fetched once for every caption / beam that attends to it.
+//
+// Two kernels, both built on v_mfma_f32_32x32x16_f16 with the scores computed
+// TRANSPOSED (S^T = K·Q^T) so a lane owns one query row and the online softmax
+// is lane-local (one cross-half shuffle per key tile), and with the output
+// accumulated TRANSPOSED too (O^T = V^T·P^T) so the running rescale and the
+// final 1/l are lane-local as well and a lane stores 4 contiguous d values:
+//
+//   attn_lds_kernel    rows > 32: K ([keys][64], rows padded to 144 B) and V^T
+//                      ([64][keys], stride keys+4) staged once in LDS (strides
+//                      chosen so ds_read_b128/_b64 fragment reads are conflict
+//                      free); each wave owns 32 virtual rows, 4 or 8 waves.
+//   attn_direct_kernel rows <= 32 (decode steps, prefill): every K/V element is
+//                      used by one wave only, so fragments are loaded straight
+//                      from HBM/L2 into MFMA operands (no LDS round trip); the 4
+//                      waves split the key tiles (flash-decoding) and merge their
+//                      (m, l, O) partials through 17 KB of LDS.
+//
+// The key order inside a 16-key MFMA step is the order the S^T accumulator
+// layout leaves the P values in ({0-3,8-11} / {4-7,12-15} per half-wave); the
+// V^T fragment reads use the same order, so P feeds the second MFMA without any
+// permute.
 #include "common.h"
 
 namespace {
@@ -24,65 +36,164 @@ struct AttnP {
   const f16* k;
   const f16* vt;
   f16* out;
-  const int32_t* kv_len;
-  const int32_t* kv_index;
-  int Bq, H, Nq, Nk, Tq_cap, Tk_cap, NP, kv_group, causal, causal_off, ldo;
+  const int32_t* kv_len;       // per query batch, or null
+  const int32_t* kv_index;     // per query batch -> kv batch (only with kv_group == 1 semantics), or null
+  const int32_t* group_start;  // [n_kv+1] prefix of query batches per kv batch, or null
+  int Bq, H, Nq, Nk, Tq_cap, Tk_cap, NP, kv_group, causal, causal_off, ldo, n_kv;
 };
 
 constexpr int KROW = 72;  // halfs per K row in LDS (64 + 8 pad)
 
-template <int NKT>
-__global__ __launch_bounds__(256) void attn_kernel(const AttnP p) {
+struct RowInfo {
+  int qb;     // query batch of this lane's virtual row
+  int t;      // position inside the batch
+  int klim;   // keys >= klim are excluded for this row
+  bool valid;
+};
+
+// Resolve the work unit: kv batch + [first, first+count) query batches.
+__device__ __forceinline__ void resolve_unit(const AttnP& p, int z, int& bk, int& first, int& count) {
+  if (p.group_start != nullptr) {
+    bk = z;
+    first = p.group_start[z];
+    count = p.group_start[z + 1] - first;
+  } else if (p.kv_index != nullptr) {
+    bk = p.kv_index[z];
+    first = z;
+    count = 1;
+  } else {
+    bk = z;
+    first = z * p.kv_group;
+    count = p.kv_group;
+  }
+}
+
+__device__ __forceinline__ RowInfo row_info(const AttnP& p, int v, int first, int rows) {
+  RowInfo r;
+  r.valid = v < rows;
+  const int vc = r.valid ? v : rows - 1;
+  const int g = vc / p.Nq;
+  r.qb = first + g;
+  r.t = vc - g * p.Nq;
+  int klim = p.Nk;
+  if (p.kv_len != nullptr) {
+    const int L = p.kv_len[r.qb];
+    klim = L < klim ? L : klim;
+  }
+  if (p.causal) {
+    const int c = r.t + p.causal_off + 1;
+    klim = c < klim ? c : klim;
+  }
+  r.klim = klim;
+  return r;
+}
+
+// One key tile of online softmax + P·V for the 32 rows of a wave.
+// S: scores of this tile (S^T layout: lane = row, 16 keys per half-wave).
+template <typename VFrag>
+__device__ __forceinline__ void softmax_pv_tile(f32x16& S, int key0, int klim, bool need_mask, float& m, float& l,
+                                                f32x16 (&O)[2], VFrag&& vfrag) {
+  const int hi = (threadIdx.x & 63) >> 5;
+  if (need_mask) {
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int key = key0 + (r & 3) + 8 * (r >> 2) + 4 * hi;
+      if (key >= klim) S[r] = -INFINITY;
+    }
+  }
+  float mt = S[0];
+#pragma unroll
+  for (int r = 1; r < 16; ++r) mt = fmaxf(mt, S[r]);
+  mt = fmaxf(mt, __shfl_xor(mt, 32, 64));
+  const float mn = fmaxf(m, mt);
+  const float msafe = mn == -INFINITY ? 0.f : mn;
+  const float alpha = __expf(m - msafe);  // m == -inf -> 0
+  float ps = 0.f;
+#pragma unroll
+  for (int r = 0; r < 16; ++r) {
+    const float e = __expf(S[r] - msafe);
+    S[r] = e;
+    ps += e;
+  }
+  l = l * alpha + ps;
+  m = mn;
+#pragma unroll
+  for (int dt = 0; dt < 2; ++dt)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) O[dt][r] *= alpha;
+#pragma unroll
+  for (int hb = 0; hb < 2; ++hb) {
+    f16x8 pf;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) pf[j] = (f16)S[hb * 8 + j];
+#pragma unroll
+    for (int dt = 0; dt < 2; ++dt) {
+      const f16x8 vf = vfrag(dt, hb);
+      // O^T[d][q] += V^T[d][keys] · P^T[keys][q]
+      O[dt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(vf, pf, O[dt], 0, 0, 0);
+    }
+  }
+}
+
+// O[dt][r] is (d = dt*32 + (r&3) + 8*(r>>2) + 4*hi, row = lane&31): 4 contiguous d per register quad.
+__device__ __forceinline__ void store_rows(const AttnP& p, const RowInfo& ri, int h, const f32x16 (&O)[2], float inv) {
+  if (!ri.valid) return;
+  const int hi = (threadIdx.x & 63) >> 5;
+  f16* og = p.out + ((size_t)ri.qb * p.Nq + ri.t) * p.ldo + h * 64 + 4 * hi;
+#pragma unroll
+  for (int dt = 0; dt < 2; ++dt)
+#pragma unroll
+    for (int rq = 0; rq < 4; ++rq) {
+      const f16x4 v = {(f16)(O[dt][rq * 4 + 0] * inv), (f16)(O[dt][rq * 4 + 1] * inv), (f16)(O[dt][rq * 4 + 2] * inv),
+                       (f16)(O[dt][rq * 4 + 3] * inv)};
+      *(f16x4*)(og + dt * 32 + rq * 8) = v;
+    }
+}
+
+// ------------------------------------------------------------------ LDS-staged kernel
+template <int NKT, int NW>
+__global__ __launch_bounds__(NW * 64) void attn_lds_kernel(const AttnP p) {
   constexpr int NKEY = NKT * 32;
   constexpr int VROW = NKEY + 4;  // halfs per V^T row in LDS
+  constexpr int NT = NW * 64;
   extern __shared__ __attribute__((aligned(16))) char smem[];
-  f16* Ks = (f16*)smem;                       // [NKEY][KROW]
-  f16* Vs = (f16*)(smem + NKEY * KROW * 2);   // [64][VROW]
+  f16* Ks = (f16*)smem;                      // [NKEY][KROW]
+  f16* Vs = (f16*)(smem + NKEY * KROW * 2);  // [64][VROW]
 
   const int tid = threadIdx.x;
   const int lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int hi = lane >> 5, l31 = lane & 31;
-  const int h = blockIdx.y, bq = blockIdx.z;
-  const int bk = p.kv_index != nullptr ? p.kv_index[bq] : bq / p.kv_group;
-  int kvlen = p.Nk;
-  if (p.kv_len != nullptr) {
-    const int v = p.kv_len[bq];
-    kvlen = v < kvlen ? v : kvlen;
-  }
+  const int h = blockIdx.y;
+  int bk, first, count;
+  resolve_unit(p, blockIdx.z, bk, first, count);
+  const int rows = count * p.Nq;
+  if ((int)blockIdx.x * (NW * 32) >= rows) return;  // uniform: this row tile is empty for this unit
+  const int nk = p.Nk;
 
-  // ---- stage K -------------------------------------------------------------
+  // ---- stage K (rows >= Nk zero) ----------------------------------------------------------------
   {
     const f16* kg = p.k + ((size_t)bk * p.H + h) * p.Tk_cap * 64;
-#pragma unroll
-    for (int it = 0; it < NKT; ++it) {
-      const int q = it * 256 + tid;
+    for (int q = tid; q < NKEY * 8; q += NT) {
       const int row = q >> 3, c = q & 7;
       f16x8 v = {0, 0, 0, 0, 0, 0, 0, 0};
-      if (row < kvlen) v = *(const f16x8*)(kg + (size_t)row * 64 + c * 8);
+      if (row < nk) v = *(const f16x8*)(kg + (size_t)row * 64 + c * 8);
       *(f16x8*)(Ks + row * KROW + c * 8) = v;
     }
   }
-  // ---- stage V^T -----------------------------------------------------------
+  // ---- stage V^T (keys >= Nk zero: masked P is 0 but 0*garbage must stay 0) -------------------------
   {
     const f16* vg = p.vt + ((size_t)bk * p.H + h) * 64 * (size_t)p.NP;
-#pragma unroll
-    for (int it = 0; it < NKT; ++it) {
-      const int q = it * 256 + tid;
+    for (int q = tid; q < 64 * NKT * 4; q += NT) {
       const int d = q / (NKT * 4), kc = q - d * (NKT * 4);
       const int key0 = kc * 8;
       f16x8 v = {0, 0, 0, 0, 0, 0, 0, 0};
-      if (key0 < kvlen && key0 + 8 <= p.NP) {
+      if (key0 + 8 <= nk) {
         v = *(const f16x8*)(vg + (size_t)d * p.NP + key0);
-        if (key0 + 8 > kvlen) {
-#pragma unroll
-          for (int e = 0; e < 8; ++e)
-            if (key0 + e >= kvlen) v[e] = (f16)0.f;
-        }
-      } else if (key0 < kvlen) {  // ragged tail of the global row
+      } else if (key0 < nk) {
 #pragma unroll
         for (int e = 0; e < 8; ++e)
-          if (key0 + e < kvlen && key0 + e < p.NP) v[e] = vg[(size_t)d * p.NP + key0 + e];
+          if (key0 + e < nk) v[e] = vg[(size_t)d * p.NP + key0 + e];
       }
       f16* dst = Vs + d * VROW + key0;
       *(f16x4*)(dst) = f16x4{v[0], v[1], v[2], v[3]};
@@ -91,104 +202,172 @@ __global__ __launch_bounds__(256) void attn_kernel(const AttnP p) {
   }
   __syncthreads();
 
-  const int q0 = blockIdx.x * 128 + wave * 32;
-  if (q0 >= p.Nq) return;
+  const int v0 = blockIdx.x * (NW * 32) + wave * 32;
+  if (v0 >= rows) return;
+  const RowInfo ri = row_info(p, v0 + l31, first, rows);
 
-  // ---- Q fragments (B operand: n = query = lane&31, k = d) ----------------------
   f16x8 qf[4];
   {
-    int row = q0 + l31;
-    row = row < p.Nq ? row : p.Nq - 1;
-    const f16* qg = p.q + (((size_t)bq * p.H + h) * p.Tq_cap + row) * 64 + hi * 8;
+    const f16* qg = p.q + (((size_t)ri.qb * p.H + h) * p.Tq_cap + ri.t) * 64 + hi * 8;
 #pragma unroll
     for (int ks = 0; ks < 4; ++ks) qf[ks] = *(const f16x8*)(qg + ks * 16);
   }
-
-  // ---- S^T = K · Q^T ---------------------------------------------------------------
-  f32x16 S[NKT];
+  // smallest klim in the wave decides from which tile on masking is needed
+  int kmin = ri.klim;
 #pragma unroll
-  for (int kt = 0; kt < NKT; ++kt) {
-#pragma unroll
-    for (int r = 0; r < 16; ++r) S[kt][r] = 0.f;
-#pragma unroll
-    for (int ks = 0; ks < 4; ++ks) {
-      const f16x8 kf = *(const f16x8*)(Ks + (kt * 32 + l31) * KROW + ks * 16 + hi * 8);
-      S[kt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(kf, qf[ks], S[kt], 0, 0, 0);
-    }
+  for (int o = 32; o > 0; o >>= 1) {
+    const int x = __shfl_xor(kmin, o, 64);
+    kmin = x < kmin ? x : kmin;
   }
 
-  // ---- mask + softmax over this lane's query row ----------------------------------
-  const int qpos = q0 + l31;
-  int klim = kvlen;  // keys >= klim are excluded
-  if (p.causal) {
-    const int c = qpos + p.causal_off + 1;
-    klim = c < klim ? c : klim;
-  }
-  float mx = -INFINITY;
-#pragma unroll
-  for (int kt = 0; kt < NKT; ++kt)
-#pragma unroll
-    for (int r = 0; r < 16; ++r) {
-      const int key = kt * 32 + (r & 3) + 8 * (r >> 2) + 4 * hi;
-      const float s = key < klim ? S[kt][r] : -INFINITY;
-      S[kt][r] = s;
-      mx = fmaxf(mx, s);
-    }
-  mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
-  if (mx == -INFINITY) mx = 0.f;
-  float sum = 0.f;
-#pragma unroll
-  for (int kt = 0; kt < NKT; ++kt)
-#pragma unroll
-    for (int r = 0; r < 16; ++r) {
-      const float e = __expf(S[kt][r] - mx);
-      S[kt][r] = e;
-      sum += e;
-    }
-  sum += __shfl_xor(sum, 32, 64);
-  const float inv = sum > 0.f ? 1.0f / sum : 0.f;
-
-  // ---- O = P · V ---------------------------------------------------------------------
+  float m = -INFINITY, l = 0.f;
   f32x16 O[2];
 #pragma unroll
   for (int dt = 0; dt < 2; ++dt)
 #pragma unroll
     for (int r = 0; r < 16; ++r) O[dt][r] = 0.f;
+
+#pragma unroll 1
+  for (int kt = 0; kt < NKT; ++kt) {
+    f32x16 S;
 #pragma unroll
-  for (int blk = 0; blk < 2 * NKT; ++blk) {
-    const int kt = blk >> 1, hb = blk & 1;
-    f16x8 pf;
+    for (int r = 0; r < 16; ++r) S[r] = 0.f;
 #pragma unroll
-    for (int j = 0; j < 8; ++j) pf[j] = (f16)S[kt][hb * 8 + j];
-#pragma unroll
-    for (int dt = 0; dt < 2; ++dt) {
-      const f16* vrow = Vs + (dt * 32 + l31) * VROW + blk * 16 + 4 * hi;
+    for (int ks = 0; ks < 4; ++ks) {
+      const f16x8 kf = *(const f16x8*)(Ks + (kt * 32 + l31) * KROW + ks * 16 + hi * 8);
+      S = __builtin_amdgcn_mfma_f32_32x32x16_f16(kf, qf[ks], S, 0, 0, 0);
+    }
+    const bool need_mask = (kt * 32 + 32) > kmin;
+    softmax_pv_tile(S, kt * 32, ri.klim, need_mask, m, l, O, [&](int dt, int hb) {
+      const f16* vrow = Vs + (dt * 32 + l31) * VROW + (kt * 2 + hb) * 16 + 4 * hi;
       const f16x4 lo = *(const f16x4*)(vrow);
       const f16x4 up = *(const f16x4*)(vrow + 8);
-      const f16x8 vf = {lo[0], lo[1], lo[2], lo[3], up[0], up[1], up[2], up[3]};
-      O[dt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(pf, vf, O[dt], 0, 0, 0);
+      return f16x8{lo[0], lo[1], lo[2], lo[3], up[0], up[1], up[2], up[3]};
+    });
+  }
+  l += __shfl_xor(l, 32, 64);
+  store_rows(p, ri, h, O, l > 0.f ? 1.0f / l : 0.f);
+}
+
+// ------------------------------------------------------------------ direct (no K/V staging) kernel
+// rows <= 32.  4 waves; wave w handles key tiles w, w+4, ...; partials merged by wave 0.
+template <int NKT>
+__global__ __launch_bounds__(256) void attn_direct_kernel(const AttnP p) {
+  __shared__ float part_m[4][32];
+  __shared__ float part_l[4][32];
+  __shared__ float part_o[4][64][33];  // [wave][d][row] (+1 pad)
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int hi = lane >> 5, l31 = lane & 31;
+  const int h = blockIdx.y;
+  int bk, first, count;
+  resolve_unit(p, blockIdx.z, bk, first, count);
+  const int rows = count * p.Nq;
+  if (rows <= 0) return;  // uniform: a kv batch nobody attends to
+  const int nk = p.Nk;
+  const RowInfo ri = row_info(p, l31, first, rows);
+
+  float m = -INFINITY, l = 0.f;
+  f32x16 O[2];
+#pragma unroll
+  for (int dt = 0; dt < 2; ++dt)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) O[dt][r] = 0.f;
+
+  const f16* kg = p.k + ((size_t)bk * p.H + h) * p.Tk_cap * 64;
+  const f16* vg = p.vt + ((size_t)bk * p.H + h) * 64 * (size_t)p.NP;
+  const int ntiles = (nk + 31) >> 5;
+  if (wave < ntiles) {
+    f16x8 qf[4];
+    {
+      const f16* qg = p.q + (((size_t)ri.qb * p.H + h) * p.Tq_cap + ri.t) * 64 + hi * 8;
+#pragma unroll
+      for (int ks = 0; ks < 4; ++ks) qf[ks] = *(const f16x8*)(qg + ks * 16);
+    }
+    int kmin = ri.klim;
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+      const int x = __shfl_xor(kmin, o, 64);
+      kmin = x < kmin ? x : kmin;
+    }
+#pragma unroll
+    for (int i = 0; i < (NKT + 3) / 4; ++i) {
+      const int kt = wave + 4 * i;
+      if (kt >= ntiles) break;
+      int krow = kt * 32 + l31;
+      krow = krow < nk ? krow : nk - 1;  // clamped rows are masked below
+      const f16* kr = kg + (size_t)krow * 64 + hi * 8;
+      f32x16 S;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) S[r] = 0.f;
+#pragma unroll
+      for (int ks = 0; ks < 4; ++ks) S = __builtin_amdgcn_mfma_f32_32x32x16_f16(*(const f16x8*)(kr + ks * 16), qf[ks], S, 0, 0, 0);
+      const bool tail = (kt * 32 + 32) > nk;  // tile reaches past the last key: V^T needs zeroing too
+      const bool need_mask = (kt * 32 + 32) > kmin;
+      softmax_pv_tile(S, kt * 32, ri.klim, need_mask, m, l, O, [&](int dt, int hb) {
+        const int key0 = (kt * 2 + hb) * 16 + 4 * hi;
+        const f16* vrow = vg + (size_t)(dt * 32 + l31) * p.NP + key0;
+        f16x8 v = {0, 0, 0, 0, 0, 0, 0, 0};
+        if (!tail) {
+          const f16x4 lo = *(const f16x4*)(vrow);
+          const f16x4 up = *(const f16x4*)(vrow + 8);
+          v = f16x8{lo[0], lo[1], lo[2], lo[3], up[0], up[1], up[2], up[3]};
+        } else {
+#pragma unroll
+          for (int e = 0; e < 4; ++e) {
+            if (key0 + e < nk) v[e] = vrow[e];
+            if (key0 + 8 + e < nk) v[4 + e] = vrow[8 + e];
+          }
+        }
+        return v;
+      });
     }
   }
-
-  // ---- store: O[dt][r] is (query = (r&3)+8*(r>>2)+4*hi, d = dt*32 + lane&31) -------
-  f16* og = p.out + (size_t)bq * p.Nq * p.ldo + h * 64;
+  // ---- merge the waves' partials --------------------------------------------------------------
+  l += __shfl_xor(l, 32, 64);
+  if (hi == 0) { part_m[wave][l31] = m; part_l[wave][l31] = l; }
 #pragma unroll
-  for (int r = 0; r < 16; ++r) {
-    const int qq = (r & 3) + 8 * (r >> 2) + 4 * hi;
-    const float il = __shfl(inv, qq, 64);
-    const int row = q0 + qq;
-    if (row < p.Nq) {
+  for (int dt = 0; dt < 2; ++dt)
 #pragma unroll
-      for (int dt = 0; dt < 2; ++dt) og[(size_t)row * p.ldo + dt * 32 + l31] = (f16)(O[dt][r] * il);
+    for (int r = 0; r < 16; ++r) part_o[wave][dt * 32 + (r & 3) + 8 * (r >> 2) + 4 * hi][l31] = O[dt][r];
+  __syncthreads();
+  // all 256 threads: thread = (row = tid&31, d-block = tid>>5 of 8 d values)
+  {
+    const int row = tid & 31, db = tid >> 5;
+    if (row < rows) {
+      float mm = part_m[0][row];
+#pragma unroll
+      for (int w = 1; w < 4; ++w) mm = fmaxf(mm, part_m[w][row]);
+      float sc[4], lt = 0.f;
+#pragma unroll
+      for (int w = 0; w < 4; ++w) {
+        sc[w] = part_m[w][row] == -INFINITY ? 0.f : __expf(part_m[w][row] - mm);
+        lt += part_l[w][row] * sc[w];
+      }
+      const float inv = lt > 0.f ? 1.0f / lt : 0.f;
+      const int g = row / p.Nq;
+      const int qb = first + g, t = row - g * p.Nq;
+      f16x8 o8;
+#pragma unroll
+      for (int e = 0; e < 8; ++e) {
+        const int d = db * 8 + e;
+        float acc = 0.f;
+#pragma unroll
+        for (int w = 0; w < 4; ++w) acc += part_o[w][d][row] * sc[w];
+        o8[e] = (f16)(acc * inv);
+      }
+      *(f16x8*)(p.out + ((size_t)qb * p.Nq + t) * p.ldo + h * 64 + db * 8) = o8;
     }
   }
 }
 
-template <int NKT>
-int launch(const AttnP& p, hipStream_t s) {
+template <int NKT, int NW>
+int launch_lds(const AttnP& p, int max_rows, hipStream_t s) {
   constexpr int smem = NKT * 32 * KROW * 2 + 64 * (NKT * 32 + 4) * 2;
   static bool attr_set = false;
-  auto kern = attn_kernel<NKT>;
+  auto kern = attn_lds_kernel<NKT, NW>;
   if (!attr_set) {
     hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, smem);
     if (e != hipSuccess) {
@@ -197,42 +376,66 @@ int launch(const AttnP& p, hipStream_t s) {
     }
     attr_set = true;
   }
-  dim3 grid((p.Nq + 127) / 128, p.H, p.Bq);
-  hipLaunchKernelGGL(kern, grid, dim3(256), smem, s, p);
+  dim3 grid((max_rows + NW * 32 - 1) / (NW * 32), p.H, p.n_kv);
+  hipLaunchKernelGGL(kern, grid, dim3(NW * 64), smem, s, p);
   VIDIL_CHECK_LAUNCH("attention");
   return VIDIL_OK;
 }
 
+template <int NKT>
+int launch_any(const AttnP& p, int max_rows, hipStream_t s) {
+  if (max_rows <= 32) {
+    hipLaunchKernelGGL(attn_direct_kernel<NKT>, dim3(1, p.H, p.n_kv), dim3(256), 0, s, p);
+    VIDIL_CHECK_LAUNCH("attention/direct");
+    return VIDIL_OK;
+  }
+  if (max_rows > 128) return launch_lds<NKT, 8>(p, max_rows, s);
+  return launch_lds<NKT, 4>(p, max_rows, s);
+}
+
 }  // namespace
 
-extern "C" int vidil_attention(const void* q, const void* k, const void* vt, void* out,
-                               const int32_t* kv_len, const int32_t* kv_index, int32_t Bq, int32_t H, int32_t Nq,
-                               int32_t Nk, int32_t Tq_cap, int32_t Tk_cap, int32_t NP,
-                               int32_t kv_group, int32_t causal, int32_t causal_off,
-                               int32_t ldo, void* stream) {
+extern "C" int vidil_attention(const void* q, const void* k, const void* vt, void* out, const int32_t* kv_len,
+                               const int32_t* kv_index, const int32_t* group_start, int32_t n_kv, int32_t max_group,
+                               int32_t Bq, int32_t H, int32_t Nq, int32_t Nk, int32_t Tq_cap, int32_t Tk_cap, int32_t NP,
+                               int32_t kv_group, int32_t causal, int32_t causal_off, int32_t ldo, void* stream) {
   VIDIL_REQUIRE(q && k && vt && out, "attention: null pointer");
   VIDIL_REQUIRE(Bq > 0 && H > 0 && Nq > 0 && Nk > 0, "attention: bad shape Bq=%d H=%d Nq=%d Nk=%d", Bq, H, Nq, Nk);
-  VIDIL_REQUIRE(kv_group > 0 && (kv_index != nullptr || Bq % kv_group == 0), "attention: Bq=%d not a multiple of kv_group=%d", Bq, kv_group);
   VIDIL_REQUIRE(Tq_cap >= Nq && Tk_cap >= Nk && NP >= Nk, "attention: capacities too small");
   VIDIL_REQUIRE(NP % 8 == 0, "attention: NP=%d must be a multiple of 8", NP);
-  VIDIL_REQUIRE(ldo >= H * 64, "attention: ldo=%d < H*64", ldo);
-  VIDIL_REQUIRE(H <= 65535 && Bq <= 65535 * 1, "attention: grid too large (H=%d Bq=%d)", H, Bq);
-  AttnP p{(const f16*)q, (const f16*)k, (const f16*)vt, (f16*)out, kv_len, kv_index, Bq, H, Nq, Nk,
-          Tq_cap, Tk_cap, NP, kv_group, causal, causal_off, ldo};
+  VIDIL_REQUIRE(ldo >= H * 64 && ldo % 8 == 0, "attention: ldo=%d must be >= H*64 and a multiple of 8", ldo);
+  VIDIL_REQUIRE(kv_group > 0, "attention: kv_group=%d", kv_group);
+  int units, max_rows;
+  if (group_start != nullptr) {
+    VIDIL_REQUIRE(kv_index == nullptr, "attention: group_start and kv_index are mutually exclusive");
+    VIDIL_REQUIRE(n_kv > 0 && max_group > 0, "attention: group_start needs n_kv and max_group");
+    units = n_kv;
+    max_rows = max_group * Nq;
+  } else if (kv_index != nullptr) {
+    units = Bq;
+    max_rows = Nq;
+  } else {
+    VIDIL_REQUIRE(Bq % kv_group == 0, "attention: Bq=%d not a multiple of kv_group=%d", Bq, kv_group);
+    units = Bq / kv_group;
+    max_rows = kv_group * Nq;
+  }
+  VIDIL_REQUIRE(H <= 65535 && units <= 65535, "attention: grid too large (H=%d units=%d)", H, units);
+  AttnP p{(const f16*)q, (const f16*)k, (const f16*)vt, (f16*)out, kv_len, kv_index, group_start, Bq, H, Nq, Nk,
+          Tq_cap, Tk_cap, NP, kv_group, causal, causal_off, ldo, units};
   hipStream_t s = (hipStream_t)stream;
   const int nkt = (Nk + 31) / 32;
   switch (nkt) {
-    case 1: return launch<1>(p, s);
-    case 2: return launch<2>(p, s);
-    case 3: return launch<3>(p, s);
-    case 4: return launch<4>(p, s);
-    case 5: return launch<5>(p, s);
-    case 6: return launch<6>(p, s);
-    case 7: return launch<7>(p, s);
-    case 8: return launch<8>(p, s);
-    case 9: return launch<9>(p, s);
+    case 1: return launch_any<1>(p, max_rows, s);
+    case 2: return launch_any<2>(p, max_rows, s);
+    case 3: return launch_any<3>(p, max_rows, s);
+    case 4: return launch_any<4>(p, max_rows, s);
+    case 5: return launch_any<5>(p, max_rows, s);
+    case 6: return launch_any<6>(p, max_rows, s);
+    case 7: return launch_any<7>(p, max_rows, s);
+    case 8: return launch_any<8>(p, max_rows, s);
+    case 9: return launch_any<9>(p, max_rows, s);
     default: break;
   }
-  vidil_set_error("attention: Nk=%d > 288 not supported by the in-register softmax kernel", Nk);
+  vidil_set_error("attention: Nk=%d > 288 not supported by these kernels", Nk);
   return VIDIL_EUNSUP;
 }

@@ -14,6 +14,7 @@
 //     panel) run on one XCD and hit its private L2.
 //   * epilogues: bias / GELU / residual / per-head Q-K-V^T scatter / patch
 //     row remap + positional embedding, all on the f32 accumulators.
+#include <stdlib.h>
 #include "common.h"
 
 namespace {
@@ -168,7 +169,7 @@ __global__ __launch_bounds__(256) void gemm_kernel(const vidil_gemm_args p) {
           if constexpr (ACT == VIDIL_ACT_QUICK_GELU) v = quick_gelu(v);
           const bool ok = col_ok && row < M;
           if constexpr (EPI == VIDIL_EPI_F16) {
-            if (ok) ((f16*)p.out)[(size_t)row * p.ldo + col] = (f16)v;
+            if (ok) ((f16*)p.out)[(size_t)row * p.ldo + col] = to_f16(v);
           } else if constexpr (EPI == VIDIL_EPI_F32) {
             if (ok) {
               const size_t o = (size_t)row * p.ldo + col;
@@ -180,11 +181,11 @@ __global__ __launch_bounds__(256) void gemm_kernel(const vidil_gemm_args p) {
               const int h = hcol >> 6, d = hcol & 63;
               const size_t bh = (size_t)b * p.H + h;
               if (part == 0) {
-                ((f16*)p.q)[(bh * p.Tq_cap + t) * 64 + d] = (f16)(v * p.q_scale);
+                ((f16*)p.q)[(bh * p.Tq_cap + t) * 64 + d] = to_f16(v * p.q_scale);
               } else if (part == 1) {
-                ((f16*)p.k)[(bh * p.Tk_cap + p.t_off + t) * 64 + d] = (f16)v;
+                ((f16*)p.k)[(bh * p.Tk_cap + p.t_off + t) * 64 + d] = to_f16(v);
               } else {
-                ((f16*)p.vt)[(bh * 64 + d) * (size_t)p.NP + p.t_off + t] = (f16)v;
+                ((f16*)p.vt)[(bh * 64 + d) * (size_t)p.NP + p.t_off + t] = to_f16(v);
               }
             }
             if (++t == p.T) { t = 0; ++b; }
@@ -225,6 +226,11 @@ int pick_tile(const vidil_gemm_args& a, hipStream_t s) {
   // Fill 256 CUs (2 workgroups each at 128x128): shrink the tile when the
   // grid would otherwise be too small (decode-step GEMMs with M of a few
   // hundred rows).
+  static const bool allow256 = []() {
+    const char* e = getenv("VIDIL_GEMM256");
+    return !(e && e[0] == '0');
+  }();
+  if (allow256 && vidil_gemm256_eligible(a)) return vidil_gemm256_launch(a, s);
   const long t128 = (long)((a.M + 127) / 128) * ((a.N + 127) / 128);
   if (t128 >= 384 || a.M > 4096) return launch<128, 128, EPI, ACT>(a, s);
   const long t64n = (long)((a.M + 127) / 128) * ((a.N + 63) / 64);

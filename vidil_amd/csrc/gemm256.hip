@@ -1,0 +1,397 @@
+// gemm256.hip — the large-M f16 GEMM of the hot path: C[M,N] = A[M,K] · W[N,K]^T
+// with the same fused epilogues as gemm.hip, tiled 256x256x64 over 8 waves.
+//
+// Why a second kernel: a 128x128 tile needs 64 FLOP per byte staged from L2, i.e.
+// ~39 TB/s of L2->LDS traffic at the 2.5 PFLOP/s MFMA peak — more than the 8 L2s
+// deliver — so it tops out near 0.5 PFLOP/s.  256x256 halves the bytes per FLOP and
+// the schedule below keeps the matrix pipe fed while LDS is being read.
+//
+// Structure (one workgroup = 512 threads = 8 waves = 2 per SIMD, 128 KiB LDS):
+//   * LDS ring: 2 K-tiles x 4 half-tiles (A rows 0-127 / 128-255, W rows 0-127 /
+//     128-255), 16 KiB each, filled by global_load_lds_dwordx4 (no VGPR round trip).
+//     Rows are 128 B; the 16-B slot index is XORed with (row>>1)&7 on the SOURCE
+//     address and on the ds_read_b128 side (conflict-free fragment reads).
+//   * wave (g, wc): g = wave>>2 picks the A half (its 128 output rows), wc the 64
+//     output columns.  The K-tile is processed in two HALF-PERIODS of 16 MFMAs
+//     (v_mfma_f32_32x32x16_f16): output rows 0-63, then rows 64-127 of the wave.
+//   * the two groups run STAGGERED by one half-period.  A group entering a K-tile
+//     reads its 8 W fragments (kept in registers for both half-periods) and its
+//     first A fragments from LDS before its first MFMA; at that moment the other
+//     group (the other wave on every SIMD) is mid-tile with its W fragments
+//     resident and its A fragments software-pipelined one k-step ahead, so the
+//     matrix pipe does not wait for LDS.
+//   * half-tiles are prefetched two half-periods ahead with COUNTED waits
+//     (s_waitcnt vmcnt(2)/(6), never 0 in the loop) and raw s_barrier, so LDS-DMA
+//     stays in flight across barriers.  Issue order per K-tile s: W0(s), W1(s),
+//     A0(s), A1(s).  Even half-period 2v issues W0,W1,A0 of tile v+1; odd 2v+1
+//     issues A1 of tile v+1.  (Derivation of the hazards: DESIGN.md §gemm256.)
+//   * MFMA operands are swapped (D = W_frag · A_frag^T) so a lane ends up with 4
+//     CONSECUTIVE output columns of one row; the epilogue transposes through the
+//     (now idle) LDS so every global store is 16 B per lane and 128-256 B per row.
+#include <type_traits>
+
+#include "common.h"
+
+namespace {
+
+constexpr int SLOT = 16384;      // one half-tile: 128 rows x 64 halfs
+constexpr int BUF = 4 * SLOT;     // one K-tile: A0, A1, W0, W1
+constexpr int LDS_BYTES = 2 * BUF;
+
+__device__ __forceinline__ void glds16(const f16* g, char* lds) {
+  __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)g,
+                                   (__attribute__((address_space(3))) void*)lds, 16, 0, 0);
+}
+
+template <int EPI, int ACT>
+__global__ __launch_bounds__(512) void gemm256_kernel(const vidil_gemm_args p) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int grp = wave >> 2;  // A half owned by this wave == stagger group
+  const int wc = wave & 3;
+  const int hi = lane >> 5, l31 = lane & 31;
+
+  const int M = p.M, N = p.N, K = p.K;
+  const int lda = p.lda > 0 ? p.lda : K;
+  const int tiles_n = (N + 255) >> 8;
+  const int tiles_m = (M + 255) >> 8;
+  int logical;
+  {
+    const int nblk = tiles_m * tiles_n;
+    const int bid = blockIdx.x;
+    const int xcd = bid & 7, q = nblk >> 3, r = nblk & 7;
+    logical = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (bid >> 3);
+  }
+  const int tile_m = logical / tiles_n;
+  const int tile_n = logical - tile_m * tiles_n;
+  const int m0 = tile_m << 8, n0 = tile_n << 8;
+  const int nk = K >> 6;
+
+  // ---- staging sources: half-tile hf of A / W, two 16-B chunks per thread ------------------------
+  // (32-bit element offsets from the two uniform base pointers: 8 VGPRs instead of 16 for pointers — this
+  //  kernel lives at the 256-register limit and a spilled pointer costs a vmcnt(0) drain per reload)
+  int gA[2][2];
+  int gW[2][2];
+#pragma unroll
+  for (int hf = 0; hf < 2; ++hf)
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      const int q = i * 512 + tid;
+      const int r = q >> 3, sl = q & 7;
+      const int c = sl ^ ((r >> 1) & 7);
+      int ra = m0 + hf * 128 + r;
+      ra = ra < M ? ra : M - 1;
+      int rw = n0 + hf * 128 + r;
+      rw = rw < N ? rw : N - 1;
+      gA[hf][i] = ra * lda + c * 8;
+      gW[hf][i] = rw * K + c * 8;
+    }
+  const f16* const baseA = (const f16*)p.A;
+  const f16* const baseW = (const f16*)p.W;
+  // slot ids inside a K-tile buffer: 0 = A0, 1 = A1, 2 = W0, 3 = W1.  Tiles past the end re-fetch the
+  // last tile into the slot the schedule says is free, so the counted waits stay uniform.
+  auto issue = [&](const f16* base, const int(&g)[2], int tile, int slot) {
+    const int tt = tile < nk ? tile : nk - 1;
+    char* dst = smem + (tile & 1) * BUF + slot * SLOT + wave * 1024;
+    const f16* src = base + tt * 64;
+    glds16(src + g[0], dst);
+    glds16(src + g[1], dst + 8192);
+  };
+
+  f32x16 acc[4][2];
+#pragma unroll
+  for (int it = 0; it < 4; ++it)
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[it][j][r] = 0.f;
+
+  const int sw = (l31 >> 1) & 7;
+  const int a_off = grp * SLOT + l31 * 128;
+  const int w_off = (2 + (wc >> 1)) * SLOT + ((wc & 1) * 64 + l31) * 128;
+  int slot_of[4];
+#pragma unroll
+  for (int ks = 0; ks < 4; ++ks) slot_of[ks] = ((ks * 2 + hi) ^ sw) << 4;
+
+  f16x8 wf[2][4];   // W fragments of the current K-tile (both column tiles), resident for both half-periods
+
+  const int nhp = 2 * nk;
+  // DMA of GLOBAL half-period h, in three pieces so it can be interleaved with MFMAs (an LDS-DMA instruction
+  // costs the issuing wave 100+ cycles of issue time; back to back at the top of a half-period they would
+  // idle the matrix pipe): even h issues W0, W1, A0 of tile h/2+1, odd h issues A1 of tile (h-1)/2+1.
+  auto dma_piece = [&](int h, int piece) {
+    if (h >= nhp) return;
+    const int v = (h >> 1) + 1;
+    if (h & 1) {
+      if (piece == 0) issue(baseA, gA[1], v, 1);
+    } else {
+      if (piece == 0) issue(baseW, gW[0], v, 2);
+      if (piece == 1) issue(baseW, gW[1], v, 3);
+      if (piece == 2) issue(baseA, gA[0], v, 0);
+    }
+  };
+  // Start of GLOBAL half-period h (all 8 waves execute this together).  What h reads has landed once at
+  // most 1 (even h: A1 of the same tile) or 3 (odd h: W0, W1, A0 of the next tile) newer half-tile DMAs
+  // (2 instructions each) are still in flight; the barrier then makes every wave's DMA visible to every
+  // wave and orders the previous half-period's LDS reads before this half-period's DMA reuses their slots.
+  auto sync = [&](int h) {
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    if (h & 1) {
+      asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+    } else {
+      asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
+    }
+    __builtin_amdgcn_s_barrier();
+  };
+
+  // One half-period = 4 k-steps x (2 row tiles x 2 column tiles) MFMAs on output rows RH*64 .. RH*64+63 of
+  // the wave; A fragments stream from LDS one k-step ahead of the MFMAs that consume them, and this
+  // half-period's DMA pieces are issued behind the MFMAs of k-steps 0..2.
+  auto half_period = [&](auto rh_tag, const char* buf, int h) {
+    constexpr int RH = decltype(rh_tag)::value;
+    const char* ab = buf + a_off + RH * 8192;
+    f16x8 a[4][2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i) a[0][i] = *(const f16x8*)(ab + i * 4096 + slot_of[0]);
+    if constexpr (RH == 0) {
+#pragma unroll
+      for (int ks = 0; ks < 4; ++ks)
+#pragma unroll
+        for (int j = 0; j < 2; ++j) wf[j][ks] = *(const f16x8*)(buf + w_off + j * 4096 + slot_of[ks]);
+    }
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks) {
+      if (ks < 3) {
+#pragma unroll
+        for (int i = 0; i < 2; ++i) a[ks + 1][i] = *(const f16x8*)(ab + i * 4096 + slot_of[ks + 1]);
+      }
+#pragma unroll
+      for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+          acc[RH * 2 + i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wf[j][ks], a[ks][i], acc[RH * 2 + i][j], 0, 0, 0);
+      if (ks < 3) dma_piece(h, ks);
+    }
+  };
+
+  // ---- prologue: W0(0), W1(0), A0(0), A1(0) ------------------------------------------------------------
+  issue(baseW, gW[0], 0, 2);
+  issue(baseW, gW[1], 0, 3);
+  issue(baseA, gA[0], 0, 0);
+  issue(baseA, gA[1], 0, 1);
+
+  // Both groups run the same straight-line [first half, second half] body per K-tile (so the accumulators
+  // never pass through a branch); group 1 simply starts one half-period later and group 0 idles in the last.
+  int h = 0;
+  if (grp == 1) {
+    sync(h);
+    dma_piece(h, 0); dma_piece(h, 1); dma_piece(h, 2);
+    ++h;
+  }
+  for (int u = 0; u < nk; ++u) {
+    const char* buf = smem + (u & 1) * BUF;
+    sync(h);
+    half_period(std::integral_constant<int, 0>{}, buf, h);
+    ++h;
+    sync(h);
+    half_period(std::integral_constant<int, 1>{}, buf, h);
+    ++h;
+  }
+  if (grp == 0) sync(h);   // h == nhp: nothing left to issue
+  asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+  __builtin_amdgcn_s_barrier();
+
+  // ================================================================================ epilogue
+  // acc[it][j][rq*4+e]: row = m_w + it*32 + l31 ; col = n_w + j*32 + rq*8 + hi*4 + e
+  const int m_w = m0 + grp * 128;
+  const int n_w = n0 + wc * 64;
+  if (n_w >= N) return;
+  char* ep = smem + wave * SLOT;  // private 16 KiB transposition buffer of this wave
+
+  // bias folded into the accumulators once (4 consecutive columns per register quad)
+  if (p.bias != nullptr) {
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int rq = 0; rq < 4; ++rq) {
+        const int col = n_w + j * 32 + rq * 8 + hi * 4;
+        if (col + 4 <= N) {
+          const f32x4 b4 = *(const f32x4*)(p.bias + col);
+#pragma unroll
+          for (int it = 0; it < 4; ++it)
+#pragma unroll
+            for (int e = 0; e < 4; ++e) acc[it][j][rq * 4 + e] += b4[e];
+        }
+      }
+  }
+  auto value = [&](int it, int j, int rq, int e) {
+    float v = acc[it][j][rq * 4 + e];
+    if constexpr (ACT == VIDIL_ACT_GELU_ERF) v = gelu_erf(v);
+    if constexpr (ACT == VIDIL_ACT_QUICK_GELU) v = quick_gelu(v);
+    return v;
+  };
+
+  int part = 0, head = 0;
+  if constexpr (EPI == VIDIL_EPI_HEADS) {
+    const int hd = p.H * 64;
+    part = p.part0 + n_w / hd;
+    head = (n_w % hd) >> 6;
+  }
+
+  if constexpr (EPI == VIDIL_EPI_HEADS) {
+    if (part == 2) {
+      // V^T: element (row m, column d) goes to VT[b][h][d][t_off+t]; consecutive lanes = consecutive t
+#pragma unroll
+      for (int it = 0; it < 4; ++it) {
+        const int m = m_w + it * 32 + l31;
+        if (m < M) {
+          const int b = m / p.T, t = m - b * p.T;
+          f16* dst = (f16*)p.vt + (((size_t)b * p.H + head) * 64) * (size_t)p.NP + p.t_off + t;
+#pragma unroll
+          for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int rq = 0; rq < 4; ++rq)
+#pragma unroll
+              for (int e = 0; e < 4; ++e) dst[(size_t)(j * 32 + rq * 8 + hi * 4 + e) * p.NP] = to_f16(value(it, j, rq, e));
+        }
+      }
+      return;
+    }
+  }
+
+  if constexpr (EPI == VIDIL_EPI_F16 || EPI == VIDIL_EPI_HEADS) {
+    // ---- f16 rows of 64 columns: [128][64] halfs, 16-B chunk index XOR (row&7) ----------------------
+    const float scale = (EPI == VIDIL_EPI_HEADS && part == 0) ? p.q_scale : 1.0f;
+#pragma unroll
+    for (int it = 0; it < 4; ++it) {
+      const int row = it * 32 + l31;
+#pragma unroll
+      for (int j = 0; j < 2; ++j)
+#pragma unroll
+        for (int rq = 0; rq < 4; ++rq) {
+          const f16x4 v = {to_f16(value(it, j, rq, 0) * scale), to_f16(value(it, j, rq, 1) * scale),
+                           to_f16(value(it, j, rq, 2) * scale), to_f16(value(it, j, rq, 3) * scale)};
+          *(f16x4*)(ep + row * 128 + (((j * 4 + rq) ^ (row & 7)) << 4) + hi * 8) = v;
+        }
+    }
+    const int ch = lane & 7;
+#pragma unroll 4
+    for (int iter = 0; iter < 16; ++iter) {
+      const int row = iter * 8 + (lane >> 3);
+      const f16x8 v = *(const f16x8*)(ep + row * 128 + ((ch ^ (row & 7)) << 4));
+      const int m = m_w + row;
+      const int col = n_w + ch * 8;
+      if (m < M && col + 8 <= N) {
+        if constexpr (EPI == VIDIL_EPI_F16) {
+          *(f16x8*)((f16*)p.out + (size_t)m * p.ldo + col) = v;
+        } else {
+          const int b = m / p.T, t = m - b * p.T;
+          const size_t bh = (size_t)b * p.H + head;
+          if (part == 0) {
+            *(f16x8*)((f16*)p.q + (bh * p.Tq_cap + t) * 64 + ch * 8) = v;
+          } else {
+            *(f16x8*)((f16*)p.k + (bh * p.Tk_cap + p.t_off + t) * 64 + ch * 8) = v;
+          }
+        }
+      }
+    }
+  } else {
+    // ---- f32 rows of 64 columns, two passes of 64 rows: [64][64] floats, chunk XOR (row&7) ------------
+#pragma unroll
+    for (int pass = 0; pass < 2; ++pass) {
+#pragma unroll
+      for (int i = 0; i < 2; ++i) {
+        const int it = pass * 2 + i;
+        const int lr = i * 32 + l31;
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+          for (int rq = 0; rq < 4; ++rq) {
+            const f32x4 v = {value(it, j, rq, 0), value(it, j, rq, 1), value(it, j, rq, 2), value(it, j, rq, 3)};
+            *(f32x4*)(ep + lr * 256 + (((j * 8 + rq * 2 + hi) ^ (lr & 7)) << 4)) = v;
+          }
+      }
+      const int ch = lane & 15;
+#pragma unroll 4
+      for (int iter = 0; iter < 16; ++iter) {
+        const int lr = iter * 4 + (lane >> 4);
+        f32x4 v = *(const f32x4*)(ep + lr * 256 + ((ch ^ (lr & 7)) << 4));
+        const int m = m_w + pass * 64 + lr;
+        const int col = n_w + ch * 4;
+        if (m < M && col + 4 <= N) {
+          if constexpr (EPI == VIDIL_EPI_F32) {
+            const size_t o = (size_t)m * p.ldo + col;
+            if (p.resid != nullptr) v += *(const f32x4*)(p.resid + o);
+            *(f32x4*)((float*)p.out + o) = v;
+          } else {  // EPI_PATCH
+            const int b = m / p.tpi, t = m - b * p.tpi;
+            v += *(const f32x4*)(p.pos + (size_t)(t + 1) * N + col);
+            *(f32x4*)((float*)p.out + ((size_t)m + b + 1) * p.ldo + col) = v;
+          }
+        }
+      }
+    }
+  }
+}
+
+template <int EPI, int ACT>
+int launch256(const vidil_gemm_args& a, hipStream_t s) {
+  static bool attr_set = false;
+  auto kern = gemm256_kernel<EPI, ACT>;
+  if (!attr_set) {
+    hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES);
+    if (e != hipSuccess) {
+      vidil_set_error("gemm256: hipFuncSetAttribute failed: %s", hipGetErrorString(e));
+      return VIDIL_ELAUNCH;
+    }
+    attr_set = true;
+  }
+  const int tiles = ((a.M + 255) / 256) * ((a.N + 255) / 256);
+  hipLaunchKernelGGL(kern, dim3(tiles), dim3(512), LDS_BYTES, s, a);
+  VIDIL_CHECK_LAUNCH("gemm256");
+  return VIDIL_OK;
+}
+
+}  // namespace
+
+// Returns true when the 256x256 kernel can run this problem with vector epilogues (checked by the caller).
+bool vidil_gemm256_eligible(const vidil_gemm_args& a) {
+  const long tiles = (long)((a.M + 255) / 256) * ((a.N + 255) / 256);
+  if (tiles < 160) return false;                   // too few workgroups to fill 256 CUs: small-tile kernel
+  if (a.K < 128) return false;
+  const long lda = a.lda > 0 ? a.lda : a.K;
+  if ((long)a.M * lda >= (1L << 31) || (long)a.N * a.K >= (1L << 31)) return false;   // 32-bit staging offsets
+  auto al16 = [](const void* p) { return ((uintptr_t)p & 15) == 0; };
+  if (a.bias && !al16(a.bias)) return false;
+  switch (a.epi) {
+    case VIDIL_EPI_F16:
+      return a.N % 8 == 0 && a.ldo % 8 == 0 && al16(a.out);
+    case VIDIL_EPI_F32:
+      return a.N % 4 == 0 && a.ldo % 4 == 0 && al16(a.out) && (!a.resid || al16(a.resid));
+    case VIDIL_EPI_PATCH:
+      return a.N % 4 == 0 && a.ldo % 4 == 0 && al16(a.out) && al16(a.pos);
+    case VIDIL_EPI_HEADS:
+      return (!a.q || al16(a.q)) && (!a.k || al16(a.k));
+    default:
+      return false;
+  }
+}
+
+int vidil_gemm256_launch(const vidil_gemm_args& a, hipStream_t s) {
+  switch (a.epi) {
+    case VIDIL_EPI_F16:
+      if (a.act == VIDIL_ACT_NONE) return launch256<VIDIL_EPI_F16, VIDIL_ACT_NONE>(a, s);
+      if (a.act == VIDIL_ACT_GELU_ERF) return launch256<VIDIL_EPI_F16, VIDIL_ACT_GELU_ERF>(a, s);
+      return launch256<VIDIL_EPI_F16, VIDIL_ACT_QUICK_GELU>(a, s);
+    case VIDIL_EPI_F32:
+      if (a.act == VIDIL_ACT_NONE) return launch256<VIDIL_EPI_F32, VIDIL_ACT_NONE>(a, s);
+      if (a.act == VIDIL_ACT_GELU_ERF) return launch256<VIDIL_EPI_F32, VIDIL_ACT_GELU_ERF>(a, s);
+      return launch256<VIDIL_EPI_F32, VIDIL_ACT_QUICK_GELU>(a, s);
+    case VIDIL_EPI_HEADS:
+      return launch256<VIDIL_EPI_HEADS, VIDIL_ACT_NONE>(a, s);
+    default:
+      return launch256<VIDIL_EPI_PATCH, VIDIL_ACT_NONE>(a, s);
+  }
+}

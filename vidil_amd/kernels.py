@@ -114,12 +114,15 @@ def layernorm(x, gamma, beta, eps, *, M=None, D=None, x_stride=None, out16=None,
 
 
 def attention(q, k, vt, out, *, Bq, H, Nq, Nk, Tq_cap, Tk_cap, NP, kv_group=1, causal=False,
-              causal_off=0, kv_len=None, kv_index=None, ldo=None):
+              causal_off=0, kv_len=None, kv_index=None, group_start=None, max_group=0, ldo=None):
+    """group_start: int32 [n_kv+1] device prefix table (query batches per kv batch), with max_group."""
     lib = _lib.load()
     ldo = ldo if ldo is not None else H * 64
+    n_kv = 0 if group_start is None else group_start.numel() - 1
     check(lib.vidil_attention(_ptr(q, torch.float16, "attn.q"), _ptr(k, torch.float16, "attn.k"),
                               _ptr(vt, torch.float16, "attn.vt"), _ptr(out, torch.float16, "attn.out"),
                               _ptr(kv_len, torch.int32, "attn.kv_len"), _ptr(kv_index, torch.int32, "attn.kv_index"),
+                              _ptr(group_start, torch.int32, "attn.group_start"), n_kv, max_group,
                               Bq, H, Nq, Nk, Tq_cap, Tk_cap, NP,
                               kv_group, int(bool(causal)), causal_off, ldo, _stream()), "attention")
     return out

@@ -185,7 +185,7 @@ class BertModel(PackedCache, nn.Module):
 
     # ------------------------------------------------------------------ layers
     def run_layers(self, h32, h16, *, rows, T, self_k, self_vt, t_off, Tk_cap, NPs, causal, kv_len,
-                   cross: CrossKV, cross_index=None, cross_group=1, ws=None):
+                   cross: CrossKV, cross_index=None, cross_group=1, cross_groups=None, cross_max_group=0, ws=None):
         """Run every layer on the f32/f16 hidden pair (both [rows*T, C], updated in place).
 
         self_k / self_vt: [L][rows,H,Tk_cap,64] / [L][rows,H,64,NPs] — this call's keys are appended at
@@ -216,17 +216,12 @@ class BertModel(PackedCache, nn.Module):
             K.gemm(o, d["ao_w"], d["ao_b"], out=tmp, resid=h32)
             K.layernorm(tmp, d["ao_g"], d["ao_bt"], eps, out16=h16, out32=h32)
             if cross is not None:
-                if T == 1 and cross_index is None and cross_group > 1:
-                    # decode step: the cross_group beams of an image become the query rows of ONE
-                    # attention batch, so the image's K/V are staged once, not once per beam.
-                    G = cross_group
-                    K.gemm(h16, d["cq_w"], d["cq_b"], heads=dict(q=q, T=G, H=H, part0=0, Tq_cap=G, q_scale=0.125))
-                    K.attention(q, cross.k[i], cross.vt[i], o, Bq=rows // G, H=H, Nq=G, Nk=cross.Te, Tq_cap=G,
-                                Tk_cap=cross.Te, NP=cross.NP)
-                else:
-                    K.gemm(h16, d["cq_w"], d["cq_b"], heads=dict(q=q, T=T, H=H, part0=0, Tq_cap=T, q_scale=0.125))
-                    K.attention(q, cross.k[i], cross.vt[i], o, Bq=rows, H=H, Nq=T, Nk=cross.Te, Tq_cap=T,
-                                Tk_cap=cross.Te, NP=cross.NP, kv_group=cross_group, kv_index=cross_index)
+                # every query batch that shares an image (the beams of a caption search, the captions of a
+                # frame) is served by one fetch of that image's K/V: see vidil_attention's grouping forms
+                K.gemm(h16, d["cq_w"], d["cq_b"], heads=dict(q=q, T=T, H=H, part0=0, Tq_cap=T, q_scale=0.125))
+                K.attention(q, cross.k[i], cross.vt[i], o, Bq=rows, H=H, Nq=T, Nk=cross.Te, Tq_cap=T,
+                            Tk_cap=cross.Te, NP=cross.NP, kv_group=cross_group, kv_index=cross_index,
+                            group_start=cross_groups, max_group=cross_max_group)
                 K.gemm(o, d["co_w"], d["co_b"], out=tmp, resid=h32)
                 K.layernorm(tmp, d["co_g"], d["co_bt"], eps, out16=h16, out32=h32)
             K.gemm(h16, d["i_w"], d["i_b"], out=inter, act=K.ACT_GELU_ERF)
@@ -247,9 +242,10 @@ class BertModel(PackedCache, nn.Module):
         K.layernorm(raw, p["emb_g"], p["emb_b"], self.config.layer_norm_eps, out16=h16, out32=h32)
         return h32, h16
 
-    def encode(self, ids_i32, kv_len_i32, cross: CrossKV, cross_index):
+    def encode(self, ids_i32, kv_len_i32, cross: CrossKV, cross_index=None, cross_groups=None, cross_max_group=0):
         """ITM encoder pass (models/blip_itm.py:51-56): ids int32 [P,T] right-padded, kv_len [P] = number of
-        real tokens, pair p attends to image ``cross_index[p]``.  Returns h32 [P*T, C]."""
+        real tokens.  Pair p attends to image ``cross_index[p]``, or — image-major pair order — image j serves
+        pairs cross_groups[j] .. cross_groups[j+1]-1.  Returns (h32, h16) [P*T, C]."""
         require_cuda(ids_i32, "BertModel.encode")
         P, T = ids_i32.shape
         H = self.config.num_attention_heads
@@ -261,7 +257,8 @@ class BertModel(PackedCache, nn.Module):
         sv = torch.empty((1, P, H, 64, NPs), dtype=torch.float16, device=dev).expand(L, -1, -1, -1, -1)
         # (one scratch K / V^T buffer is reused by every layer: the encoder keeps no cache)
         self.run_layers(h32, h16, rows=P, T=T, self_k=sk, self_vt=sv, t_off=0, Tk_cap=T, NPs=NPs, causal=False,
-                        kv_len=kv_len_i32, cross=cross, cross_index=cross_index)
+                        kv_len=kv_len_i32, cross=cross, cross_index=cross_index, cross_groups=cross_groups,
+                        cross_max_group=cross_max_group)
         return h32, h16
 
     def forward(self, *a, **k):
