@@ -78,7 +78,11 @@ class GemmTimer:
         self.records = []
 
     @staticmethod
-    def tile_of(M, N):
+    def tile_of(M, N, K=768, f16_out=True):
+        """Mirror of the dispatch in csrc/gemm.hip::pick_tile / gemm256.hip::vidil_gemm256_eligible."""
+        t256 = ((M + 255) // 256) * ((N + 255) // 256)
+        if t256 >= 160 and K >= 128 and N % (8 if f16_out else 4) == 0:
+            return "256x256"
         t128 = ((M + 127) // 128) * ((N + 127) // 128)
         if t128 >= 384 or M > 4096:
             return "128x128"
@@ -101,7 +105,8 @@ class GemmTimer:
             e1.record()
             epi = "heads" if kw.get("heads") else "patch" if kw.get("patch") else \
                 ("f32" if (kw.get("out") is not None and kw["out"].dtype == torch.float32) or kw.get("out_dtype") == torch.float32 else "f16")
-            timer.records.append((timer.tile_of(M, N), epi, kw.get("act", 0), 2.0 * M * N * Kd, e0, e1))
+            timer.records.append((timer.tile_of(M, N, Kd, epi in ("f16", "heads")), epi, kw.get("act", 0),
+                                  2.0 * M * N * Kd, e0, e1))
             return r
 
         K.gemm = timed
@@ -114,8 +119,14 @@ class GemmTimer:
     def summary(self):
         torch.cuda.synchronize()
         agg = {}
+        epi_id = dict(f16=0, f32=1, heads=2, patch=3)
         for tile, epi, act, flops, e0, e1 in self.records:
-            key = f"gemm_kernel<{tile},{epi},act{act}>"
+            # same spelling as the kernel names in the rocprofv3 trace (profiles/*.md)
+            if tile == "256x256":
+                key = f"gemm256_kernel<{epi_id[epi]}, {act}>"
+            else:
+                bm, bn = tile.split("x")
+                key = f"gemm_kernel<{bm}, {bn}, {epi_id[epi]}, {act}>"
             a = agg.setdefault(key, [0, 0.0, 0.0])
             a[0] += 1
             a[1] += flops
@@ -245,8 +256,17 @@ def main():
         key = max(agg, key=lambda k: agg[k][2])
         n, flops, secs = agg[key]
         ach = flops / secs / 1e12
+        # HBM bytes per launch of that kernel from the committed PMC passes of this same command
+        # (tools/profile_bench.sh -> profiles/pmc_traffic.json); null when no profile has been taken.
+        traffic = None
+        try:
+            pmc = json.load(open(os.path.join(ROOT, "profiles", "pmc_traffic.json")))
+            traffic = pmc["kernels"].get(key, {}).get("hbm_bytes_per_launch")
+        except (OSError, ValueError, KeyError):
+            pass
         result["roofline"] = {"bound": "mfma", "kernel": key, "achieved": round(ach, 1), "peak": MFMA_F16_PEAK_TFLOPS,
-                              "unit": "TFLOP/s", "frac": round(ach / MFMA_F16_PEAK_TFLOPS, 4), "traffic": None,
+                              "unit": "TFLOP/s", "frac": round(ach / MFMA_F16_PEAK_TFLOPS, 4), "traffic": traffic,
+                              "algorithmic_flop_per_launch": round(flops / n),
                               "launches_per_step": n, "avg_launch_us": round(secs / n * 1e6, 2),
                               "all_gemm": {k: {"launches": v[0], "tflops": round(v[1] / v[2] / 1e12, 1),
                                                "ms": round(v[2] * 1e3, 3)} for k, v in agg.items()}}
