@@ -363,6 +363,51 @@ __global__ __launch_bounds__(256) void attn_direct_kernel(const AttnP p) {
   }
 }
 
+// ------------------------------------------------------------------ one wave, one key tile
+// rows <= 32 and Nk <= 32 (decoder self-attention over the cached tokens): a single wave per (unit, head),
+// operands straight from memory, no LDS and no barrier.
+__global__ __launch_bounds__(64) void attn_wave_kernel(const AttnP p) {
+  const int lane = threadIdx.x & 63;
+  const int hi = lane >> 5, l31 = lane & 31;
+  const int h = blockIdx.y;
+  int bk, first, count;
+  resolve_unit(p, blockIdx.z, bk, first, count);
+  const int rows = count * p.Nq;
+  if (rows <= 0) return;
+  const int nk = p.Nk;
+  const RowInfo ri = row_info(p, l31, first, rows);
+  const f16* kg = p.k + ((size_t)bk * p.H + h) * p.Tk_cap * 64;
+  const f16* vg = p.vt + ((size_t)bk * p.H + h) * 64 * (size_t)p.NP;
+  const f16* qg = p.q + (((size_t)ri.qb * p.H + h) * p.Tq_cap + ri.t) * 64 + hi * 8;
+  int krow = l31 < nk ? l31 : nk - 1;
+  const f16* kr = kg + (size_t)krow * 64 + hi * 8;
+  f32x16 S;
+#pragma unroll
+  for (int r = 0; r < 16; ++r) S[r] = 0.f;
+#pragma unroll
+  for (int ks = 0; ks < 4; ++ks)
+    S = __builtin_amdgcn_mfma_f32_32x32x16_f16(*(const f16x8*)(kr + ks * 16), *(const f16x8*)(qg + ks * 16), S, 0, 0, 0);
+  float m = -INFINITY, l = 0.f;
+  f32x16 O[2];
+#pragma unroll
+  for (int dt = 0; dt < 2; ++dt)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) O[dt][r] = 0.f;
+  softmax_pv_tile(S, 0, ri.klim, true, m, l, O, [&](int dt, int hb) {
+    const int key0 = hb * 16 + 4 * hi;
+    const f16* vrow = vg + (size_t)(dt * 32 + l31) * p.NP + key0;
+    f16x8 v = {0, 0, 0, 0, 0, 0, 0, 0};
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      if (key0 + e < nk) v[e] = vrow[e];
+      if (key0 + 8 + e < nk) v[4 + e] = vrow[8 + e];
+    }
+    return v;
+  });
+  l += __shfl_xor(l, 32, 64);
+  store_rows(p, ri, h, O, l > 0.f ? 1.0f / l : 0.f);
+}
+
 template <int NKT, int NW>
 int launch_lds(const AttnP& p, int max_rows, hipStream_t s) {
   constexpr int smem = NKT * 32 * KROW * 2 + 64 * (NKT * 32 + 4) * 2;
@@ -384,6 +429,11 @@ int launch_lds(const AttnP& p, int max_rows, hipStream_t s) {
 
 template <int NKT>
 int launch_any(const AttnP& p, int max_rows, hipStream_t s) {
+  if (max_rows <= 32 && NKT == 1) {
+    hipLaunchKernelGGL(attn_wave_kernel, dim3(1, p.H, p.n_kv), dim3(64), 0, s, p);
+    VIDIL_CHECK_LAUNCH("attention/wave");
+    return VIDIL_OK;
+  }
   if (max_rows <= 32) {
     hipLaunchKernelGGL(attn_direct_kernel<NKT>, dim3(1, p.H, p.n_kv), dim3(256), 0, s, p);
     VIDIL_CHECK_LAUNCH("attention/direct");

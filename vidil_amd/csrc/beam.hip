@@ -68,30 +68,60 @@ __global__ __launch_bounds__(256) void lsm_topk_kernel(const float* __restrict__
 #pragma unroll
   for (int j = 0; j < K; ++j) { ts[j] = -INFINITY; ti[j] = 0x7fffffff; }
 
+  const bool vec = (V & 3) == 0;   // rows are then 16-B aligned: 4 logits per load
+  auto consider = [&](float c, int flat) {
+    if (better(c, flat, ts[K - 1], ti[K - 1])) {
+      ts[K - 1] = c; ti[K - 1] = flat;
+#pragma unroll
+      for (int j = K - 1; j > 0; --j) {
+        if (better(ts[j], ti[j], ts[j - 1], ti[j - 1])) {
+          const float s = ts[j]; ts[j] = ts[j - 1]; ts[j - 1] = s;
+          const int x = ti[j]; ti[j] = ti[j - 1]; ti[j - 1] = x;
+        }
+      }
+    }
+  };
   for (int beam = 0; beam < NB; ++beam) {
     const float* row = logits + ((size_t)b * NB + beam) * V;
+    // pass 1: row max, then sum(exp(x - max)) as torch's log_softmax does (two reductions, vector loads)
     float m = -INFINITY;
-    for (int i = tid; i < V; i += 256) m = fmaxf(m, row[i]);
+    if (vec) {
+      for (int i = tid * 4; i < V; i += 1024) {
+        const f32x4 x = *(const f32x4*)(row + i);
+        m = fmaxf(fmaxf(m, fmaxf(x[0], x[1])), fmaxf(x[2], x[3]));
+      }
+    } else {
+      for (int i = tid; i < V; i += 256) m = fmaxf(m, row[i]);
+    }
     m = block_reduce_max(m, red);
     float sum = 0.f;
-    for (int i = tid; i < V; i += 256) sum += expf(row[i] - m);
+    if (vec) {
+      for (int i = tid * 4; i < V; i += 1024) {
+        const f32x4 x = *(const f32x4*)(row + i);
+        sum += (expf(x[0] - m) + expf(x[1] - m)) + (expf(x[2] - m) + expf(x[3] - m));
+      }
+    } else {
+      for (int i = tid; i < V; i += 256) sum += expf(row[i] - m);
+    }
     sum = block_reduce_sum(sum, red);
     const float lse = logf(sum);
     const float bs = beam_scores[b * NB + beam];
-    for (int i = tid; i < V; i += 256) {
-      float lp = (row[i] - m) - lse;
-      if (i == ban) lp = -INFINITY;
-      const float c = lp + bs;
-      const int flat = beam * V + i;
-      if (better(c, flat, ts[K - 1], ti[K - 1])) {
-        ts[K - 1] = c; ti[K - 1] = flat;
+    // pass 2: candidates.  A thread's elements arrive in ascending flat index (ties keep the lower index).
+    if (vec) {
+      for (int i = tid * 4; i < V; i += 1024) {
+        const f32x4 x = *(const f32x4*)(row + i);
 #pragma unroll
-        for (int j = K - 1; j > 0; --j) {
-          if (better(ts[j], ti[j], ts[j - 1], ti[j - 1])) {
-            const float s = ts[j]; ts[j] = ts[j - 1]; ts[j - 1] = s;
-            const int x = ti[j]; ti[j] = ti[j - 1]; ti[j - 1] = x;
-          }
+        for (int e = 0; e < 4; ++e) {
+          float lp = (x[e] - m) - lse;
+          if (i + e == ban) lp = -INFINITY;
+          consider(lp + bs, beam * V + i + e);
         }
+      }
+    } else {
+      for (int i = tid; i < V; i += 256) {
+        float lp = (row[i] - m) - lse;
+        if (i == ban) lp = -INFINITY;
+        consider(lp + bs, beam * V + i);
       }
     }
   }
