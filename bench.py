@@ -163,7 +163,7 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=3)
     ap.add_argument("--warmup", type=int, default=1)
-    ap.add_argument("--videos-per-step", type=int, default=64)
+    ap.add_argument("--videos-per-step", type=int, default=128)
     ap.add_argument("--frames", type=int, default=8)
     ap.add_argument("--size", type=int, default=224)
     ap.add_argument("--cpu-sample-videos", type=int, default=1)

@@ -158,14 +158,18 @@ int vidil_l2_normalize_rows(float* x, int32_t n, int32_t D, void* stream);
 /* Beam-search step on device (HF transformers 4.15 semantics, the version    */
 /* models/med.py:7-8 names; call site models/blip.py:154-161).                */
 /* ------------------------------------------------------------------------ */
-/* per image b (rows b*nb .. b*nb+nb-1 of logits [R,V]):                      */
+/* per image b (rows b*nbl .. b*nbl+nbl-1 of logits [B*nbl,V]):                */
 /*   lp = log_softmax(logits[row]);  if ban_token>=0: lp[ban_token] = -inf;   */
-/*   cand = lp + beam_scores[row];  top (2*nb) over nb*V, sorted descending,  */
-/*   ties -> lower flat index first.                                          */
+/*   cand = lp + beam_scores[b*nb+beam];  top (2*nb) over the candidates,     */
+/*   sorted descending, ties -> lower flat index first.                       */
+/* beams_in_logits (nbl) is nb normally; 1 on the first step, where all beams */
+/* of an image are still identical and only beam 0 (score 0; the others carry */
+/* -1e9 and can never reach the top 2nb) was run through the decoder.         */
 /* out_scores f32 [B, 2nb], out_index i32 [B, 2nb] (flat index beam*V+tok).   */
 int vidil_logsoftmax_topk(const float* logits, const float* beam_scores,
-                          int32_t B, int32_t nb, int32_t V, int32_t ban_token,
-                          float* out_scores, int32_t* out_index, void* stream);
+                          int32_t B, int32_t nb, int32_t beams_in_logits,
+                          int32_t V, int32_t ban_token, float* out_scores,
+                          int32_t* out_index, void* stream);
 
 typedef struct vidil_beam_state {
   int32_t* seqs;        /* [B*nb, max_len] token ids (current beams)          */

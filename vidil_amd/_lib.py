@@ -60,7 +60,7 @@ SIGNATURES = {
     "vidil_embed_tokens": (_i32, [_p, _p, _p, _p, _i32, _i32, _i32, _i32, _i32, _p]),
     "vidil_gather_rows_f32": (_i32, [_p, _p, _p, _i32, _i32, _p]),
     "vidil_l2_normalize_rows": (_i32, [_p, _i32, _i32, _p]),
-    "vidil_logsoftmax_topk": (_i32, [_p, _p, _i32, _i32, _i32, _i32, _p, _p, _p]),
+    "vidil_logsoftmax_topk": (_i32, [_p, _p, _i32, _i32, _i32, _i32, _i32, _p, _p, _p]),
     "vidil_beam_update": (_i32, [C.POINTER(BeamState), _p, _p] + [_i32] * 7 + [_p]),
     "vidil_beam_finalize": (_i32, [C.POINTER(BeamState)] + [_i32] * 6 + [_p, _p, _p, _p]),
     "vidil_kv_reorder": (_i32, [_p, _p, _p, _i32, _i32, _i64, _p]),

@@ -102,19 +102,27 @@ class DecoderSession:
         self.cur = 0
         self.ws_prefill, self.ws_step = {}, {}
         self.logits = None
+        self.compact = False   # True while the cache holds ONE row per image (after a shared prefill)
 
-    def prefill(self, ids_i32, P):
-        """ids_i32: int32 [R*P] prompt tokens of every row.  Returns last-position logits f32 [R,V]."""
+    def prefill(self, ids_i32, P, shared=False):
+        """Prompt pass.  shared=False: ids_i32 int32 [R*P], every row decoded -> logits f32 [R,V] (what HF
+        generate() does).  shared=True: ids_i32 int32 [B*P], ONE row per image -> logits f32 [B,V]: the nb beams of
+        an image are identical until the first beam update (models/blip.py:130-138 repeats the same prompt and
+        image nb times), so their prompt pass is computed once; the first ``step`` expands the cache rows."""
+        rows = self.B if shared else self.R
         h32, h16 = self.bert.embed(ids_i32, P, 0)
-        self.bert.run_layers(h32, h16, rows=self.R, T=P, self_k=self.kc[self.cur], self_vt=self.vc[self.cur], t_off=0,
+        self.bert.run_layers(h32, h16, rows=rows, T=P, self_k=self.kc[self.cur], self_vt=self.vc[self.cur], t_off=0,
                              Tk_cap=self.Tcap, NPs=self.NPs, causal=True, kv_len=None, cross=self.cross,
-                             cross_group=self.nb, ws=self.ws_prefill)
-        self.logits = self.dec.lm_logits(h16, self.R, P)
-        return self.logits
+                             cross_group=1 if shared else self.nb, ws=self.ws_prefill)
+        self.compact = shared
+        return self.dec.lm_logits(h16, rows, P)
 
     def step(self, next_tok_i32, beam_idx_i32, past_len):
         """Reorder the KV cache rows by ``beam_idx`` (models/med.py:951-955), then one cached forward of the
         single new token at position ``past_len``.  Returns logits f32 [R,V]."""
+        if self.compact:   # cache row of image b is b: global source row b*nb+j -> b
+            beam_idx_i32 = torch.div(beam_idx_i32, self.nb, rounding_mode="floor").to(torch.int32)
+            self.compact = False
         K.kv_reorder(self.kc[self.cur], self.kc[self.cur ^ 1], beam_idx_i32, self.L, self.R)
         K.kv_reorder(self.vc[self.cur], self.vc[self.cur ^ 1], beam_idx_i32, self.L, self.R)
         self.cur ^= 1
@@ -164,12 +172,13 @@ class BLIP_Decoder(nn.Module):
         prompt = self.prompt_ids(B, dev)
         P = prompt.shape[1]
         bufs.reset(prompt)
-        # ---- prefill over the prompt (all beams of an image start identical)
-        logits = sess.prefill(bufs.seqs[:, :P].contiguous().view(-1), P)
+        # ---- prompt pass, once per image: the beams of an image are identical until the first update
+        logits = sess.prefill(prompt.contiguous().view(-1), P, shared=True)
         cur_len = P
         while True:
             ban = eos if cur_len < min_length else -1
-            cs, ci = K.logsoftmax_topk(logits, bufs.beam_scores, B, nb, ban)
+            cs, ci = K.logsoftmax_topk(logits, bufs.beam_scores, B, nb, ban,
+                                       beams_in_logits=1 if cur_len == P else nb)
             if trace is not None:
                 trace.logits.append(logits.clone())
                 trace.cand_scores.append(cs.clone())

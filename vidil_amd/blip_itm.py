@@ -65,8 +65,8 @@ class BLIP_ITM(PackedCache, nn.Module):
         cross = te.project_cross_kv(enc16, n_images, Te)
         # The reference pads every caption to 35 tokens (models/blip_itm.py:46).  Padded keys are masked and a
         # padded row never feeds a real one, so the [CLS] output is unchanged if the batch is cut to its
-        # longest real caption (rounded up to 8 for the V^T row stride); this removes the all-padding columns.
-        t_eff = min(ids.shape[1], (int(lens.max().item()) + 7) // 8 * 8) if ids.shape[0] else ids.shape[1]
+        # longest real caption; this removes the all-padding columns.
+        t_eff = min(ids.shape[1], int(lens.max().item())) if ids.shape[0] else ids.shape[1]
         ids = ids[:, :t_eff].to(dev).contiguous()
         lens = lens.to(dev).contiguous()
         if group_start is not None:

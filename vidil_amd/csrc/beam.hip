@@ -54,8 +54,8 @@ __device__ float block_reduce_sum(float v, float* red) {
 
 template <int NB>
 __global__ __launch_bounds__(256) void lsm_topk_kernel(const float* __restrict__ logits,
-                                                       const float* __restrict__ beam_scores, int V, int ban,
-                                                       float* __restrict__ out_s, int* __restrict__ out_i) {
+                                                       const float* __restrict__ beam_scores, int NBL, int V,
+                                                       int ban, float* __restrict__ out_s, int* __restrict__ out_i) {
   constexpr int K = 2 * NB;
   __shared__ float red[4];
   __shared__ float ls[256 * K];
@@ -81,8 +81,8 @@ __global__ __launch_bounds__(256) void lsm_topk_kernel(const float* __restrict__
       }
     }
   };
-  for (int beam = 0; beam < NB; ++beam) {
-    const float* row = logits + ((size_t)b * NB + beam) * V;
+  for (int beam = 0; beam < NBL; ++beam) {
+    const float* row = logits + ((size_t)b * NBL + beam) * V;
     // pass 1: row max, then sum(exp(x - max)) as torch's log_softmax does (two reductions, vector loads)
     float m = -INFINITY;
     if (vec) {
@@ -258,17 +258,20 @@ __global__ __launch_bounds__(256) void kv_reorder_kernel(const uint4* __restrict
 
 }  // namespace
 
-extern "C" int vidil_logsoftmax_topk(const float* logits, const float* beam_scores, int32_t B, int32_t nb, int32_t V,
-                                     int32_t ban_token, float* out_scores, int32_t* out_index, void* stream) {
+extern "C" int vidil_logsoftmax_topk(const float* logits, const float* beam_scores, int32_t B, int32_t nb,
+                                     int32_t beams_in_logits, int32_t V, int32_t ban_token, float* out_scores,
+                                     int32_t* out_index, void* stream) {
+  const int nbl = beams_in_logits;
+  VIDIL_REQUIRE(nbl >= 1 && nbl <= nb, "logsoftmax_topk: beams_in_logits=%d must be in [1, num_beams=%d]", nbl, nb);
   VIDIL_REQUIRE(logits && beam_scores && out_scores && out_index, "logsoftmax_topk: null pointer");
   VIDIL_REQUIRE(B > 0 && V > 0, "logsoftmax_topk: bad shape");
   VIDIL_REQUIRE((long)nb * V < 0x7fffffffL, "logsoftmax_topk: nb*V overflows int32");
   hipStream_t s = (hipStream_t)stream;
   switch (nb) {
-    case 1: hipLaunchKernelGGL(lsm_topk_kernel<1>, dim3(B), dim3(256), 0, s, logits, beam_scores, V, ban_token, out_scores, out_index); break;
-    case 2: hipLaunchKernelGGL(lsm_topk_kernel<2>, dim3(B), dim3(256), 0, s, logits, beam_scores, V, ban_token, out_scores, out_index); break;
-    case 3: hipLaunchKernelGGL(lsm_topk_kernel<3>, dim3(B), dim3(256), 0, s, logits, beam_scores, V, ban_token, out_scores, out_index); break;
-    case 4: hipLaunchKernelGGL(lsm_topk_kernel<4>, dim3(B), dim3(256), 0, s, logits, beam_scores, V, ban_token, out_scores, out_index); break;
+    case 1: hipLaunchKernelGGL(lsm_topk_kernel<1>, dim3(B), dim3(256), 0, s, logits, beam_scores, nbl, V, ban_token, out_scores, out_index); break;
+    case 2: hipLaunchKernelGGL(lsm_topk_kernel<2>, dim3(B), dim3(256), 0, s, logits, beam_scores, nbl, V, ban_token, out_scores, out_index); break;
+    case 3: hipLaunchKernelGGL(lsm_topk_kernel<3>, dim3(B), dim3(256), 0, s, logits, beam_scores, nbl, V, ban_token, out_scores, out_index); break;
+    case 4: hipLaunchKernelGGL(lsm_topk_kernel<4>, dim3(B), dim3(256), 0, s, logits, beam_scores, nbl, V, ban_token, out_scores, out_index); break;
     default:
       vidil_set_error("logsoftmax_topk: num_beams=%d not supported (1..4)", nb);
       return VIDIL_EUNSUP;

@@ -186,7 +186,7 @@ def l2_normalize_rows(x):
 
 
 # ------------------------------------------------------------------------ beam search
-def logsoftmax_topk(logits, beam_scores, B, nb, ban_token=-1, out_scores=None, out_index=None):
+def logsoftmax_topk(logits, beam_scores, B, nb, ban_token=-1, out_scores=None, out_index=None, beams_in_logits=None):
     V = logits.shape[-1]
     dev = logits.device
     if out_scores is None:
@@ -194,7 +194,8 @@ def logsoftmax_topk(logits, beam_scores, B, nb, ban_token=-1, out_scores=None, o
     if out_index is None:
         out_index = torch.empty((B, 2 * nb), dtype=torch.int32, device=dev)
     check(_lib.load().vidil_logsoftmax_topk(_ptr(logits, torch.float32, "topk.logits"),
-                                            _ptr(beam_scores, torch.float32, "topk.beam_scores"), B, nb, V,
+                                            _ptr(beam_scores, torch.float32, "topk.beam_scores"), B, nb,
+                                            nb if beams_in_logits is None else beams_in_logits, V,
                                             ban_token, _ptr(out_scores, torch.float32), _ptr(out_index, torch.int32),
                                             _stream()), "logsoftmax_topk")
     return out_scores, out_index
