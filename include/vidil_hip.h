@@ -68,7 +68,9 @@ typedef struct vidil_gemm_args {
    * row m -> b = m/T, t = m%T.
    *   part 0: Q [b][h][t][64]            f16, value * q_scale, row capacity Tq_cap
    *   part 1: K [b][h][t_off+t][64]      f16, row capacity Tk_cap
-   *   part 2: VT[b][h][d][t_off+t]       f16, row stride NP (multiple of 8)     */
+   *   part 2: VT[b][h][d][vt(t_off+t)]   f16, row stride NP (multiple of 16); keys of
+   *           every 16-key block are stored in the order 0-3, 8-11, 4-7, 12-15:
+   *           vt(t) = t ^ 12 when bits 2 and 3 of t differ, else t (see vidil_attention) */
   void* q;
   void* k;
   void* vt;
@@ -98,7 +100,9 @@ int vidil_layernorm(const float* x, int64_t x_stride, const float* gamma,
 /* ------------------------------------------------------------------------ */
 /* Attention for short sequences (Nk <= 288): softmax(Q K^T [+mask]) V.       */
 /* Q  f16 [Bq][H][Tq_cap][64] (already scaled by 1/sqrt(64)),                 */
-/* K  f16 [Bk][H][Tk_cap][64], VT f16 [Bk][H][64][NP].                         */
+/* K  f16 [Bk][H][Tk_cap][64], VT f16 [Bk][H][64][NP] with NP % 16 == 0 and    */
+/* the key axis of every 16-key block permuted to 0-3, 8-11, 4-7, 12-15 (the   */
+/* order the transposed-score MFMA layout consumes; written by EPI_HEADS).     */
 /* Which key/value batch a query batch b reads — three forms, all of which let */
 /* every query that shares a K/V (the captions of a frame, the beams of an     */
 /* image) be served by ONE staging of that K/V:                               */

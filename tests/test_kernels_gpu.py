@@ -78,7 +78,7 @@ def test_gemm_heads_epilogue():
     k = _k()
     B, T, H = 3, 197, 12
     M, K, N = B * T, 768, 3 * H * 64
-    NP = 200
+    NP = 208
     a = _rand(M, K, seed=8).half()
     w = _rand(N, K, scale=0.05, seed=9).half()
     bias = _rand(N, seed=10)
@@ -91,10 +91,12 @@ def test_gemm_heads_epilogue():
     tol = dict(rtol=2e-3, atol=2e-3)
     assert torch.allclose(q.float().cpu(), ref[:, :, 0].permute(0, 2, 1, 3) * 0.125, **tol)
     assert torch.allclose(kk.float().cpu(), ref[:, :, 1].permute(0, 2, 1, 3), **tol)
-    assert torch.allclose(vt.float().cpu()[..., :T], ref[:, :, 2].permute(0, 2, 3, 1), **tol)
-    assert torch.all(vt[..., T:] == 0)
+    cols = k.vt_columns(T)
+    assert torch.allclose(vt.float().cpu()[..., cols], ref[:, :, 2].permute(0, 2, 3, 1), **tol)
+    unused = torch.ones(NP, dtype=torch.bool); unused[cols] = False
+    assert torch.all(vt.cpu()[..., unused] == 0)
     # KV-cache append: parts 1,2 only, at an offset
-    Tc = 24
+    Tc = 32
     kc = torch.zeros(B, H, Tc, 64, dtype=torch.float16, device=DEV)
     vc = torch.zeros(B, H, 64, Tc, dtype=torch.float16, device=DEV)
     a1 = _rand(B, K, seed=11).half()
@@ -103,7 +105,7 @@ def test_gemm_heads_epilogue():
            heads=dict(k=kc, vt=vc, T=1, H=H, part0=1, t_off=5, Tk_cap=Tc, NP=Tc))
     r1 = (a1.float() @ w_kv.float().t() + bias[H * 64:]).view(B, 2, H, 64)
     assert torch.allclose(kc[:, :, 5].float().cpu(), r1[:, 0], **tol)
-    assert torch.allclose(vc[:, :, :, 5].float().cpu(), r1[:, 1], **tol)
+    assert torch.allclose(vc[:, :, :, k.vt_pos(5)].float().cpu(), r1[:, 1], **tol)   # key 5 lives in column 9
     assert torch.all(kc[:, :, :5] == 0) and torch.all(kc[:, :, 6:] == 0)
 
 
@@ -185,7 +187,7 @@ def test_gemm256_heads_and_patch_epilogues():
     k = _k()
     B, T, H = 128, 197, 12
     M, K, N = B * T, 768, 3 * H * 64
-    NP = 200
+    NP = 208
     a = _rand(M, K, seed=77).half()
     w = _rand(N, K, scale=0.05, seed=78).half()
     bias = _rand(N, seed=79)
@@ -198,8 +200,10 @@ def test_gemm256_heads_and_patch_epilogues():
     tol = dict(rtol=2e-3, atol=3e-3)
     assert torch.allclose(q.float().cpu(), ref[:, :, 0].permute(0, 2, 1, 3) * 0.125, **tol)
     assert torch.allclose(kk.float().cpu(), ref[:, :, 1].permute(0, 2, 1, 3), **tol)
-    assert torch.allclose(vt.float().cpu()[..., :T], ref[:, :, 2].permute(0, 2, 3, 1), **tol)
-    assert torch.all(vt[..., T:] == 0)
+    cols = k.vt_columns(T)
+    assert torch.allclose(vt.float().cpu()[..., cols], ref[:, :, 2].permute(0, 2, 3, 1), **tol)
+    unused = torch.ones(NP, dtype=torch.bool); unused[cols] = False
+    assert torch.all(vt.cpu()[..., unused] == 0)
     # bit-identical to the small-tile kernel on a 2-frame batch
     q2 = torch.zeros(2, H, T, 64, dtype=torch.float16, device=DEV)
     k2 = torch.zeros(2, H, T, 64, dtype=torch.float16, device=DEV)
@@ -212,7 +216,7 @@ def test_gemm256_heads_and_patch_epilogues():
     kk.zero_(); vt.zero_()
     k.gemm(a.to(DEV), w2.to(DEV), b2.to(DEV), heads=dict(k=kk, vt=vt, T=T, H=H, part0=1, Tk_cap=T, NP=NP))
     assert torch.allclose(kk.float().cpu(), ref[:, :, 1].permute(0, 2, 1, 3), **tol)
-    assert torch.allclose(vt.float().cpu()[..., :T], ref[:, :, 2].permute(0, 2, 3, 1), **tol)
+    assert torch.allclose(vt.float().cpu()[..., cols], ref[:, :, 2].permute(0, 2, 3, 1), **tol)
     # patch epilogue
     tpi = 196
     ap = _rand(B * tpi, K, seed=80).half()
@@ -287,7 +291,7 @@ def _attn_ref(q, kk, v, kv_len=None, causal=False, causal_off=0, kv_group=1):
 def test_attention(Bq, H, Nq, Nk, kv_group, causal, use_len):
     k = _k()
     Bk = Bq // kv_group
-    NP = (Nk + 7) // 8 * 8
+    NP = (Nk + 15) // 16 * 16
     q = _rand(Bq, H, Nq, 64, seed=30).half()
     kk = _rand(Bk, H, Nk, 64, seed=31).half()
     v = _rand(Bk, H, Nk, 64, seed=32).half()
@@ -295,9 +299,8 @@ def test_attention(Bq, H, Nq, Nk, kv_group, causal, use_len):
     if use_len:
         kv_len = torch.tensor([(7 * i) % Nk + 1 for i in range(Bq)], dtype=torch.int32)
     ref = _attn_ref(q.float() * 0.125, kk.float(), v.float(), kv_len, causal, 0, kv_group)
-    vt = torch.zeros(Bk, H, 64, NP, dtype=torch.float16)
-    vt[..., :Nk] = v.transpose(-1, -2)
-    vt[..., Nk:] = float("nan")  # padding must never leak
+    vt = torch.full((Bk, H, 64, NP), float("nan"), dtype=torch.float16)  # padding must never leak
+    vt[..., k.vt_columns(Nk)] = v.transpose(-1, -2)
     out = torch.zeros(Bq * Nq, H * 64, dtype=torch.float16, device=DEV)
     k.attention((q * 0.125).half().to(DEV), kk.to(DEV), vt.to(DEV), out, Bq=Bq, H=H, Nq=Nq, Nk=Nk, Tq_cap=Nq,
                 Tk_cap=Nk, NP=NP, kv_group=kv_group, causal=causal, kv_len=None if kv_len is None else kv_len.to(DEV))
@@ -319,7 +322,7 @@ def test_attention_grouped_by_prefix_table(Nq, Nk, counts, use_len):
     H = 12
     n_kv = len(counts)
     Bq = sum(counts)
-    NP = (Nk + 7) // 8 * 8
+    NP = (Nk + 15) // 16 * 16
     q = (_rand(Bq, H, Nq, 64, seed=33) * 0.125).half()
     kk = _rand(n_kv, H, Nk, 64, seed=34).half()
     v = _rand(n_kv, H, Nk, 64, seed=35).half()
@@ -329,7 +332,7 @@ def test_attention_grouped_by_prefix_table(Nq, Nk, counts, use_len):
     kv_len = torch.tensor([(5 * i) % Nk + 1 for i in range(Bq)], dtype=torch.int32) if use_len else None
     ref = _attn_ref(q.float(), kk.float()[kv_of], v.float()[kv_of], kv_len)
     vt = torch.full((n_kv, H, 64, NP), float("nan"), dtype=torch.float16)
-    vt[..., :Nk] = v.transpose(-1, -2)
+    vt[..., k.vt_columns(Nk)] = v.transpose(-1, -2)
     out = torch.full((Bq * Nq, H * 64), 7.0, dtype=torch.float16, device=DEV)
     k.attention(q.to(DEV), kk.to(DEV), vt.to(DEV), out, Bq=Bq, H=H, Nq=Nq, Nk=Nk, Tq_cap=Nq, Tk_cap=Nk, NP=NP,
                 group_start=gs.to(DEV), max_group=max(counts), kv_len=None if kv_len is None else kv_len.to(DEV))

@@ -62,7 +62,7 @@ def test_decoder_small_vs_golden_prefill_reorder_and_steps():
     dec = load_into(BertLMHeadModel(_small_med_cfg()), sd, "text_decoder.").to(DEV)
     bert = dec.bert
     enc = torch.from_numpy(g["enc"])                                  # [3,17,256]
-    B, Te, nb, R, L, H, Tcap = 3, 17, 2, 6, 2, 4, 8
+    B, Te, nb, R, L, H, Tcap = 3, 17, 2, 6, 2, 4, 16
     enc16 = enc.reshape(B * Te, 256).to(DEV).half().contiguous()
     cross = bert.project_cross_kv(enc16, B, Te)
     kc = [torch.zeros((L, R, H, Tcap, 64), dtype=torch.float16, device=DEV) for _ in range(2)]

@@ -96,7 +96,7 @@ class DecoderSession:
         Te = enc16.shape[0] // B
         self.cross = self.bert.project_cross_kv(enc16, B, Te)
         self.Tcap = max_length
-        self.NPs = (max_length + 7) // 8 * 8
+        self.NPs = (max_length + 15) // 16 * 16
         self.kc = [torch.empty((self.L, self.R, self.H, self.Tcap, 64), dtype=torch.float16, device=dev) for _ in range(2)]
         self.vc = [torch.empty((self.L, self.R, self.H, 64, self.NPs), dtype=torch.float16, device=dev) for _ in range(2)]
         self.cur = 0

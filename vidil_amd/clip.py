@@ -136,7 +136,7 @@ def _run_layers(layers, x, B, T, H, eps, *, causal=False, kv_len=None):
     """Pre-LN CLIP encoder layers on the f32 residual stream x [B*T, D] (in place)."""
     dev = x.device
     M, D = x.shape
-    NP = (T + 7) // 8 * 8
+    NP = (T + 15) // 16 * 16
     xn = torch.empty((M, D), dtype=torch.float16, device=dev)
     q = torch.empty((B, H, T, 64), dtype=torch.float16, device=dev)
     k = torch.empty((B, H, T, 64), dtype=torch.float16, device=dev)

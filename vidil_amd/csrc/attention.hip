@@ -14,8 +14,8 @@
 // final 1/l are lane-local as well and a lane stores 4 contiguous d values:
 //
 //   attn_lds_kernel    rows > 32: K ([keys][64], rows padded to 144 B) and V^T
-//                      ([64][keys], stride keys+4) staged once in LDS (strides
-//                      chosen so ds_read_b128/_b64 fragment reads are conflict
+//                      ([64][keys], stride keys+8) staged once in LDS (strides
+//                      chosen so the ds_read_b128 fragment reads are conflict
 //                      free); each wave owns 32 virtual rows, 4 or 8 waves.
 //   attn_direct_kernel rows <= 32 (decode steps, prefill): every K/V element is
 //                      used by one wave only, so fragments are loaded straight
@@ -24,9 +24,11 @@
 //                      (m, l, O) partials through 17 KB of LDS.
 //
 // The key order inside a 16-key MFMA step is the order the S^T accumulator
-// layout leaves the P values in ({0-3,8-11} / {4-7,12-15} per half-wave); the
-// V^T fragment reads use the same order, so P feeds the second MFMA without any
-// permute.
+// layout leaves the P values in ({0-3,8-11} / {4-7,12-15} per half-wave).  V^T
+// is STORED in that order (key t lives in column vt_pos(t), common.h: inside
+// each 16-key block the 4-key groups 1 and 2 are swapped), so a half-wave's 8
+// keys are one contiguous 16-byte read and P feeds the second MFMA without any
+// permute.  NP (the V^T row stride) is a multiple of 16 for that reason.
 #include "common.h"
 
 namespace {
@@ -154,7 +156,8 @@ __device__ __forceinline__ void store_rows(const AttnP& p, const RowInfo& ri, in
 template <int NKT, int NW>
 __global__ __launch_bounds__(NW * 64) void attn_lds_kernel(const AttnP p) {
   constexpr int NKEY = NKT * 32;
-  constexpr int VROW = NKEY + 4;  // halfs per V^T row in LDS
+  constexpr int VROW = NKEY + 8;  // halfs per V^T row in LDS: 16-B aligned rows, (2*NKEY+16)/16 odd ->
+                                  // the ds_read_b128 of 16 different rows hit 16 different 16-B bank slots
   constexpr int NT = NW * 64;
   extern __shared__ __attribute__((aligned(16))) char smem[];
   f16* Ks = (f16*)smem;                      // [NKEY][KROW]
@@ -186,18 +189,18 @@ __global__ __launch_bounds__(NW * 64) void attn_lds_kernel(const AttnP p) {
     const f16* vg = p.vt + ((size_t)bk * p.H + h) * 64 * (size_t)p.NP;
     for (int q = tid; q < 64 * NKT * 4; q += NT) {
       const int d = q / (NKT * 4), kc = q - d * (NKT * 4);
-      const int key0 = kc * 8;
+      const int pos0 = kc * 8;                // storage columns pos0..pos0+7 (key = vt_pos(column))
+      const int blk_end = (pos0 | 15) + 1;    // end of the 16-key block this chunk belongs to
       f16x8 v = {0, 0, 0, 0, 0, 0, 0, 0};
-      if (key0 + 8 <= nk) {
-        v = *(const f16x8*)(vg + (size_t)d * p.NP + key0);
-      } else if (key0 < nk) {
+      if (blk_end <= nk) {
+        v = *(const f16x8*)(vg + (size_t)d * p.NP + pos0);
+      } else if ((pos0 & ~15) < nk && pos0 + 8 <= p.NP) {
+        v = *(const f16x8*)(vg + (size_t)d * p.NP + pos0);
 #pragma unroll
         for (int e = 0; e < 8; ++e)
-          if (key0 + e < nk) v[e] = vg[(size_t)d * p.NP + key0 + e];
+          if (vt_pos(pos0 + e) >= nk) v[e] = (f16)0.f;
       }
-      f16* dst = Vs + d * VROW + key0;
-      *(f16x4*)(dst) = f16x4{v[0], v[1], v[2], v[3]};
-      *(f16x4*)(dst + 4) = f16x4{v[4], v[5], v[6], v[7]};
+      *(f16x8*)(Vs + d * VROW + pos0) = v;
     }
   }
   __syncthreads();
@@ -239,10 +242,7 @@ __global__ __launch_bounds__(NW * 64) void attn_lds_kernel(const AttnP p) {
     }
     const bool need_mask = (kt * 32 + 32) > kmin;
     softmax_pv_tile(S, kt * 32, ri.klim, need_mask, m, l, O, [&](int dt, int hb) {
-      const f16* vrow = Vs + (dt * 32 + l31) * VROW + (kt * 2 + hb) * 16 + 4 * hi;
-      const f16x4 lo = *(const f16x4*)(vrow);
-      const f16x4 up = *(const f16x4*)(vrow + 8);
-      return f16x8{lo[0], lo[1], lo[2], lo[3], up[0], up[1], up[2], up[3]};
+      return *(const f16x8*)(Vs + (dt * 32 + l31) * VROW + (kt * 2 + hb) * 16 + 8 * hi);
     });
   }
   l += __shfl_xor(l, 32, 64);
@@ -307,18 +307,15 @@ __global__ __launch_bounds__(256) void attn_direct_kernel(const AttnP p) {
       const bool tail = (kt * 32 + 32) > nk;  // tile reaches past the last key: V^T needs zeroing too
       const bool need_mask = (kt * 32 + 32) > kmin;
       softmax_pv_tile(S, kt * 32, ri.klim, need_mask, m, l, O, [&](int dt, int hb) {
-        const int key0 = (kt * 2 + hb) * 16 + 4 * hi;
-        const f16* vrow = vg + (size_t)(dt * 32 + l31) * p.NP + key0;
+        // this half-wave's 8 keys of the 16-key block are 16 contiguous bytes (vt_pos order)
+        const int blk0 = (kt * 2 + hb) * 16;
         f16x8 v = {0, 0, 0, 0, 0, 0, 0, 0};
-        if (!tail) {
-          const f16x4 lo = *(const f16x4*)(vrow);
-          const f16x4 up = *(const f16x4*)(vrow + 8);
-          v = f16x8{lo[0], lo[1], lo[2], lo[3], up[0], up[1], up[2], up[3]};
-        } else {
+        if (blk0 < nk) {
+          v = *(const f16x8*)(vg + (size_t)(dt * 32 + l31) * p.NP + blk0 + 8 * hi);
+          if (tail) {
 #pragma unroll
-          for (int e = 0; e < 4; ++e) {
-            if (key0 + e < nk) v[e] = vrow[e];
-            if (key0 + 8 + e < nk) v[4 + e] = vrow[8 + e];
+            for (int e = 0; e < 8; ++e)
+              if (blk0 + 4 * hi + (e & 3) + 8 * (e >> 2) >= nk) v[e] = (f16)0.f;
           }
         }
         return v;
@@ -394,13 +391,13 @@ __global__ __launch_bounds__(64) void attn_wave_kernel(const AttnP p) {
 #pragma unroll
     for (int r = 0; r < 16; ++r) O[dt][r] = 0.f;
   softmax_pv_tile(S, 0, ri.klim, true, m, l, O, [&](int dt, int hb) {
-    const int key0 = hb * 16 + 4 * hi;
-    const f16* vrow = vg + (size_t)(dt * 32 + l31) * p.NP + key0;
+    const int blk0 = hb * 16;
     f16x8 v = {0, 0, 0, 0, 0, 0, 0, 0};
+    if (blk0 < nk) {
+      v = *(const f16x8*)(vg + (size_t)(dt * 32 + l31) * p.NP + blk0 + 8 * hi);
 #pragma unroll
-    for (int e = 0; e < 4; ++e) {
-      if (key0 + e < nk) v[e] = vrow[e];
-      if (key0 + 8 + e < nk) v[4 + e] = vrow[8 + e];
+      for (int e = 0; e < 8; ++e)
+        if (blk0 + 4 * hi + (e & 3) + 8 * (e >> 2) >= nk) v[e] = (f16)0.f;
     }
     return v;
   });
@@ -410,7 +407,7 @@ __global__ __launch_bounds__(64) void attn_wave_kernel(const AttnP p) {
 
 template <int NKT, int NW>
 int launch_lds(const AttnP& p, int max_rows, hipStream_t s) {
-  constexpr int smem = NKT * 32 * KROW * 2 + 64 * (NKT * 32 + 4) * 2;
+  constexpr int smem = NKT * 32 * KROW * 2 + 64 * (NKT * 32 + 8) * 2;
   static bool attr_set = false;
   auto kern = attn_lds_kernel<NKT, NW>;
   if (!attr_set) {
@@ -452,7 +449,7 @@ extern "C" int vidil_attention(const void* q, const void* k, const void* vt, voi
   VIDIL_REQUIRE(q && k && vt && out, "attention: null pointer");
   VIDIL_REQUIRE(Bq > 0 && H > 0 && Nq > 0 && Nk > 0, "attention: bad shape Bq=%d H=%d Nq=%d Nk=%d", Bq, H, Nq, Nk);
   VIDIL_REQUIRE(Tq_cap >= Nq && Tk_cap >= Nk && NP >= Nk, "attention: capacities too small");
-  VIDIL_REQUIRE(NP % 8 == 0, "attention: NP=%d must be a multiple of 8", NP);
+  VIDIL_REQUIRE(NP % 16 == 0, "attention: NP=%d must be a multiple of 16 (V^T rows hold whole 16-key blocks)", NP);
   VIDIL_REQUIRE(ldo >= H * 64 && ldo % 8 == 0, "attention: ldo=%d must be >= H*64 and a multiple of 8", ldo);
   VIDIL_REQUIRE(kv_group > 0, "attention: kv_group=%d", kv_group);
   int units, max_rows;

@@ -39,6 +39,12 @@ int vidil_gemm256w4_launch(const vidil_gemm_args& a, hipStream_t s);
     }                                                                       \
   } while (0)
 
+// V^T key order.  The transposed-score MFMA layout leaves a half-wave holding keys {0-3, 8-11} (lanes
+// 0-31) or {4-7, 12-15} (lanes 32-63) of every 16-key block, so V^T rows store the keys of a block in the
+// order 0-3, 8-11, 4-7, 12-15: each half-wave's 8 keys are then 16 contiguous bytes (one load instead of
+// two).  vt_pos maps key -> storage column (and back: it is an involution); row strides are multiples of 16.
+__host__ __device__ __forceinline__ int vt_pos(int t) { return t ^ ((((t >> 2) ^ (t >> 3)) & 1) * 12); }
+
 // device helpers --------------------------------------------------------------
 __device__ __forceinline__ float wave_sum(float v) {
 #pragma unroll

@@ -248,7 +248,7 @@ __global__ __launch_bounds__(512) void gemm256_kernel(const vidil_gemm_args p) {
         const int m = m_w + it * 32 + l31;
         if (m < M) {
           const int b = m / p.T, t = m - b * p.T;
-          f16* dst = (f16*)p.vt + (((size_t)b * p.H + head) * 64) * (size_t)p.NP + p.t_off + t;
+          f16* dst = (f16*)p.vt + (((size_t)b * p.H + head) * 64) * (size_t)p.NP + vt_pos(p.t_off + t);
 #pragma unroll
           for (int j = 0; j < 2; ++j)
 #pragma unroll

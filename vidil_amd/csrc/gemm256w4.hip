@@ -191,7 +191,7 @@ __global__ __launch_bounds__(256, 1) void gemm256w4_kernel(const vidil_gemm_args
           for (int j = 0; j < 4; ++j) {
             if (n_w + j * 32 < N) {
               const int head = head0 + (j >> 1);
-              f16* dst = (f16*)p.vt + (((size_t)b * p.H + head) * 64) * (size_t)p.NP + p.t_off + t;
+              f16* dst = (f16*)p.vt + (((size_t)b * p.H + head) * 64) * (size_t)p.NP + vt_pos(p.t_off + t);
 #pragma unroll
               for (int rq = 0; rq < 4; ++rq)
 #pragma unroll

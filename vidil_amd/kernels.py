@@ -22,6 +22,17 @@ __all__ = [
 ]
 
 
+def vt_pos(t: int) -> int:
+    """Storage column of key ``t`` in a V^T buffer (include/vidil_hip.h: 16-key blocks hold keys in the order
+    0-3, 8-11, 4-7, 12-15).  An involution: it also maps a column back to its key."""
+    return t ^ (12 if ((t >> 2) ^ (t >> 3)) & 1 else 0)
+
+
+def vt_columns(n: int):
+    """LongTensor c with c[t] = vt_pos(t) for t < n (for building / reading V^T buffers in tests)."""
+    return torch.tensor([vt_pos(t) for t in range(n)], dtype=torch.long)
+
+
 def _stream() -> int:
     return torch.cuda.current_stream().cuda_stream
 

@@ -173,7 +173,7 @@ class BertModel(PackedCache, nn.Module):
         """enc16: f16 [B*Te, encoder_width] image tokens.  One fused K|V GEMM per layer."""
         p = self.packed()
         H = self.config.num_attention_heads
-        NP = (Te + 7) // 8 * 8
+        NP = (Te + 15) // 16 * 16
         L = len(p["layers"])
         dev = enc16.device
         k = torch.empty((L, B, H, Te, 64), dtype=torch.float16, device=dev)
@@ -251,7 +251,7 @@ class BertModel(PackedCache, nn.Module):
         H = self.config.num_attention_heads
         L = self.config.num_hidden_layers
         dev = ids_i32.device
-        NPs = (T + 7) // 8 * 8
+        NPs = (T + 15) // 16 * 16
         h32, h16 = self.embed(ids_i32.reshape(-1), T, 0)
         sk = torch.empty((1, P, H, T, 64), dtype=torch.float16, device=dev).expand(L, -1, -1, -1, -1)
         sv = torch.empty((1, P, H, 64, NPs), dtype=torch.float16, device=dev).expand(L, -1, -1, -1, -1)

@@ -131,7 +131,7 @@ class VisionTransformer(PackedCache, nn.Module):
         p = self.packed()
         D, H = self.embed_dim, self.num_heads
         T = self.patch_embed.num_patches + 1
-        NP = (T + 7) // 8 * 8
+        NP = (T + 15) // 16 * 16
         dev = x.device
         M = B * T
         xn = torch.empty((M, D), dtype=torch.float16, device=dev)
