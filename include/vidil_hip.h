@@ -49,7 +49,8 @@ enum {
   VIDIL_EPI_F16 = 0,   /* out f16 [M,ldo]   = act(acc + bias)                              */
   VIDIL_EPI_F32 = 1,   /* out f32 [M,ldo]   = act(acc + bias) + resid (resid may alias out)*/
   VIDIL_EPI_HEADS = 2, /* scatter into per-head Q / K / V^T buffers (see below)            */
-  VIDIL_EPI_PATCH = 3  /* out f32 row (m + m/tpi + 1) = acc + bias + pos[(m%tpi)+1]        */
+  VIDIL_EPI_PATCH = 3, /* out f32 row (m + m/tpi + 1) = acc + bias + pos[(m%tpi)+1]        */
+  VIDIL_EPI_ARENA = 4  /* Q rows + K / V rows appended to a beam-search KV arena (below)   */
 };
 enum { VIDIL_ACT_NONE = 0, VIDIL_ACT_GELU_ERF = 1, VIDIL_ACT_QUICK_GELU = 2 };
 
@@ -76,6 +77,15 @@ typedef struct vidil_gemm_args {
   void* vt;
   int32_t T, H, part0, t_off, Tq_cap, Tk_cap, NP;
   float q_scale;
+  /* EPI_ARENA: same column / row decomposition as EPI_HEADS (T, H, part0, t_off, q_scale), but the
+   * destinations are row-major with all heads of a token contiguous (no transposition, no per-head
+   * scatter — the layout vidil_beam_attention reads):
+   *   part 0: Q     [m][H*64]                                   f16, value * q_scale
+   *   part 1: K     [t_off+t][b*slot_stride][H*64]  (arena `k`)  f16, arena_rows slots per position
+   *   part 2: V     [t_off+t][b*slot_stride][H*64]  (arena `vt`) f16 (NOT transposed)
+   * decode step: T = 1, slot_stride = 1 (row m appends position t_off of slot m);
+   * shared prompt pass: T = P, slot_stride = nb (image b's prompt lives in slot b*nb). */
+  int32_t arena_rows, slot_stride;
   /* EPI_PATCH */
   const float* pos;   /* f32 [(tpi+1), N]                                      */
   int32_t tpi;        /* patches per image                                     */
@@ -206,6 +216,30 @@ int vidil_beam_finalize(const vidil_beam_state* st, int32_t B, int32_t nb,
 /* dst[l][s] = src[l][beam_idx[s]]; a row is row_halfs f16 values.            */
 int vidil_kv_reorder(const void* src, void* dst, const int32_t* beam_idx,
                      int32_t L, int32_t rows, int64_t row_halfs, void* stream);
+
+/* ------------------------------------------------------------------------ */
+/* Beam-search KV arena: the same _reorder_cache semantics (models/med.py:    */
+/* 951-955) WITHOUT moving the cache.  Keys / values of every layer live in   */
+/* an append-only arena [position][slot][H*64] (slot = the beam row that      */
+/* produced them, written by EPI_ARENA); what is reordered each step is a     */
+/* small ancestry table anc i32 [rows][Tcap]: anc[r][t] = the slot holding    */
+/* position t of the sequence that beam row r currently continues.            */
+/*   vidil_beam_ancestry: dst[r][t] = src[beam_idx[r]][t] for t < cur_pos,    */
+/*                        dst[r][cur_pos] = r  (where row r's next K/V go).   */
+/*   vidil_beam_attention: one query token per beam row r (q f16 [rows][H*64],*/
+/*     pre-scaled) over positions 0..n_keys-1 of its ancestry:                */
+/*     out[r][h*64+d] = softmax_t(q_rh . K[t][anc[r][t]][h]) V[t][anc[r][t]][h]*/
+/*     f32 scores / softmax / accumulation, f16 output (row stride ldo).      */
+/*     n_keys <= 64.  Replaces the cached self-attention of models/med.py:    */
+/*     178-220 on decode steps (past_key_values + _reorder_cache).            */
+/* ------------------------------------------------------------------------ */
+int vidil_beam_ancestry(const int32_t* anc_src, int32_t* anc_dst,
+                        const int32_t* beam_idx, int32_t rows, int32_t Tcap,
+                        int32_t cur_pos, void* stream);
+int vidil_beam_attention(const void* q, const void* k_arena, const void* v_arena,
+                         const int32_t* anc, void* out, int32_t rows, int32_t H,
+                         int32_t n_keys, int32_t arena_rows, int32_t Tcap,
+                         int32_t ldo, void* stream);
 
 /* ------------------------------------------------------------------------ */
 /* Ontology scan + per-frame top-k (run_visual_tokenization.py:276,298-308).  */

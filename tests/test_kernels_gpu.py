@@ -417,6 +417,81 @@ def test_kv_reorder():
     assert torch.equal(dst.cpu(), src.cpu()[:, idx.long()])
 
 
+def test_gemm_arena_epilogue():
+    """EPI_ARENA: Q rows + K/V rows appended at [position][slot][H*64]; decode step (T=1) and prompt block (T=P)."""
+    k = _k()
+    H, C, K_ = 4, 256, 128
+    Tcap, R, nb = 8, 12, 3
+    w = _rand(3 * C, K_, scale=0.05, seed=60).half()
+    bias = _rand(3 * C, seed=61)
+    tol = dict(rtol=2e-3, atol=2e-3)
+    ka = torch.zeros(Tcap, R, C, dtype=torch.float16, device=DEV)
+    va = torch.zeros(Tcap, R, C, dtype=torch.float16, device=DEV)
+    # prompt block: B = R/nb images x P tokens, K|V only, slot b*nb
+    B, P = R // nb, 3
+    a = _rand(B * P, K_, seed=62).half()
+    ref = (a.float() @ w.float().t() + bias).view(B, P, 3, C)
+    k.gemm(a.to(DEV), w[C:].to(DEV).contiguous(), bias[C:].to(DEV).contiguous(),
+           arena=dict(k=ka, v=va, T=P, H=H, part0=1, t_off=0, Tcap=Tcap, arena_rows=R, slot_stride=nb))
+    assert torch.allclose(ka[:P, ::nb].float().cpu(), ref[:, :, 1].permute(1, 0, 2), **tol)
+    assert torch.allclose(va[:P, ::nb].float().cpu(), ref[:, :, 2].permute(1, 0, 2), **tol)
+    touched = torch.zeros(Tcap, R, dtype=torch.bool); touched[:P, ::nb] = True
+    assert torch.all(ka.cpu()[~touched] == 0) and torch.all(va.cpu()[~touched] == 0)
+    # decode step: R rows, one token each, position 5, Q scaled
+    a1 = _rand(R, K_, seed=63).half()
+    r1 = (a1.float() @ w.float().t() + bias).view(R, 3, C)
+    q = torch.zeros(R, C, dtype=torch.float16, device=DEV)
+    k.gemm(a1.to(DEV), w.to(DEV), bias.to(DEV),
+           arena=dict(q=q, k=ka, v=va, T=1, H=H, part0=0, t_off=5, Tcap=Tcap, arena_rows=R, slot_stride=1, q_scale=0.125))
+    assert torch.allclose(q.float().cpu(), r1[:, 0] * 0.125, **tol)
+    assert torch.allclose(ka[5].float().cpu(), r1[:, 1], **tol)
+    assert torch.allclose(va[5].float().cpu(), r1[:, 2], **tol)
+    assert torch.all(ka.cpu()[6:] == 0)
+    with pytest.raises(k.VidilHipError):   # position beyond the arena capacity
+        k.gemm(a1.to(DEV), w.to(DEV), bias.to(DEV),
+               arena=dict(q=q, k=ka, v=va, T=1, H=H, part0=0, t_off=Tcap, Tcap=Tcap, arena_rows=R, slot_stride=1))
+
+
+def test_beam_ancestry():
+    k = _k()
+    rows, Tcap, pos = 9, 12, 5
+    g = torch.Generator().manual_seed(64)
+    src = torch.randint(0, rows, (rows, Tcap), generator=g, dtype=torch.int32)
+    idx = torch.tensor([2, 2, 0, 5, 5, 5, 8, 7, 6], dtype=torch.int32)
+    dst = torch.full((rows, Tcap), -1, dtype=torch.int32, device=DEV)
+    k.beam_ancestry(src.to(DEV), dst, idx.to(DEV), pos)
+    d = dst.cpu()
+    assert torch.equal(d[:, :pos], src[idx.long(), :pos])
+    assert torch.equal(d[:, pos], torch.arange(rows, dtype=torch.int32))
+
+
+@pytest.mark.parametrize("rows,H,n_keys,Tcap", [(7, 12, 1, 20), (96, 12, 5, 20), (33, 4, 20, 20), (10, 12, 32, 40),
+                                                  (6, 2, 47, 64)])
+def test_beam_attention_vs_torch(rows, H, n_keys, Tcap):
+    """Softmax attention of one query per (row, head) over keys gathered through a random ancestry table;
+    unused arena cells are NaN and must never be read into a result."""
+    k = _k()
+    C = H * 64
+    g = torch.Generator().manual_seed(65 + n_keys)
+    q = _rand(rows, C, seed=66).half()
+    ka = torch.full((Tcap, rows, C), float("nan"), dtype=torch.float16)
+    va = torch.full((Tcap, rows, C), float("nan"), dtype=torch.float16)
+    anc = torch.randint(0, rows, (rows, Tcap), generator=g, dtype=torch.int32)
+    used = torch.zeros(Tcap, rows, dtype=torch.bool)
+    used[torch.arange(n_keys)[None, :].expand(rows, -1), anc[:, :n_keys].long()] = True
+    ka[used] = _rand(int(used.sum()), C, seed=67).half()
+    va[used] = _rand(int(used.sum()), C, seed=68).half()
+    out = torch.zeros(rows, C, dtype=torch.float16, device=DEV)
+    k.beam_attention(q.to(DEV), ka.to(DEV), va.to(DEV), anc.to(DEV), out, rows=rows, H=H, n_keys=n_keys)
+    t = torch.arange(n_keys)
+    kg = ka[t[None, :], anc[:, :n_keys].long()].float().view(rows, n_keys, H, 64)     # [r, t, h, d]
+    vg = va[t[None, :], anc[:, :n_keys].long()].float().view(rows, n_keys, H, 64)
+    s = torch.einsum("rhd,rthd->rht", q.float().view(rows, H, 64), kg)
+    ref = torch.einsum("rht,rthd->rhd", torch.softmax(s, dim=-1), vg).reshape(rows, C)
+    assert not torch.isnan(out).any()
+    assert torch.allclose(out.float().cpu(), ref, rtol=2e-3, atol=2e-3)
+
+
 # ------------------------------------------------------------------------ ontology scan
 def _scan_oracle():
     here = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))

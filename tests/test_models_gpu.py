@@ -87,6 +87,34 @@ def test_decoder_small_vs_golden_prefill_reorder_and_steps():
         logits_close(dec.lm_logits(h16, R, 1).cpu(), torch.from_numpy(g[key_ref]))
 
 
+def test_decoder_session_small_vs_golden_arena_and_ancestry():
+    """The same golden sequence through the product's DecoderSession: prompt pass -> beam reorder (ancestry
+    table, the KV arena itself never moves) -> two cached steps."""
+    from vidil_amd.blip import DecoderSession
+    from vidil_amd.med import BertLMHeadModel
+
+    sd, g = load_golden("med_decoder_small.npz")
+    dec = load_into(BertLMHeadModel(_small_med_cfg()), sd, "text_decoder.").to(DEV)
+    enc = torch.from_numpy(g["enc"])                                  # [3,17,256]
+    B, nb, R = 3, 2, 6
+    sess = DecoderSession(dec, enc.reshape(B * 17, 256).to(DEV).half().contiguous(), B, nb, max_length=8)
+    ids = torch.from_numpy(g["ids"]).to(torch.int32).to(DEV)          # [6,4]: every row has its own prompt
+    logits_close(sess.prefill(ids.reshape(-1), 4, shared=False).cpu(), torch.from_numpy(g["logits0"]))
+    kref = torch.from_numpy(g["k_cache_l1"])                          # [6,4,4,64] = [row, head, t, d]
+    got = sess.arena.k[1][:4].float().cpu().view(4, R, 4, 64).permute(1, 2, 0, 3)
+    assert (got - kref).abs().max().item() < 5e-3
+    beam_idx = torch.from_numpy(g["beam_idx"]).to(torch.int32).to(DEV)
+    ident = torch.arange(R, dtype=torch.int32, device=DEV)
+    tok1 = torch.from_numpy(g["ids1"][:, -1].copy()).to(torch.int32).to(DEV)
+    logits_close(sess.step(tok1, beam_idx, 4).cpu(), torch.from_numpy(g["logits1"]))
+    tok2 = torch.from_numpy(g["ids2"][:, -1].copy()).to(torch.int32).to(DEV)
+    logits_close(sess.step(tok2, ident, 5).cpu(), torch.from_numpy(g["logits2"]))
+    # ancestry after the two steps: prompt positions follow beam_idx, then each row's own slots
+    anc = sess.arena.anc.cpu()
+    assert torch.equal(anc[:, :4], beam_idx.cpu()[:, None].expand(-1, 4))
+    assert torch.equal(anc[:, 4], ident.cpu()) and torch.equal(anc[:, 5], ident.cpu())
+
+
 def test_itm_small_vs_golden_with_padding():
     from vidil_amd.med import BertModel
 

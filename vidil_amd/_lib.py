@@ -15,7 +15,7 @@ import torch  # noqa: F401  -- MUST precede the CDLL below: torch ships its own 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "csrc", "libvidil_hip.so")
 
-EPI_F16, EPI_F32, EPI_HEADS, EPI_PATCH = 0, 1, 2, 3
+EPI_F16, EPI_F32, EPI_HEADS, EPI_PATCH, EPI_ARENA = 0, 1, 2, 3, 4
 ACT_NONE, ACT_GELU_ERF, ACT_QUICK_GELU = 0, 1, 2
 
 
@@ -32,6 +32,7 @@ class GemmArgs(C.Structure):
         ("T", C.c_int32), ("H", C.c_int32), ("part0", C.c_int32), ("t_off", C.c_int32),
         ("Tq_cap", C.c_int32), ("Tk_cap", C.c_int32), ("NP", C.c_int32),
         ("q_scale", C.c_float),
+        ("arena_rows", C.c_int32), ("slot_stride", C.c_int32),
         ("pos", C.c_void_p), ("tpi", C.c_int32),
     ]
 
@@ -64,6 +65,8 @@ SIGNATURES = {
     "vidil_beam_update": (_i32, [C.POINTER(BeamState), _p, _p] + [_i32] * 7 + [_p]),
     "vidil_beam_finalize": (_i32, [C.POINTER(BeamState)] + [_i32] * 6 + [_p, _p, _p, _p]),
     "vidil_kv_reorder": (_i32, [_p, _p, _p, _i32, _i32, _i64, _p]),
+    "vidil_beam_ancestry": (_i32, [_p, _p, _p, _i32, _i32, _i32, _p]),
+    "vidil_beam_attention": (_i32, [_p, _p, _p, _p, _p] + [_i32] * 6 + [_p]),
     "vidil_scan_topk_ws_bytes": (_i64, [_i32, _i32, _i32]),
     "vidil_scan_topk": (_i32, [_p, _p, _i32, _i32, _i32, C.POINTER(_i32), C.POINTER(_i32), _i32, _p, _p, _p, _p]),
 }

@@ -16,7 +16,7 @@ import torch
 import torch.nn as nn
 
 from . import kernels as K
-from .med import BertConfig, BertLMHeadModel
+from .med import BeamArena, BertConfig, BertLMHeadModel
 from .packing import require_cuda
 from .tokenizer import init_tokenizer  # noqa: F401  (re-exported, reference API)
 from .vit import VisionTransformer, interpolate_pos_embed
@@ -85,7 +85,8 @@ class DecodeTrace:
 
 class DecoderSession:
     """Device-resident decoding state of R = B*nb sequences over B images: per-image cross K/V (projected
-    once), double-buffered self-attention KV cache, and the two forward entry points the beam loop needs."""
+    once), the append-only self-attention KV arena + ancestry table, and the two forward entry points the beam
+    loop needs."""
 
     def __init__(self, text_decoder, enc16, B, nb, max_length):
         self.dec, self.bert = text_decoder, text_decoder.bert
@@ -96,40 +97,38 @@ class DecoderSession:
         Te = enc16.shape[0] // B
         self.cross = self.bert.project_cross_kv(enc16, B, Te)
         self.Tcap = max_length
-        self.NPs = (max_length + 15) // 16 * 16
-        self.kc = [torch.empty((self.L, self.R, self.H, self.Tcap, 64), dtype=torch.float16, device=dev) for _ in range(2)]
-        self.vc = [torch.empty((self.L, self.R, self.H, 64, self.NPs), dtype=torch.float16, device=dev) for _ in range(2)]
-        self.cur = 0
+        self.arena = BeamArena(self.L, self.Tcap, self.R, cfg.hidden_size, dev)
         self.ws_prefill, self.ws_step = {}, {}
         self.logits = None
-        self.compact = False   # True while the cache holds ONE row per image (after a shared prefill)
 
     def prefill(self, ids_i32, P, shared=False):
         """Prompt pass.  shared=False: ids_i32 int32 [R*P], every row decoded -> logits f32 [R,V] (what HF
         generate() does).  shared=True: ids_i32 int32 [B*P], ONE row per image -> logits f32 [B,V]: the nb beams of
         an image are identical until the first beam update (models/blip.py:130-138 repeats the same prompt and
-        image nb times), so their prompt pass is computed once; the first ``step`` expands the cache rows."""
+        image nb times), so their prompt pass is computed once and its K/V are stored once (arena slot b*nb, which
+        the ancestry rows of all nb beams point at)."""
         rows = self.B if shared else self.R
+        dev = ids_i32.device
         h32, h16 = self.bert.embed(ids_i32, P, 0)
-        self.bert.run_layers(h32, h16, rows=rows, T=P, self_k=self.kc[self.cur], self_vt=self.vc[self.cur], t_off=0,
-                             Tk_cap=self.Tcap, NPs=self.NPs, causal=True, kv_len=None, cross=self.cross,
-                             cross_group=1 if shared else self.nb, ws=self.ws_prefill)
-        self.compact = shared
+        NPp = (P + 15) // 16 * 16
+        # the prompt block attends to itself through one scratch K / V^T pair shared by all layers
+        sk = torch.empty((1, rows, self.H, P, 64), dtype=torch.float16, device=dev).expand(self.L, -1, -1, -1, -1)
+        sv = torch.empty((1, rows, self.H, 64, NPp), dtype=torch.float16, device=dev).expand(self.L, -1, -1, -1, -1)
+        self.arena.init_prompt(P, self.nb if shared else 1)
+        self.bert.run_layers(h32, h16, rows=rows, T=P, self_k=sk, self_vt=sv, t_off=0, Tk_cap=P, NPs=NPp, causal=True,
+                             kv_len=None, cross=self.cross, cross_group=1 if shared else self.nb, ws=self.ws_prefill,
+                             arena=self.arena, arena_slot_stride=self.nb if shared else 1)
         return self.dec.lm_logits(h16, rows, P)
 
     def step(self, next_tok_i32, beam_idx_i32, past_len):
-        """Reorder the KV cache rows by ``beam_idx`` (models/med.py:951-955), then one cached forward of the
-        single new token at position ``past_len``.  Returns logits f32 [R,V]."""
-        if self.compact:   # cache row of image b is b: global source row b*nb+j -> b
-            beam_idx_i32 = torch.div(beam_idx_i32, self.nb, rounding_mode="floor").to(torch.int32)
-            self.compact = False
-        K.kv_reorder(self.kc[self.cur], self.kc[self.cur ^ 1], beam_idx_i32, self.L, self.R)
-        K.kv_reorder(self.vc[self.cur], self.vc[self.cur ^ 1], beam_idx_i32, self.L, self.R)
-        self.cur ^= 1
+        """Re-point the beams at their new histories (``beam_idx``: models/med.py:951-955 _reorder_cache, here a
+        reorder of the ancestry table only), then one cached forward of the single new token at position
+        ``past_len``.  Returns logits f32 [R,V]."""
+        self.arena.reorder(beam_idx_i32, past_len)
         h32, h16 = self.bert.embed(next_tok_i32, 1, past_len)
-        self.bert.run_layers(h32, h16, rows=self.R, T=1, self_k=self.kc[self.cur], self_vt=self.vc[self.cur],
-                             t_off=past_len, Tk_cap=self.Tcap, NPs=self.NPs, causal=False, kv_len=None,
-                             cross=self.cross, cross_group=self.nb, ws=self.ws_step)
+        self.bert.run_layers(h32, h16, rows=self.R, T=1, self_k=None, self_vt=None, t_off=past_len, Tk_cap=self.Tcap,
+                             NPs=0, causal=False, kv_len=None, cross=self.cross, cross_group=self.nb, ws=self.ws_step,
+                             arena=self.arena)
         self.logits = self.dec.lm_logits(h16, self.R, 1, out=self.logits)
         return self.logits
 

@@ -178,7 +178,7 @@ __global__ __launch_bounds__(256) void gemm_kernel(const vidil_gemm_args p) {
     const float bias = (p.bias != nullptr && col_ok) ? p.bias[col] : 0.f;
     // EPI_HEADS column decomposition
     int part = 0, hcol = 0;
-    if constexpr (EPI == VIDIL_EPI_HEADS) {
+    if constexpr (EPI == VIDIL_EPI_HEADS || EPI == VIDIL_EPI_ARENA) {
       const int hd = p.H * 64;
       part = p.part0 + col / hd;
       hcol = col % hd;  // h*64 + d
@@ -189,7 +189,7 @@ __global__ __launch_bounds__(256) void gemm_kernel(const vidil_gemm_args p) {
       for (int rq = 0; rq < 4; ++rq) {
         const int row_base = m0 + wm * (BM / 2) + i * 32 + 8 * rq + 4 * hi;
         int b = 0, t = 0;
-        if constexpr (EPI == VIDIL_EPI_HEADS) {
+        if constexpr (EPI == VIDIL_EPI_HEADS || EPI == VIDIL_EPI_ARENA) {
           b = row_base / p.T;
           t = row_base - b * p.T;
         } else if constexpr (EPI == VIDIL_EPI_PATCH) {
@@ -221,6 +221,17 @@ __global__ __launch_bounds__(256) void gemm_kernel(const vidil_gemm_args p) {
                 ((f16*)p.k)[(bh * p.Tk_cap + p.t_off + t) * 64 + d] = to_f16(v);
               } else {
                 ((f16*)p.vt)[(bh * 64 + d) * (size_t)p.NP + vt_pos(p.t_off + t)] = to_f16(v);
+              }
+            }
+            if (++t == p.T) { t = 0; ++b; }
+          } else if constexpr (EPI == VIDIL_EPI_ARENA) {
+            if (ok) {
+              const size_t hd = (size_t)p.H * 64;
+              if (part == 0) {
+                ((f16*)p.q)[(size_t)row * hd + hcol] = to_f16(v * p.q_scale);
+              } else {
+                f16* dst = (f16*)(part == 1 ? p.k : p.vt);
+                dst[((size_t)(p.t_off + t) * p.arena_rows + (size_t)b * p.slot_stride) * hd + hcol] = to_f16(v);
               }
             }
             if (++t == p.T) { t = 0; ++b; }
@@ -336,6 +347,23 @@ extern "C" int vidil_gemm_f16(const vidil_gemm_args* args, void* stream) {
       }
       VIDIL_REQUIRE(a.M % a.T == 0, "gemm/heads: M=%d not a multiple of T=%d", a.M, a.T);
       return pick_tile<VIDIL_EPI_HEADS, VIDIL_ACT_NONE>(a, s);
+    }
+    case VIDIL_EPI_ARENA: {
+      VIDIL_REQUIRE(a.act == VIDIL_ACT_NONE, "gemm/arena: no activation");
+      VIDIL_REQUIRE(a.H > 0 && a.T > 0 && a.N % (a.H * 64) == 0, "gemm/arena: N=%d not a multiple of H*64 (H=%d)", a.N, a.H);
+      const int nparts = a.N / (a.H * 64);
+      VIDIL_REQUIRE(a.part0 >= 0 && a.part0 + nparts <= 3, "gemm/arena: part0=%d with %d parts", a.part0, nparts);
+      VIDIL_REQUIRE(a.M % a.T == 0, "gemm/arena: M=%d not a multiple of T=%d", a.M, a.T);
+      VIDIL_REQUIRE(a.part0 > 0 || a.q, "gemm/arena: null q");
+      if (a.part0 + nparts > 1) {
+        VIDIL_REQUIRE(a.k && (a.part0 + nparts < 3 || a.vt), "gemm/arena: null k / v arena");
+        VIDIL_REQUIRE(a.Tk_cap >= a.t_off + a.T, "gemm/arena: positions %d..%d exceed the arena capacity Tk_cap=%d", a.t_off,
+                      a.t_off + a.T - 1, a.Tk_cap);
+        VIDIL_REQUIRE(a.t_off >= 0 && a.slot_stride > 0 && (long)(a.M / a.T - 1) * a.slot_stride < a.arena_rows,
+                      "gemm/arena: %d sequences at slot stride %d do not fit %d arena rows", a.M / a.T, a.slot_stride,
+                      a.arena_rows);
+      }
+      return pick_tile<VIDIL_EPI_ARENA, VIDIL_ACT_NONE>(a, s);
     }
     case VIDIL_EPI_PATCH:
       VIDIL_REQUIRE(a.act == VIDIL_ACT_NONE, "gemm/patch: no activation");

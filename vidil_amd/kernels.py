@@ -11,8 +11,8 @@ import ctypes as C
 import torch
 
 from . import _lib
-from ._lib import (ACT_GELU_ERF, ACT_NONE, ACT_QUICK_GELU, EPI_F16, EPI_F32, EPI_HEADS,
-                   EPI_PATCH, BeamState, GemmArgs, VidilHipError, check)
+from ._lib import (ACT_GELU_ERF, ACT_NONE, ACT_QUICK_GELU, EPI_ARENA, EPI_F16, EPI_F32,
+                   EPI_HEADS, EPI_PATCH, BeamState, GemmArgs, VidilHipError, check)
 
 __all__ = [
     "gemm", "layernorm", "attention", "patchify_f32", "patchify_u8", "set_cls_row",
@@ -51,13 +51,15 @@ def _ptr(t, dtype=None, name="tensor"):
 
 # --------------------------------------------------------------------------- GEMM
 def gemm(a, w, bias=None, *, out=None, out_dtype=torch.float16, act=ACT_NONE, resid=None,
-         heads=None, patch=None, M=None, lda=None):
+         heads=None, patch=None, arena=None, M=None, lda=None):
     """C = A · W^T with a fused epilogue.
 
     a [M,K] f16, w [N,K] f16, bias f32 [N] or None.
       * default: returns/fills ``out`` [M,N] (f16 or f32 by ``out_dtype``); f32 may add ``resid``.
       * heads=dict(q=,k=,vt=,T=,H=,part0=,t_off=,Tq_cap=,Tk_cap=,NP=,q_scale=): per-head scatter.
       * patch=dict(out=,pos=,tpi=): patch-embedding epilogue (row remap + pos embed).
+      * arena=dict(q=,k=,v=,T=,H=,part0=,t_off=,arena_rows=,slot_stride=,Tcap=,q_scale=): Q rows + K/V rows
+        appended to a beam-search KV arena [position][slot][H*64] (see vidil_beam_attention).
     """
     lib = _lib.load()
     K_ = w.shape[1]
@@ -89,6 +91,18 @@ def gemm(a, w, bias=None, *, out=None, out_dtype=torch.float16, act=ACT_NONE, re
         g.Tk_cap = heads.get("Tk_cap", heads["T"])
         g.NP = heads.get("NP", 0)
         g.q_scale = heads.get("q_scale", 1.0)
+    elif arena is not None:
+        g.epi = EPI_ARENA
+        g.q = _ptr(arena.get("q"), torch.float16, "gemm.arena.q")
+        g.k = _ptr(arena.get("k"), torch.float16, "gemm.arena.k")
+        g.vt = _ptr(arena.get("v"), torch.float16, "gemm.arena.v")
+        g.T, g.H = arena["T"], arena["H"]
+        g.part0 = arena.get("part0", 0)
+        g.t_off = arena.get("t_off", 0)
+        g.Tk_cap = arena.get("Tcap", 0)
+        g.arena_rows = arena.get("arena_rows", 0)
+        g.slot_stride = arena.get("slot_stride", 1)
+        g.q_scale = arena.get("q_scale", 1.0)
     elif patch is not None:
         g.epi = EPI_PATCH
         ret = patch["out"]
@@ -275,6 +289,23 @@ def kv_reorder(src, dst, beam_idx, L, rows):
     row_halfs = src.numel() // (L * rows)
     check(_lib.load().vidil_kv_reorder(_ptr(src, torch.float16), _ptr(dst, torch.float16),
                                        _ptr(beam_idx, torch.int32), L, rows, row_halfs, _stream()), "kv_reorder")
+
+
+def beam_ancestry(anc_src, anc_dst, beam_idx, cur_pos):
+    """anc_dst[r][:cur_pos] = anc_src[beam_idx[r]][:cur_pos]; anc_dst[r][cur_pos] = r  (i32 [rows,Tcap] tables)."""
+    rows, Tcap = anc_src.shape
+    check(_lib.load().vidil_beam_ancestry(_ptr(anc_src, torch.int32), _ptr(anc_dst, torch.int32),
+                                          _ptr(beam_idx, torch.int32), rows, Tcap, cur_pos, _stream()), "beam_ancestry")
+
+
+def beam_attention(q, k_arena, v_arena, anc, out, *, rows, H, n_keys, ldo=None):
+    """Decode-step self-attention over the KV arena: q f16 [rows,H*64]; arenas f16 [Tcap,arena_rows,H*64];
+    anc i32 [rows,Tcap]; out f16 [rows,ldo]."""
+    Tcap, arena_rows = k_arena.shape[0], k_arena.shape[1]
+    check(_lib.load().vidil_beam_attention(_ptr(q, torch.float16), _ptr(k_arena, torch.float16),
+                                           _ptr(v_arena, torch.float16), _ptr(anc, torch.int32),
+                                           _ptr(out, torch.float16), rows, H, n_keys, arena_rows, anc.shape[1],
+                                           ldo if ldo is not None else out.shape[-1], _stream()), "beam_attention")
 
 
 # ------------------------------------------------------------------------- ontology scan

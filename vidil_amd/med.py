@@ -131,6 +131,34 @@ class CrossKV:
         self.k, self.vt, self.B, self.Te, self.NP = k, vt, B, Te, NP
 
 
+class BeamArena:
+    """Append-only self-attention K/V of a beam search (all layers): k, v f16 [L][Tcap][rows][H*64], written at
+    [position][slot = producing beam row]; ``anc`` i32 [rows][Tcap] maps (beam row, position) -> slot and is the
+    only thing reordered per step (vidil_beam_ancestry) — the reference's _reorder_cache without moving the cache."""
+
+    def __init__(self, L, Tcap, rows, C, device):
+        self.L, self.Tcap, self.rows = L, Tcap, rows
+        self.k = torch.empty((L, Tcap, rows, C), dtype=torch.float16, device=device)
+        self.v = torch.empty((L, Tcap, rows, C), dtype=torch.float16, device=device)
+        self._anc = [torch.zeros((rows, Tcap), dtype=torch.int32, device=device) for _ in range(2)]
+        self._cur = 0
+
+    @property
+    def anc(self):
+        return self._anc[self._cur]
+
+    def init_prompt(self, P, group):
+        """Positions 0..P-1 of beam row r live in slot (r // group) * group (group = nb after a shared prompt
+        pass over one row per image, 1 when every row ran its own prompt pass)."""
+        r = torch.arange(self.rows, dtype=torch.int32, device=self.k.device)
+        self.anc[:, :P] = (torch.div(r, group, rounding_mode="floor") * group).to(torch.int32)[:, None]
+
+    def reorder(self, beam_idx_i32, cur_pos):
+        """Beam row r now continues old row beam_idx[r]; its next K/V (position cur_pos) go to slot r."""
+        K.beam_ancestry(self._anc[self._cur], self._anc[self._cur ^ 1], beam_idx_i32, cur_pos)
+        self._cur ^= 1
+
+
 class BertModel(PackedCache, nn.Module):
     """ITM text encoder / decoder trunk.  ``forward`` is not the generic HF signature: the hot
     path calls ``encode`` (ITM) or is driven by ``BertLMHeadModel``."""
@@ -185,11 +213,17 @@ class BertModel(PackedCache, nn.Module):
 
     # ------------------------------------------------------------------ layers
     def run_layers(self, h32, h16, *, rows, T, self_k, self_vt, t_off, Tk_cap, NPs, causal, kv_len,
-                   cross: CrossKV, cross_index=None, cross_group=1, cross_groups=None, cross_max_group=0, ws=None):
+                   cross: CrossKV, cross_index=None, cross_group=1, cross_groups=None, cross_max_group=0, ws=None,
+                   arena: "BeamArena" = None, arena_slot_stride=1):
         """Run every layer on the f32/f16 hidden pair (both [rows*T, C], updated in place).
 
         self_k / self_vt: [L][rows,H,Tk_cap,64] / [L][rows,H,64,NPs] — this call's keys are appended at
         ``t_off`` and attention runs over t_off+T keys (causal inside the new block when ``causal``).
+
+        arena (beam-search decoding): with T == 1 the new key/value of row r is appended at
+        arena[position t_off][slot r] and attention follows the row's ancestry (self_k / self_vt unused);
+        with T > 1 (prompt pass, t_off == 0) attention runs over the block as above and the block's K/V are
+        ALSO written to the arena at slots r*arena_slot_stride.
         """
         p = self.packed()
         cfg = self.config
@@ -207,12 +241,24 @@ class BertModel(PackedCache, nn.Module):
         tmp = torch.empty((M, C), dtype=torch.float32, device=dev)
         inter = torch.empty((M, cfg.intermediate_size), dtype=torch.float16, device=dev)
         Nk = t_off + T
+        if arena is not None and T > 1 and t_off != 0:
+            raise K.VidilHipError("run_layers: a multi-token block can only be appended to a beam arena at position 0")
         for i, d in enumerate(p["layers"]):
-            K.gemm(h16, d["qkv_w"], d["qkv_b"],
-                   heads=dict(q=q, k=self_k[i], vt=self_vt[i], T=T, H=H, part0=0, t_off=t_off, Tq_cap=T,
-                              Tk_cap=Tk_cap, NP=NPs, q_scale=0.125))
-            K.attention(q, self_k[i], self_vt[i], o, Bq=rows, H=H, Nq=T, Nk=Nk, Tq_cap=T, Tk_cap=Tk_cap, NP=NPs,
-                        causal=causal, causal_off=t_off, kv_len=kv_len)
+            if arena is not None and T == 1:
+                K.gemm(h16, d["qkv_w"], d["qkv_b"],
+                       arena=dict(q=q, k=arena.k[i], v=arena.v[i], T=1, H=H, part0=0, t_off=t_off, Tcap=arena.Tcap,
+                                  arena_rows=arena.rows, slot_stride=1, q_scale=0.125))
+                K.beam_attention(q, arena.k[i], arena.v[i], arena.anc, o, rows=rows, H=H, n_keys=Nk)
+            else:
+                K.gemm(h16, d["qkv_w"], d["qkv_b"],
+                       heads=dict(q=q, k=self_k[i], vt=self_vt[i], T=T, H=H, part0=0, t_off=t_off, Tq_cap=T,
+                                  Tk_cap=Tk_cap, NP=NPs, q_scale=0.125))
+                K.attention(q, self_k[i], self_vt[i], o, Bq=rows, H=H, Nq=T, Nk=Nk, Tq_cap=T, Tk_cap=Tk_cap, NP=NPs,
+                            causal=causal, causal_off=t_off, kv_len=kv_len)
+                if arena is not None:   # the prompt's K/V, once more, in the arena layout (a prompt is a few tokens)
+                    K.gemm(h16, d["qkv_w"][C:], d["qkv_b"][C:],
+                           arena=dict(k=arena.k[i], v=arena.v[i], T=T, H=H, part0=1, t_off=0, Tcap=arena.Tcap,
+                                      arena_rows=arena.rows, slot_stride=arena_slot_stride))
             K.gemm(o, d["ao_w"], d["ao_b"], out=tmp, resid=h32)
             K.layernorm(tmp, d["ao_g"], d["ao_bt"], eps, out16=h16, out32=h32)
             if cross is not None:
