@@ -292,31 +292,54 @@ __global__ __launch_bounds__(256) void attn_direct_kernel(const AttnP p) {
       const int x = __shfl_xor(kmin, o, 64);
       kmin = x < kmin ? x : kmin;
     }
+    // This kernel streams each K / V^T byte exactly once and is HBM-bound, so every load of the wave's (up
+    // to NI) key tiles is issued before the first MFMA: 16 x 16 B per lane in flight instead of 4.
+    constexpr int NI = (NKT + 3) / 4;
+    f16x8 kf[NI][4], vf[NI][2][2];
 #pragma unroll
-    for (int i = 0; i < (NKT + 3) / 4; ++i) {
+    for (int i = 0; i < NI; ++i) {
+      const int kt = wave + 4 * i;
+#pragma unroll
+      for (int ks = 0; ks < 4; ++ks) kf[i][ks] = f16x8{0, 0, 0, 0, 0, 0, 0, 0};
+#pragma unroll
+      for (int dt = 0; dt < 2; ++dt)
+#pragma unroll
+        for (int hb = 0; hb < 2; ++hb) vf[i][dt][hb] = f16x8{0, 0, 0, 0, 0, 0, 0, 0};
+      if (kt < ntiles) {
+        int krow = kt * 32 + l31;
+        krow = krow < nk ? krow : nk - 1;  // clamped rows are masked below
+        const f16* kr = kg + (size_t)krow * 64 + hi * 8;
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks) kf[i][ks] = *(const f16x8*)(kr + ks * 16);
+#pragma unroll
+        for (int hb = 0; hb < 2; ++hb) {
+          // this half-wave's 8 keys of the 16-key block are 16 contiguous bytes (vt_pos order)
+          const int blk0 = (kt * 2 + hb) * 16;
+          if (blk0 < nk) {
+#pragma unroll
+            for (int dt = 0; dt < 2; ++dt) vf[i][dt][hb] = *(const f16x8*)(vg + (size_t)(dt * 32 + l31) * p.NP + blk0 + 8 * hi);
+          }
+        }
+      }
+    }
+#pragma unroll
+    for (int i = 0; i < NI; ++i) {
       const int kt = wave + 4 * i;
       if (kt >= ntiles) break;
-      int krow = kt * 32 + l31;
-      krow = krow < nk ? krow : nk - 1;  // clamped rows are masked below
-      const f16* kr = kg + (size_t)krow * 64 + hi * 8;
       f32x16 S;
 #pragma unroll
       for (int r = 0; r < 16; ++r) S[r] = 0.f;
 #pragma unroll
-      for (int ks = 0; ks < 4; ++ks) S = __builtin_amdgcn_mfma_f32_32x32x16_f16(*(const f16x8*)(kr + ks * 16), qf[ks], S, 0, 0, 0);
+      for (int ks = 0; ks < 4; ++ks) S = __builtin_amdgcn_mfma_f32_32x32x16_f16(kf[i][ks], qf[ks], S, 0, 0, 0);
       const bool tail = (kt * 32 + 32) > nk;  // tile reaches past the last key: V^T needs zeroing too
       const bool need_mask = (kt * 32 + 32) > kmin;
       softmax_pv_tile(S, kt * 32, ri.klim, need_mask, m, l, O, [&](int dt, int hb) {
-        // this half-wave's 8 keys of the 16-key block are 16 contiguous bytes (vt_pos order)
         const int blk0 = (kt * 2 + hb) * 16;
-        f16x8 v = {0, 0, 0, 0, 0, 0, 0, 0};
-        if (blk0 < nk) {
-          v = *(const f16x8*)(vg + (size_t)(dt * 32 + l31) * p.NP + blk0 + 8 * hi);
-          if (tail) {
+        f16x8 v = vf[i][dt][hb];
+        if (tail) {
 #pragma unroll
-            for (int e = 0; e < 8; ++e)
-              if (blk0 + 4 * hi + (e & 3) + 8 * (e >> 2) >= nk) v[e] = (f16)0.f;
-          }
+          for (int e = 0; e < 8; ++e)
+            if (blk0 + 4 * hi + (e & 3) + 8 * (e >> 2) >= nk) v[e] = (f16)0.f;
         }
         return v;
       });
