@@ -39,8 +39,8 @@ def main():
             b_ = m // T
             q = torch.empty(b_, H, T, 64, dtype=torch.float16, device=dev)
             kk = torch.empty_like(q)
-            vt = torch.empty(b_, H, 64, 200, dtype=torch.float16, device=dev)
-            hd = dict(q=q, k=kk, vt=vt, T=T, H=H, part0=0, Tq_cap=T, Tk_cap=T, NP=200, q_scale=0.125)
+            vt = torch.empty(b_, H, 64, 208, dtype=torch.float16, device=dev)
+            hd = dict(q=q, k=kk, vt=vt, T=T, H=H, part0=0, Tq_cap=T, Tk_cap=T, NP=208, q_scale=0.125)
             fn = lambda: K.gemm(a, w, bias, heads=hd)  # noqa: E731
         elif epi == "f32":
             x = torch.randn(m, n, device=dev)

@@ -56,9 +56,6 @@ __device__ __forceinline__ float wave_max(float v) {
   for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
   return v;
 }
-// erf by Abramowitz & Stegun 7.1.26 (|error| <= 1.5e-7, far below the f16 rounding of the value it
-// feeds): 1 rcp + 1 exp + 5 fma instead of libm's branchy erff — the GELU epilogue runs on 3072 columns
-// of every ViT/MED row and was VALU-bound with erff.
 // f32 -> f16 with the value pinned in a f32 register first: otherwise the compiler may fuse the last
 // multiply of an epilogue with the conversion (v_fma_mixlo_f16, ONE rounding) in one kernel and not in
 // another (two roundings), and the two disagree on f16 midpoints.
@@ -67,25 +64,36 @@ __device__ __forceinline__ f16 to_f16(float v) {
   return (f16)v;
 }
 
-// Every step is an explicit correctly-rounded intrinsic so the instruction sequence (hence every bit of the
-// result) is the same in every kernel instantiation: outputs must not depend on which GEMM kernel a batch
-// size selects.
-__device__ __forceinline__ float erf_as(float x) {
-  const float ax = fabsf(x);
-  const float t = __frcp_rn(__fmaf_rn(0.3275911f, ax, 1.0f));
-  float p = __fmaf_rn(1.061405429f, t, -1.453152027f);
-  p = __fmaf_rn(p, t, 1.421413741f);
-  p = __fmaf_rn(p, t, -0.284496736f);
-  p = __fmaf_rn(p, t, 0.254829592f);
-  const float e = __expf(-__fmul_rn(ax, ax));
-  const float y = __fsub_rn(1.0f, __fmul_rn(__fmul_rn(p, t), e));
-  return copysignf(y, x);
+// erf by Abramowitz & Stegun 7.1.26 (|error| <= 1.5e-7, far below the f16 rounding of the value it
+// feeds): 1 v_rcp + 1 v_exp + 5 fma instead of libm's branchy erff.  The GELU epilogue runs on 3072 columns
+// of every ViT/MED row and is VALU time the matrix pipe spends idle (one workgroup per CU), so it works on
+// PAIRS of values with the packed-f32 instructions (v_pk_fma_f32 / v_pk_mul_f32 / v_pk_add_f32: two lanes'
+// worth of IEEE f32 per issue; per component they round exactly like the scalar instructions).
+// Every step is an explicit operation (no contraction, no IEEE-division expansion: v_rcp_f32 is 1 ulp and one
+// instruction instead of ten) so the instruction sequence, hence every bit of the result, is the same in
+// every kernel instantiation: outputs must not depend on which GEMM kernel a batch size selects.
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ f32x2 pk_fma(f32x2 a, f32x2 b, f32x2 c) { return __builtin_elementwise_fma(a, b, c); }
+__device__ __forceinline__ f32x2 pk_splat(float v) { return f32x2{v, v}; }
+__device__ __forceinline__ f32x2 gelu_erf2(f32x2 x) {
+  const f32x2 xs = x * pk_splat(0.70710678118654752440f);
+  const f32x2 ax = __builtin_elementwise_abs(xs);
+  const f32x2 den = pk_fma(pk_splat(0.3275911f), ax, pk_splat(1.0f));
+  const f32x2 t = {__builtin_amdgcn_rcpf(den[0]), __builtin_amdgcn_rcpf(den[1])};
+  f32x2 p = pk_fma(pk_splat(1.061405429f), t, pk_splat(-1.453152027f));
+  p = pk_fma(p, t, pk_splat(1.421413741f));
+  p = pk_fma(p, t, pk_splat(-0.284496736f));
+  p = pk_fma(p, t, pk_splat(0.254829592f));
+  const f32x2 arg = (ax * ax) * pk_splat(-1.4426950408889634f);   // exp(-x^2) = 2^(-x^2 log2 e)
+  const f32x2 e = {__builtin_amdgcn_exp2f(arg[0]), __builtin_amdgcn_exp2f(arg[1])};
+  const f32x2 y = pk_fma(-(p * t), e, pk_splat(1.0f));             // erf(|xs|)
+  const f32x2 er = {copysignf(y[0], xs[0]), copysignf(y[1], xs[1])};
+  return (x * pk_splat(0.5f)) * (er + pk_splat(1.0f));
 }
-__device__ __forceinline__ float gelu_erf(float x) {
-  const float e = erf_as(__fmul_rn(x, 0.70710678118654752440f));
-  return __fmul_rn(__fmul_rn(0.5f, x), __fadd_rn(1.0f, e));
+__device__ __forceinline__ f32x2 quick_gelu2(f32x2 x) {
+  const f32x2 arg = x * pk_splat(-1.702f * 1.4426950408889634f);   // exp(-1.702 x) as a power of two
+  const f32x2 d = f32x2{__builtin_amdgcn_exp2f(arg[0]), __builtin_amdgcn_exp2f(arg[1])} + pk_splat(1.0f);
+  return x * f32x2{__builtin_amdgcn_rcpf(d[0]), __builtin_amdgcn_rcpf(d[1])};
 }
-__device__ __forceinline__ float quick_gelu(float x) {
-  const float d = __fadd_rn(1.0f, __expf(__fmul_rn(-1.702f, x)));
-  return __fdiv_rn(x, d);
-}
+__device__ __forceinline__ float gelu_erf(float x) { return gelu_erf2(f32x2{x, x})[0]; }
+__device__ __forceinline__ float quick_gelu(float x) { return quick_gelu2(f32x2{x, x})[0]; }

@@ -171,11 +171,26 @@ __global__ __launch_bounds__(256) void gemm_kernel(const vidil_gemm_args p) {
   // ---------------------------------------------------------------- epilogue
   // acc[i][j][r] : row = m0 + wm*BM/2 + i*32 + (r&3) + 8*(r>>2) + 4*hi
   //                col = n0 + wn*BN/2 + j*32 + (lane&31)
+  // bias, then the activation in place on pairs of accumulators (packed-f32 instructions)
+#pragma unroll
+  for (int j = 0; j < TN; ++j) {
+    const int col = n0 + wn * (BN / 2) + j * 32 + l31;
+    const float bias = (p.bias != nullptr && col < N) ? p.bias[col] : 0.f;
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+      for (int r = 0; r < 16; r += 2) {
+        f32x2 v = {acc[i][j][r] + bias, acc[i][j][r + 1] + bias};
+        if constexpr (ACT == VIDIL_ACT_GELU_ERF) v = gelu_erf2(v);
+        if constexpr (ACT == VIDIL_ACT_QUICK_GELU) v = quick_gelu2(v);
+        acc[i][j][r] = v[0];
+        acc[i][j][r + 1] = v[1];
+      }
+  }
 #pragma unroll
   for (int j = 0; j < TN; ++j) {
     const int col = n0 + wn * (BN / 2) + j * 32 + l31;
     const bool col_ok = col < N;
-    const float bias = (p.bias != nullptr && col_ok) ? p.bias[col] : 0.f;
     // EPI_HEADS column decomposition
     int part = 0, hcol = 0;
     if constexpr (EPI == VIDIL_EPI_HEADS || EPI == VIDIL_EPI_ARENA) {
@@ -199,9 +214,7 @@ __global__ __launch_bounds__(256) void gemm_kernel(const vidil_gemm_args p) {
 #pragma unroll
         for (int rr = 0; rr < 4; ++rr) {
           const int row = row_base + rr;
-          float v = acc[i][j][rq * 4 + rr] + bias;
-          if constexpr (ACT == VIDIL_ACT_GELU_ERF) v = gelu_erf(v);
-          if constexpr (ACT == VIDIL_ACT_QUICK_GELU) v = quick_gelu(v);
+          float v = acc[i][j][rq * 4 + rr];
           const bool ok = col_ok && row < M;
           if constexpr (EPI == VIDIL_EPI_F16) {
             if (ok) ((f16*)p.out)[(size_t)row * p.ldo + col] = to_f16(v);

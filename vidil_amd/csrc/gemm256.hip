@@ -226,12 +226,21 @@ __global__ __launch_bounds__(512) void gemm256_kernel(const vidil_gemm_args p) {
         }
       }
   }
-  auto value = [&](int it, int j, int rq, int e) {
-    float v = acc[it][j][rq * 4 + e];
-    if constexpr (ACT == VIDIL_ACT_GELU_ERF) v = gelu_erf(v);
-    if constexpr (ACT == VIDIL_ACT_QUICK_GELU) v = quick_gelu(v);
-    return v;
-  };
+  // activation in place, two accumulators per packed-f32 instruction
+  if constexpr (ACT != VIDIL_ACT_NONE) {
+#pragma unroll
+    for (int it = 0; it < 4; ++it)
+#pragma unroll
+      for (int j = 0; j < 2; ++j)
+#pragma unroll
+        for (int r = 0; r < 16; r += 2) {
+          f32x2 v = {acc[it][j][r], acc[it][j][r + 1]};
+          v = ACT == VIDIL_ACT_GELU_ERF ? gelu_erf2(v) : quick_gelu2(v);
+          acc[it][j][r] = v[0];
+          acc[it][j][r + 1] = v[1];
+        }
+  }
+  auto value = [&](int it, int j, int rq, int e) { return acc[it][j][rq * 4 + e]; };
 
   int part = 0, head = 0;
   if constexpr (EPI == VIDIL_EPI_HEADS) {
