@@ -1,7 +1,7 @@
 #!/usr/bin/env python
 """bench.py — frames/sec of VidIL's frame-encoding hot path on MI355X.
 
-One "step" = one batch of synthetic videos (default 64 videos x 8 frames, 224^2 uint8,
+One "step" = one batch of synthetic videos (default 128 videos x 8 frames, 224^2 uint8,
 already resident in HBM) through the WHOLE path: BLIP ViT-B/16 caption (beam 3,
 max_length 20) + CapFilt ITM filter + CLIP ViT-B/32 visual tokens against a vg-sized
 ontology (42,759 classes), including the host-side string work and the device->host
