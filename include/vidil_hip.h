@@ -137,6 +137,28 @@ int vidil_attention(const void* q, const void* k, const void* vt, void* out,
                     int32_t ldo, void* stream);
 
 /* ------------------------------------------------------------------------ */
+/* One separable pass of Pillow's antialiased resize on 8-bit interleaved RGB */
+/* frames (ImagingResampleHorizontal_8bpc / Vertical_8bpc of Pillow's          */
+/* Resample.c): every output byte = clip8((2^21 + sum_i px_i * k_i) >> 22)     */
+/* with 22-bit fixed-point weights — integer arithmetic, bit-exact with PIL.   */
+/*   bounds i32 [n_out][2] = (first source index, tap count) per output index, */
+/*   coeffs i32 [n_out][ksize] (device pointers; built by the host from        */
+/*   precompute_coeffs + normalize_coeffs_8bpc, see vidil_amd/preprocess.py).  */
+/*   vertical == 0: src u8 [B][in_h][in_w][3] -> dst [B][out_h][out_w][3],     */
+/*     dst row y reads src row src_row0 + y (n_out = out_w);                   */
+/*   vertical != 0: src [B][in_h][out_w][3] -> dst [B][out_h][out_w][3]        */
+/*     (n_out = out_h, in_w == out_w, src_row0 == 0).                          */
+/* replaces: transforms.Resize((S,S), BICUBIC) on PIL frames                   */
+/* (run_video_CapFilt.py:128-134) and HF CLIPProcessor's shortest-edge resize  */
+/* + centre crop (run_visual_tokenization.py:138-142), both PIL Image.resize.  */
+/* ------------------------------------------------------------------------ */
+int vidil_resample_u8(const uint8_t* src, uint8_t* dst, int32_t B, int32_t in_h,
+                      int32_t in_w, int32_t out_h, int32_t out_w,
+                      int32_t vertical, const int32_t* bounds,
+                      const int32_t* coeffs, int32_t ksize, int32_t src_row0,
+                      void* stream);
+
+/* ------------------------------------------------------------------------ */
 /* Frame -> patch rows (im2col for stride==kernel conv), fused with dtype     */
 /* conversion.  out f16 [B*(S/ps)^2, 3*ps*ps], column = c*ps*ps + py*ps + px  */
 /* (the flattening of a conv weight [N,3,ps,ps]).                             */

@@ -57,6 +57,7 @@ SIGNATURES = {
     "vidil_attention": (_i32, [_p, _p, _p, _p, _p, _p, _p] + [_i32] * 13 + [_p]),
     "vidil_patchify_f32": (_i32, [_p, _p, _i32, _i32, _i32, _p]),
     "vidil_patchify_u8": (_i32, [_p, _p, _i32, _i32, _i32, C.POINTER(_f32), C.POINTER(_f32), _p]),
+    "vidil_resample_u8": (_i32, [_p, _p] + [_i32] * 6 + [_p, _p, _i32, _i32, _p]),
     "vidil_set_cls_row": (_i32, [_p, _p, _p, _i32, _i32, _i32, _p]),
     "vidil_embed_tokens": (_i32, [_p, _p, _p, _p, _i32, _i32, _i32, _i32, _i32, _p]),
     "vidil_gather_rows_f32": (_i32, [_p, _p, _p, _i32, _i32, _p]),

@@ -19,6 +19,7 @@ import torch
 from . import dist as vdist
 from .blip import CLIP_MEAN, CLIP_STD, blip_decoder
 from .blip_itm import blip_itm
+from .preprocess import blip_frames
 
 
 @torch.no_grad()
@@ -108,11 +109,12 @@ class CapFiltEngine:
 
     @torch.no_grad()
     def process(self, items, frames_u8):
-        """items: list of dicts {'video_id', 'text': [original captions]}; frames_u8: uint8 [Nv,F,S,S,3]
-        device tensor.  Fills item['text'] / item['unfiltered_text'] like run_video_CapFilt.py:166-204."""
+        """items: list of dicts {'video_id', 'text': [original captions]}; frames_u8: uint8 [Nv,F,H,W,3]
+        device tensor (any H x W: resized to S x S like ``process_frame``, run_video_CapFilt.py:128-134).
+        Fills item['text'] / item['unfiltered_text'] like run_video_CapFilt.py:166-204."""
         cfg = self.config
         Nv, F = frames_u8.shape[0], frames_u8.shape[1]
-        flat = frames_u8.reshape(Nv * F, *frames_u8.shape[2:])
+        flat = blip_frames(frames_u8.reshape(Nv * F, *frames_u8.shape[2:]), cfg.get("image_size", 224))
         generated = [[] for _ in range(Nv)]
         if cfg.get("caption", True):
             if cfg.get("generation_mode", "beam") != "beam":

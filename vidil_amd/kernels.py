@@ -153,6 +153,18 @@ def attention(q, k, vt, out, *, Bq, H, Nq, Nk, Tq_cap, Tk_cap, NP, kv_group=1, c
     return out
 
 
+def resample_u8(src, dst, bounds, coeffs, *, vertical, src_row0=0):
+    """One pass of Pillow's 8-bit resize: src u8 [B,in_h,in_w,3] -> dst u8 [B,out_h,out_w,3] (see vidil_resample_u8)."""
+    B, in_h, in_w, _ = src.shape
+    _, out_h, out_w, _ = dst.shape
+    check(_lib.load().vidil_resample_u8(_ptr(src, torch.uint8, "resample.src"), _ptr(dst, torch.uint8, "resample.dst"),
+                                        B, in_h, in_w, out_h, out_w, 1 if vertical else 0,
+                                        _ptr(bounds, torch.int32, "resample.bounds"),
+                                        _ptr(coeffs, torch.int32, "resample.coeffs"), coeffs.shape[1], src_row0,
+                                        _stream()), "resample_u8")
+    return dst
+
+
 def patchify_f32(img, ps, out=None):
     lib = _lib.load()
     B, Cc, S, S2 = img.shape

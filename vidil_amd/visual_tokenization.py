@@ -20,6 +20,7 @@ import torch
 
 from . import dist as vdist
 from . import kernels as K
+from .preprocess import clip_frames
 
 CATEGORIES = ("objects", "attributes", "scenes", "verbs")
 
@@ -134,8 +135,9 @@ class VisualTokenizer:
 
     @torch.no_grad()
     def frame_topk(self, frames_u8):
-        """uint8 [NF,S,S,3] -> (i32 [NF,4,topk] class indices within each category, f32 scores), on device."""
-        emb = self.model.encode_image_u8(frames_u8)
+        """uint8 [NF,H,W,3] -> (i32 [NF,4,topk] class indices within each category, f32 scores), on device.
+        Frames that are not S x S get the CLIPProcessor treatment (shortest edge -> S bicubic, centre crop)."""
+        emb = self.model.encode_image_u8(clip_frames(frames_u8, self.model.config.vision_config.image_size))
         need = K.scan_topk_ws_bytes(emb.shape[0], self.index.matrix.shape[0], self.topk)
         if self.index.workspace is None or self.index.workspace.numel() < need:
             self.index.workspace = torch.empty((need,), dtype=torch.uint8, device=self.device)
