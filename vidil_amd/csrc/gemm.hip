@@ -187,6 +187,30 @@ __global__ __launch_bounds__(256) void gemm_kernel(const vidil_gemm_args p) {
         acc[i][j][r + 1] = v[1];
       }
   }
+  // residual added up front: every load of the lane is in flight at once (inside the store loop each load
+  // would have to wait for the previous store, because resid may alias out)
+  if constexpr (EPI == VIDIL_EPI_F32) {
+    if (p.resid != nullptr) {
+      float rv[TM][TN][16];
+#pragma unroll
+      for (int j = 0; j < TN; ++j) {
+        const int col = n0 + wn * (BN / 2) + j * 32 + l31;
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+          for (int r = 0; r < 16; ++r) {
+            const int row = m0 + wm * (BM / 2) + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * hi;
+            rv[i][j][r] = (col < N && row < M) ? p.resid[(size_t)row * p.ldo + col] : 0.f;
+          }
+      }
+#pragma unroll
+      for (int j = 0; j < TN; ++j)
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+          for (int r = 0; r < 16; ++r) acc[i][j][r] += rv[i][j][r];
+    }
+  }
 #pragma unroll
   for (int j = 0; j < TN; ++j) {
     const int col = n0 + wn * (BN / 2) + j * 32 + l31;
@@ -220,9 +244,7 @@ __global__ __launch_bounds__(256) void gemm_kernel(const vidil_gemm_args p) {
             if (ok) ((f16*)p.out)[(size_t)row * p.ldo + col] = to_f16(v);
           } else if constexpr (EPI == VIDIL_EPI_F32) {
             if (ok) {
-              const size_t o = (size_t)row * p.ldo + col;
-              if (p.resid != nullptr) v += p.resid[o];
-              ((float*)p.out)[o] = v;
+              ((float*)p.out)[(size_t)row * p.ldo + col] = v;
             }
           } else if constexpr (EPI == VIDIL_EPI_HEADS) {
             if (ok) {

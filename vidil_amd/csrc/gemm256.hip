@@ -310,6 +310,27 @@ __global__ __launch_bounds__(512) void gemm256_kernel(const vidil_gemm_args p) {
     // ---- f32 rows of 64 columns, two passes of 64 rows: [64][64] floats, chunk XOR (row&7) ------------
 #pragma unroll
     for (int pass = 0; pass < 2; ++pass) {
+      // residual / position rows of this pass: all 16 loads of a lane go out before the LDS round trip, so
+      // their latency is paid once per pass (the dependent load -> add -> store chain paid it per group)
+      f32x4 add[16];
+      {
+        const int ch = lane & 15;
+        const int col = n_w + ch * 4;
+#pragma unroll
+        for (int iter = 0; iter < 16; ++iter) {
+          const int lr = iter * 4 + (lane >> 4);
+          const int m = m_w + pass * 64 + lr;
+          add[iter] = f32x4{0.f, 0.f, 0.f, 0.f};
+          if (m < M && col + 4 <= N) {
+            if constexpr (EPI == VIDIL_EPI_F32) {
+              if (p.resid != nullptr) add[iter] = *(const f32x4*)(p.resid + (size_t)m * p.ldo + col);
+            } else {  // EPI_PATCH
+              const int t = m % p.tpi;
+              add[iter] = *(const f32x4*)(p.pos + (size_t)(t + 1) * N + col);
+            }
+          }
+        }
+      }
 #pragma unroll
       for (int i = 0; i < 2; ++i) {
         const int it = pass * 2 + i;
@@ -323,20 +344,18 @@ __global__ __launch_bounds__(512) void gemm256_kernel(const vidil_gemm_args p) {
           }
       }
       const int ch = lane & 15;
-#pragma unroll 4
+#pragma unroll
       for (int iter = 0; iter < 16; ++iter) {
         const int lr = iter * 4 + (lane >> 4);
         f32x4 v = *(const f32x4*)(ep + lr * 256 + ((ch ^ (lr & 7)) << 4));
         const int m = m_w + pass * 64 + lr;
         const int col = n_w + ch * 4;
         if (m < M && col + 4 <= N) {
+          v += add[iter];
           if constexpr (EPI == VIDIL_EPI_F32) {
-            const size_t o = (size_t)m * p.ldo + col;
-            if (p.resid != nullptr) v += *(const f32x4*)(p.resid + o);
-            *(f32x4*)((float*)p.out + o) = v;
+            *(f32x4*)((float*)p.out + (size_t)m * p.ldo + col) = v;
           } else {  // EPI_PATCH
-            const int b = m / p.tpi, t = m - b * p.tpi;
-            v += *(const f32x4*)(p.pos + (size_t)(t + 1) * N + col);
+            const int b = m / p.tpi;
             *(f32x4*)((float*)p.out + ((size_t)m + b + 1) * p.ldo + col) = v;
           }
         }
