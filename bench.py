@@ -83,12 +83,11 @@ class GemmTimer:
         t256 = ((M + 255) // 256) * ((N + 255) // 256)
         if t256 >= 160 and K >= 128 and N % (8 if f16_out else 4) == 0:
             return "256x256"
-        t128 = ((M + 127) // 128) * ((N + 127) // 128)
-        if t128 >= 384 or M > 4096:
-            return "128x128"
-        if ((M + 127) // 128) * ((N + 63) // 64) >= 256 and M >= 128:
-            return "128x64"
-        return "64x64"
+        if ((M + 63) // 64) * ((N + 63) // 64) <= 1280:
+            return "64x64x3"
+        if ((M + 127) // 128) * ((N + 63) // 64) <= 2560:
+            return "128x64x2"
+        return "128x128x2"
 
     def install(self):
         from vidil_amd import kernels as K
@@ -103,9 +102,12 @@ class GemmTimer:
             e0.record()
             r = timer._orig(a, w, bias, **kw)
             e1.record()
-            epi = "heads" if kw.get("heads") else "patch" if kw.get("patch") else \
+            epi = "heads" if kw.get("heads") else "patch" if kw.get("patch") else "arena" if kw.get("arena") else \
                 ("f32" if (kw.get("out") is not None and kw["out"].dtype == torch.float32) or kw.get("out_dtype") == torch.float32 else "f16")
-            timer.records.append((timer.tile_of(M, N, Kd, epi in ("f16", "heads")), epi, kw.get("act", 0),
+            tile = timer.tile_of(M, N, Kd, epi in ("f16", "heads"))
+            if epi == "arena" and tile == "256x256":      # EPI_ARENA is served by the small-tile kernel only
+                tile = timer.tile_of(M, N, 0)
+            timer.records.append((tile, epi, kw.get("act", 0),
                                   2.0 * M * N * Kd, e0, e1))
             return r
 
@@ -119,14 +121,14 @@ class GemmTimer:
     def summary(self):
         torch.cuda.synchronize()
         agg = {}
-        epi_id = dict(f16=0, f32=1, heads=2, patch=3)
+        epi_id = dict(f16=0, f32=1, heads=2, patch=3, arena=4)
         for tile, epi, act, flops, e0, e1 in self.records:
             # same spelling as the kernel names in the rocprofv3 trace (profiles/*.md)
             if tile == "256x256":
                 key = f"gemm256_kernel<{epi_id[epi]}, {act}>"
             else:
-                bm, bn = tile.split("x")
-                key = f"gemm_kernel<{bm}, {bn}, {epi_id[epi]}, {act}>"
+                bm, bn, st = tile.split("x")
+                key = f"gemm_kernel<{bm}, {bn}, {st}, {epi_id[epi]}, {act}>"
             a = agg.setdefault(key, [0, 0.0, 0.0])
             a[0] += 1
             a[1] += flops
@@ -161,8 +163,8 @@ def cpu_baseline(cap, flt, clip, tok, onto_embeds, onto_texts, n_videos, frames,
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=3)
-    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=5)
+    ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--videos-per-step", type=int, default=128)
     ap.add_argument("--frames", type=int, default=8)
     ap.add_argument("--size", type=int, default=224)

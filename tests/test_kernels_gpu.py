@@ -287,6 +287,11 @@ def _attn_ref(q, kk, v, kv_len=None, causal=False, causal_off=0, kv_group=1):
     (2, 12, 3, 197, 1, False, False),      # decode cross, 3 beams as query rows
     (2, 16, 257, 257, 1, False, False),    # CLIP-L/14
     (2, 12, 4, 4, 1, True, False),         # decoder prefill
+    (2, 12, 577, 577, 1, False, False),    # ViT-B/16 at 384^2: three 224-key chunks through LDS
+    (6, 12, 1, 577, 3, False, False),      # decode cross over 577 image tokens (direct kernel, rounds)
+    (6, 4, 35, 577, 3, False, False),      # ITM cross at 384^2 (105 rows per image, chunked)
+    (3, 4, 300, 320, 1, False, True),      # 10 key tiles with per-batch key lengths
+    (2, 2, 40, 768, 1, False, False),      # the largest supported key count
 ])
 def test_attention(Bq, H, Nq, Nk, kv_group, causal, use_len):
     k = _k()
@@ -500,9 +505,10 @@ def _scan_oracle():
     return lib
 
 
-def test_scan_topk_bit_exact_vs_oracle():
+@pytest.mark.parametrize("D", [512, 768])     # CLIP-B/32 and CLIP-L/14 projection widths
+def test_scan_topk_bit_exact_vs_oracle(D):
     k = _k()
-    NF, D, topk = 45, 512, 5
+    NF, topk = 45, 5
     seg_len = [1999, 700, 365, 33]
     seg_start, n = [], 0
     for L in seg_len:

@@ -278,6 +278,59 @@ def test_full_itm_vs_oracle(full_models):
     assert (p_got - p_ref).abs().max().item() < 1e-3
 
 
+def test_blip_at_384_vit_decoder_and_itm_vs_oracle():
+    """image_size 384 (what every pipeline_config_*.yaml of the reference sets): 577 image tokens, i.e. chunked
+    LDS attention in the ViT / ITM cross-attention and the multi-round direct kernel in the decode cross-attention."""
+    from oracle import clip_ref, med_ref, vit_ref
+    from vidil_amd.blip import BLIP_Decoder, DecoderSession
+    from vidil_amd.blip_itm import BLIP_ITM
+    from vidil_amd.tokenizer import SyntheticBertTokenizer
+
+    torch.manual_seed(1)
+    tok = SyntheticBertTokenizer()
+    cap = BLIP_Decoder(image_size=384, vit="base", tokenizer=tok).eval()
+    itm = BLIP_ITM(image_size=384, vit="base", tokenizer=tok).eval()
+    perturb_(cap, 300); perturb_(itm, 301)
+    sd = {k: v.clone() for k, v in cap.state_dict().items()}
+    sd_itm = {k: v.clone() for k, v in itm.state_dict().items()}
+    cap, itm = cap.to(DEV), itm.to(DEV)
+    B, nb = 2, 3
+    u8 = synthetic_frames(1, B, size=384, first_video=9)[0]
+    x = clip_ref.preprocess_u8(u8)
+    with torch.no_grad():
+        y_ref = vit_ref.vit_forward(sd, x)
+    assert y_ref.shape == (B, 577, 768)
+    y32, y16 = cap.visual_encoder.forward_u8(torch.from_numpy(u8).to(DEV), clip_ref.CLIP_MEAN, clip_ref.CLIP_STD)
+    d = (y32.cpu() - y_ref).abs()
+    assert d.max().item() < 1e-2 and d.mean().item() < 1e-3
+    # prompt pass + two cached steps (identity beam order), logits vs the fp32 oracle
+    enc3 = y_ref.repeat_interleave(nb, dim=0)
+    prompt = cap.prompt_ids(B, "cpu").long().repeat_interleave(nb, dim=0)
+    sess = DecoderSession(cap.text_decoder, y16, B, nb, 20)
+    with torch.no_grad():
+        ref0, cache = med_ref.decoder_logits(sd, prompt, enc3, None)
+    lg = sess.prefill(prompt.to(torch.int32).reshape(-1).to(DEV), prompt.shape[1])
+    logits_close(lg.cpu(), ref0)
+    ids = prompt
+    ident = torch.arange(B * nb, dtype=torch.int32, device=DEV)
+    for step in range(2):
+        nxt = ref0.argmax(-1) if step == 0 else ref.argmax(-1)
+        ids = torch.cat([ids, nxt[:, None]], 1)
+        with torch.no_grad():
+            ref, cache = med_ref.decoder_logits(sd, ids, enc3, cache)
+        lg = sess.step(nxt.to(torch.int32).to(DEV), ident, ids.shape[1] - 1)
+        logits_close(lg.cpu(), ref)
+    # ITM at 384
+    xi = x
+    caps = ["w2000 w2001 w2002", "a picture of w77 w78 w79 w80"]
+    idt, lens = itm.tokenize(caps)
+    am = (torch.arange(35)[None] < lens[:, None]).long()
+    with torch.no_grad():
+        ref_itm = med_ref.itm_logits(sd_itm, vit_ref.vit_forward(sd_itm, xi), idt.long(), am)
+    got = itm(xi.to(DEV), caps).cpu()
+    assert (got - ref_itm).abs().max().item() < 2e-3
+
+
 def test_full_clip_vs_oracle(full_models):
     from oracle import clip_ref
 
@@ -295,6 +348,38 @@ def test_full_clip_vs_oracle(full_models):
     assert (ie - ie_ref).abs().max().item() < 5e-4 and (te - te_ref).abs().max().item() < 5e-4
     out = clip(pixel_values=x.to(DEV))
     assert out.text_embeds is None and (out.image_embeds.cpu() - ie_ref).abs().max().item() < 5e-4
+
+
+def test_clip_vit_l14_geometry_vs_oracle():
+    """openai/clip-vit-large-patch14 (the model every pipeline_config_*.yaml of the reference names): patch 14 =>
+    588-column patch rows (zero padded to 640 for the GEMM), 257 tokens, width 1024 / 16 heads, text width 768,
+    projection 768.  Depth is cut to 3 + 2 layers to keep the CPU oracle fast; every shape is the real one."""
+    from oracle import clip_ref
+    from vidil_amd.clip import CLIPConfig, CLIPModel, CLIPTextConfig, CLIPVisionConfig
+
+    torch.manual_seed(3)
+    cfg = CLIPConfig(CLIPVisionConfig(hidden_size=1024, intermediate_size=4096, num_hidden_layers=3, num_attention_heads=16,
+                                      patch_size=14),
+                     CLIPTextConfig(hidden_size=768, intermediate_size=3072, num_attention_heads=12, num_hidden_layers=2), 768)
+    m = CLIPModel(cfg).eval()
+    perturb_(m, 400)
+    sd = {k: v.clone() for k, v in m.state_dict().items()}
+    m = m.to(DEV)
+    u8 = synthetic_frames(1, 3, first_video=21)[0]
+    x = clip_ref.preprocess_u8(u8)
+    with torch.no_grad():
+        ie_ref = clip_ref.image_embeds(sd, x, layers=3, heads=16, patch=14)
+    assert ie_ref.shape == (3, 768)
+    ie = m.encode_image_u8(torch.from_numpy(u8).to(DEV)).cpu()
+    assert (ie - ie_ref).abs().max().item() < 5e-4
+    assert (m.encode_image(x.to(DEV)).cpu() - ie_ref).abs().max().item() < 5e-4
+    g = torch.Generator().manual_seed(5)
+    tids = torch.randint(1000, 40000, (4, 9), generator=g)
+    tids[:, 0] = 49406
+    tids[:, -1] = 49407
+    with torch.no_grad():
+        te_ref = clip_ref.text_embeds(sd, tids, layers=2, heads=12)
+    assert (m.encode_text(tids.to(DEV)).cpu() - te_ref).abs().max().item() < 5e-4
 
 
 # =============================================================== device beam search vs the oracle (bit-exact ids)

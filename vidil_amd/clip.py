@@ -17,7 +17,7 @@ import torch
 import torch.nn as nn
 
 from . import kernels as K
-from .packing import PackedCache, require_cuda, v32, w16
+from .packing import PackedCache, require_cuda, v32, w16, w16_patch
 
 CLIP_MEAN = (0.48145466, 0.4578275, 0.40821073)
 CLIP_STD = (0.26862954, 0.26130258, 0.27577711)
@@ -181,7 +181,7 @@ class CLIPModel(PackedCache, nn.Module):
         vm, tm = self.vision_model, self.text_model
         D = self.config.vision_config.hidden_size
         return dict(
-            pe_w=w16(vm.embeddings.patch_embedding.weight.reshape(D, -1)),
+            pe_w=w16_patch(vm.embeddings.patch_embedding.weight),
             cls=v32(vm.embeddings.class_embedding), pos=v32(vm.embeddings.position_embedding.weight).view(-1, D),
             pre_g=v32(vm.pre_layrnorm.weight), pre_b=v32(vm.pre_layrnorm.bias),
             post_g=v32(vm.post_layernorm.weight), post_b=v32(vm.post_layernorm.bias),

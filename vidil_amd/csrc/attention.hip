@@ -174,40 +174,9 @@ __global__ __launch_bounds__(NW * 64) void attn_lds_kernel(const AttnP p) {
   if ((int)blockIdx.x * (NW * 32) >= rows) return;  // uniform: this row tile is empty for this unit
   const int nk = p.Nk;
 
-  // ---- stage K (rows >= Nk zero) ----------------------------------------------------------------
-  {
-    const f16* kg = p.k + ((size_t)bk * p.H + h) * p.Tk_cap * 64;
-    for (int q = tid; q < NKEY * 8; q += NT) {
-      const int row = q >> 3, c = q & 7;
-      f16x8 v = {0, 0, 0, 0, 0, 0, 0, 0};
-      if (row < nk) v = *(const f16x8*)(kg + (size_t)row * 64 + c * 8);
-      *(f16x8*)(Ks + row * KROW + c * 8) = v;
-    }
-  }
-  // ---- stage V^T (keys >= Nk zero: masked P is 0 but 0*garbage must stay 0) -------------------------
-  {
-    const f16* vg = p.vt + ((size_t)bk * p.H + h) * 64 * (size_t)p.NP;
-    for (int q = tid; q < 64 * NKT * 4; q += NT) {
-      const int d = q / (NKT * 4), kc = q - d * (NKT * 4);
-      const int pos0 = kc * 8;                // storage columns pos0..pos0+7 (key = vt_pos(column))
-      const int blk_end = (pos0 | 15) + 1;    // end of the 16-key block this chunk belongs to
-      f16x8 v = {0, 0, 0, 0, 0, 0, 0, 0};
-      if (blk_end <= nk) {
-        v = *(const f16x8*)(vg + (size_t)d * p.NP + pos0);
-      } else if ((pos0 & ~15) < nk && pos0 + 8 <= p.NP) {
-        v = *(const f16x8*)(vg + (size_t)d * p.NP + pos0);
-#pragma unroll
-        for (int e = 0; e < 8; ++e)
-          if (vt_pos(pos0 + e) >= nk) v[e] = (f16)0.f;
-      }
-      *(f16x8*)(Vs + d * VROW + pos0) = v;
-    }
-  }
-  __syncthreads();
-
   const int v0 = blockIdx.x * (NW * 32) + wave * 32;
-  if (v0 >= rows) return;
-  const RowInfo ri = row_info(p, v0 + l31, first, rows);
+  const bool active = v0 < rows;            // waves without rows still stage and meet the barriers
+  const RowInfo ri = row_info(p, (active ? v0 : 0) + l31, first, rows);
 
   f16x8 qf[4];
   {
@@ -230,21 +199,57 @@ __global__ __launch_bounds__(NW * 64) void attn_lds_kernel(const AttnP p) {
 #pragma unroll
     for (int r = 0; r < 16; ++r) O[dt][r] = 0.f;
 
+  const f16* kg = p.k + ((size_t)bk * p.H + h) * p.Tk_cap * 64;
+  const f16* vg = p.vt + ((size_t)bk * p.H + h) * 64 * (size_t)p.NP;
+  // Keys are consumed in chunks of NKEY (one chunk when Nk <= NKEY; 577-key ViT@384 sequences take three
+  // 224-key chunks): stage the chunk, run its key tiles through the online softmax, re-stage.
 #pragma unroll 1
-  for (int kt = 0; kt < NKT; ++kt) {
-    f32x16 S;
-#pragma unroll
-    for (int r = 0; r < 16; ++r) S[r] = 0.f;
-#pragma unroll
-    for (int ks = 0; ks < 4; ++ks) {
-      const f16x8 kf = *(const f16x8*)(Ks + (kt * 32 + l31) * KROW + ks * 16 + hi * 8);
-      S = __builtin_amdgcn_mfma_f32_32x32x16_f16(kf, qf[ks], S, 0, 0, 0);
+  for (int k0 = 0; k0 < nk; k0 += NKEY) {
+    if (k0 > 0) __syncthreads();            // every wave is done reading the previous chunk
+    // ---- stage K rows k0 .. k0+NKEY-1 (rows >= Nk zero) ------------------------------------------------
+    for (int q = tid; q < NKEY * 8; q += NT) {
+      const int row = q >> 3, c = q & 7;
+      f16x8 v = {0, 0, 0, 0, 0, 0, 0, 0};
+      if (k0 + row < nk) v = *(const f16x8*)(kg + (size_t)(k0 + row) * 64 + c * 8);
+      *(f16x8*)(Ks + row * KROW + c * 8) = v;
     }
-    const bool need_mask = (kt * 32 + 32) > kmin;
-    softmax_pv_tile(S, kt * 32, ri.klim, need_mask, m, l, O, [&](int dt, int hb) {
-      return *(const f16x8*)(Vs + (dt * 32 + l31) * VROW + (kt * 2 + hb) * 16 + 8 * hi);
-    });
+    // ---- stage V^T columns k0 .. (keys >= Nk zero: masked P is 0 but 0*garbage must stay 0) --------------
+    for (int q = tid; q < 64 * NKT * 4; q += NT) {
+      const int d = q / (NKT * 4), kc = q - d * (NKT * 4);
+      const int pos0 = k0 + kc * 8;           // storage columns pos0..pos0+7 (key = vt_pos(column))
+      const int blk_end = (pos0 | 15) + 1;    // end of the 16-key block this chunk belongs to
+      f16x8 v = {0, 0, 0, 0, 0, 0, 0, 0};
+      if (blk_end <= nk) {
+        v = *(const f16x8*)(vg + (size_t)d * p.NP + pos0);
+      } else if ((pos0 & ~15) < nk && pos0 + 8 <= p.NP) {
+        v = *(const f16x8*)(vg + (size_t)d * p.NP + pos0);
+#pragma unroll
+        for (int e = 0; e < 8; ++e)
+          if (vt_pos(pos0 + e) >= nk) v[e] = (f16)0.f;
+      }
+      *(f16x8*)(Vs + d * VROW + kc * 8) = v;
+    }
+    __syncthreads();
+    if (!active) continue;
+
+#pragma unroll 1
+    for (int kt = 0; kt < NKT; ++kt) {
+      if (k0 + kt * 32 >= nk) break;
+      f32x16 S;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) S[r] = 0.f;
+#pragma unroll
+      for (int ks = 0; ks < 4; ++ks) {
+        const f16x8 kf = *(const f16x8*)(Ks + (kt * 32 + l31) * KROW + ks * 16 + hi * 8);
+        S = __builtin_amdgcn_mfma_f32_32x32x16_f16(kf, qf[ks], S, 0, 0, 0);
+      }
+      const bool need_mask = (k0 + kt * 32 + 32) > kmin;
+      softmax_pv_tile(S, k0 + kt * 32, ri.klim, need_mask, m, l, O, [&](int dt, int hb) {
+        return *(const f16x8*)(Vs + (dt * 32 + l31) * VROW + (kt * 2 + hb) * 16 + 8 * hi);
+      });
+    }
   }
+  if (!active) return;
   l += __shfl_xor(l, 32, 64);
   store_rows(p, ri, h, O, l > 0.f ? 1.0f / l : 0.f);
 }
@@ -294,11 +299,17 @@ __global__ __launch_bounds__(256) void attn_direct_kernel(const AttnP p) {
     }
     // This kernel streams each K / V^T byte exactly once and is HBM-bound, so every load of the wave's (up
     // to NI) key tiles is issued before the first MFMA: 16 x 16 B per lane in flight instead of 4.
-    constexpr int NI = (NKT + 3) / 4;
+    // Sequences longer than 8 key tiles (577 image tokens at 384^2) go through rounds of 2 tiles per wave.
+    constexpr int NI = NKT >= 8 ? 2 : (NKT + 3) / 4;
+    constexpr int ROUNDS = (NKT + 4 * NI - 1) / (4 * NI);
+#pragma unroll 1
+    for (int round = 0; round < ROUNDS; ++round) {
+    const int kt0 = round * 4 * NI + wave;
+    if (kt0 >= ntiles) break;
     f16x8 kf[NI][4], vf[NI][2][2];
 #pragma unroll
     for (int i = 0; i < NI; ++i) {
-      const int kt = wave + 4 * i;
+      const int kt = kt0 + 4 * i;
 #pragma unroll
       for (int ks = 0; ks < 4; ++ks) kf[i][ks] = f16x8{0, 0, 0, 0, 0, 0, 0, 0};
 #pragma unroll
@@ -324,7 +335,7 @@ __global__ __launch_bounds__(256) void attn_direct_kernel(const AttnP p) {
     }
 #pragma unroll
     for (int i = 0; i < NI; ++i) {
-      const int kt = wave + 4 * i;
+      const int kt = kt0 + 4 * i;
       if (kt >= ntiles) break;
       f32x16 S;
 #pragma unroll
@@ -344,6 +355,7 @@ __global__ __launch_bounds__(256) void attn_direct_kernel(const AttnP p) {
         return v;
       });
     }
+    }  // rounds
   }
   // ---- merge the waves' partials --------------------------------------------------------------
   l += __shfl_xor(l, 32, 64);
@@ -506,6 +518,17 @@ extern "C" int vidil_attention(const void* q, const void* k, const void* vt, voi
     case 9: return launch_any<9>(p, max_rows, s);
     default: break;
   }
-  vidil_set_error("attention: Nk=%d > 288 not supported by these kernels", Nk);
+  // longer sequences (577 tokens of a 384^2 ViT-B/16, 257+ of others): rounds of key tiles in the direct
+  // kernel, 224-key chunks re-staged through LDS in the staged kernel
+  if (nkt <= 24) {
+    if (max_rows <= 32) {
+      hipLaunchKernelGGL(attn_direct_kernel<24>, dim3(1, p.H, p.n_kv), dim3(256), 0, s, p);
+      VIDIL_CHECK_LAUNCH("attention/direct");
+      return VIDIL_OK;
+    }
+    if (max_rows > 128) return launch_lds<7, 8>(p, max_rows, s);
+    return launch_lds<7, 4>(p, max_rows, s);
+  }
+  vidil_set_error("attention: Nk=%d > 768 not supported by these kernels", Nk);
   return VIDIL_EUNSUP;
 }

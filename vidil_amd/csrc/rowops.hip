@@ -105,6 +105,36 @@ __global__ __launch_bounds__(256) void patchify_u8_kernel(const uint8_t* __restr
   }
 }
 
+// Any patch size (CLIP ViT-L/14: ps = 14, 588 columns): one thread per output element; rows are ldk =
+// round_up(3*ps*ps, 64) halfs long and zero padded so the patch-embedding GEMM keeps its K % 64 == 0 contract
+// (the weight is zero padded the same way by the host packing: exact).
+template <bool U8>
+__global__ __launch_bounds__(256) void patchify_any_kernel(const void* __restrict__ img, f16* __restrict__ out, int B, int S,
+                                                           int ps, int ldk, Norm3 nm) {
+  const int G = S / ps;
+  const int pp = ps * ps;
+  const size_t total = (size_t)B * G * G * ldk;
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+    const int col = (int)(i % ldk);
+    size_t r = i / ldk;
+    const int px = r % G; r /= G;
+    const int py = r % G; r /= G;
+    const int b = (int)r;
+    float v = 0.f;
+    if (col < 3 * pp) {
+      const int c = col / pp, rem = col - c * pp;
+      const int y = rem / ps, x = rem - y * ps;
+      const size_t row = py * ps + y, cx = px * ps + x;
+      if constexpr (U8) {
+        v = (float)((const uint8_t*)img)[(((size_t)b * S + row) * S + cx) * 3 + c] * nm.scale[c] + nm.shift[c];
+      } else {
+        v = ((const float*)img)[(((size_t)b * 3 + c) * S + row) * S + cx];
+      }
+    }
+    out[i] = (f16)v;
+  }
+}
+
 __global__ void set_cls_kernel(float* __restrict__ x, const float* __restrict__ cls, const float* __restrict__ pos0,
                                int B, int T, int D) {
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
@@ -186,7 +216,15 @@ extern "C" int vidil_layernorm(const float* x, int64_t x_stride, const float* ga
 
 extern "C" int vidil_patchify_f32(const float* img, void* out, int32_t B, int32_t S, int32_t ps, void* stream) {
   VIDIL_REQUIRE(img && out && B > 0, "patchify_f32: bad args");
-  VIDIL_REQUIRE(ps % 8 == 0 && S % ps == 0, "patchify_f32: S=%d ps=%d (ps%%8==0, S%%ps==0 required)", S, ps);
+  VIDIL_REQUIRE(ps > 0 && S % ps == 0, "patchify_f32: S=%d ps=%d (S%%ps==0 required)", S, ps);
+  if (ps % 8 != 0) {
+    const int ldk = (3 * ps * ps + 63) / 64 * 64;
+    const size_t n = (size_t)B * (S / ps) * (S / ps) * ldk;
+    hipLaunchKernelGGL(patchify_any_kernel<false>, dim3(grid_for(n, 256)), dim3(256), 0, (hipStream_t)stream, (const void*)img,
+                       (f16*)out, B, S, ps, ldk, Norm3{});
+    VIDIL_CHECK_LAUNCH("patchify_f32");
+    return VIDIL_OK;
+  }
   const size_t total = (size_t)B * (S / ps) * (S / ps) * 3 * ps * (ps / 8);
   hipLaunchKernelGGL(patchify_f32_kernel, dim3(grid_for(total, 256)), dim3(256), 0, (hipStream_t)stream, img, (f16*)out, B, S, ps);
   VIDIL_CHECK_LAUNCH("patchify_f32");
@@ -196,12 +234,20 @@ extern "C" int vidil_patchify_f32(const float* img, void* out, int32_t B, int32_
 extern "C" int vidil_patchify_u8(const uint8_t* img, void* out, int32_t B, int32_t S, int32_t ps,
                                  const float* mean3_host, const float* std3_host, void* stream) {
   VIDIL_REQUIRE(img && out && mean3_host && std3_host && B > 0, "patchify_u8: bad args");
-  VIDIL_REQUIRE(ps % 8 == 0 && S % ps == 0, "patchify_u8: S=%d ps=%d (ps%%8==0, S%%ps==0 required)", S, ps);
+  VIDIL_REQUIRE(ps > 0 && S % ps == 0, "patchify_u8: S=%d ps=%d (S%%ps==0 required)", S, ps);
   Norm3 nm;
   for (int c = 0; c < 3; ++c) {
     // (x/255 - mean)/std  ==  x * (1/(255*std)) - mean/std ; evaluated in f32 on device
     nm.scale[c] = 1.0f / (255.0f * std3_host[c]);
     nm.shift[c] = -mean3_host[c] / std3_host[c];
+  }
+  if (ps % 8 != 0) {
+    const int ldk = (3 * ps * ps + 63) / 64 * 64;
+    const size_t n = (size_t)B * (S / ps) * (S / ps) * ldk;
+    hipLaunchKernelGGL(patchify_any_kernel<true>, dim3(grid_for(n, 256)), dim3(256), 0, (hipStream_t)stream, (const void*)img,
+                       (f16*)out, B, S, ps, ldk, nm);
+    VIDIL_CHECK_LAUNCH("patchify_u8");
+    return VIDIL_OK;
   }
   const size_t total = (size_t)B * (S / ps) * (S / ps) * ps * (ps / 8);
   hipLaunchKernelGGL(patchify_u8_kernel, dim3(grid_for(total, 256)), dim3(256), 0, (hipStream_t)stream, img, (f16*)out, B, S, ps, nm);

@@ -165,6 +165,11 @@ def resample_u8(src, dst, bounds, coeffs, *, vertical, src_row0=0):
     return dst
 
 
+def patch_row_halfs(ps: int) -> int:
+    """Columns of a patch row: 3*ps*ps rounded up to a multiple of 64 (zero padded; == 3*ps*ps when ps % 8 == 0)."""
+    return (3 * ps * ps + 63) // 64 * 64
+
+
 def patchify_f32(img, ps, out=None):
     lib = _lib.load()
     B, Cc, S, S2 = img.shape
@@ -172,7 +177,7 @@ def patchify_f32(img, ps, out=None):
         raise VidilHipError(f"patchify_f32: expected [B,3,S,S], got {tuple(img.shape)}")
     G = S // ps
     if out is None:
-        out = torch.empty((B * G * G, 3 * ps * ps), dtype=torch.float16, device=img.device)
+        out = torch.empty((B * G * G, patch_row_halfs(ps)), dtype=torch.float16, device=img.device)
     check(lib.vidil_patchify_f32(_ptr(img, torch.float32, "patchify.img"), _ptr(out, torch.float16, "patchify.out"),
                                  B, S, ps, _stream()), "patchify_f32")
     return out
@@ -185,7 +190,7 @@ def patchify_u8(img, ps, mean, std, out=None):
         raise VidilHipError(f"patchify_u8: expected [B,S,S,3], got {tuple(img.shape)}")
     G = S // ps
     if out is None:
-        out = torch.empty((B * G * G, 3 * ps * ps), dtype=torch.float16, device=img.device)
+        out = torch.empty((B * G * G, patch_row_halfs(ps)), dtype=torch.float16, device=img.device)
     m3 = (C.c_float * 3)(*[float(v) for v in mean])
     s3 = (C.c_float * 3)(*[float(v) for v in std])
     check(lib.vidil_patchify_u8(_ptr(img, torch.uint8, "patchify.img"), _ptr(out, torch.float16, "patchify.out"),

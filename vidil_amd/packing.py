@@ -16,6 +16,17 @@ def w16(*weights):
     return w.detach().to(torch.float16).contiguous()
 
 
+def w16_patch(conv_weight):
+    """Patch-embedding conv weight [N,3,ps,ps] -> f16 [N, round_up(3*ps*ps, 64)], zero padded along K so the GEMM's
+    K % 64 == 0 contract holds for any patch size (CLIP ViT-L/14: 588 -> 640; the patch rows are padded alike)."""
+    w = conv_weight.detach().reshape(conv_weight.shape[0], -1).to(torch.float16)
+    K = w.shape[1]
+    Kp = (K + 63) // 64 * 64
+    if Kp != K:
+        w = torch.nn.functional.pad(w, (0, Kp - K))
+    return w.contiguous()
+
+
 def v32(*vecs):
     """Concatenate bias/LN vectors, contiguous f32 (None if every part is None)."""
     if all(v is None for v in vecs):

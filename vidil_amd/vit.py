@@ -23,7 +23,7 @@ import torch
 import torch.nn as nn
 
 from . import kernels as K
-from .packing import PackedCache, require_cuda, v32, w16
+from .packing import PackedCache, require_cuda, v32, w16, w16_patch
 
 
 class PatchEmbed(nn.Module):
@@ -102,7 +102,7 @@ class VisionTransformer(PackedCache, nn.Module):
         D = self.embed_dim
         pe = self.patch_embed.proj
         p = dict(
-            pe_w=w16(pe.weight.reshape(D, -1)), pe_b=v32(pe.bias),
+            pe_w=w16_patch(pe.weight), pe_b=v32(pe.bias),
             cls=v32(self.cls_token), pos=v32(self.pos_embed).view(-1, D),
             norm_g=v32(self.norm.weight), norm_b=v32(self.norm.bias), blocks=[])
         for b in self.blocks:
