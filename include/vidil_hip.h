@@ -108,7 +108,7 @@ int vidil_layernorm(const float* x, int64_t x_stride, const float* gamma,
                     void* out_f16, float* out_f32, void* stream);
 
 /* ------------------------------------------------------------------------ */
-/* Attention for short sequences (Nk <= 288): softmax(Q K^T [+mask]) V.       */
+/* Attention for short sequences (Nk <= 768): softmax(Q K^T [+mask]) V.       */
 /* Q  f16 [Bq][H][Tq_cap][64] (already scaled by 1/sqrt(64)),                 */
 /* K  f16 [Bk][H][Tk_cap][64], VT f16 [Bk][H][64][NP] with NP % 16 == 0 and    */
 /* the key axis of every 16-key block permuted to 0-3, 8-11, 4-7, 12-15 (the   */
