@@ -350,6 +350,39 @@ def test_full_clip_vs_oracle(full_models):
     assert out.text_embeds is None and (out.image_embeds.cpu() - ie_ref).abs().max().item() < 5e-4
 
 
+def test_blip_vit_large_vs_oracle():
+    """vit='large' (models/blip.py:317-322: width 1024, depth 24, 16 heads; BASELINE config 4): ViT output and the
+    prompt-pass caption logits (cross-attention over 1024-wide image tokens) against the fp32 oracle."""
+    from oracle import clip_ref, med_ref, vit_ref
+    from vidil_amd.blip import BLIP_Decoder, DecoderSession
+    from vidil_amd.tokenizer import SyntheticBertTokenizer
+
+    torch.manual_seed(2)
+    cap = BLIP_Decoder(image_size=224, vit="large", tokenizer=SyntheticBertTokenizer()).eval()
+    perturb_(cap, 500)
+    sd = {k: v.clone() for k, v in cap.state_dict().items()}
+    cap = cap.to(DEV)
+    B, nb = 2, 3
+    u8 = synthetic_frames(1, B, first_video=31)[0]
+    x = clip_ref.preprocess_u8(u8)
+    with torch.no_grad():
+        y_ref = vit_ref.vit_forward(sd, x, depth=24, heads=16)
+    assert y_ref.shape == (B, 197, 1024)
+    y32, y16 = cap.visual_encoder.forward_u8(torch.from_numpy(u8).to(DEV), clip_ref.CLIP_MEAN, clip_ref.CLIP_STD)
+    d = (y32.cpu() - y_ref).abs()
+    assert d.max().item() < 2e-2 and d.mean().item() < 2e-3
+    prompt = cap.prompt_ids(B, "cpu").long()
+    with torch.no_grad():
+        ref0, _ = med_ref.decoder_logits(sd, prompt, y_ref, None)
+    sess = DecoderSession(cap.text_decoder, y16, B, nb, 20)
+    lg = sess.prefill(prompt.to(torch.int32).reshape(-1).to(DEV), prompt.shape[1], shared=True)   # one row per image
+    # twice the depth of the base encoder in front of the decoder: the 1e-3 (relative to the logit scale) of the
+    # base configuration becomes 2e-3 here (measured 1.1e-3); the mean bound is unchanged
+    dl = (lg.cpu() - ref0).abs()
+    scale = max(1.0, ref0.abs().max().item())
+    assert dl.max().item() <= 2e-3 * scale and dl.mean().item() <= 5e-4 * scale, (dl.max().item(), dl.mean().item(), scale)
+
+
 def test_clip_vit_l14_geometry_vs_oracle():
     """openai/clip-vit-large-patch14 (the model every pipeline_config_*.yaml of the reference names): patch 14 =>
     588-column patch rows (zero padded to 640 for the GEMM), 257 tokens, width 1024 / 16 heads, text width 768,
