@@ -60,7 +60,7 @@ def test_argument_validation_without_a_gpu():
     g.A, g.W, g.M, g.N, g.K = 16, 16, 8, 8, 100
     assert lib.vidil_gemm_f16(ctypes.byref(g), None) == -1
     assert b"multiple of 64" in lib.vidil_last_error()
-    assert lib.vidil_attention(16, 16, 16, 16, None, None, None, 0, 0, 1, 12, 4, 400, 4, 400, 400, 1, 0, 0, 768, None) == -3
+    assert lib.vidil_attention(16, 16, 16, 16, None, None, None, 0, 0, 1, 12, 4, 800, 4, 800, 800, 1, 0, 0, 768, None) == -3
     assert b"not supported" in lib.vidil_last_error()
     assert lib.vidil_scan_topk_ws_bytes(128, 42784, 5) > 0
 
