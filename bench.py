@@ -180,9 +180,15 @@ def main():
 
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an AMD GPU (no CPU fallback for the product path)")
-    rank, world, local = vdist.init_distributed_mode(backend="nccl") if args.gpus > 1 else (0, 1, 0)
+    # (developer smoke of the N > 1 launch path on a one-GPU box: VIDIL_BENCH_SMOKE_ONE_DEVICE=1 puts every rank
+    #  on cuda:0 and rendezvous over gloo; the real multi-GPU run is one rank per GPU over RCCL)
+    one_device = os.environ.get("VIDIL_BENCH_SMOKE_ONE_DEVICE") == "1"
+    backend = "gloo" if one_device else "nccl"
+    rank, world, local = vdist.init_distributed_mode(backend=backend) if args.gpus > 1 else (0, 1, 0)
     if args.gpus > 1 and world != args.gpus:
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}; launch with torch.distributed.run")
+    if one_device:
+        local = 0
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
 
