@@ -264,6 +264,28 @@ int vidil_beam_attention(const void* q, const void* k_arena, const void* v_arena
                          int32_t ldo, void* stream);
 
 /* ------------------------------------------------------------------------ */
+/* One nucleus-sampling step (HF transformers 4.15 sample() as configured by  */
+/* models/blip.py:140-151: do_sample, top_p, repetition_penalty 1.1, BertConfig */
+/* default top_k 50, min/max length).  Per unfinished row b of logits f32 [B,V]:*/
+/*   repetition penalty on every distinct token of seqs[b][0..cur_len) (s<0 ?  */
+/*   s*p : s/p); cur_len < min_length => s[eos] = -inf; keep the top_k scores  */
+/*   (ties with the k-th kept); nucleus cut at top_p in descending order; draw */
+/*   from the softmax of the survivors.  The draw is this library's contract   */
+/*   (torch.multinomial's generator stream cannot be reproduced): u =          */
+/*   Philox4x32-10(key = seed, counter = (row_offset + b, step, 0, 0))[0] >> 8 */
+/*   scaled to [0,1), inverse CDF over candidates ordered (score desc, id asc). */
+/* Writes next_tok[b] and seqs[b][cur_len] (pad for finished rows), sets       */
+/* done[b] / increments n_done when eos is drawn.  V*4 B must fit 150 KB LDS.  */
+/* ------------------------------------------------------------------------ */
+int vidil_sample_top_k_top_p(const float* logits, int32_t* seqs, int32_t* done,
+                             int32_t* n_done, int32_t* next_tok, int32_t B,
+                             int32_t V, int32_t max_len, int32_t cur_len,
+                             int32_t min_length, int32_t eos_id, int32_t pad_id,
+                             int32_t top_k, float top_p, float rep_penalty,
+                             uint64_t seed, int32_t step, int32_t row_offset,
+                             void* stream);
+
+/* ------------------------------------------------------------------------ */
 /* Ontology scan + per-frame top-k (run_visual_tokenization.py:276,298-308).  */
 /* img f32 [NF,D] ; txt f32 [NCpad,D] where each category c occupies rows     */
 /* seg_start[c] .. seg_start[c]+seg_len[c]-1 and seg_start[c] % 32 == 0.      */

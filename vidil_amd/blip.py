@@ -192,6 +192,45 @@ class BLIP_Decoder(nn.Module):
         out_tok, out_len, _ = K.beam_finalize(bufs, cur_len, eos, pad)
         return out_tok, out_len
 
+    # ------------------------------------------------------------------ nucleus sampling
+    @torch.no_grad()
+    def sample_ids(self, enc16, B, *, top_p=0.9, max_length=30, min_length=10, top_k=50, repetition_penalty=1.1,
+                   seed=None, row_offset=0, check_done_every=4):
+        """Nucleus sampling (models/blip.py:140-151: HF sample() with top_p, BertConfig's default top_k = 50 and the
+        hard-coded repetition_penalty = 1.1), one sequence per image.  Returns tokens i32 [B,max_length] (prompt, drawn
+        tokens, [SEP] when drawn, then [PAD]).  The random draw follows this library's Philox contract (see
+        vidil_sample_top_k_top_p): deterministic in (seed, row_offset + image index, step)."""
+        require_cuda(enc16, "BLIP_Decoder.generate")
+        tok = self.tokenizer
+        eos, pad = tok.sep_token_id, tok.pad_token_id
+        dev = enc16.device
+        if seed is None:
+            self._sample_calls = getattr(self, "_sample_calls", 0) + 1
+            seed = (torch.initial_seed() + (self._sample_calls << 32)) & 0xFFFFFFFFFFFFFFFF
+        sess = DecoderSession(self.text_decoder, enc16, B, 1, max_length)
+        prompt = self.prompt_ids(B, dev)
+        P = prompt.shape[1]
+        seqs = torch.full((B, max_length), pad, dtype=torch.int32, device=dev)
+        seqs[:, :P] = prompt
+        done = torch.zeros((B,), dtype=torch.int32, device=dev)
+        n_done = torch.zeros((1,), dtype=torch.int32, device=dev)
+        next_tok = torch.zeros((B,), dtype=torch.int32, device=dev)
+        ident = torch.arange(B, dtype=torch.int32, device=dev)
+        logits = sess.prefill(prompt.contiguous().view(-1), P, shared=True)     # one row per image == every row
+        cur_len, step = P, 0
+        while True:
+            K.sample_top_k_top_p(logits, seqs, done, n_done, next_tok, cur_len=cur_len, min_length=min_length, eos_id=eos,
+                                 pad_id=pad, top_k=top_k, top_p=top_p, rep_penalty=repetition_penalty, seed=seed, step=step,
+                                 row_offset=row_offset)
+            cur_len += 1
+            step += 1
+            if cur_len >= max_length:
+                break
+            if check_done_every and (step % check_done_every == 0) and int(n_done.item()) == B:
+                break
+            logits = sess.step(next_tok, ident, cur_len - 1)
+        return seqs
+
     def decode_captions(self, out_tok):
         captions = []
         for row in out_tok.cpu().tolist():
@@ -204,9 +243,11 @@ class BLIP_Decoder(nn.Module):
                  repetition_penalty=1.0):
         """Reference: models/blip.py:127-167.  image f32 [B,3,S,S] on the GPU -> list of B captions."""
         if sample:
-            raise NotImplementedError("nucleus sampling (generation_mode != 'beam') is not built yet; see DESIGN.md §next")
+            _, y16 = self.visual_encoder.forward_both(image)
+            return self.decode_captions(self.sample_ids(y16, image.shape[0], top_p=top_p, max_length=max_length,
+                                                        min_length=min_length))
         if repetition_penalty != 1.0:
-            raise NotImplementedError("repetition_penalty != 1.0 is not on the hot path")
+            raise NotImplementedError("repetition_penalty != 1.0 with beam search is not on the hot path")
         _, y16 = self.visual_encoder.forward_both(image)
         out_tok, _ = self.generate_ids(y16, image.shape[0], num_beams=num_beams, max_length=max_length,
                                        min_length=min_length)

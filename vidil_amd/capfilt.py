@@ -117,10 +117,12 @@ class CapFiltEngine:
         flat = blip_frames(frames_u8.reshape(Nv * F, *frames_u8.shape[2:]), cfg.get("image_size", 224))
         generated = [[] for _ in range(Nv)]
         if cfg.get("caption", True):
-            if cfg.get("generation_mode", "beam") != "beam":
-                raise NotImplementedError("generation_mode != 'beam' is not built yet")
             _, y16 = self.captioner.visual_encoder.forward_u8(flat, CLIP_MEAN, CLIP_STD)
-            out_tok, _ = self.captioner.generate_ids(y16, Nv * F, num_beams=3, max_length=20, min_length=5)
+            if cfg.get("generation_mode", "beam") == "beam":
+                out_tok, _ = self.captioner.generate_ids(y16, Nv * F, num_beams=3, max_length=20, min_length=5)
+            else:   # nucleus sampling, run_video_CapFilt.py:103-104
+                out_tok = self.captioner.sample_ids(y16, Nv * F, top_p=0.9, max_length=20, min_length=5,
+                                                    seed=cfg.get("sample_seed"))
             caps = self.captioner.decode_captions(out_tok)
             self.last_frame_captions = caps
             generated = [dedup(caps[v * F:(v + 1) * F]) for v in range(Nv)]

@@ -308,6 +308,17 @@ def kv_reorder(src, dst, beam_idx, L, rows):
                                        _ptr(beam_idx, torch.int32), L, rows, row_halfs, _stream()), "kv_reorder")
 
 
+def sample_top_k_top_p(logits, seqs, done, n_done, next_tok, *, cur_len, min_length, eos_id, pad_id, top_k=50,
+                       top_p=0.9, rep_penalty=1.1, seed=0, step=0, row_offset=0):
+    """One nucleus-sampling step on logits f32 [B,V] (see vidil_sample_top_k_top_p); appends to seqs i32 [B,max_len]."""
+    B, V = logits.shape
+    check(_lib.load().vidil_sample_top_k_top_p(_ptr(logits, torch.float32, "sample.logits"), _ptr(seqs, torch.int32),
+                                               _ptr(done, torch.int32), _ptr(n_done, torch.int32),
+                                               _ptr(next_tok, torch.int32), B, V, seqs.shape[1], cur_len, min_length,
+                                               eos_id, pad_id, top_k, float(top_p), float(rep_penalty), int(seed), step,
+                                               row_offset, _stream()), "sample_top_k_top_p")
+
+
 def beam_ancestry(anc_src, anc_dst, beam_idx, cur_pos):
     """anc_dst[r][:cur_pos] = anc_src[beam_idx[r]][:cur_pos]; anc_dst[r][cur_pos] = r  (i32 [rows,Tcap] tables)."""
     rows, Tcap = anc_src.shape
