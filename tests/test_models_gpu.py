@@ -278,6 +278,34 @@ def test_full_itm_vs_oracle(full_models):
     assert (p_got - p_ref).abs().max().item() < 1e-3
 
 
+def test_captured_decode_graphs_replay_the_eager_result(full_models):
+    """generate_ids reuses its session per shape: call 1 runs eagerly, call 2 captures one HIP graph per decode step,
+    call 3+ replays them.  All must produce the tokens of a fresh eager search — also on a DIFFERENT batch, which
+    exercises the in-place re-projection of the cross K/V and the reset of arena / beam-buffer orientation."""
+    from oracle import clip_ref
+
+    cap = full_models["cap"]
+    B = 4
+    outs = {}
+    for name, first in (("a", 50), ("b", 51)):
+        u8 = synthetic_frames(1, B, first_video=first)[0]
+        _, y16 = cap.visual_encoder.forward_u8(torch.from_numpy(u8).to(DEV), clip_ref.CLIP_MEAN, clip_ref.CLIP_STD)
+        outs[name] = y16.clone()
+    cap.__dict__.pop("_decode_state", None)
+    os.environ["VIDIL_DECODE_GRAPHS"] = "0"
+    try:
+        ref = {k: cap.generate_ids(v, B, num_beams=3, max_length=20, min_length=5)[0].cpu() for k, v in outs.items()}
+    finally:
+        os.environ.pop("VIDIL_DECODE_GRAPHS")
+    cap.__dict__.pop("_decode_state", None)
+    seq = ["a", "b", "a", "b", "b", "a"]          # eager, capture, replay x4
+    for i, k in enumerate(seq):
+        tok = cap.generate_ids(outs[k], B, num_beams=3, max_length=20, min_length=5)[0].cpu()
+        assert torch.equal(tok, ref[k]), (i, k)
+    st = next(iter(cap._decode_state.values()))
+    assert st["graphs_ok"] and len(st["graphs"]) >= 10 and st["calls"] == len(seq)
+
+
 def test_blip_at_384_vit_decoder_and_itm_vs_oracle():
     """image_size 384 (what every pipeline_config_*.yaml of the reference sets): 577 image tokens, i.e. chunked
     LDS attention in the ViT / ITM cross-attention and the multi-round direct kernel in the decode cross-attention."""

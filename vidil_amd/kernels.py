@@ -266,6 +266,8 @@ class BeamBuffers:
         """prompt_ids: int32 [B, P]; beams of an image start identical, scores [0,-1e9,...]."""
         B, nb = self.B, self.nb
         P = prompt_ids.shape[1]
+        if getattr(self, "swapped", False):   # every search starts from the same buffer orientation (captured
+            self.swap()                        # decode-step graphs bake the pointers of each step in)
         self.seqs.zero_()
         self.seqs[:, :P] = prompt_ids.repeat_interleave(nb, dim=0)
         bs = torch.full((B, nb), -1e9, dtype=torch.float32, device=self.seqs.device)
@@ -281,6 +283,7 @@ class BeamBuffers:
 
     def swap(self):
         self.seqs, self.seqs_next = self.seqs_next, self.seqs
+        self.swapped = not getattr(self, "swapped", False)
 
 
 def beam_update(bufs: BeamBuffers, cand_scores, cand_index, V, cur_len, eos_id, pad_id):

@@ -197,15 +197,19 @@ class BertModel(PackedCache, nn.Module):
         return p
 
     # --------------------------------------------------------- cross K/V (once per image)
-    def project_cross_kv(self, enc16, B, Te):
-        """enc16: f16 [B*Te, encoder_width] image tokens.  One fused K|V GEMM per layer."""
+    def project_cross_kv(self, enc16, B, Te, out: "CrossKV" = None):
+        """enc16: f16 [B*Te, encoder_width] image tokens.  One fused K|V GEMM per layer.  ``out``: buffers of a
+        previous call with the same (B, Te) to overwrite (keeps device addresses stable for captured graphs)."""
         p = self.packed()
         H = self.config.num_attention_heads
         NP = (Te + 15) // 16 * 16
         L = len(p["layers"])
         dev = enc16.device
-        k = torch.empty((L, B, H, Te, 64), dtype=torch.float16, device=dev)
-        vt = torch.empty((L, B, H, 64, NP), dtype=torch.float16, device=dev)
+        if out is not None and (out.B, out.Te, out.NP) == (B, Te, NP) and out.k.device == dev:
+            k, vt = out.k, out.vt
+        else:
+            k = torch.empty((L, B, H, Te, 64), dtype=torch.float16, device=dev)
+            vt = torch.empty((L, B, H, 64, NP), dtype=torch.float16, device=dev)
         for i, d in enumerate(p["layers"]):
             K.gemm(enc16, d["ckv_w"], d["ckv_b"],
                    heads=dict(k=k[i], vt=vt[i], T=Te, H=H, part0=1, t_off=0, Tk_cap=Te, NP=NP))
