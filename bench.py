@@ -218,6 +218,21 @@ def main():
             print(f"[bench +{time.perf_counter() - t_start:7.1f}s] {msg}", file=sys.stderr, flush=True)
 
     log("models + inputs ready")
+    # one-time initialisation, like weight packing: the first batch of a shape runs the decode steps eagerly, the
+    # second captures them into HIP graphs; steady state starts with the third (independent of --warmup)
+    # ... and a fresh box needs a few seconds of load before clocks and caches settle: keep priming (at most 8
+    # steps) until two consecutive steps agree within 2 %.
+    prev = None
+    for i in range(8):
+        torch.cuda.synchronize()
+        t_p = time.perf_counter()
+        step()
+        torch.cuda.synchronize()
+        t_p = time.perf_counter() - t_p
+        if i >= 2 and prev is not None and abs(t_p - prev) <= 0.02 * prev:
+            break
+        prev = t_p
+    log(f"sessions primed after {i + 1} steps (decode-step graphs captured, last step {t_p * 1e3:.1f} ms)")
     for _ in range(args.warmup):
         step()
         torch.cuda.synchronize()
