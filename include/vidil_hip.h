@@ -300,6 +300,20 @@ int vidil_scan_topk(const float* img, const float* txt, int32_t NF, int32_t D,
                     const int32_t* seg_len_host, int32_t topk, void* partial,
                     int32_t* out_index, float* out_score, void* stream);
 
+/* ------------------------------------------------------------------------ */
+/* BLIP retrieval backend of the visual tokenizer (--encoder_version blip,    */
+/* run_visual_tokenization.py:277-293): `sims_matrix = image_embeds @          */
+/* text_embeds.t()` then `sims.topk(k_test)` per frame before the ITM re-rank. */
+/*   vidil_scan_scores: out f32 [NF,NC] = img [NF,D] · txt [NC,D]^T with the    */
+/*     same exact k-ordered f32 chain as vidil_scan_topk;                      */
+/*   vidil_topk_rows: the k (<= 128) largest of each of R rows of N (<= 38400)  */
+/*     values, sorted by (value desc, index asc): out_v f32 [R,k], out_i i32.  */
+/* ------------------------------------------------------------------------ */
+int vidil_scan_scores(const float* img, const float* txt, int32_t NF, int32_t D,
+                      int32_t NC, float* out, void* stream);
+int vidil_topk_rows(const float* x, int64_t row_stride, int32_t R, int32_t N,
+                    int32_t k, float* out_v, int32_t* out_i, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

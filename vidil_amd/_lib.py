@@ -69,6 +69,8 @@ SIGNATURES = {
     "vidil_beam_ancestry": (_i32, [_p, _p, _p, _i32, _i32, _i32, _p]),
     "vidil_beam_attention": (_i32, [_p, _p, _p, _p, _p] + [_i32] * 6 + [_p]),
     "vidil_sample_top_k_top_p": (_i32, [_p, _p, _p, _p, _p] + [_i32] * 8 + [_f32, _f32, C.c_uint64, _i32, _i32, _p]),
+    "vidil_scan_scores": (_i32, [_p, _p, _i32, _i32, _i32, _p, _p]),
+    "vidil_topk_rows": (_i32, [_p, _i64, _i32, _i32, _i32, _p, _p, _p]),
     "vidil_scan_topk_ws_bytes": (_i64, [_i32, _i32, _i32]),
     "vidil_scan_topk": (_i32, [_p, _p, _i32, _i32, _i32, C.POINTER(_i32), C.POINTER(_i32), _i32, _p, _p, _p, _p]),
 }

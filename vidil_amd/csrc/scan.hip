@@ -165,6 +165,56 @@ __global__ void scan_merge_kernel(const ScanP p, int32_t* __restrict__ out_i, fl
   }
 }
 
+// Dense variant for the BLIP retrieval backend (--encoder_version blip needs the k_test = 128 best texts per frame,
+// too many for per-lane register lists): the same exact-f32 score of every (frame, text row), written out.
+__global__ __launch_bounds__(256) void scores_kernel(const float* __restrict__ img, const float* __restrict__ txt, int NF, int D,
+                                                     int NC, float* __restrict__ out) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int FROW = D + 4;
+  float* Fs = (float*)smem;
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int hi = lane >> 5, l31 = lane & 31;
+  const int ftile = blockIdx.y;
+  {
+    const int vec_per_row = D / 4;
+    for (int q = tid; q < 32 * vec_per_row; q += 256) {
+      const int r = q / vec_per_row, c = q - r * vec_per_row;
+      const int f = ftile * 32 + r;
+      f32x4 v = {0.f, 0.f, 0.f, 0.f};
+      if (f < NF) v = *(const f32x4*)(img + (size_t)f * D + c * 4);
+      *(f32x4*)(Fs + r * FROW + c * 4) = v;
+    }
+  }
+  __syncthreads();
+  const float* frow = Fs + l31 * FROW + 4 * hi;
+  const int f = ftile * 32 + l31;
+  const int ntiles = (NC + 31) / 32;
+  for (int tt = wave; tt < CT; tt += 4) {
+    const int tile = blockIdx.x * CT + tt;
+    if (tile >= ntiles) break;
+    const int cls = tile * 32 + l31;
+    const float* trow = txt + (size_t)(cls < NC ? cls : NC - 1) * D + 4 * hi;
+    f32x16 acc;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+#pragma unroll 4
+    for (int c = 0; c < D / 8; ++c) {
+      const f32x4 a = *(const f32x4*)(trow + c * 8);
+      const f32x4 b = *(const f32x4*)(frow + c * 8);
+#pragma unroll
+      for (int j = 0; j < 4; ++j) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[j], b[j], acc, 0, 0, 0);
+    }
+    if (f < NF) {
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int c2 = tile * 32 + (r & 3) + 8 * (r >> 2) + 4 * hi;
+        if (c2 < NC) out[(size_t)f * NC + c2] = acc[r];
+      }
+    }
+  }
+}
+
 int total_chunks(int ncat, const int32_t* seg_len, int* prefix) {
   int n = 0;
   for (int c = 0; c < ncat; ++c) {
@@ -230,5 +280,26 @@ extern "C" int vidil_scan_topk(const float* img, const float* txt, int32_t NF, i
   const int nthreads = NF * ncat;
   hipLaunchKernelGGL(mkern, dim3((nthreads + 127) / 128), dim3(128), 0, s, p, out_index, out_score);
   VIDIL_CHECK_LAUNCH("scan_topk/merge");
+  return VIDIL_OK;
+}
+
+extern "C" int vidil_scan_scores(const float* img, const float* txt, int32_t NF, int32_t D, int32_t NC, float* out,
+                                 void* stream) {
+  VIDIL_REQUIRE(img && txt && out, "scan_scores: null pointer");
+  VIDIL_REQUIRE(NF > 0 && NC > 0 && D >= 8 && D % 8 == 0 && D <= 1024, "scan_scores: NF=%d NC=%d D=%d (D%%8==0, D<=1024)", NF, NC, D);
+  const int ftiles = (NF + 31) / 32;
+  VIDIL_REQUIRE(ftiles <= 65535, "scan_scores: too many frames in one call (%d)", NF);
+  const int smem = 32 * (D + 4) * 4;
+  static int attr_smem = 0;
+  if (smem > attr_smem) {
+    if (hipFuncSetAttribute((const void*)scores_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, smem) != hipSuccess) {
+      vidil_set_error("scan_scores: hipFuncSetAttribute failed");
+      return VIDIL_ELAUNCH;
+    }
+    attr_smem = smem;
+  }
+  const int chunks = ((NC + 31) / 32 + CT - 1) / CT;
+  hipLaunchKernelGGL(scores_kernel, dim3(chunks, ftiles), dim3(256), smem, (hipStream_t)stream, img, txt, NF, D, NC, out);
+  VIDIL_CHECK_LAUNCH("scan_scores");
   return VIDIL_OK;
 }

@@ -339,6 +339,30 @@ def beam_attention(q, k_arena, v_arena, anc, out, *, rows, H, n_keys, ldo=None):
                                            ldo if ldo is not None else out.shape[-1], _stream()), "beam_attention")
 
 
+def scan_scores(img, txt):
+    """Exact-f32 dense scores img [NF,D] · txt [NC,D]^T -> f32 [NF,NC] (the chain of vidil_scan_topk)."""
+    NF, D = img.shape
+    NC = txt.shape[0]
+    out = torch.empty((NF, NC), dtype=torch.float32, device=img.device)
+    check(_lib.load().vidil_scan_scores(_ptr(img, torch.float32, "scores.img"), _ptr(txt, torch.float32, "scores.txt"), NF, D,
+                                        NC, _ptr(out, torch.float32), _stream()), "scan_scores")
+    return out
+
+
+def topk_rows(x, k):
+    """Sorted top-k of every row of f32 [R,N] (value desc, index asc): (values f32 [R,k], indices i32 [R,k])."""
+    if x.dim() != 2 or x.stride(1) != 1:
+        raise VidilHipError(f"topk_rows: expected a 2-D f32 tensor with contiguous rows, got {tuple(x.shape)} strides {x.stride()}")
+    R, N = x.shape
+    ov = torch.empty((R, k), dtype=torch.float32, device=x.device)
+    oi = torch.empty((R, k), dtype=torch.int32, device=x.device)
+    if x.dtype != torch.float32 or not x.is_cuda:
+        raise VidilHipError("topk_rows: expected a float32 tensor on the GPU (there is no CPU fallback)")
+    check(_lib.load().vidil_topk_rows(C.c_void_p(x.data_ptr()), x.stride(0), R, N, k, _ptr(ov, torch.float32),
+                                      _ptr(oi, torch.int32), _stream()), "topk_rows")
+    return ov, oi
+
+
 # ------------------------------------------------------------------------- ontology scan
 def scan_topk_ws_bytes(NF, NCpad, topk):
     return int(_lib.load().vidil_scan_topk_ws_bytes(NF, NCpad, topk))

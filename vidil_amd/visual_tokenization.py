@@ -162,6 +162,59 @@ class VisualTokenizer:
         return out
 
 
+class BlipVisualTokenizer(VisualTokenizer):
+    """``--encoder_version blip`` (run_visual_tokenization.py:113-133,152-159,277-293): BLIP ITC similarity against
+    every ontology text, then, per frame and category, the k_test most similar texts re-ranked by
+    ``itm_head(...)[:,1] + sim`` — every other text keeps -100 in the reference's score matrix, so the per-frame
+    top-k is the top-k of the re-ranked candidates.
+
+    ``model``: vidil_amd.blip_retrieval.BLIP_Retrieval.  Text features are computed once here (the reference does it
+    once per run, :224-232)."""
+
+    def __init__(self, config, model, visual_token_texts, device, pairs_per_pass=16384):
+        self.config = config
+        self.device = torch.device(device)
+        self.model = model.eval().to(self.device)
+        self.texts = visual_token_texts
+        self.topk = config.get("topk_visualize", 5)
+        self.k_test = config.get("k_test", 128)
+        self.image_size = config.get("image_size", 384)
+        self.pairs_per_pass = pairs_per_pass
+        self.text_repr = {}
+        for key in CATEGORIES:
+            emb, ids, lens = self.model.text_features(list(visual_token_texts[key]), self.device)
+            self.text_repr[key] = dict(embeds=emb.contiguous(), ids=ids.contiguous(), lens=lens.contiguous())
+
+    @torch.no_grad()
+    def frame_topk(self, frames_u8):
+        from .preprocess import blip_frames
+
+        frames = blip_frames(frames_u8, self.image_size)
+        NF = frames.shape[0]
+        y16, img = self.model.image_features_u8(frames)
+        Te = y16.shape[0] // NF
+        out_i = torch.full((NF, len(CATEGORIES), self.topk), -1, dtype=torch.int32, device=self.device)
+        out_s = torch.full((NF, len(CATEGORIES), self.topk), float("-inf"), dtype=torch.float32, device=self.device)
+        for c, key in enumerate(CATEGORIES):
+            rep = self.text_repr[key]
+            n_txt = rep["embeds"].shape[0]
+            k = min(self.k_test, n_txt)
+            sims = K.scan_scores(img, rep["embeds"])                        # [NF, n_txt] exact f32
+            top_s, top_i = K.topk_rows(sims, k)                             # [NF, k] sorted
+            per_pass = max(1, self.pairs_per_pass // k)                     # frames per ITM pass
+            for f0 in range(0, NF, per_pass):
+                f1 = min(NF, f0 + per_pass)
+                idx = top_i[f0:f1].reshape(-1).long()
+                group_start = (torch.arange(f1 - f0 + 1, dtype=torch.int32, device=self.device) * k)
+                itm = self.model.rerank(y16[f0 * Te:f1 * Te], f1 - f0, rep["ids"][idx], rep["lens"][idx], group_start, k)
+                score = (itm + top_s[f0:f1].reshape(-1)).view(f1 - f0, k).contiguous()   # :292 score + topk_sim
+                kk = min(self.topk, k)
+                best_s, best_j = K.topk_rows(score, kk)
+                out_i[f0:f1, c, :kk] = torch.gather(top_i[f0:f1], 1, best_j.long())
+                out_s[f0:f1, c, :kk] = best_s
+        return out_i, out_s
+
+
 def write_outputs(output_dir, videoid_2_visual_tokens):
     """run_visual_tokenization.py:447-463 with the tmp-file merge replaced by a gather of JSON bytes."""
     parts = vdist.gather_json(videoid_2_visual_tokens)
