@@ -1,7 +1,7 @@
 #!/usr/bin/env python
 """bench.py — frames/sec of VidIL's frame-encoding hot path on MI355X.
 
-One "step" = one batch of synthetic videos (default 192 videos x 8 frames, 224^2 uint8,
+One "step" = one batch of synthetic videos (default 384 videos x 8 frames, 224^2 uint8,
 already resident in HBM) through the WHOLE path: BLIP ViT-B/16 caption (beam 3,
 max_length 20) + CapFilt ITM filter + CLIP ViT-B/32 visual tokens against a vg-sized
 ontology (42,759 classes), including the host-side string work and the device->host
@@ -165,9 +165,10 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=5)
     ap.add_argument("--warmup", type=int, default=2)
-    # 192 videos = 1536 frames per step: 302,592 ViT rows = 1182 row tiles of 256, i.e. 13.85 rounds of 256-tile
-    # workgroups on the N = 768 GEMMs (98.9 % of the last round filled; 128 videos give 9.23 rounds = 92 %)
-    ap.add_argument("--videos-per-step", type=int, default=192)
+    # 384 videos = 3072 frames per step: 605,184 ViT rows = 2364 row tiles of 256, i.e. 27.7 rounds of 256-tile
+    # workgroups on the N = 768 GEMMs (98.9 % of the last round filled; 128 videos give 9.23 rounds = 92 %), and
+    # 9216 beam rows per decode step (measured: 128 -> 3.7k, 192 -> 3.8-3.95k, 384 -> 4.1k, 576 -> 3.9k frames/s)
+    ap.add_argument("--videos-per-step", type=int, default=384)
     ap.add_argument("--frames", type=int, default=8)
     ap.add_argument("--size", type=int, default=224, help="frame / BLIP image size (the headline metric is 224)")
     ap.add_argument("--clip", choices=["b32", "l14"], default="b32", help="CLIP tower (headline metric: ViT-B/32)")
