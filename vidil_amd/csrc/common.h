@@ -19,8 +19,6 @@ void vidil_set_error(const char* fmt, ...);
 // gemm256.hip: the 256x256 8-wave kernel for large problems (dispatched from vidil_gemm_f16)
 bool vidil_gemm256_eligible(const vidil_gemm_args& a);
 int vidil_gemm256_launch(const vidil_gemm_args& a, hipStream_t s);
-// gemm256w4.hip: same tile on 4 waves (one per SIMD, 512 registers each)
-int vidil_gemm256w4_launch(const vidil_gemm_args& a, hipStream_t s);
 
 #define VIDIL_REQUIRE(cond, ...)                \
   do {                                          \

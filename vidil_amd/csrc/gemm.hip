@@ -311,16 +311,7 @@ int pick_tile(const vidil_gemm_args& a, hipStream_t s) {
     const char* e = getenv("VIDIL_GEMM256");
     return !(e && e[0] == '0');
   }();
-  static const bool use_w4 = []() {
-    // default: the 8-wave kernel (0.83-0.87 PFLOP/s on the ViT shapes); "w4" selects the one-wave-per-SIMD
-    // variant (0.71-0.74 measured) for A/B testing
-    const char* e = getenv("VIDIL_GEMM256_VARIANT");
-    return e && e[0] == 'w' && e[1] == '4';
-  }();
-  if (allow256 && vidil_gemm256_eligible(a)) {
-    const bool heads_ok = a.epi != VIDIL_EPI_HEADS || (a.H * 64) % 128 == 0;
-    return (use_w4 && heads_ok) ? vidil_gemm256w4_launch(a, s) : vidil_gemm256_launch(a, s);
-  }
+  if (allow256 && vidil_gemm256_eligible(a)) return vidil_gemm256_launch(a, s);
 #ifdef VIDIL_GEMM_TUNE
   // developer builds only: VIDIL_GEMM_TILE=<BM>x<BN>x<ST> forces one configuration
   if (const char* e = getenv("VIDIL_GEMM_TILE")) {
