@@ -223,7 +223,8 @@ class BLIP_Decoder(nn.Module):
             elif use_graphs:
                 try:
                     g = torch.cuda.CUDAGraph()
-                    with torch.cuda.graph(g, pool=st["pool"]):
+                    # thread_local: other threads (the RCCL watchdog of a multi-GPU run) may touch the runtime meanwhile
+                    with torch.cuda.graph(g, pool=st["pool"], capture_error_mode="thread_local"):
                         unit(cur_len)
                     st["pool"] = g.pool()
                     st["graphs"][cur_len] = g
