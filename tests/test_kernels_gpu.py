@@ -505,6 +505,42 @@ def _scan_oracle():
     return lib
 
 
+def test_scan_topk_full_vg_ontology_config1_size_bit_exact():
+    """BASELINE config 1 at full size: 128 frames against the 42,759-class vg ontology (19,958 / 15,026 / 365 /
+    7,410, duplicate scene rows included): every index and every score bit equal to the C oracle, lists sorted."""
+    k = _k()
+    NF, D, topk = 128, 512, 5
+    seg_len = [19958, 15026, 365, 7410]
+    seg_start, n = [], 0
+    for L in seg_len:
+        seg_start.append(n)
+        n += (L + 31) // 32 * 32
+    g = torch.Generator().manual_seed(77)
+    txt = torch.zeros(n, D)
+    for s0, L in zip(seg_start, seg_len):
+        e = torch.randn(L, D, generator=g)
+        txt[s0:s0 + L] = e / e.norm(dim=-1, keepdim=True)
+    for j in range(1, 25):                                         # 'outdoor' x25, 'indoor' x25 in the real scenes list
+        txt[seg_start[2] + 40 + j] = txt[seg_start[2] + 40]
+        txt[seg_start[2] + 100 + j] = txt[seg_start[2] + 100]
+    img = torch.randn(NF, D, generator=g)
+    img = img / img.norm(dim=-1, keepdim=True)
+    oi, os_ = k.scan_topk(img.to(DEV), txt.to(DEV), seg_start, seg_len, topk)
+    lib = _scan_oracle()
+    ri = np.zeros((NF, 4, topk), np.int32)
+    rs = np.zeros((NF, 4, topk), np.float32)
+    imgc, txtc = np.ascontiguousarray(img.numpy()), np.ascontiguousarray(txt.numpy())
+    lib.vidil_ref_scan_topk(imgc.ctypes.data_as(ctypes.c_void_p), txtc.ctypes.data_as(ctypes.c_void_p), NF, D, 4,
+                            (ctypes.c_int32 * 4)(*seg_start), (ctypes.c_int32 * 4)(*seg_len), topk,
+                            ri.ctypes.data_as(ctypes.c_void_p), rs.ctypes.data_as(ctypes.c_void_p))
+    got_i, got_s = oi.cpu().numpy(), os_.cpu().numpy()
+    assert np.array_equal(got_i, ri)
+    assert np.array_equal(got_s.view(np.uint32), rs.view(np.uint32))
+    assert np.all(got_s[..., :-1] >= got_s[..., 1:])               # sorted descending
+    for c, L in enumerate(seg_len):
+        assert got_i[:, c].min() >= 0 and got_i[:, c].max() < L
+
+
 @pytest.mark.parametrize("D", [512, 768])     # CLIP-B/32 and CLIP-L/14 projection widths
 def test_scan_topk_bit_exact_vs_oracle(D):
     k = _k()
