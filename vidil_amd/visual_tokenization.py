@@ -150,7 +150,13 @@ class VisualTokenizer:
         aggregated_tokens}} (the schema visual_token_generation/prompts.py reads)."""
         Nv, F = frames_u8.shape[0], frames_u8.shape[1]
         idx, _ = self.frame_topk(frames_u8.reshape(Nv * F, *frames_u8.shape[2:]))
-        idx = idx.cpu().numpy().reshape(Nv, F, len(CATEGORIES), self.topk)
+        return self.assemble(video_ids, idx, captions, F)
+
+    def assemble(self, video_ids, idx_dev, captions, F):
+        """Host half of ``process``: device top-k indices i32 [Nv*F, 4, topk] -> the per-video token dicts.  Split out
+        so a caller can run ``frame_topk`` on a side stream next to CapFilt (they are independent until here)."""
+        Nv = len(video_ids)
+        idx = idx_dev.cpu().numpy().reshape(Nv, F, len(CATEGORIES), self.topk)
         out = {}
         for v, vid in enumerate(video_ids):
             frame_tokens = []
