@@ -83,6 +83,9 @@ class GemmTimer:
         t256 = ((M + 255) // 256) * ((N + 255) // 256)
         if t256 >= 160 and K >= 128 and N % (8 if f16_out else 4) == 0:
             return "256x256"
+        n128 = ((M + 127) // 128) * ((N + 127) // 128)
+        if n128 >= 200 and N <= 1024:
+            return "128x128x2" if n128 > 256 else "128x128x3"
         if ((M + 63) // 64) * ((N + 63) // 64) <= 1280:
             return "64x64x3"
         if ((M + 127) // 128) * ((N + 63) // 64) <= 2560:

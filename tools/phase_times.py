@@ -23,7 +23,7 @@ def main():
     dev = torch.device("cuda")
     cap, flt, clip, tok = bench.build_models(dev)
     cap, flt, clip = cap.to(dev), flt.to(dev), clip.to(dev)
-    Nv, F = 128, 8
+    Nv, F = (int(sys.argv[1]) if len(sys.argv) > 1 else 384), 8
     frames = torch.from_numpy(bench.synthetic_frames(Nv, F, 224)).to(dev).reshape(Nv * F, 224, 224, 3)
     B = Nv * F
     t, (y32, y16) = timed(lambda: cap.visual_encoder.forward_u8(frames, CLIP_MEAN, CLIP_STD))

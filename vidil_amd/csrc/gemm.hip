@@ -32,21 +32,28 @@ __device__ __forceinline__ void wait_vm() {
   asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
 }
 
+// waves along N: the 128x128 tile runs on 8 waves (2 x 4, two per SIMD, 64x32 outputs each) so that one workgroup
+// already overlaps LDS-DMA issue with MFMAs; the smaller tiles use 4 waves (2 x 2) and rely on co-resident workgroups
+constexpr int waves_n(int bm, int bn) { return (bm == 128 && bn == 128) ? 4 : 2; }
+
 template <int BM, int BN, int ST, int EPI, int ACT>
-__global__ __launch_bounds__(256) void gemm_kernel(const vidil_gemm_args p) {
+__global__ __launch_bounds__(2 * waves_n(BM, BN) * 64) void gemm_kernel(const vidil_gemm_args p) {
+  constexpr int NWN = waves_n(BM, BN);
+  constexpr int NT = 2 * NWN * 64;   // threads
+  constexpr int WN = BN / NWN;       // output columns per wave
   constexpr int TM = BM / 64;  // 32x32 tiles per wave along M
-  constexpr int TN = BN / 64;
+  constexpr int TN = WN / 32;
   constexpr int A_BYTES = BM * BK * 2;
   constexpr int STAGE_BYTES = (BM + BN) * BK * 2;
   constexpr int PRE = ST - 1;  // K-tiles in flight ahead of the one being multiplied
-  constexpr int LA = BM * 8 / 256;  // 16-B chunks per thread per stage (A)
-  constexpr int LB = BN * 8 / 256;
+  constexpr int LA = BM * 8 / NT;  // 16-B chunks per thread per stage (A)
+  constexpr int LB = BN * 8 / NT;
   extern __shared__ __attribute__((aligned(16))) char smem[];
 
   const int tid = threadIdx.x;
   const int lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int wm = wave >> 1, wn = wave & 1;
+  const int wm = wave / NWN, wn = wave % NWN;
   const int hi = lane >> 5;
   const int l31 = lane & 31;
 
@@ -74,7 +81,7 @@ __global__ __launch_bounds__(256) void gemm_kernel(const vidil_gemm_args p) {
   const f16* gb[LB];
 #pragma unroll
   for (int i = 0; i < LA; ++i) {
-    const int q = i * 256 + tid;
+    const int q = i * NT + tid;
     const int r = q >> 3, s = q & 7;
     const int c = s ^ ((r >> 1) & 7);
     int row = m0 + r;
@@ -83,7 +90,7 @@ __global__ __launch_bounds__(256) void gemm_kernel(const vidil_gemm_args p) {
   }
 #pragma unroll
   for (int i = 0; i < LB; ++i) {
-    const int q = i * 256 + tid;
+    const int q = i * NT + tid;
     const int r = q >> 3, s = q & 7;
     const int c = s ^ ((r >> 1) & 7);
     int row = n0 + r;
@@ -98,13 +105,13 @@ __global__ __launch_bounds__(256) void gemm_kernel(const vidil_gemm_args p) {
     for (int i = 0; i < LA; ++i) {
       __builtin_amdgcn_global_load_lds(
           (const __attribute__((address_space(1))) void*)(ga[i] + kt * BK),
-          (__attribute__((address_space(3))) void*)(la + (i * 256 + wave * 64) * 16), 16, 0, 0);
+          (__attribute__((address_space(3))) void*)(la + (i * NT + wave * 64) * 16), 16, 0, 0);
     }
 #pragma unroll
     for (int i = 0; i < LB; ++i) {
       __builtin_amdgcn_global_load_lds(
           (const __attribute__((address_space(1))) void*)(gb[i] + kt * BK),
-          (__attribute__((address_space(3))) void*)(lb + (i * 256 + wave * 64) * 16), 16, 0, 0);
+          (__attribute__((address_space(3))) void*)(lb + (i * NT + wave * 64) * 16), 16, 0, 0);
     }
   };
 
@@ -118,7 +125,7 @@ __global__ __launch_bounds__(256) void gemm_kernel(const vidil_gemm_args p) {
 
   const int sw = (lane >> 1) & 7;  // ((row>>1)&7) with row = 32*x + (lane&31)
   const int a_row_off = (wm * (BM / 2) + l31) * 128;
-  const int b_row_off = (wn * (BN / 2) + l31) * 128;
+  const int b_row_off = (wn * WN + l31) * 128;
 
   // ST-deep ring: K-tile kt lives in buffer kt % ST and PRE tiles are in flight ahead of it, so the decode-step
   // GEMMs (one workgroup per CU, nothing else to hide the L2 latency behind) do not pay a full load latency
@@ -174,7 +181,7 @@ __global__ __launch_bounds__(256) void gemm_kernel(const vidil_gemm_args p) {
   // bias, then the activation in place on pairs of accumulators (packed-f32 instructions)
 #pragma unroll
   for (int j = 0; j < TN; ++j) {
-    const int col = n0 + wn * (BN / 2) + j * 32 + l31;
+    const int col = n0 + wn * WN + j * 32 + l31;
     const float bias = (p.bias != nullptr && col < N) ? p.bias[col] : 0.f;
 #pragma unroll
     for (int i = 0; i < TM; ++i)
@@ -194,7 +201,7 @@ __global__ __launch_bounds__(256) void gemm_kernel(const vidil_gemm_args p) {
       float rv[TM][TN][16];
 #pragma unroll
       for (int j = 0; j < TN; ++j) {
-        const int col = n0 + wn * (BN / 2) + j * 32 + l31;
+        const int col = n0 + wn * WN + j * 32 + l31;
 #pragma unroll
         for (int i = 0; i < TM; ++i)
 #pragma unroll
@@ -213,7 +220,7 @@ __global__ __launch_bounds__(256) void gemm_kernel(const vidil_gemm_args p) {
   }
 #pragma unroll
   for (int j = 0; j < TN; ++j) {
-    const int col = n0 + wn * (BN / 2) + j * 32 + l31;
+    const int col = n0 + wn * WN + j * 32 + l31;
     const bool col_ok = col < N;
     // EPI_HEADS column decomposition
     int part = 0, hcol = 0;
@@ -297,7 +304,7 @@ int launch(const vidil_gemm_args& a, hipStream_t s) {
     attr_set = true;
   }
   const int tiles = ((a.M + BM - 1) / BM) * ((a.N + BN - 1) / BN);
-  hipLaunchKernelGGL(kern, dim3(tiles), dim3(256), smem, s, a);
+  hipLaunchKernelGGL(kern, dim3(tiles), dim3(2 * waves_n(BM, BN) * 64), smem, s, a);
   VIDIL_CHECK_LAUNCH("gemm");
   return VIDIL_OK;
 }
@@ -330,6 +337,14 @@ int pick_tile(const vidil_gemm_args& a, hipStream_t s) {
   // share a SIMD (an LDS-DMA instruction costs its wave ~100 cycles of issue time that only another wave can
   // fill with MFMAs), not bytes per FLOP: grow the tile only once there are >= ~5 workgroups per CU.
   // (measured on the decode-step shapes M = 384..3072, tools/tune_gemm.py)
+  // narrow outputs (N <= 1024: attention / cross-attention / FFN output projections of a decode step) with at least
+  // ~200 128x128 tiles: the 8-wave 128x128 tile, 2-deep ring when two workgroups share a CU, 3-deep when alone
+  // (M = 9216, K = 3072: 61 us against 74 us on 128x64; M = 4608: 33 against 43)
+  const long n128 = (long)((a.M + 127) / 128) * ((a.N + 127) / 128);
+  if (n128 >= 200 && a.N <= 1024) {
+    if (n128 > 256) return launch<128, 128, 2, EPI, ACT>(a, s);
+    return launch<128, 128, 3, EPI, ACT>(a, s);
+  }
   const long n64 = (long)((a.M + 63) / 64) * ((a.N + 63) / 64);
   if (n64 <= 1280) return launch<64, 64, ST_64x64, EPI, ACT>(a, s);
   const long n128x64 = (long)((a.M + 127) / 128) * ((a.N + 63) / 64);
