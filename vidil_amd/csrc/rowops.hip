@@ -22,7 +22,7 @@ __global__ __launch_bounds__(256) void layernorm_kernel(const float* __restrict_
   float s = 0.f;
 #pragma unroll
   for (int i = 0; i < VPL; ++i) {
-    v[i] = *(const f32x4*)(xr + i * 256 + lane * 4);
+    v[i] = __builtin_nontemporal_load((const f32x4*)(xr + i * 256 + lane * 4));   // streamed once: do not keep in L2
     s += (v[i][0] + v[i][1]) + (v[i][2] + v[i][3]);
   }
   const float mean = wave_sum(s) * (1.0f / D);
@@ -46,7 +46,8 @@ __global__ __launch_bounds__(256) void layernorm_kernel(const float* __restrict_
 #pragma unroll
     for (int e = 0; e < 4; ++e) y[e] = (v[i][e] - mean) * rstd * g[e] + b[e];
     if (out32 != nullptr) *(f32x4*)(out32 + (size_t)row * D + c) = y;
-    if (out16 != nullptr) *(f16x4*)(out16 + (size_t)row * D + c) = f16x4{(f16)y[0], (f16)y[1], (f16)y[2], (f16)y[3]};
+    if (out16 != nullptr)
+      __builtin_nontemporal_store(f16x4{(f16)y[0], (f16)y[1], (f16)y[2], (f16)y[3]}, (f16x4*)(out16 + (size_t)row * D + c));
   }
 }
 
