@@ -71,7 +71,9 @@ typedef struct vidil_gemm_args {
    *   part 1: K [b][h][t_off+t][64]      f16, row capacity Tk_cap
    *   part 2: VT[b][h][d][vt(t_off+t)]   f16, row stride NP (multiple of 16); keys of
    *           every 16-key block are stored in the order 0-3, 8-11, 4-7, 12-15:
-   *           vt(t) = t ^ 12 when bits 2 and 3 of t differ, else t (see vidil_attention) */
+   *           vt(t) = t ^ 12 when bits 2 and 3 of t differ, else t (see vidil_attention)
+   *   NP == 0: part 2 is stored ROW-MAJOR instead, V [b][h][t_off+t][64] in `vt` with row capacity Tk_cap
+   *           (16-byte stores like K; consumed by vidil_attention's staged kernel, which transposes in LDS) */
   void* q;
   void* k;
   void* vt;
@@ -113,6 +115,10 @@ int vidil_layernorm(const float* x, int64_t x_stride, const float* gamma,
 /* K  f16 [Bk][H][Tk_cap][64], VT f16 [Bk][H][64][NP] with NP % 16 == 0 and    */
 /* the key axis of every 16-key block permuted to 0-3, 8-11, 4-7, 12-15 (the   */
 /* order the transposed-score MFMA layout consumes; written by EPI_HEADS).     */
+/* NP == 0: `vt` holds V ROW-MAJOR [Bk][H][Tk_cap][64] (like K) and is          */
+/* transposed while it is staged into LDS — allowed when every work unit has   */
+/* more than 32 query rows (the encoder self-attention of the ViT / CLIP       */
+/* towers); the short-query kernels read V^T fragments straight from memory.   */
 /* Which key/value batch a query batch b reads — three forms, all of which let */
 /* every query that shares a K/V (the captions of a frame, the beams of an     */
 /* image) be served by ONE staging of that K/V:                               */

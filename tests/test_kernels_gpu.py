@@ -315,6 +315,32 @@ def test_attention(Bq, H, Nq, Nk, kv_group, causal, use_len):
     assert torch.allclose(got, ref, rtol=3e-3, atol=3e-3), (got - ref).abs().max()
 
 
+@pytest.mark.parametrize("B,H,T,big", [(3, 12, 197, False), (2, 4, 577, False), (260, 12, 197, True)])
+def test_row_major_v_from_qkv_gemm_through_staged_attention(B, H, T, big):
+    """NP = 0: the QKV GEMM (small-tile and 256x256 kernels) stores V like K, the LDS-staged attention transposes it
+    while staging.  Result == attention computed from the same Q, K, V in fp32."""
+    k = _k()
+    C = H * 64
+    a = _rand(B * T, C, seed=90).half()
+    w = _rand(3 * C, C, scale=0.05, seed=91).half()
+    bias = _rand(3 * C, seed=92)
+    q = torch.empty(B, H, T, 64, dtype=torch.float16, device=DEV)
+    kk = torch.empty_like(q)
+    v = torch.full((B, H, T, 64), float("nan"), dtype=torch.float16, device=DEV)
+    k.gemm(a.to(DEV), w.to(DEV), bias.to(DEV),
+           heads=dict(q=q, k=kk, vt=v, T=T, H=H, part0=0, t_off=0, Tq_cap=T, Tk_cap=T, NP=0, q_scale=0.125))
+    ref_qkv = (a.to(DEV).float() @ w.to(DEV).float().t() + bias.to(DEV)).view(B, T, 3, H, 64)
+    assert torch.allclose(v.float(), ref_qkv[:, :, 2].permute(0, 2, 1, 3), rtol=2e-3, atol=2e-3)
+    out = torch.zeros(B * T, C, dtype=torch.float16, device=DEV)
+    k.attention(q, kk, v, out, Bq=B, H=H, Nq=T, Nk=T, Tq_cap=T, Tk_cap=T, NP=0)
+    nb = 4 if big else B                                   # the fp32 reference on a few batches is enough at scale
+    s = torch.einsum("bhqd,bhkd->bhqk", q[:nb].float(), kk[:nb].float())
+    ref = torch.einsum("bhqk,bhkd->bhqd", torch.softmax(s, -1), v[:nb].float()).permute(0, 2, 1, 3).reshape(nb * T, C)
+    assert torch.allclose(out[:nb * T].float(), ref, rtol=3e-3, atol=3e-3)
+    with pytest.raises(k.VidilHipError):                   # the direct kernels (<= 32 rows) need V^T
+        k.attention(q, kk, v, out, Bq=B, H=H, Nq=3, Nk=T, Tq_cap=T, Tk_cap=T, NP=0)
+
+
 @pytest.mark.parametrize("Nq,Nk,counts,use_len", [
     (35, 197, [3, 0, 8, 1, 5], False),     # ITM cross: captions per frame vary, one frame has none (LDS kernel, 4/8 waves)
     (1, 197, [3, 3, 3, 3], False),         # decode cross via the table form (direct kernel)

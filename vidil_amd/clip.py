@@ -136,11 +136,13 @@ def _run_layers(layers, x, B, T, H, eps, *, causal=False, kv_len=None):
     """Pre-LN CLIP encoder layers on the f32 residual stream x [B*T, D] (in place)."""
     dev = x.device
     M, D = x.shape
-    NP = (T + 15) // 16 * 16
+    # more than 32 rows -> LDS-staged attention, which takes V row-major (NP = 0: plain 16-B stores from the QKV GEMM);
+    # short text batches go through the direct kernels, which read V^T fragments straight from memory
+    NP = 0 if T > 32 else (T + 15) // 16 * 16
     xn = torch.empty((M, D), dtype=torch.float16, device=dev)
     q = torch.empty((B, H, T, 64), dtype=torch.float16, device=dev)
     k = torch.empty((B, H, T, 64), dtype=torch.float16, device=dev)
-    vt = torch.empty((B, H, 64, NP), dtype=torch.float16, device=dev)
+    vt = torch.empty((B, H, T, 64) if NP == 0 else (B, H, 64, NP), dtype=torch.float16, device=dev)
     o = torch.empty((M, D), dtype=torch.float16, device=dev)
     hid = torch.empty((M, layers[0]["fc1_w"].shape[0]), dtype=torch.float16, device=dev)
     heads = dict(q=q, k=k, vt=vt, T=T, H=H, part0=0, t_off=0, Tq_cap=T, Tk_cap=T, NP=NP, q_scale=0.125)

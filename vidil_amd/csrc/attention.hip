@@ -213,8 +213,23 @@ __global__ __launch_bounds__(NW * 64) void attn_lds_kernel(const AttnP p) {
       if (k0 + row < nk) v = *(const f16x8*)(kg + (size_t)(k0 + row) * 64 + c * 8);
       *(f16x8*)(Ks + row * KROW + c * 8) = v;
     }
+    // ---- V given ROW-MAJOR ([keys][64], NP == 0: the QKV GEMM then stores V like K, 16 B per lane, instead of
+    //      scattering V^T with 2-byte stores): transpose while staging.  Lanes walk consecutive keys, so for a
+    //      fixed d the 64 lanes of a wave write 128 contiguous bytes of one V^T row (no bank conflicts); the
+    //      16-byte global reads of a wave cover 64 key rows and are re-used from L1 by the next d-chunk.
+    if (p.NP == 0) {
+      const f16* vrow = p.vt + ((size_t)bk * p.H + h) * p.Tk_cap * 64;
+      for (int q = tid; q < NKEY * 8; q += NT) {
+        const int c = q / NKEY, r = q - c * NKEY;
+        f16x8 v = {0, 0, 0, 0, 0, 0, 0, 0};
+        if (k0 + r < nk) v = *(const f16x8*)(vrow + (size_t)(k0 + r) * 64 + c * 8);
+        const int col = vt_pos(r);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) Vs[(c * 8 + e) * VROW + col] = v[e];
+      }
+    }
     // ---- stage V^T columns k0 .. (keys >= Nk zero: masked P is 0 but 0*garbage must stay 0) --------------
-    for (int q = tid; q < 64 * NKT * 4; q += NT) {
+    for (int q = tid; p.NP != 0 && q < 64 * NKT * 4; q += NT) {
       const int d = q / (NKT * 4), kc = q - d * (NKT * 4);
       const int pos0 = k0 + kc * 8;           // storage columns pos0..pos0+7 (key = vt_pos(column))
       const int blk_end = (pos0 | 15) + 1;    // end of the 16-key block this chunk belongs to
@@ -483,7 +498,7 @@ extern "C" int vidil_attention(const void* q, const void* k, const void* vt, voi
                                int32_t kv_group, int32_t causal, int32_t causal_off, int32_t ldo, void* stream) {
   VIDIL_REQUIRE(q && k && vt && out, "attention: null pointer");
   VIDIL_REQUIRE(Bq > 0 && H > 0 && Nq > 0 && Nk > 0, "attention: bad shape Bq=%d H=%d Nq=%d Nk=%d", Bq, H, Nq, Nk);
-  VIDIL_REQUIRE(Tq_cap >= Nq && Tk_cap >= Nk && NP >= Nk, "attention: capacities too small");
+  VIDIL_REQUIRE(Tq_cap >= Nq && Tk_cap >= Nk && (NP == 0 || NP >= Nk), "attention: capacities too small");
   VIDIL_REQUIRE(NP % 16 == 0, "attention: NP=%d must be a multiple of 16 (V^T rows hold whole 16-key blocks)", NP);
   VIDIL_REQUIRE(ldo >= H * 64 && ldo % 8 == 0, "attention: ldo=%d must be >= H*64 and a multiple of 8", ldo);
   VIDIL_REQUIRE(kv_group > 0, "attention: kv_group=%d", kv_group);
@@ -506,6 +521,9 @@ extern "C" int vidil_attention(const void* q, const void* k, const void* vt, voi
           Tq_cap, Tk_cap, NP, kv_group, causal, causal_off, ldo, units};
   hipStream_t s = (hipStream_t)stream;
   const int nkt = (Nk + 31) / 32;
+  // NP == 0: `vt` holds V row-major [Bk][H][Tk_cap][64]; only the LDS-staged kernel transposes on the way in
+  VIDIL_REQUIRE(NP != 0 || max_rows > 32, "attention: row-major V (NP == 0) needs more than 32 query rows per unit (got %d)",
+                max_rows);
   switch (nkt) {
     case 1: return launch_any<1>(p, max_rows, s);
     case 2: return launch_any<2>(p, max_rows, s);

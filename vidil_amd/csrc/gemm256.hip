@@ -284,7 +284,7 @@ __global__ __launch_bounds__(512) void gemm256_kernel(const vidil_gemm_args p) {
   }
 
   if constexpr (EPI == VIDIL_EPI_HEADS) {
-    if (part == 2) {
+    if (part == 2 && p.NP != 0) {   // (NP == 0: V stays row-major and takes the 16-B store path of K below)
       // V^T: element (row m, column d) goes to VT[b][h][d][t_off+t]; consecutive lanes = consecutive t
 #pragma unroll
       for (int it = 0; it < 4; ++it) {
@@ -338,7 +338,8 @@ __global__ __launch_bounds__(512) void gemm256_kernel(const vidil_gemm_args p) {
             if (part == 0) {
               *(f16x8*)((f16*)p.q + (bh * p.Tq_cap + t) * 64 + ch * 8) = v;
             } else {
-              *(f16x8*)((f16*)p.k + (bh * p.Tk_cap + p.t_off + t) * 64 + ch * 8) = v;
+              f16* kv = (f16*)(part == 1 ? p.k : p.vt);
+              *(f16x8*)(kv + (bh * p.Tk_cap + p.t_off + t) * 64 + ch * 8) = v;
             }
           }
         }
@@ -454,7 +455,7 @@ bool vidil_gemm256_eligible(const vidil_gemm_args& a) {
     case VIDIL_EPI_PATCH:
       return a.N % 4 == 0 && a.ldo % 4 == 0 && al16(a.out) && al16(a.pos);
     case VIDIL_EPI_HEADS:
-      return (!a.q || al16(a.q)) && (!a.k || al16(a.k));
+      return (!a.q || al16(a.q)) && (!a.k || al16(a.k)) && (a.NP != 0 || !a.vt || al16(a.vt));
     default:
       return false;
   }

@@ -131,13 +131,15 @@ class VisionTransformer(PackedCache, nn.Module):
         p = self.packed()
         D, H = self.embed_dim, self.num_heads
         T = self.patch_embed.num_patches + 1
-        NP = (T + 15) // 16 * 16
+        # V stays row-major (NP = 0): the QKV GEMM stores it like K with 16-B stores and the staged attention kernel
+        # transposes it on the way into LDS — cheaper than scattering V^T from the GEMM epilogue (T > 32 rows here)
+        NP = 0 if T > 32 else (T + 15) // 16 * 16     # (tiny test geometries fall back to V^T + the direct kernels)
         dev = x.device
         M = B * T
         xn = torch.empty((M, D), dtype=torch.float16, device=dev)
         q = torch.empty((B, H, T, 64), dtype=torch.float16, device=dev)
         k = torch.empty((B, H, T, 64), dtype=torch.float16, device=dev)
-        vt = torch.empty((B, H, 64, NP), dtype=torch.float16, device=dev)
+        vt = torch.empty((B, H, T, 64) if NP == 0 else (B, H, 64, NP), dtype=torch.float16, device=dev)
         o = torch.empty((M, D), dtype=torch.float16, device=dev)
         hid = torch.empty((M, p["blocks"][0]["fc1_w"].shape[0]), dtype=torch.float16, device=dev)
         heads = dict(q=q, k=k, vt=vt, T=T, H=H, part0=0, t_off=0, Tq_cap=T, Tk_cap=T, NP=NP, q_scale=0.125)
