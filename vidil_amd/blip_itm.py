@@ -62,11 +62,14 @@ class BLIP_ITM(PackedCache, nn.Module):
         te = self.text_encoder
         dev = enc16.device
         Te = enc16.shape[0] // n_images
-        cross = te.project_cross_kv(enc16, n_images, Te)
         # The reference pads every caption to 35 tokens (models/blip_itm.py:46).  Padded keys are masked and a
         # padded row never feeds a real one, so the [CLS] output is unchanged if the batch is cut to its
         # longest real caption; this removes the all-padding columns.
         t_eff = min(ids.shape[1], int(lens.max().item())) if ids.shape[0] else ids.shape[1]
+        # image-major groups with more than 32 query rows go through the staged attention kernel, which takes V
+        # row-major (plain 16-B stores from the K|V GEMM instead of the V^T scatter)
+        rows_per_image = (max_group if group_start is not None else 1) * t_eff
+        cross = te.project_cross_kv(enc16, n_images, Te, v_rowmajor=rows_per_image > 32)
         ids = ids[:, :t_eff].to(dev).contiguous()
         lens = lens.to(dev).contiguous()
         if group_start is not None:

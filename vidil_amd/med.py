@@ -197,19 +197,21 @@ class BertModel(PackedCache, nn.Module):
         return p
 
     # --------------------------------------------------------- cross K/V (once per image)
-    def project_cross_kv(self, enc16, B, Te, out: "CrossKV" = None):
+    def project_cross_kv(self, enc16, B, Te, out: "CrossKV" = None, v_rowmajor=False):
         """enc16: f16 [B*Te, encoder_width] image tokens.  One fused K|V GEMM per layer.  ``out``: buffers of a
-        previous call with the same (B, Te) to overwrite (keeps device addresses stable for captured graphs)."""
+        previous call with the same (B, Te) to overwrite (keeps device addresses stable for captured graphs).
+        ``v_rowmajor``: keep V as [L][B,H,Te,64] (NP = 0) — for consumers whose every cross-attention launch has more
+        than 32 query rows per image (the staged kernel transposes in LDS); the decode steps need V^T."""
         p = self.packed()
         H = self.config.num_attention_heads
-        NP = (Te + 15) // 16 * 16
+        NP = 0 if v_rowmajor else (Te + 15) // 16 * 16
         L = len(p["layers"])
         dev = enc16.device
         if out is not None and (out.B, out.Te, out.NP) == (B, Te, NP) and out.k.device == dev:
             k, vt = out.k, out.vt
         else:
             k = torch.empty((L, B, H, Te, 64), dtype=torch.float16, device=dev)
-            vt = torch.empty((L, B, H, 64, NP), dtype=torch.float16, device=dev)
+            vt = torch.empty((L, B, H, Te, 64) if v_rowmajor else (L, B, H, 64, NP), dtype=torch.float16, device=dev)
         for i, d in enumerate(p["layers"]):
             K.gemm(enc16, d["ckv_w"], d["ckv_b"],
                    heads=dict(k=k[i], vt=vt[i], T=Te, H=H, part0=1, t_off=0, Tk_cap=Te, NP=NP))
