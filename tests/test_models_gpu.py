@@ -304,6 +304,24 @@ def test_captured_decode_graphs_replay_the_eager_result(full_models):
         assert torch.equal(tok, ref[k]), (i, k)
     st = next(iter(cap._decode_state.values()))
     assert st["graphs_ok"] and len(st["graphs"]) >= 10 and st["calls"] == len(seq)
+    # parameters changed after the capture (a checkpoint load, here an in-place edit of the LM-head bias): the graphs
+    # hold the addresses of the OLD packed weights and must not be replayed
+    bias = cap.text_decoder.cls.predictions.bias
+    delta = torch.zeros_like(bias)
+    delta[1000:1200] = 3.0
+    with torch.no_grad():
+        bias.add_(delta)
+    try:
+        changed = cap.generate_ids(outs["a"], B, num_beams=3, max_length=20, min_length=5)[0].cpu()
+        cap.__dict__.pop("_decode_state", None)
+        os.environ["VIDIL_DECODE_GRAPHS"] = "0"
+        want = cap.generate_ids(outs["a"], B, num_beams=3, max_length=20, min_length=5)[0].cpu()
+        assert torch.equal(changed, want) and not torch.equal(changed, ref["a"])
+    finally:
+        os.environ.pop("VIDIL_DECODE_GRAPHS", None)
+        with torch.no_grad():
+            bias.sub_(delta)
+        cap.__dict__.pop("_decode_state", None)
 
 
 def test_blip_at_384_vit_decoder_and_itm_vs_oracle():

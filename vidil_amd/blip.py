@@ -180,11 +180,14 @@ class BLIP_Decoder(nn.Module):
         key = (B, nb, max_length, min_length, str(dev), enc16.shape[0] // B)
         cache = self.__dict__.setdefault("_decode_state", {})
         st = cache.get(key)
+        packs = (dec.packed(), bert.packed())     # captured graphs hold the addresses of these packed weights
+        if st is not None and not (st["packs"][0] is packs[0] and st["packs"][1] is packs[1]):
+            st = None                              # parameters changed since the capture (e.g. a checkpoint was loaded)
         if st is None:
             if len(cache) >= 4:
                 cache.clear()
             st = cache[key] = dict(sess=DecoderSession(dec, enc16, B, nb, max_length),
-                                   bufs=K.BeamBuffers(B, nb, max_length, dev), graphs={}, pool=None, calls=0,
+                                   bufs=K.BeamBuffers(B, nb, max_length, dev), graphs={}, pool=None, calls=0, packs=packs,
                                    graphs_ok=os.environ.get("VIDIL_DECODE_GRAPHS", "1") != "0")
         else:
             st["sess"].rebind(enc16)
