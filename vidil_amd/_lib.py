@@ -13,7 +13,8 @@ import torch  # noqa: F401  -- MUST precede the CDLL below: torch ships its own 
 # first would bind libvidil_hip.so to a second HIP runtime that has no initialised device.
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "csrc", "libvidil_hip.so")
+# VIDIL_HIP_LIB: developer override (A/B-ing two builds of the same ABI on one box)
+LIB_PATH = os.environ.get("VIDIL_HIP_LIB") or os.path.join(_HERE, "csrc", "libvidil_hip.so")
 
 EPI_F16, EPI_F32, EPI_HEADS, EPI_PATCH, EPI_ARENA = 0, 1, 2, 3, 4
 ACT_NONE, ACT_GELU_ERF, ACT_QUICK_GELU = 0, 1, 2

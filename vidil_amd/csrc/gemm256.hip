@@ -48,9 +48,28 @@ __device__ __forceinline__ void glds16(const f16* g, char* lds) {
 template <int EPI>
 constexpr bool kPersistent = EPI != VIDIL_EPI_HEADS;
 
+#ifdef VIDIL_GEMM_PROBE
+// developer build only (make EXTRA=-DVIDIL_GEMM_PROBE, tools/probe_gemm_clock.py): shader cycles and 100-MHz
+// reference ticks workgroup 0 spent in its last launch -> the clock the kernel actually ran at
+__device__ unsigned long long g_probe[2];
+struct Probe {
+  unsigned long long t0, r0;
+  __device__ Probe() : t0(__builtin_readcyclecounter()), r0(__builtin_amdgcn_s_memrealtime()) {}
+  __device__ ~Probe() {
+    if (blockIdx.x == 0 && threadIdx.x == 0) {
+      g_probe[0] = __builtin_readcyclecounter() - t0;
+      g_probe[1] = __builtin_amdgcn_s_memrealtime() - r0;
+    }
+  }
+};
+#endif
+
 template <int EPI, int ACT>
 __global__ __launch_bounds__(512) void gemm256_kernel(const vidil_gemm_args p) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
+#ifdef VIDIL_GEMM_PROBE
+  Probe probe;
+#endif
   const int tid = threadIdx.x;
   const int lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -437,6 +456,12 @@ int launch256(const vidil_gemm_args& a, hipStream_t s) {
 }
 
 }  // namespace
+
+#ifdef VIDIL_GEMM_PROBE
+extern "C" int vidil_debug_gemm_probe(unsigned long long* out2) {
+  return hipMemcpyFromSymbol(out2, HIP_SYMBOL(g_probe), 16) == hipSuccess ? 0 : -1;
+}
+#endif
 
 // Returns true when the 256x256 kernel can run this problem with vector epilogues (checked by the caller).
 bool vidil_gemm256_eligible(const vidil_gemm_args& a) {
