@@ -136,6 +136,43 @@ def test_itm_small_vs_golden_with_padding():
     itm = K.gemm(h16.view(-1), w, b, out_dtype=torch.float32, M=3, lda=35 * 256).cpu()
     assert (itm - torch.from_numpy(g["itm"])).abs().max().item() < 2e-3
 
+    # encode_cls: the last layer on the [CLS] rows only -> the same token-0 state (and ITM logits)
+    c32, c16 = enc_model.encode_cls(ids, lens, cross, torch.arange(3, dtype=torch.int32, device=DEV))
+    assert c32.shape == (3, 256) and c16.shape == (3, 256)
+    assert (c32.cpu() - hid[:, 0]).abs().max().item() < 6e-3
+    assert (c32.cpu() - got[:, 0]).abs().max().item() < 2e-3          # vs encode(): other attention kernel, same math
+    itm_c = K.gemm(c16, w, b, out_dtype=torch.float32).cpu()
+    assert (itm_c - torch.from_numpy(g["itm"])).abs().max().item() < 2e-3
+
+
+def test_encode_cls_image_major_groups_rowmajor_cross():
+    """The CapFilt form: image-major pair order (group_start), several captions per image, row-major cross V for
+    layers 0..L-2 and V^T for the last; compared with encode() on the same pairs through kv_index."""
+    from vidil_amd.med import BertModel
+
+    sd, g = load_golden("med_itm_small.npz")
+    enc_model = load_into(BertModel(_small_med_cfg()), sd, "text_encoder.").to(DEV)
+    enc16 = torch.from_numpy(g["enc"]).reshape(-1, 256).to(DEV).half().contiguous()
+    n_img, Te = 3, 17
+    counts = [2, 0, 3]                                                 # captions per image (one image without any)
+    pair_img = [j for j, c in enumerate(counts) for _ in range(c)]
+    src = torch.from_numpy(g["ids"]).to(torch.int32)
+    mask = torch.from_numpy(g["mask"])
+    pick = [0, 1, 2, 0, 1]
+    ids = src[pick].to(DEV).contiguous()
+    lens = mask.sum(1).to(torch.int32)[pick].to(DEV).contiguous()
+    group_start = torch.tensor([0, 2, 2, 5], dtype=torch.int32, device=DEV)
+    # T = 35 tokens x up to 3 captions = 105 query rows per image in layers 0..L-2 -> row-major V there
+    cross_rm = enc_model.project_cross_kv(enc16, n_img, Te, v_rowmajor=True, last_layer_vt=True)
+    c32, c16 = enc_model.encode_cls(ids, lens, cross_rm, cross_groups=group_start, cross_max_group=3)
+    cross_vt = enc_model.project_cross_kv(enc16, n_img, Te)
+    h32, _ = enc_model.encode(ids, lens, cross_vt, torch.tensor(pair_img, dtype=torch.int32, device=DEV))
+    ref = h32.view(5, 35, 256)[:, 0]
+    assert (c32 - ref).abs().max().item() < 2e-3
+    with pytest.raises(Exception):
+        enc_model.encode_cls(ids, lens, enc_model.project_cross_kv(enc16, n_img, Te, v_rowmajor=True),
+                             cross_groups=group_start, cross_max_group=3)
+
 
 def test_clip_small_vs_golden():
     from vidil_amd.clip import CLIPConfig, CLIPModel, CLIPTextConfig, CLIPVisionConfig

@@ -69,21 +69,20 @@ class BLIP_ITM(PackedCache, nn.Module):
         # image-major groups with more than 32 query rows go through the staged attention kernel, which takes V
         # row-major (plain 16-B stores from the K|V GEMM instead of the V^T scatter)
         rows_per_image = (max_group if group_start is not None else 1) * t_eff
-        cross = te.project_cross_kv(enc16, n_images, Te, v_rowmajor=rows_per_image > 32)
+        cross = te.project_cross_kv(enc16, n_images, Te, v_rowmajor=rows_per_image > 32, last_layer_vt=True)
         ids = ids[:, :t_eff].to(dev).contiguous()
         lens = lens.to(dev).contiguous()
         if group_start is not None:
             group_start = group_start.to(dev).to(torch.int32).contiguous()
         else:
             image_index = image_index.to(dev).to(torch.int32).contiguous()
-        P, T = ids.shape
-        C = te.config.hidden_size
-        _, h16 = te.encode(ids, lens, cross, cross_index=image_index, cross_groups=group_start,
-                           cross_max_group=max_group)
-        # itm_head on token 0 of every pair: the GEMM reads rows p*T of h16 (strided A operand)
+        P = ids.shape[0]
+        # only token 0 feeds the itm_head: the last layer runs on the [CLS] rows alone (BertModel.encode_cls)
+        _, c16 = te.encode_cls(ids, lens, cross, cross_index=image_index, cross_groups=group_start,
+                               cross_max_group=max_group)
         p = self.packed()
         out = torch.empty((P, 2), dtype=torch.float32, device=dev)
-        K.gemm(h16.view(-1), p["itm_w"], p["itm_b"], out=out, M=P, lda=T * C)
+        K.gemm(c16, p["itm_w"], p["itm_b"], out=out)
         return out
 
     @torch.no_grad()

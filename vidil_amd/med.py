@@ -127,8 +127,10 @@ def _init_bert(module, std):
 class CrossKV:
     """Per-image cross-attention keys / values^T of every layer: K [L][B,H,Te,64], VT [L][B,H,64,NP]."""
 
-    def __init__(self, k, vt, B, Te, NP):
+    def __init__(self, k, vt, B, Te, NP, last_vt=None, last_NP=0):
         self.k, self.vt, self.B, self.Te, self.NP = k, vt, B, Te, NP
+        # optional second copy of the LAST layer's values in V^T layout (see project_cross_kv(last_layer_vt=True))
+        self.last_vt, self.last_NP = last_vt, last_NP
 
 
 class BeamArena:
@@ -197,14 +199,17 @@ class BertModel(PackedCache, nn.Module):
         return p
 
     # --------------------------------------------------------- cross K/V (once per image)
-    def project_cross_kv(self, enc16, B, Te, out: "CrossKV" = None, v_rowmajor=False):
+    def project_cross_kv(self, enc16, B, Te, out: "CrossKV" = None, v_rowmajor=False, last_layer_vt=False):
         """enc16: f16 [B*Te, encoder_width] image tokens.  One fused K|V GEMM per layer.  ``out``: buffers of a
         previous call with the same (B, Te) to overwrite (keeps device addresses stable for captured graphs).
         ``v_rowmajor``: keep V as [L][B,H,Te,64] (NP = 0) — for consumers whose every cross-attention launch has more
-        than 32 query rows per image (the staged kernel transposes in LDS); the decode steps need V^T."""
+        than 32 query rows per image (the staged kernel transposes in LDS); the decode steps need V^T.
+        ``last_layer_vt`` (with v_rowmajor): the last layer's V goes to a V^T buffer instead (``last_vt``) — its
+        consumer is encode_cls, whose last layer has one query row per pair."""
         p = self.packed()
         H = self.config.num_attention_heads
-        NP = 0 if v_rowmajor else (Te + 15) // 16 * 16
+        NPt = (Te + 15) // 16 * 16
+        NP = 0 if v_rowmajor else NPt
         L = len(p["layers"])
         dev = enc16.device
         if out is not None and (out.B, out.Te, out.NP) == (B, Te, NP) and out.k.device == dev:
@@ -212,15 +217,22 @@ class BertModel(PackedCache, nn.Module):
         else:
             k = torch.empty((L, B, H, Te, 64), dtype=torch.float16, device=dev)
             vt = torch.empty((L, B, H, Te, 64) if v_rowmajor else (L, B, H, 64, NP), dtype=torch.float16, device=dev)
+        last_vt = None
+        if v_rowmajor and last_layer_vt:
+            last_vt = torch.empty((B, H, 64, NPt), dtype=torch.float16, device=dev)
         for i, d in enumerate(p["layers"]):
-            K.gemm(enc16, d["ckv_w"], d["ckv_b"],
-                   heads=dict(k=k[i], vt=vt[i], T=Te, H=H, part0=1, t_off=0, Tk_cap=Te, NP=NP))
-        return CrossKV(k, vt, B, Te, NP)
+            if last_vt is not None and i == L - 1:
+                K.gemm(enc16, d["ckv_w"], d["ckv_b"],
+                       heads=dict(k=k[i], vt=last_vt, T=Te, H=H, part0=1, t_off=0, Tk_cap=Te, NP=NPt))
+            else:
+                K.gemm(enc16, d["ckv_w"], d["ckv_b"],
+                       heads=dict(k=k[i], vt=vt[i], T=Te, H=H, part0=1, t_off=0, Tk_cap=Te, NP=NP))
+        return CrossKV(k, vt, B, Te, NP, last_vt, NPt if last_vt is not None else 0)
 
     # ------------------------------------------------------------------ layers
     def run_layers(self, h32, h16, *, rows, T, self_k, self_vt, t_off, Tk_cap, NPs, causal, kv_len,
                    cross: CrossKV, cross_index=None, cross_group=1, cross_groups=None, cross_max_group=0, ws=None,
-                   arena: "BeamArena" = None, arena_slot_stride=1):
+                   arena: "BeamArena" = None, arena_slot_stride=1, n_layers=None):
         """Run every layer on the f32/f16 hidden pair (both [rows*T, C], updated in place).
 
         self_k / self_vt: [L][rows,H,Tk_cap,64] / [L][rows,H,64,NPs] — this call's keys are appended at
@@ -249,7 +261,7 @@ class BertModel(PackedCache, nn.Module):
         Nk = t_off + T
         if arena is not None and T > 1 and t_off != 0:
             raise K.VidilHipError("run_layers: a multi-token block can only be appended to a beam arena at position 0")
-        for i, d in enumerate(p["layers"]):
+        for i, d in enumerate(p["layers"][:n_layers]):   # n_layers: only the first n (encode_cls runs the last itself)
             if arena is not None and T == 1:
                 K.gemm(h16, d["qkv_w"], d["qkv_b"],
                        arena=dict(q=q, k=arena.k[i], v=arena.v[i], T=1, H=H, part0=0, t_off=t_off, Tcap=arena.Tcap,
@@ -312,6 +324,58 @@ class BertModel(PackedCache, nn.Module):
                         kv_len=kv_len_i32, cross=cross, cross_index=cross_index, cross_groups=cross_groups,
                         cross_max_group=cross_max_group)
         return h32, h16
+
+    def encode_cls(self, ids_i32, kv_len_i32, cross: CrossKV, cross_index=None, cross_groups=None, cross_max_group=0):
+        """encode() for consumers of the [CLS] position only (the ITM head, models/blip_itm.py:57): same arguments,
+        returns (h32, h16) [P, C] — token 0 of every pair after the last layer.
+
+        Layers 0..L-2 run on every token.  In the last layer only the keys and values of the self-attention depend on
+        the other tokens, so it computes K|V for all P*T rows and everything else — the query, both attention
+        outputs, the three dense+LayerNorm blocks and the feed-forward — for the P [CLS] rows alone (1/T of the
+        layer's GEMM rows).  The arithmetic per [CLS] row is unchanged.  Needs ``cross.last_vt`` when the cross
+        values are row-major (one query row per pair goes through the direct attention kernel)."""
+        require_cuda(ids_i32, "BertModel.encode_cls")
+        p = self.packed()
+        cfg = self.config
+        P, T = ids_i32.shape
+        H, C, L = cfg.num_attention_heads, cfg.hidden_size, cfg.num_hidden_layers
+        eps = cfg.layer_norm_eps
+        dev = ids_i32.device
+        NPs = (T + 15) // 16 * 16
+        if cross is not None and cross.NP == 0 and cross.last_vt is None:
+            raise K.VidilHipError("encode_cls: row-major cross values need project_cross_kv(last_layer_vt=True)")
+        h32, h16 = self.embed(ids_i32.reshape(-1), T, 0)
+        sk = torch.empty((P, H, T, 64), dtype=torch.float16, device=dev)
+        sv = torch.empty((P, H, 64, NPs), dtype=torch.float16, device=dev)
+        self.run_layers(h32, h16, rows=P, T=T, self_k=sk.unsqueeze(0).expand(L, -1, -1, -1, -1),
+                        self_vt=sv.unsqueeze(0).expand(L, -1, -1, -1, -1), t_off=0, Tk_cap=T, NPs=NPs, causal=False,
+                        kv_len=kv_len_i32, cross=cross, cross_index=cross_index, cross_groups=cross_groups,
+                        cross_max_group=cross_max_group, n_layers=L - 1)
+        d = p["layers"][L - 1]
+        q1 = torch.empty((P, H, 1, 64), dtype=torch.float16, device=dev)
+        o1 = torch.empty((P, C), dtype=torch.float16, device=dev)
+        tmp = torch.empty((P, C), dtype=torch.float32, device=dev)
+        c16 = torch.empty((P, C), dtype=torch.float16, device=dev)
+        c32 = h32.view(P, T, C)[:, 0].contiguous()
+        # self-attention: keys / values of every token, query of token 0 (A rows p*T of h16: strided operand)
+        K.gemm(h16, d["qkv_w"][C:], d["qkv_b"][C:], heads=dict(k=sk, vt=sv, T=T, H=H, part0=1, t_off=0, Tk_cap=T, NP=NPs))
+        K.gemm(h16.view(-1), d["qkv_w"][:C], d["qkv_b"][:C], M=P, lda=T * C,
+               heads=dict(q=q1, T=1, H=H, part0=0, Tq_cap=1, q_scale=0.125))
+        K.attention(q1, sk, sv, o1, Bq=P, H=H, Nq=1, Nk=T, Tq_cap=1, Tk_cap=T, NP=NPs, causal=False, causal_off=0,
+                    kv_len=kv_len_i32)
+        K.gemm(o1, d["ao_w"], d["ao_b"], out=tmp, resid=c32)
+        K.layernorm(tmp, d["ao_g"], d["ao_bt"], eps, out16=c16, out32=c32)
+        if cross is not None:
+            vt, NP = (cross.vt[L - 1], cross.NP) if cross.last_vt is None else (cross.last_vt, cross.last_NP)
+            K.gemm(c16, d["cq_w"], d["cq_b"], heads=dict(q=q1, T=1, H=H, part0=0, Tq_cap=1, q_scale=0.125))
+            K.attention(q1, cross.k[L - 1], vt, o1, Bq=P, H=H, Nq=1, Nk=cross.Te, Tq_cap=1, Tk_cap=cross.Te, NP=NP,
+                        kv_index=cross_index, group_start=cross_groups, max_group=cross_max_group)
+            K.gemm(o1, d["co_w"], d["co_b"], out=tmp, resid=c32)
+            K.layernorm(tmp, d["co_g"], d["co_bt"], eps, out16=c16, out32=c32)
+        inter = K.gemm(c16, d["i_w"], d["i_b"], act=K.ACT_GELU_ERF)
+        K.gemm(inter, d["o_w"], d["o_b"], out=tmp, resid=c32)
+        K.layernorm(tmp, d["o_g"], d["o_bt"], eps, out16=c16, out32=c32)
+        return c32, c16
 
     def forward(self, *a, **k):
         raise NotImplementedError("use BertModel.encode / BLIP_ITM on the hot path")
