@@ -59,6 +59,21 @@ def preprocess_u8(frames_u8):
     return (x - mean) / std
 
 
+def pooled_output(sd, pixel_values, *, layers=12, heads=12, patch=32):
+    """CLIPModel(...).vision_model_output.pooler_output: post_layernorm of the class token, [F,3,S,S] -> [F,D]
+    (what data/video_pretrain_dataset.py:199-202 clusters for 'clip-kmeans')."""
+    p = "vision_model."
+    B = pixel_values.shape[0]
+    x = F.conv2d(pixel_values, sd[p + "embeddings.patch_embedding.weight"], None, stride=patch)
+    x = x.flatten(2).transpose(1, 2)
+    cls = sd[p + "embeddings.class_embedding"].expand(B, 1, -1)
+    x = torch.cat([cls, x], dim=1) + sd[p + "embeddings.position_embedding.weight"][None, : x.shape[1] + 1]
+    x = _ln(sd, p + "pre_layrnorm", x)
+    for i in range(layers):
+        x = encoder_layer(sd, f"{p}encoder.layers.{i}.", x, heads)
+    return _ln(sd, p + "post_layernorm", x[:, 0])
+
+
 def image_embeds(sd, pixel_values, *, layers=12, heads=12, patch=32):
     """CLIPModel(...).image_embeds: [F,3,S,S] -> unit-norm [F,P]."""
     p = "vision_model."

@@ -194,7 +194,7 @@ class CLIPModel(PackedCache, nn.Module):
             tproj=w16(self.text_projection.weight), tlayers=_pack_layers(tm.encoder))
 
     # ------------------------------------------------------------------ vision tower
-    def _vision_from_patches(self, patches16, B):
+    def _vision_from_patches(self, patches16, B, pooled=False):
         p = self.packed()
         vc = self.config.vision_config
         D, H = vc.hidden_size, vc.num_attention_heads
@@ -207,7 +207,11 @@ class CLIPModel(PackedCache, nn.Module):
         K.layernorm(x, p["pre_g"], p["pre_b"], vc.layer_norm_eps, out32=x)
         _run_layers(p["vlayers"], x, B, T, H, vc.layer_norm_eps)
         pooled16 = torch.empty((B, D), dtype=torch.float16, device=dev)
-        K.layernorm(x, p["post_g"], p["post_b"], vc.layer_norm_eps, M=B, D=D, x_stride=T * D, out16=pooled16)
+        pooled32 = torch.empty((B, D), dtype=torch.float32, device=dev) if pooled else None
+        K.layernorm(x, p["post_g"], p["post_b"], vc.layer_norm_eps, M=B, D=D, x_stride=T * D, out16=pooled16,
+                    out32=pooled32)
+        if pooled:
+            return pooled32
         emb = K.gemm(pooled16, p["vproj"], None, out_dtype=torch.float32)
         return K.l2_normalize_rows(emb)
 
@@ -226,6 +230,16 @@ class CLIPModel(PackedCache, nn.Module):
         ps = self.config.vision_config.patch_size
         patches = K.patchify_u8(frames_u8.contiguous(), ps, CLIP_MEAN, CLIP_STD)
         return self._vision_from_patches(patches, frames_u8.shape[0])
+
+    @torch.no_grad()
+    def pooled_image_u8(self, frames_u8):
+        """uint8 [F,S,S,3] -> f32 [F,D]: HF's vision ``pooler_output`` (post_layernorm of the class token, before
+        visual_projection) — what the reference's 'clip-kmeans' frame selection clusters
+        (data/video_pretrain_dataset.py:199-202)."""
+        require_cuda(frames_u8, "CLIPModel.pooled_image_u8")
+        ps = self.config.vision_config.patch_size
+        patches = K.patchify_u8(frames_u8.contiguous(), ps, CLIP_MEAN, CLIP_STD)
+        return self._vision_from_patches(patches, frames_u8.shape[0], pooled=True)
 
     # ------------------------------------------------------------------ text tower
     @torch.no_grad()
