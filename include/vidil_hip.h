@@ -91,6 +91,11 @@ typedef struct vidil_gemm_args {
   /* EPI_PATCH */
   const float* pos;   /* f32 [(tpi+1), N]                                      */
   int32_t tpi;        /* patches per image                                     */
+  /* EPI_HEADS, parts 1 and 2: non-zero = FRAGMENT-TILED K and V (NP ignored, Tk_cap a multiple of 32): every
+   * (b, h) owns Tk_cap/32 tiles of 32 keys x 64 dims (2048 f16) in the operand order of the direct attention kernel,
+   *   K tile [c/8][key%32][c%8];  V tile [key%32/16][d/32][g%2][d%32][(g/2)*4 + key%4], g = (key%16)/4,
+   * so each of that kernel's wave loads is one contiguous KiB.  Consumer: vidil_attention(kv_tiled = 1). */
+  int32_t kv_tiled;
 } vidil_gemm_args;
 
 /* replaces: nn.Linear calls of models/vit.py:35-41,72,84; models/med.py:153-171,
@@ -119,6 +124,10 @@ int vidil_layernorm(const float* x, int64_t x_stride, const float* gamma,
 /* transposed while it is staged into LDS — allowed when every work unit has   */
 /* more than 32 query rows (the encoder self-attention of the ViT / CLIP       */
 /* towers); the short-query kernels read V^T fragments straight from memory.   */
+/* kv_tiled != 0: `k` and `vt` are FRAGMENT-TILED (vidil_gemm_args.kv_tiled;    */
+/* [Bk][H][Tk_cap/32][2048], NP ignored, Tk_cap % 32 == 0) — allowed when every */
+/* work unit has at most 32 query rows (the cross-attention of the caption      */
+/* decoder, which re-reads the image K/V from HBM on every decode step).        */
 /* Which key/value batch a query batch b reads — three forms, all of which let */
 /* every query that shares a K/V (the captions of a frame, the beams of an     */
 /* image) be served by ONE staging of that K/V:                               */
@@ -140,7 +149,7 @@ int vidil_attention(const void* q, const void* k, const void* vt, void* out,
                     int32_t Bq, int32_t H, int32_t Nq,
                     int32_t Nk, int32_t Tq_cap, int32_t Tk_cap, int32_t NP,
                     int32_t kv_group, int32_t causal, int32_t causal_off,
-                    int32_t ldo, void* stream);
+                    int32_t ldo, int32_t kv_tiled, void* stream);
 
 /* ------------------------------------------------------------------------ */
 /* One separable pass of Pillow's antialiased resize on 8-bit interleaved RGB */

@@ -30,7 +30,7 @@ def test_library_exports_every_declared_symbol():
         assert hasattr(lib, n), f"{n} declared in include/vidil_hip.h but not exported"
     assert set(names) == set(_lib.SIGNATURES), set(names) ^ set(_lib.SIGNATURES)
     assert lib.vidil_num_entry_points() == len(names)
-    assert lib.vidil_abi_version() == 2
+    assert lib.vidil_abi_version() == 3
 
 
 def test_gemm_args_struct_matches_header_field_order():
@@ -60,8 +60,13 @@ def test_argument_validation_without_a_gpu():
     g.A, g.W, g.M, g.N, g.K = 16, 16, 8, 8, 100
     assert lib.vidil_gemm_f16(ctypes.byref(g), None) == -1
     assert b"multiple of 64" in lib.vidil_last_error()
-    assert lib.vidil_attention(16, 16, 16, 16, None, None, None, 0, 0, 1, 12, 4, 800, 4, 800, 800, 1, 0, 0, 768, None) == -3
+    assert lib.vidil_attention(16, 16, 16, 16, None, None, None, 0, 0, 1, 12, 4, 800, 4, 800, 800, 1, 0, 0, 768, 0, None) == -3
     assert b"not supported" in lib.vidil_last_error()
+    # fragment-tiled K/V: key capacity a multiple of 32, at most 32 query rows per unit
+    assert lib.vidil_attention(16, 16, 16, 16, None, None, None, 0, 0, 3, 12, 1, 197, 1, 200, 0, 3, 0, 0, 768, 1, None) == -1
+    assert b"multiple of 32" in lib.vidil_last_error()
+    assert lib.vidil_attention(16, 16, 16, 16, None, None, None, 0, 0, 40, 12, 1, 197, 1, 224, 0, 40, 0, 0, 768, 1, None) == -1
+    assert b"at most 32 query rows" in lib.vidil_last_error()
     assert lib.vidil_scan_topk_ws_bytes(128, 42784, 5) > 0
 
 

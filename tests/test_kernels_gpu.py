@@ -341,6 +341,62 @@ def test_row_major_v_from_qkv_gemm_through_staged_attention(B, H, T, big):
         k.attention(q, kk, v, out, Bq=B, H=H, Nq=3, Nk=T, Tq_cap=T, Tk_cap=T, NP=0)
 
 
+@pytest.mark.parametrize("B,H,T,beams", [(3, 12, 197, 3), (2, 4, 577, 3), (4, 4, 17, 1), (2, 12, 64, 32), (260, 12, 197, 3)])
+def test_fragment_tiled_kv_from_gemm_through_direct_attention(B, H, T, beams):
+    """kv_tiled: the cross K|V GEMM (small-tile and 256x256 kernels) writes 32-key fragment tiles, the direct
+    attention kernel reads them with contiguous wave loads.  Checked: the layout itself, bit-identity of the two
+    GEMM kernels, unwritten tile padding never leaking, and the attention result vs fp32."""
+    k = _k()
+    C = H * 64
+    Tc = (T + 31) // 32 * 32
+    a = _rand(B * T, C, seed=93).half().to(DEV)
+    w = _rand(2 * C, C, scale=0.05, seed=94).half().to(DEV)
+    bias = _rand(2 * C, seed=95).to(DEV)
+    kt = torch.full((B, H, Tc * 64), float("nan"), dtype=torch.float16, device=DEV)
+    vt = torch.full((B, H, Tc * 64), float("nan"), dtype=torch.float16, device=DEV)
+    k.gemm(a, w, bias, heads=dict(k=kt, vt=vt, T=T, H=H, part0=1, t_off=0, Tk_cap=Tc, tiled=True))
+    ref_kv = (a.float() @ w.float().t() + bias).view(B, T, 2, H, 64)
+    k_off, v_off = (o.to(DEV) for o in k.kv_tile_offsets(T))
+    kk = kt[:, :, k_off]                                                   # [B,H,T,64] gathered back
+    vv = vt[:, :, v_off]
+    assert torch.allclose(kk.float(), ref_kv[:, :, 0].permute(0, 2, 1, 3), rtol=2e-3, atol=2e-3)
+    assert torch.allclose(vv.float(), ref_kv[:, :, 1].permute(0, 2, 1, 3), rtol=2e-3, atol=2e-3)
+    written = torch.zeros(Tc * 64, dtype=torch.bool, device=DEV)
+    written[k_off.reshape(-1)] = True
+    assert int(written.sum()) == T * 64 and torch.isnan(kt[:, :, ~written]).all()     # every slot once, padding untouched
+    written.zero_()
+    written[v_off.reshape(-1)] = True
+    assert int(written.sum()) == T * 64 and torch.isnan(vt[:, :, ~written]).all()
+    # same bits as the row-major / V^T epilogues of the same GEMM (only the addresses differ)
+    NP = (T + 15) // 16 * 16
+    k_rm = torch.empty(B, H, T, 64, dtype=torch.float16, device=DEV)
+    v_t = torch.zeros(B, H, 64, NP, dtype=torch.float16, device=DEV)
+    k.gemm(a, w, bias, heads=dict(k=k_rm, vt=v_t, T=T, H=H, part0=1, t_off=0, Tk_cap=T, NP=NP))
+    assert torch.equal(kk, k_rm) and torch.equal(vv, v_t[..., k.vt_columns(T).to(DEV)].transpose(-1, -2))
+    if B * T >= 40960:   # this size ran the 256x256 kernel: its first two images must equal a small-tile launch
+        k2 = torch.full((2, H, Tc * 64), float("nan"), dtype=torch.float16, device=DEV)
+        v2 = torch.full((2, H, Tc * 64), float("nan"), dtype=torch.float16, device=DEV)
+        k.gemm(a[:2 * T].contiguous(), w, bias, heads=dict(k=k2, vt=v2, T=T, H=H, part0=1, t_off=0, Tk_cap=Tc, tiled=True))
+        assert torch.equal(k2[:, :, k_off], kk[:2]) and torch.equal(v2[:, :, v_off], vv[:2])
+    # attention: `beams` query rows per image
+    q = (_rand(B * beams, H, 1, 64, seed=96) * 0.125).half().to(DEV)
+    out = torch.zeros(B * beams, C, dtype=torch.float16, device=DEV)
+    k.attention(q, kt, vt, out, Bq=B * beams, H=H, Nq=1, Nk=T, Tq_cap=1, Tk_cap=Tc, NP=0, kv_group=beams, kv_tiled=True)
+    nb = min(B, 4)
+    ref = _attn_ref(q[:nb * beams].float().cpu(), kk[:nb].float().cpu(), vv[:nb].float().cpu(), None, False, 0, beams)
+    got = out[:nb * beams].float().cpu().view(nb * beams, 1, C)
+    assert torch.isfinite(out).all()
+    assert torch.allclose(got, ref, rtol=3e-3, atol=3e-3), (got - ref).abs().max()
+    # and the same launch through the V^T layout gives the same numbers up to the summation order of the key tiles
+    out2 = torch.zeros_like(out)
+    k.attention(q, k_rm, v_t, out2, Bq=B * beams, H=H, Nq=1, Nk=T, Tq_cap=1, Tk_cap=T, NP=NP, kv_group=beams)
+    assert torch.allclose(out.float(), out2.float(), rtol=2e-3, atol=2e-3)
+    if B * beams > 32:
+        with pytest.raises(k.VidilHipError):               # more than 32 query rows per unit: not with tiles
+            k.attention(q, kt, vt, out, Bq=B * beams, H=H, Nq=1, Nk=T, Tq_cap=1, Tk_cap=Tc, NP=0, kv_group=B * beams,
+                        kv_tiled=True)
+
+
 @pytest.mark.parametrize("Nq,Nk,counts,use_len", [
     (35, 197, [3, 0, 8, 1, 5], False),     # ITM cross: captions per frame vary, one frame has none (LDS kernel, 4/8 waves)
     (1, 197, [3, 3, 3, 3], False),         # decode cross via the table form (direct kernel)

@@ -87,9 +87,10 @@ def test_decoder_small_vs_golden_prefill_reorder_and_steps():
         logits_close(dec.lm_logits(h16, R, 1).cpu(), torch.from_numpy(g[key_ref]))
 
 
-def test_decoder_session_small_vs_golden_arena_and_ancestry():
+@pytest.mark.parametrize("tiled_cross", [False, True])
+def test_decoder_session_small_vs_golden_arena_and_ancestry(tiled_cross):
     """The same golden sequence through the product's DecoderSession: prompt pass -> beam reorder (ancestry
-    table, the KV arena itself never moves) -> two cached steps."""
+    table, the KV arena itself never moves) -> two cached steps; with the image K/V as K + V^T and as fragment tiles."""
     from vidil_amd.blip import DecoderSession
     from vidil_amd.med import BertLMHeadModel
 
@@ -97,7 +98,9 @@ def test_decoder_session_small_vs_golden_arena_and_ancestry():
     dec = load_into(BertLMHeadModel(_small_med_cfg()), sd, "text_decoder.").to(DEV)
     enc = torch.from_numpy(g["enc"])                                  # [3,17,256]
     B, nb, R = 3, 2, 6
-    sess = DecoderSession(dec, enc.reshape(B * 17, 256).to(DEV).half().contiguous(), B, nb, max_length=8)
+    sess = DecoderSession(dec, enc.reshape(B * 17, 256).to(DEV).half().contiguous(), B, nb, max_length=8,
+                          tiled_cross=tiled_cross)
+    assert sess.cross.tiled == tiled_cross
     ids = torch.from_numpy(g["ids"]).to(torch.int32).to(DEV)          # [6,4]: every row has its own prompt
     logits_close(sess.prefill(ids.reshape(-1), 4, shared=False).cpu(), torch.from_numpy(g["logits0"]))
     kref = torch.from_numpy(g["k_cache_l1"])                          # [6,4,4,64] = [row, head, t, d]

@@ -34,7 +34,7 @@ class GemmArgs(C.Structure):
         ("Tq_cap", C.c_int32), ("Tk_cap", C.c_int32), ("NP", C.c_int32),
         ("q_scale", C.c_float),
         ("arena_rows", C.c_int32), ("slot_stride", C.c_int32),
-        ("pos", C.c_void_p), ("tpi", C.c_int32),
+        ("pos", C.c_void_p), ("tpi", C.c_int32), ("kv_tiled", C.c_int32),
     ]
 
 
@@ -55,7 +55,7 @@ SIGNATURES = {
     "vidil_num_entry_points": (_i32, []),
     "vidil_gemm_f16": (_i32, [C.POINTER(GemmArgs), _p]),
     "vidil_layernorm": (_i32, [_p, _i64, _p, _p, _f32, _i32, _i32, _p, _p, _p]),
-    "vidil_attention": (_i32, [_p, _p, _p, _p, _p, _p, _p] + [_i32] * 13 + [_p]),
+    "vidil_attention": (_i32, [_p, _p, _p, _p, _p, _p, _p] + [_i32] * 14 + [_p]),
     "vidil_patchify_f32": (_i32, [_p, _p, _i32, _i32, _i32, _p]),
     "vidil_patchify_u8": (_i32, [_p, _p, _i32, _i32, _i32, C.POINTER(_f32), C.POINTER(_f32), _p]),
     "vidil_resample_u8": (_i32, [_p, _p] + [_i32] * 6 + [_p, _p, _i32, _i32, _p]),

@@ -88,14 +88,18 @@ class DecoderSession:
     once), the append-only self-attention KV arena + ancestry table, and the two forward entry points the beam
     loop needs."""
 
-    def __init__(self, text_decoder, enc16, B, nb, max_length):
+    def __init__(self, text_decoder, enc16, B, nb, max_length, tiled_cross=False):
+        """tiled_cross: keep the image K/V in fragment tiles (BertModel.project_cross_kv(tiled=True)) — every decode
+        step streams them from HBM once, in whole KiB per wave load; the caller guarantees that no launch has more
+        than 32 query rows per image (nb beams x 1 token, or the prompt's tokens)."""
         self.dec, self.bert = text_decoder, text_decoder.bert
         cfg = text_decoder.config
         dev = enc16.device
         self.B, self.nb, self.R = B, nb, B * nb
         self.H, self.L = cfg.num_attention_heads, cfg.num_hidden_layers
         Te = enc16.shape[0] // B
-        self.cross = self.bert.project_cross_kv(enc16, B, Te)
+        self.tiled_cross = tiled_cross
+        self.cross = self.bert.project_cross_kv(enc16, B, Te, tiled=tiled_cross)
         self.Tcap = max_length
         self.arena = BeamArena(self.L, self.Tcap, self.R, cfg.hidden_size, dev)
         self.ws_prefill, self.ws_step = {}, {}
@@ -105,7 +109,7 @@ class DecoderSession:
         """Start a new search on another batch of the same shape IN THE SAME BUFFERS (cross K/V re-projected in place,
         arena orientation reset): device addresses stay what the captured decode-step graphs recorded."""
         Te = enc16.shape[0] // self.B
-        self.cross = self.bert.project_cross_kv(enc16, self.B, Te, out=self.cross)
+        self.cross = self.bert.project_cross_kv(enc16, self.B, Te, out=self.cross, tiled=self.tiled_cross)
         self.arena._cur = 0
 
     def prefill(self, ids_i32, P, shared=False):
@@ -177,7 +181,9 @@ class BLIP_Decoder(nn.Module):
         # saving the allocations it keeps every device address stable, which is what lets the decode steps — ~160
         # launches of 8-30 us kernels each, issued faster by the GPU than Python can enqueue them — be captured once
         # into HIP graphs (one per step index: the position is baked into the launches) and replayed.
-        key = (B, nb, max_length, min_length, str(dev), enc16.shape[0] // B)
+        prompt = self.prompt_ids(B, dev)
+        P = prompt.shape[1]
+        key = (B, nb, max_length, min_length, str(dev), enc16.shape[0] // B, P)
         cache = self.__dict__.setdefault("_decode_state", {})
         st = cache.get(key)
         packs = (dec.packed(), bert.packed())     # captured graphs hold the addresses of these packed weights
@@ -186,15 +192,14 @@ class BLIP_Decoder(nn.Module):
         if st is None:
             if len(cache) >= 4:
                 cache.clear()
-            st = cache[key] = dict(sess=DecoderSession(dec, enc16, B, nb, max_length),
+            # (the shared prompt pass has P query rows per image, a decode step nb)
+            st = cache[key] = dict(sess=DecoderSession(dec, enc16, B, nb, max_length, tiled_cross=P <= 32 and nb <= 32),
                                    bufs=K.BeamBuffers(B, nb, max_length, dev), graphs={}, pool=None, calls=0, packs=packs,
                                    graphs_ok=os.environ.get("VIDIL_DECODE_GRAPHS", "1") != "0")
         else:
             st["sess"].rebind(enc16)
         st["calls"] += 1
         sess, bufs = st["sess"], st["bufs"]
-        prompt = self.prompt_ids(B, dev)
-        P = prompt.shape[1]
         bufs.reset(prompt)
 
         def first_unit(logits):
@@ -261,9 +266,9 @@ class BLIP_Decoder(nn.Module):
         if seed is None:
             self._sample_calls = getattr(self, "_sample_calls", 0) + 1
             seed = (torch.initial_seed() + (self._sample_calls << 32)) & 0xFFFFFFFFFFFFFFFF
-        sess = DecoderSession(self.text_decoder, enc16, B, 1, max_length)
         prompt = self.prompt_ids(B, dev)
         P = prompt.shape[1]
+        sess = DecoderSession(self.text_decoder, enc16, B, 1, max_length, tiled_cross=P <= 32)
         seqs = torch.full((B, max_length), pad, dtype=torch.int32, device=dev)
         seqs[:, :P] = prompt
         done = torch.zeros((B,), dtype=torch.int32, device=dev)

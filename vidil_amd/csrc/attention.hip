@@ -42,6 +42,7 @@ struct AttnP {
   const int32_t* kv_index;     // per query batch -> kv batch (only with kv_group == 1 semantics), or null
   const int32_t* group_start;  // [n_kv+1] prefix of query batches per kv batch, or null
   int Bq, H, Nq, Nk, Tq_cap, Tk_cap, NP, kv_group, causal, causal_off, ldo, n_kv;
+  int tiled;                   // K and V in 32-key fragment tiles (common.h: ktile_off / vtile_off); direct kernel only
 };
 
 constexpr int KROW = 72;  // halfs per K row in LDS (64 + 8 pad)
@@ -297,7 +298,7 @@ __global__ __launch_bounds__(256) void attn_direct_kernel(const AttnP p) {
     for (int r = 0; r < 16; ++r) O[dt][r] = 0.f;
 
   const f16* kg = p.k + ((size_t)bk * p.H + h) * p.Tk_cap * 64;
-  const f16* vg = p.vt + ((size_t)bk * p.H + h) * 64 * (size_t)p.NP;
+  const f16* vg = p.vt + ((size_t)bk * p.H + h) * 64 * (size_t)(p.tiled ? p.Tk_cap : p.NP);
   const int ntiles = (nk + 31) >> 5;
   if (wave < ntiles) {
     f16x8 qf[4];
@@ -331,7 +332,23 @@ __global__ __launch_bounds__(256) void attn_direct_kernel(const AttnP p) {
       for (int dt = 0; dt < 2; ++dt)
 #pragma unroll
         for (int hb = 0; hb < 2; ++hb) vf[i][dt][hb] = f16x8{0, 0, 0, 0, 0, 0, 0, 0};
-      if (kt < ntiles) {
+      if (kt < ntiles && p.tiled) {
+        // fragment tiles: each instruction of the wave reads one contiguous KiB; rows / key groups past the
+        // last key are not fetched (they stay zero and are masked below)
+        const f16* kt_base = kg + (size_t)kt * 2048 + (hi * 32 + l31) * 8;
+        if (kt * 32 + l31 < nk) {
+#pragma unroll
+          for (int ks = 0; ks < 4; ++ks) kf[i][ks] = *(const f16x8*)(kt_base + ks * 512);
+        }
+        const f16* vt_base = vg + (size_t)kt * 2048 + (hi * 32 + l31) * 8;
+#pragma unroll
+        for (int hb = 0; hb < 2; ++hb) {
+          if ((kt * 2 + hb) * 16 + 4 * hi < nk) {
+#pragma unroll
+            for (int dt = 0; dt < 2; ++dt) vf[i][dt][hb] = *(const f16x8*)(vt_base + (hb * 2 + dt) * 512);
+          }
+        }
+      } else if (kt < ntiles) {
         int krow = kt * 32 + l31;
         krow = krow < nk ? krow : nk - 1;  // clamped rows are masked below
         const f16* kr = kg + (size_t)krow * 64 + hi * 8;
@@ -476,7 +493,7 @@ int launch_lds(const AttnP& p, int max_rows, hipStream_t s) {
 
 template <int NKT>
 int launch_any(const AttnP& p, int max_rows, hipStream_t s) {
-  if (max_rows <= 32 && NKT == 1) {
+  if (max_rows <= 32 && NKT == 1 && !p.tiled) {
     hipLaunchKernelGGL(attn_wave_kernel, dim3(1, p.H, p.n_kv), dim3(64), 0, s, p);
     VIDIL_CHECK_LAUNCH("attention/wave");
     return VIDIL_OK;
@@ -495,9 +512,15 @@ int launch_any(const AttnP& p, int max_rows, hipStream_t s) {
 extern "C" int vidil_attention(const void* q, const void* k, const void* vt, void* out, const int32_t* kv_len,
                                const int32_t* kv_index, const int32_t* group_start, int32_t n_kv, int32_t max_group,
                                int32_t Bq, int32_t H, int32_t Nq, int32_t Nk, int32_t Tq_cap, int32_t Tk_cap, int32_t NP,
-                               int32_t kv_group, int32_t causal, int32_t causal_off, int32_t ldo, void* stream) {
+                               int32_t kv_group, int32_t causal, int32_t causal_off, int32_t ldo, int32_t kv_tiled,
+                               void* stream) {
   VIDIL_REQUIRE(q && k && vt && out, "attention: null pointer");
   VIDIL_REQUIRE(Bq > 0 && H > 0 && Nq > 0 && Nk > 0, "attention: bad shape Bq=%d H=%d Nq=%d Nk=%d", Bq, H, Nq, Nk);
+  if (kv_tiled) {
+    VIDIL_REQUIRE(Tq_cap >= Nq && Tk_cap >= Nk && Tk_cap % 32 == 0,
+                  "attention: tiled K/V need Tk_cap=%d >= Nk=%d and a multiple of 32", Tk_cap, Nk);
+    NP = Tk_cap;   // unused by the tiled loads; keeps the checks below meaningful
+  }
   VIDIL_REQUIRE(Tq_cap >= Nq && Tk_cap >= Nk && (NP == 0 || NP >= Nk), "attention: capacities too small");
   VIDIL_REQUIRE(NP % 16 == 0, "attention: NP=%d must be a multiple of 16 (V^T rows hold whole 16-key blocks)", NP);
   VIDIL_REQUIRE(ldo >= H * 64 && ldo % 8 == 0, "attention: ldo=%d must be >= H*64 and a multiple of 8", ldo);
@@ -518,9 +541,10 @@ extern "C" int vidil_attention(const void* q, const void* k, const void* vt, voi
   }
   VIDIL_REQUIRE(H <= 65535 && units <= 65535, "attention: grid too large (H=%d units=%d)", H, units);
   AttnP p{(const f16*)q, (const f16*)k, (const f16*)vt, (f16*)out, kv_len, kv_index, group_start, Bq, H, Nq, Nk,
-          Tq_cap, Tk_cap, NP, kv_group, causal, causal_off, ldo, units};
+          Tq_cap, Tk_cap, NP, kv_group, causal, causal_off, ldo, units, kv_tiled ? 1 : 0};
   hipStream_t s = (hipStream_t)stream;
   const int nkt = (Nk + 31) / 32;
+  VIDIL_REQUIRE(!kv_tiled || max_rows <= 32, "attention: tiled K/V serve at most 32 query rows per unit (got %d)", max_rows);
   // NP == 0: `vt` holds V row-major [Bk][H][Tk_cap][64]; only the LDS-staged kernel transposes on the way in
   VIDIL_REQUIRE(NP != 0 || max_rows > 32, "attention: row-major V (NP == 0) needs more than 32 query rows per unit (got %d)",
                 max_rows);

@@ -43,6 +43,21 @@ int vidil_gemm256_launch(const vidil_gemm_args& a, hipStream_t s);
 // two).  vt_pos maps key -> storage column (and back: it is an involution); row strides are multiples of 16.
 __host__ __device__ __forceinline__ int vt_pos(int t) { return t ^ ((((t >> 2) ^ (t >> 3)) & 1) * 12); }
 
+// Fragment-tiled K / V (vidil_gemm_args.kv_tiled, vidil_attention kv_tiled): a (batch, head) owns Tk_cap/32 tiles
+// of 32 keys x 64 dims = 2048 halfs, stored in the order the direct attention kernel's MFMA operands want them, so
+// that each of its wave-level loads is ONE contiguous KiB (64 lanes x 16 B) instead of 32-byte pieces of 32 rows:
+//   K tile: [c/8][key%32][c%8]                      (k-step ks = c/16, half-wave = (c/8)%2, lane = key%32)
+//   V tile: [key%32/16][d/32][half-wave][d%32][j]   with the 8 keys of a half-wave in vt_pos order:
+//           4-key group g = (key%16)/4 -> half-wave g%2, j = (g/2)*4 + key%4
+__host__ __device__ __forceinline__ size_t ktile_off(int t, int c) {
+  return (size_t)(t >> 5) * 2048 + (size_t)(((c >> 3) * 32 + (t & 31)) * 8 + (c & 7));
+}
+__host__ __device__ __forceinline__ size_t vtile_off(int t, int d) {
+  const int tt = t & 31, g = (tt & 15) >> 2;
+  return (size_t)(t >> 5) * 2048 +
+         (size_t)(((((tt >> 4) * 2 + (d >> 5)) * 2 + (g & 1)) * 32 + (d & 31)) * 8 + (g >> 1) * 4 + (tt & 3));
+}
+
 // device helpers --------------------------------------------------------------
 __device__ __forceinline__ float wave_sum(float v) {
 #pragma unroll

@@ -259,6 +259,10 @@ __global__ __launch_bounds__(2 * waves_n(BM, BN) * 64) void gemm_kernel(const vi
               const size_t bh = (size_t)b * p.H + h;
               if (part == 0) {
                 ((f16*)p.q)[(bh * p.Tq_cap + t) * 64 + d] = to_f16(v * p.q_scale);
+              } else if (p.kv_tiled) {               // fragment tiles (common.h)
+                const size_t base = bh * (size_t)p.Tk_cap * 64;
+                if (part == 1) ((f16*)p.k)[base + ktile_off(p.t_off + t, d)] = to_f16(v);
+                else ((f16*)p.vt)[base + vtile_off(p.t_off + t, d)] = to_f16(v);
               } else if (part == 1 || p.NP == 0) {   // NP == 0: V row-major, laid out like K
                 ((f16*)(part == 1 ? p.k : p.vt))[(bh * p.Tk_cap + p.t_off + t) * 64 + d] = to_f16(v);
               } else {
@@ -384,6 +388,11 @@ extern "C" int vidil_gemm_f16(const vidil_gemm_args* args, void* stream) {
       for (int part = a.part0; part < a.part0 + nparts; ++part) {
         if (part == 0) VIDIL_REQUIRE(a.q && a.Tq_cap >= a.T, "gemm/heads: bad q / Tq_cap");
         if (part == 1) VIDIL_REQUIRE(a.k && a.Tk_cap >= a.t_off + a.T, "gemm/heads: bad k / Tk_cap");
+        if (part >= 1 && a.kv_tiled) {
+          VIDIL_REQUIRE((part == 1 || a.vt) && a.Tk_cap >= a.t_off + a.T && a.Tk_cap % 32 == 0,
+                        "gemm/heads: tiled K/V need Tk_cap=%d >= t_off+T and a multiple of 32", a.Tk_cap);
+          continue;
+        }
         if (part == 2 && a.NP != 0)
           VIDIL_REQUIRE(a.vt && a.NP >= a.t_off + a.T && a.NP % 16 == 0, "gemm/heads: bad vt / NP (multiple of 16, >= t_off+T)");
         if (part == 2 && a.NP == 0)   // row-major V [b][h][Tk_cap][64]

@@ -303,6 +303,48 @@ __global__ __launch_bounds__(512) void gemm256_kernel(const vidil_gemm_args p) {
   }
 
   if constexpr (EPI == VIDIL_EPI_HEADS) {
+    if (part == 2 && p.kv_tiled) {
+      // V in fragment tiles (common.h vtile_off).  A lane's accumulator row is one KEY, but the layout keeps the 4
+      // keys {4q .. 4q+3} of a dimension d side by side (8 B): each block of 32 keys goes through the wave's LDS
+      // scratch as [key][d] (rows padded to 136 B), then lane d collects runs of 4 tile-aligned keys of one image
+      // and stores them as 8 B; keys cut off by the block or the image boundary are stored one by one.
+      constexpr int ROWB = 136;
+      const size_t img_stride = (size_t)p.H * p.Tk_cap * 64;
+      f16* const vbase = (f16*)p.vt + (size_t)head * p.Tk_cap * 64;
+#pragma unroll
+      for (int it = 0; it < 4; ++it) {
+        const int mb = m_w + it * 32;
+        const int rows = M - mb < 32 ? M - mb : 32;   // wave-uniform
+        if (rows <= 0) break;
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+          for (int rq = 0; rq < 4; ++rq) {
+            const f16x4 v = {to_f16(value(it, j, rq, 0)), to_f16(value(it, j, rq, 1)), to_f16(value(it, j, rq, 2)),
+                             to_f16(value(it, j, rq, 3))};
+            *(f16x4*)(ep + l31 * ROWB + (j * 32 + rq * 8 + hi * 4) * 2) = v;
+          }
+        int b = mb / p.T, t = mb - b * p.T;
+        for (int r = 0; r < rows;) {
+          const int tt = p.t_off + t;
+          f16* dst = vbase + (size_t)b * img_stride + vtile_off(tt, lane);
+          const char* src = ep + r * ROWB + lane * 2;
+          if ((tt & 3) == 0 && r + 4 <= rows && t + 4 <= p.T) {
+            const f16x4 v = {*(const f16*)src, *(const f16*)(src + ROWB), *(const f16*)(src + 2 * ROWB),
+                             *(const f16*)(src + 3 * ROWB)};
+            *(f16x4*)dst = v;
+            r += 4;
+            t += 4;
+          } else {
+            *dst = *(const f16*)src;
+            r += 1;
+            t += 1;
+          }
+          if (t >= p.T) { t -= p.T; ++b; }
+        }
+      }
+      break;
+    }
     if (part == 2 && p.NP != 0) {   // (NP == 0: V stays row-major and takes the 16-B store path of K below)
       // V^T: element (row m, column d) goes to VT[b][h][d][t_off+t]; consecutive lanes = consecutive t
 #pragma unroll
@@ -358,7 +400,11 @@ __global__ __launch_bounds__(512) void gemm256_kernel(const vidil_gemm_args p) {
               *(f16x8*)((f16*)p.q + (bh * p.Tq_cap + t) * 64 + ch * 8) = v;
             } else {
               f16* kv = (f16*)(part == 1 ? p.k : p.vt);
-              *(f16x8*)(kv + (bh * p.Tk_cap + p.t_off + t) * 64 + ch * 8) = v;
+              if (p.kv_tiled) {   // K in fragment tiles: the lane's 8 columns are one 16-B slot of its key's row
+                *(f16x8*)(kv + bh * p.Tk_cap * 64 + ktile_off(p.t_off + t, ch * 8)) = v;
+              } else {
+                *(f16x8*)(kv + (bh * p.Tk_cap + p.t_off + t) * 64 + ch * 8) = v;
+              }
             }
           }
         }
@@ -480,7 +526,7 @@ bool vidil_gemm256_eligible(const vidil_gemm_args& a) {
     case VIDIL_EPI_PATCH:
       return a.N % 4 == 0 && a.ldo % 4 == 0 && al16(a.out) && al16(a.pos);
     case VIDIL_EPI_HEADS:
-      return (!a.q || al16(a.q)) && (!a.k || al16(a.k)) && (a.NP != 0 || !a.vt || al16(a.vt));
+      return (!a.q || al16(a.q)) && (!a.k || al16(a.k)) && ((a.NP != 0 && !a.kv_tiled) || !a.vt || al16(a.vt));
     default:
       return false;
   }

@@ -33,6 +33,17 @@ def vt_columns(n: int):
     return torch.tensor([vt_pos(t) for t in range(n)], dtype=torch.long)
 
 
+def kv_tile_offsets(n: int):
+    """(k_off, v_off) LongTensors [n,64]: element offset of (key t, dim c) inside a (batch, head)'s fragment-tiled K / V
+    buffer (csrc/common.h ktile_off / vtile_off) — for building / reading tiled buffers in tests."""
+    t = torch.arange(n).view(n, 1)
+    c = torch.arange(64).view(1, 64)
+    k_off = (t >> 5) * 2048 + ((c >> 3) * 32 + (t & 31)) * 8 + (c & 7)
+    tt, g = t & 31, (t & 15) >> 2
+    v_off = (t >> 5) * 2048 + ((((tt >> 4) * 2 + (c >> 5)) * 2 + (g & 1)) * 32 + (c & 31)) * 8 + (g >> 1) * 4 + (tt & 3)
+    return k_off, v_off
+
+
 def _stream() -> int:
     return torch.cuda.current_stream().cuda_stream
 
@@ -56,7 +67,7 @@ def gemm(a, w, bias=None, *, out=None, out_dtype=torch.float16, act=ACT_NONE, re
 
     a [M,K] f16, w [N,K] f16, bias f32 [N] or None.
       * default: returns/fills ``out`` [M,N] (f16 or f32 by ``out_dtype``); f32 may add ``resid``.
-      * heads=dict(q=,k=,vt=,T=,H=,part0=,t_off=,Tq_cap=,Tk_cap=,NP=,q_scale=): per-head scatter.
+      * heads=dict(q=,k=,vt=,T=,H=,part0=,t_off=,Tq_cap=,Tk_cap=,NP=,q_scale=,tiled=): per-head scatter.
       * patch=dict(out=,pos=,tpi=): patch-embedding epilogue (row remap + pos embed).
       * arena=dict(q=,k=,v=,T=,H=,part0=,t_off=,arena_rows=,slot_stride=,Tcap=,q_scale=): Q rows + K/V rows
         appended to a beam-search KV arena [position][slot][H*64] (see vidil_beam_attention).
@@ -91,6 +102,7 @@ def gemm(a, w, bias=None, *, out=None, out_dtype=torch.float16, act=ACT_NONE, re
         g.Tk_cap = heads.get("Tk_cap", heads["T"])
         g.NP = heads.get("NP", 0)
         g.q_scale = heads.get("q_scale", 1.0)
+        g.kv_tiled = 1 if heads.get("tiled") else 0
     elif arena is not None:
         g.epi = EPI_ARENA
         g.q = _ptr(arena.get("q"), torch.float16, "gemm.arena.q")
@@ -139,8 +151,9 @@ def layernorm(x, gamma, beta, eps, *, M=None, D=None, x_stride=None, out16=None,
 
 
 def attention(q, k, vt, out, *, Bq, H, Nq, Nk, Tq_cap, Tk_cap, NP, kv_group=1, causal=False,
-              causal_off=0, kv_len=None, kv_index=None, group_start=None, max_group=0, ldo=None):
-    """group_start: int32 [n_kv+1] device prefix table (query batches per kv batch), with max_group."""
+              causal_off=0, kv_len=None, kv_index=None, group_start=None, max_group=0, ldo=None, kv_tiled=False):
+    """group_start: int32 [n_kv+1] device prefix table (query batches per kv batch), with max_group.
+    kv_tiled: k / vt are fragment-tiled (gemm heads=dict(tiled=True)); at most 32 query rows per unit."""
     lib = _lib.load()
     ldo = ldo if ldo is not None else H * 64
     n_kv = 0 if group_start is None else group_start.numel() - 1
@@ -149,7 +162,7 @@ def attention(q, k, vt, out, *, Bq, H, Nq, Nk, Tq_cap, Tk_cap, NP, kv_group=1, c
                               _ptr(kv_len, torch.int32, "attn.kv_len"), _ptr(kv_index, torch.int32, "attn.kv_index"),
                               _ptr(group_start, torch.int32, "attn.group_start"), n_kv, max_group,
                               Bq, H, Nq, Nk, Tq_cap, Tk_cap, NP,
-                              kv_group, int(bool(causal)), causal_off, ldo, _stream()), "attention")
+                              kv_group, int(bool(causal)), causal_off, ldo, int(bool(kv_tiled)), _stream()), "attention")
     return out
 
 

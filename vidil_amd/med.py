@@ -127,8 +127,10 @@ def _init_bert(module, std):
 class CrossKV:
     """Per-image cross-attention keys / values^T of every layer: K [L][B,H,Te,64], VT [L][B,H,64,NP]."""
 
-    def __init__(self, k, vt, B, Te, NP, last_vt=None, last_NP=0):
+    def __init__(self, k, vt, B, Te, NP, last_vt=None, last_NP=0, tiled=False, Tk_cap=None):
         self.k, self.vt, self.B, self.Te, self.NP = k, vt, B, Te, NP
+        # tiled: K and V of every layer in 32-key fragment tiles [L][B,H,Tk_cap/32,2048] (vidil_attention kv_tiled)
+        self.tiled, self.Tk_cap = tiled, (Te if Tk_cap is None else Tk_cap)
         # optional second copy of the LAST layer's values in V^T layout (see project_cross_kv(last_layer_vt=True))
         self.last_vt, self.last_NP = last_vt, last_NP
 
@@ -199,20 +201,35 @@ class BertModel(PackedCache, nn.Module):
         return p
 
     # --------------------------------------------------------- cross K/V (once per image)
-    def project_cross_kv(self, enc16, B, Te, out: "CrossKV" = None, v_rowmajor=False, last_layer_vt=False):
+    def project_cross_kv(self, enc16, B, Te, out: "CrossKV" = None, v_rowmajor=False, last_layer_vt=False, tiled=False):
         """enc16: f16 [B*Te, encoder_width] image tokens.  One fused K|V GEMM per layer.  ``out``: buffers of a
         previous call with the same (B, Te) to overwrite (keeps device addresses stable for captured graphs).
         ``v_rowmajor``: keep V as [L][B,H,Te,64] (NP = 0) — for consumers whose every cross-attention launch has more
         than 32 query rows per image (the staged kernel transposes in LDS); the decode steps need V^T.
         ``last_layer_vt`` (with v_rowmajor): the last layer's V goes to a V^T buffer instead (``last_vt``) — its
-        consumer is encode_cls, whose last layer has one query row per pair."""
+        consumer is encode_cls, whose last layer has one query row per pair.
+        ``tiled``: K and V in 32-key fragment tiles — for consumers whose every launch has at most 32 query rows per
+        image and which re-read the K/V from HBM many times (the decode steps of the captioner)."""
         p = self.packed()
         H = self.config.num_attention_heads
+        if tiled:
+            Tc = (Te + 31) // 32 * 32
+            L = len(p["layers"])
+            dev = enc16.device
+            if out is not None and out.tiled and (out.B, out.Te) == (B, Te) and out.k.device == dev:
+                k, v = out.k, out.vt
+            else:
+                k = torch.empty((L, B, H, Tc, 64), dtype=torch.float16, device=dev)
+                v = torch.empty((L, B, H, Tc, 64), dtype=torch.float16, device=dev)
+            for i, d in enumerate(p["layers"]):
+                K.gemm(enc16, d["ckv_w"], d["ckv_b"],
+                       heads=dict(k=k[i], vt=v[i], T=Te, H=H, part0=1, t_off=0, Tk_cap=Tc, tiled=True))
+            return CrossKV(k, v, B, Te, Tc, tiled=True, Tk_cap=Tc)
         NPt = (Te + 15) // 16 * 16
         NP = 0 if v_rowmajor else NPt
         L = len(p["layers"])
         dev = enc16.device
-        if out is not None and (out.B, out.Te, out.NP) == (B, Te, NP) and out.k.device == dev:
+        if out is not None and not out.tiled and (out.B, out.Te, out.NP) == (B, Te, NP) and out.k.device == dev:
             k, vt = out.k, out.vt
         else:
             k = torch.empty((L, B, H, Te, 64), dtype=torch.float16, device=dev)
@@ -284,8 +301,8 @@ class BertModel(PackedCache, nn.Module):
                 # frame) is served by one fetch of that image's K/V: see vidil_attention's grouping forms
                 K.gemm(h16, d["cq_w"], d["cq_b"], heads=dict(q=q, T=T, H=H, part0=0, Tq_cap=T, q_scale=0.125))
                 K.attention(q, cross.k[i], cross.vt[i], o, Bq=rows, H=H, Nq=T, Nk=cross.Te, Tq_cap=T,
-                            Tk_cap=cross.Te, NP=cross.NP, kv_group=cross_group, kv_index=cross_index,
-                            group_start=cross_groups, max_group=cross_max_group)
+                            Tk_cap=cross.Tk_cap, NP=cross.NP, kv_group=cross_group, kv_index=cross_index,
+                            group_start=cross_groups, max_group=cross_max_group, kv_tiled=cross.tiled)
                 K.gemm(o, d["co_w"], d["co_b"], out=tmp, resid=h32)
                 K.layernorm(tmp, d["co_g"], d["co_bt"], eps, out16=h16, out32=h32)
             K.gemm(h16, d["i_w"], d["i_b"], out=inter, act=K.ACT_GELU_ERF)
