@@ -22,6 +22,12 @@ def main():
     vt = torch.randn(B, H, 64, NP, device=dev).half()
     o = torch.empty(B * beams, H * 64, dtype=torch.float16, device=dev)
     fn = lambda: K.attention(q, k, vt, o, Bq=B * beams, H=H, Nq=1, Nk=Te, Tq_cap=1, Tk_cap=Tk, NP=NP, kv_group=beams)  # noqa: E731
+    if len(sys.argv) > 3 and sys.argv[3] == "tiled":                 # fragment tiles (the product's decode layout)
+        Tc = (Te + 31) // 32 * 32
+        kt = torch.randn(B, H, Tc * 64, device=dev).half()
+        vv = torch.randn(B, H, Tc * 64, device=dev).half()
+        fn = lambda: K.attention(q, kt, vv, o, Bq=B * beams, H=H, Nq=1, Nk=Te, Tq_cap=1, Tk_cap=Tc, NP=0, kv_group=beams,  # noqa: E731
+                                 kv_tiled=True)
     for _ in range(3):
         fn()
     torch.cuda.synchronize()
