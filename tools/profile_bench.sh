@@ -36,7 +36,7 @@ for k,v in sorted(rows.items(), key=lambda kv:-sum(kv[1].get("SQ_VALU_MFMA_BUSY_
     traffic[k] = {"launches": n, "fetch_kb_raw": round(f), "write_kb": round(w),
                   "hbm_bytes_per_launch": int((2 * f + w) * 1024), "mfma_util": round(util, 3)}
 import json
-json.dump({"source": "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (separate passes) of `bench.py " + "$ARGS" + "`; FETCH_SIZE doubled per MI355X_MICROARCH.md (HBM section); written by tools/profile_bench.sh",
+json.dump({"source": "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (separate passes) of 'bench.py " + "$ARGS" + "'; FETCH_SIZE doubled per MI355X_MICROARCH.md (HBM section); written by tools/profile_bench.sh",
            "kernels": traffic}, open(out + "/pmc_traffic.json", "w"), indent=1)
 PY
 ls $OUT; head -30 $OUT/kernel_summary.md; cat $OUT/bench.json | cut -c1-400
