@@ -172,6 +172,12 @@ def test_encode_cls_image_major_groups_rowmajor_cross():
     h32, _ = enc_model.encode(ids, lens, cross_vt, torch.tensor(pair_img, dtype=torch.int32, device=DEV))
     ref = h32.view(5, 35, 256)[:, 0]
     assert (c32 - ref).abs().max().item() < 2e-3
+    # pair_text: the three distinct texts once, pairs mapped onto them -> the same bits as the expanded batch
+    ids_u = src.to(DEV).contiguous()
+    lens_u = mask.sum(1).to(torch.int32).to(DEV).contiguous()
+    d32, d16 = enc_model.encode_cls(ids_u, lens_u, cross_rm, cross_groups=group_start, cross_max_group=3,
+                                    pair_text=torch.tensor(pick, dtype=torch.int64, device=DEV))
+    assert torch.equal(d32, c32) and torch.equal(d16, c16)
     with pytest.raises(Exception):
         enc_model.encode_cls(ids, lens, enc_model.project_cross_kv(enc16, n_img, Te, v_rowmajor=True),
                              cross_groups=group_start, cross_max_group=3)

@@ -53,11 +53,13 @@ class BLIP_ITM(PackedCache, nn.Module):
 
     # ------------------------------------------------------------------ de-duplicated schedule
     @torch.no_grad()
-    def itm_pairs(self, enc16, n_images, ids, lens, image_index=None, group_start=None, max_group=0):
+    def itm_pairs(self, enc16, n_images, ids, lens, image_index=None, group_start=None, max_group=0, pair_text=None):
         """enc16 f16 [n_images*Te, width]; ids i32 [P,35]; lens i32 [P].  Either image_index i32 [P] (pair ->
         image, any order) or, for IMAGE-MAJOR pair order, group_start i32 [n_images+1] (pairs of image j are
         group_start[j] .. group_start[j+1]-1, at most max_group of them), which lets one fetch of an image's
-        cross K/V serve all its captions.  Returns f32 [P,2] raw ITM logits."""
+        cross K/V serve all its captions.  pair_text (int [P]): ids / lens then hold the U DISTINCT texts and pair p
+        scores text pair_text[p] — the text-only front of the encoder runs once per text (BertModel.encode_cls).
+        Returns f32 [P,2] raw ITM logits."""
         require_cuda(enc16, "BLIP_ITM")
         te = self.text_encoder
         dev = enc16.device
@@ -76,10 +78,12 @@ class BLIP_ITM(PackedCache, nn.Module):
             group_start = group_start.to(dev).to(torch.int32).contiguous()
         else:
             image_index = image_index.to(dev).to(torch.int32).contiguous()
-        P = ids.shape[0]
+        if pair_text is not None:
+            pair_text = pair_text.to(dev).to(torch.int64).contiguous()
+        P = ids.shape[0] if pair_text is None else pair_text.numel()
         # only token 0 feeds the itm_head: the last layer runs on the [CLS] rows alone (BertModel.encode_cls)
         _, c16 = te.encode_cls(ids, lens, cross, cross_index=image_index, cross_groups=group_start,
-                               cross_max_group=max_group)
+                               cross_max_group=max_group, pair_text=pair_text)
         p = self.packed()
         out = torch.empty((P, 2), dtype=torch.float32, device=dev)
         K.gemm(c16, p["itm_w"], p["itm_b"], out=out)

@@ -188,8 +188,9 @@ class CapFiltEngine:
         pair_cap = torch.tensor(pair_cap, dtype=torch.long)
         group_start = torch.zeros(Nv * F + 1, dtype=torch.int32)
         group_start[1:] = torch.cumsum(torch.tensor(counts, dtype=torch.int32), 0)
-        logits = flt.itm_pairs(y16, Nv * F, ids[pair_cap], lens[pair_cap], group_start=group_start,
-                               max_group=max(counts))
+        # (ids / lens stay one row per distinct caption; pair_cap maps the Nv*F*C pairs onto them)
+        logits = flt.itm_pairs(y16, Nv * F, ids, lens, group_start=group_start, max_group=max(counts),
+                               pair_text=pair_cap)
         prob = torch.nn.functional.softmax(logits, dim=1)[:, 1].detach().cpu().numpy()
         gs = group_start.numpy()
         for v, caps in enumerate(caps_per_video):

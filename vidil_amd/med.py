@@ -249,7 +249,8 @@ class BertModel(PackedCache, nn.Module):
     # ------------------------------------------------------------------ layers
     def run_layers(self, h32, h16, *, rows, T, self_k, self_vt, t_off, Tk_cap, NPs, causal, kv_len,
                    cross: CrossKV, cross_index=None, cross_group=1, cross_groups=None, cross_max_group=0, ws=None,
-                   arena: "BeamArena" = None, arena_slot_stride=1, n_layers=None):
+                   arena: "BeamArena" = None, arena_slot_stride=1, n_layers=None, self_done_first=False,
+                   stop_after_self=False):
         """Run every layer on the f32/f16 hidden pair (both [rows*T, C], updated in place).
 
         self_k / self_vt: [L][rows,H,Tk_cap,64] / [L][rows,H,64,NPs] — this call's keys are appended at
@@ -278,8 +279,13 @@ class BertModel(PackedCache, nn.Module):
         Nk = t_off + T
         if arena is not None and T > 1 and t_off != 0:
             raise K.VidilHipError("run_layers: a multi-token block can only be appended to a beam arena at position 0")
-        for i, d in enumerate(p["layers"][:n_layers]):   # n_layers: only the first n (encode_cls runs the last itself)
-            if arena is not None and T == 1:
+        # n_layers: only the first n (encode_cls runs the last itself).  self_done_first / stop_after_self split layer
+        # 0 after its self-attention block (dense + residual + LayerNorm included): that block does not see the image,
+        # so encode_cls runs it once per TEXT and the rest of the stack once per (image, text) pair.
+        for i, d in enumerate(p["layers"][:n_layers]):
+            if self_done_first and i == 0:
+                pass
+            elif arena is not None and T == 1:
                 K.gemm(h16, d["qkv_w"], d["qkv_b"],
                        arena=dict(q=q, k=arena.k[i], v=arena.v[i], T=1, H=H, part0=0, t_off=t_off, Tcap=arena.Tcap,
                                   arena_rows=arena.rows, slot_stride=1, q_scale=0.125))
@@ -294,8 +300,11 @@ class BertModel(PackedCache, nn.Module):
                     K.gemm(h16, d["qkv_w"][C:], d["qkv_b"][C:],
                            arena=dict(k=arena.k[i], v=arena.v[i], T=T, H=H, part0=1, t_off=0, Tcap=arena.Tcap,
                                       arena_rows=arena.rows, slot_stride=arena_slot_stride))
-            K.gemm(o, d["ao_w"], d["ao_b"], out=tmp, resid=h32)
-            K.layernorm(tmp, d["ao_g"], d["ao_bt"], eps, out16=h16, out32=h32)
+            if not (self_done_first and i == 0):
+                K.gemm(o, d["ao_w"], d["ao_b"], out=tmp, resid=h32)
+                K.layernorm(tmp, d["ao_g"], d["ao_bt"], eps, out16=h16, out32=h32)
+            if stop_after_self:
+                break
             if cross is not None:
                 # every query batch that shares an image (the beams of a caption search, the captions of a
                 # frame) is served by one fetch of that image's K/V: see vidil_attention's grouping forms
@@ -342,7 +351,8 @@ class BertModel(PackedCache, nn.Module):
                         cross_max_group=cross_max_group)
         return h32, h16
 
-    def encode_cls(self, ids_i32, kv_len_i32, cross: CrossKV, cross_index=None, cross_groups=None, cross_max_group=0):
+    def encode_cls(self, ids_i32, kv_len_i32, cross: CrossKV, cross_index=None, cross_groups=None, cross_max_group=0,
+                   pair_text=None):
         """encode() for consumers of the [CLS] position only (the ITM head, models/blip_itm.py:57): same arguments,
         returns (h32, h16) [P, C] — token 0 of every pair after the last layer.
 
@@ -350,24 +360,47 @@ class BertModel(PackedCache, nn.Module):
         the other tokens, so it computes K|V for all P*T rows and everything else — the query, both attention
         outputs, the three dense+LayerNorm blocks and the feed-forward — for the P [CLS] rows alone (1/T of the
         layer's GEMM rows).  The arithmetic per [CLS] row is unchanged.  Needs ``cross.last_vt`` when the cross
-        values are row-major (one query row per pair goes through the direct attention kernel)."""
+        values are row-major (one query row per pair goes through the direct attention kernel).
+
+        ``pair_text`` (int64 [P], device): ids / kv_len then describe U distinct TEXTS and pair p uses text
+        pair_text[p] (CapFilt scores every caption of a video against each of its F frames).  Everything before
+        the first cross-attention — the embedding and layer 0's self-attention block — is computed once per text
+        and its rows are copied out to the pairs; same bits as running it per pair."""
         require_cuda(ids_i32, "BertModel.encode_cls")
         p = self.packed()
         cfg = self.config
-        P, T = ids_i32.shape
+        T = ids_i32.shape[1]
         H, C, L = cfg.num_attention_heads, cfg.hidden_size, cfg.num_hidden_layers
         eps = cfg.layer_norm_eps
         dev = ids_i32.device
         NPs = (T + 15) // 16 * 16
         if cross is not None and cross.NP == 0 and cross.last_vt is None:
             raise K.VidilHipError("encode_cls: row-major cross values need project_cross_kv(last_layer_vt=True)")
+
+        def scratch(rows):
+            k = torch.empty((rows, H, T, 64), dtype=torch.float16, device=dev)
+            v = torch.empty((rows, H, 64, NPs), dtype=torch.float16, device=dev)
+            return k, v, k.unsqueeze(0).expand(L, -1, -1, -1, -1), v.unsqueeze(0).expand(L, -1, -1, -1, -1)
+
         h32, h16 = self.embed(ids_i32.reshape(-1), T, 0)
-        sk = torch.empty((P, H, T, 64), dtype=torch.float16, device=dev)
-        sv = torch.empty((P, H, 64, NPs), dtype=torch.float16, device=dev)
-        self.run_layers(h32, h16, rows=P, T=T, self_k=sk.unsqueeze(0).expand(L, -1, -1, -1, -1),
-                        self_vt=sv.unsqueeze(0).expand(L, -1, -1, -1, -1), t_off=0, Tk_cap=T, NPs=NPs, causal=False,
+        shared = pair_text is not None and cross is not None and L > 1
+        if shared:
+            U = ids_i32.shape[0]
+            _, _, uk, uv = scratch(U)
+            self.run_layers(h32, h16, rows=U, T=T, self_k=uk, self_vt=uv, t_off=0, Tk_cap=T, NPs=NPs, causal=False,
+                            kv_len=kv_len_i32, cross=None, n_layers=1, stop_after_self=True)
+            h32 = h32.view(U, T, C).index_select(0, pair_text).view(-1, C)
+            h16 = h16.view(U, T, C).index_select(0, pair_text).view(-1, C)
+            kv_len_i32 = kv_len_i32.index_select(0, pair_text).contiguous()
+        elif pair_text is not None:
+            h32 = h32.view(-1, T, C).index_select(0, pair_text).view(-1, C)
+            h16 = h16.view(-1, T, C).index_select(0, pair_text).view(-1, C)
+            kv_len_i32 = kv_len_i32.index_select(0, pair_text).contiguous()
+        P = h32.shape[0] // T
+        sk, sv, sk_l, sv_l = scratch(P)
+        self.run_layers(h32, h16, rows=P, T=T, self_k=sk_l, self_vt=sv_l, t_off=0, Tk_cap=T, NPs=NPs, causal=False,
                         kv_len=kv_len_i32, cross=cross, cross_index=cross_index, cross_groups=cross_groups,
-                        cross_max_group=cross_max_group, n_layers=L - 1)
+                        cross_max_group=cross_max_group, n_layers=L - 1, self_done_first=shared)
         d = p["layers"][L - 1]
         q1 = torch.empty((P, H, 1, 64), dtype=torch.float16, device=dev)
         o1 = torch.empty((P, C), dtype=torch.float16, device=dev)
