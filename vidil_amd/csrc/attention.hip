@@ -43,6 +43,7 @@ struct AttnP {
   const int32_t* group_start;  // [n_kv+1] prefix of query batches per kv batch, or null
   int Bq, H, Nq, Nk, Tq_cap, Tk_cap, NP, kv_group, causal, causal_off, ldo, n_kv;
   int tiled;                   // K and V in 32-key fragment tiles (common.h: ktile_off / vtile_off); direct kernel only
+  int rb;                      // staged kernel, single key chunk: rounds of NW row blocks per workgroup (launch_lds)
 };
 
 constexpr int KROW = 72;  // halfs per K row in LDS (64 + 8 pad)
@@ -172,41 +173,17 @@ __global__ __launch_bounds__(NW * 64) void attn_lds_kernel(const AttnP p) {
   int bk, first, count;
   resolve_unit(p, blockIdx.z, bk, first, count);
   const int rows = count * p.Nq;
-  if ((int)blockIdx.x * (NW * 32) >= rows) return;  // uniform: this row tile is empty for this unit
   const int nk = p.Nk;
-
-  const int v0 = blockIdx.x * (NW * 32) + wave * 32;
-  const bool active = v0 < rows;            // waves without rows still stage and meet the barriers
-  const RowInfo ri = row_info(p, (active ? v0 : 0) + l31, first, rows);
-
-  f16x8 qf[4];
-  {
-    const f16* qg = p.q + (((size_t)ri.qb * p.H + h) * p.Tq_cap + ri.t) * 64 + hi * 8;
-#pragma unroll
-    for (int ks = 0; ks < 4; ++ks) qf[ks] = *(const f16x8*)(qg + ks * 16);
-  }
-  // smallest klim in the wave decides from which tile on masking is needed
-  int kmin = ri.klim;
-#pragma unroll
-  for (int o = 32; o > 0; o >>= 1) {
-    const int x = __shfl_xor(kmin, o, 64);
-    kmin = x < kmin ? x : kmin;
-  }
-
-  float m = -INFINITY, l = 0.f;
-  f32x16 O[2];
-#pragma unroll
-  for (int dt = 0; dt < 2; ++dt)
-#pragma unroll
-    for (int r = 0; r < 16; ++r) O[dt][r] = 0.f;
+  // Rows of a unit per workgroup: NW blocks of 32, or — when all keys fit one staged chunk — `rb` rounds of them
+  // (wave w then walks blocks w, w+NW, ...): a unit whose rows spill a little over NW*32 (8 captions x 35 tokens
+  // = 280 ITM rows) is then served by ONE staging of its K/V instead of two.
+  const int rows_per_wg = NW * 32 * (nk <= NKEY ? p.rb : 1);
+  const int base = blockIdx.x * rows_per_wg;
+  if (base >= rows) return;  // uniform: this row tile is empty for this unit
 
   const f16* kg = p.k + ((size_t)bk * p.H + h) * p.Tk_cap * 64;
   const f16* vg = p.vt + ((size_t)bk * p.H + h) * 64 * (size_t)p.NP;
-  // Keys are consumed in chunks of NKEY (one chunk when Nk <= NKEY; 577-key ViT@384 sequences take three
-  // 224-key chunks): stage the chunk, run its key tiles through the online softmax, re-stage.
-#pragma unroll 1
-  for (int k0 = 0; k0 < nk; k0 += NKEY) {
-    if (k0 > 0) __syncthreads();            // every wave is done reading the previous chunk
+  auto stage = [&](int k0) {
     // ---- stage K rows k0 .. k0+NKEY-1 (rows >= Nk zero) ------------------------------------------------
     for (int q = tid; q < NKEY * 8; q += NT) {
       const int row = q >> 3, c = q & 7;
@@ -245,29 +222,70 @@ __global__ __launch_bounds__(NW * 64) void attn_lds_kernel(const AttnP p) {
       }
       *(f16x8*)(Vs + d * VROW + kc * 8) = v;
     }
-    __syncthreads();
-    if (!active) continue;
+  };
+
+  // Keys are consumed in chunks of NKEY (one chunk when Nk <= NKEY; 577-key ViT@384 sequences take three
+  // 224-key chunks): stage the chunk, run its key tiles through the online softmax, re-stage.  Multi-chunk
+  // launches keep one row block per wave (its (m, l, O) lives across the chunks).
+  const int nblk = nk <= NKEY ? p.rb : 1;
+#pragma unroll 1
+  for (int rbi = 0; rbi < nblk; ++rbi) {
+    const int v0 = base + (rbi * NW + wave) * 32;
+    const bool active = v0 < rows;            // waves without rows still stage and meet the barriers
+    if (rbi > 0 && !active) break;            // (single chunk: nothing left to stage, no barrier ahead)
+    const RowInfo ri = row_info(p, (active ? v0 : 0) + l31, first, rows);
+
+    f16x8 qf[4];
+    {
+      const f16* qg = p.q + (((size_t)ri.qb * p.H + h) * p.Tq_cap + ri.t) * 64 + hi * 8;
+#pragma unroll
+      for (int ks = 0; ks < 4; ++ks) qf[ks] = *(const f16x8*)(qg + ks * 16);
+    }
+    // smallest klim in the wave decides from which tile on masking is needed
+    int kmin = ri.klim;
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+      const int x = __shfl_xor(kmin, o, 64);
+      kmin = x < kmin ? x : kmin;
+    }
+
+    float m = -INFINITY, l = 0.f;
+    f32x16 O[2];
+#pragma unroll
+    for (int dt = 0; dt < 2; ++dt)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) O[dt][r] = 0.f;
 
 #pragma unroll 1
-    for (int kt = 0; kt < NKT; ++kt) {
-      if (k0 + kt * 32 >= nk) break;
-      f32x16 S;
-#pragma unroll
-      for (int r = 0; r < 16; ++r) S[r] = 0.f;
-#pragma unroll
-      for (int ks = 0; ks < 4; ++ks) {
-        const f16x8 kf = *(const f16x8*)(Ks + (kt * 32 + l31) * KROW + ks * 16 + hi * 8);
-        S = __builtin_amdgcn_mfma_f32_32x32x16_f16(kf, qf[ks], S, 0, 0, 0);
+    for (int k0 = 0; k0 < nk; k0 += NKEY) {
+      if (rbi == 0) {
+        if (k0 > 0) __syncthreads();            // every wave is done reading the previous chunk
+        stage(k0);
+        __syncthreads();
       }
-      const bool need_mask = (k0 + kt * 32 + 32) > kmin;
-      softmax_pv_tile(S, k0 + kt * 32, ri.klim, need_mask, m, l, O, [&](int dt, int hb) {
-        return *(const f16x8*)(Vs + (dt * 32 + l31) * VROW + (kt * 2 + hb) * 16 + 8 * hi);
-      });
+      if (!active) continue;
+
+#pragma unroll 1
+      for (int kt = 0; kt < NKT; ++kt) {
+        if (k0 + kt * 32 >= nk) break;
+        f32x16 S;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) S[r] = 0.f;
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks) {
+          const f16x8 kf = *(const f16x8*)(Ks + (kt * 32 + l31) * KROW + ks * 16 + hi * 8);
+          S = __builtin_amdgcn_mfma_f32_32x32x16_f16(kf, qf[ks], S, 0, 0, 0);
+        }
+        const bool need_mask = (k0 + kt * 32 + 32) > kmin;
+        softmax_pv_tile(S, k0 + kt * 32, ri.klim, need_mask, m, l, O, [&](int dt, int hb) {
+          return *(const f16x8*)(Vs + (dt * 32 + l31) * VROW + (kt * 2 + hb) * 16 + 8 * hi);
+        });
+      }
     }
+    if (!active) break;
+    l += __shfl_xor(l, 32, 64);
+    store_rows(p, ri, h, O, l > 0.f ? 1.0f / l : 0.f);
   }
-  if (!active) return;
-  l += __shfl_xor(l, 32, 64);
-  store_rows(p, ri, h, O, l > 0.f ? 1.0f / l : 0.f);
 }
 
 // ------------------------------------------------------------------ direct (no K/V staging) kernel
@@ -485,8 +503,13 @@ int launch_lds(const AttnP& p, int max_rows, hipStream_t s) {
     }
     attr_set = true;
   }
-  dim3 grid((max_rows + NW * 32 - 1) / (NW * 32), p.H, p.n_kv);
-  hipLaunchKernelGGL(kern, grid, dim3(NW * 64), smem, s, p);
+  // rows a little over one round of NW blocks (the ITM cross-attention: 8 captions x 35 tokens = 280 rows per
+  // image with NW = 8): a second round in the same workgroup instead of a second workgroup that would stage the
+  // unit's K/V again for a handful of rows
+  AttnP q = p;
+  q.rb = (p.Nk <= NKT * 32 && max_rows > NW * 32 && max_rows <= NW * 32 + NW * 16) ? 2 : 1;
+  dim3 grid((max_rows + NW * 32 * q.rb - 1) / (NW * 32 * q.rb), p.H, p.n_kv);
+  hipLaunchKernelGGL(kern, grid, dim3(NW * 64), smem, s, q);
   VIDIL_CHECK_LAUNCH("attention");
   return VIDIL_OK;
 }
@@ -541,7 +564,7 @@ extern "C" int vidil_attention(const void* q, const void* k, const void* vt, voi
   }
   VIDIL_REQUIRE(H <= 65535 && units <= 65535, "attention: grid too large (H=%d units=%d)", H, units);
   AttnP p{(const f16*)q, (const f16*)k, (const f16*)vt, (f16*)out, kv_len, kv_index, group_start, Bq, H, Nq, Nk,
-          Tq_cap, Tk_cap, NP, kv_group, causal, causal_off, ldo, units, kv_tiled ? 1 : 0};
+          Tq_cap, Tk_cap, NP, kv_group, causal, causal_off, ldo, units, kv_tiled ? 1 : 0, 1};
   hipStream_t s = (hipStream_t)stream;
   const int nkt = (Nk + 31) / 32;
   VIDIL_REQUIRE(!kv_tiled || max_rows <= 32, "attention: tiled K/V serve at most 32 query rows per unit (got %d)", max_rows);
