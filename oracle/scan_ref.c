@@ -13,6 +13,12 @@
  * only exact ties on this path are duplicate class strings, which emit the
  * same text either way).
  *
+ * What pins THIS file to the reference form: tests/test_scan_ref_cpu.py compares its
+ * scores with numpy's `img @ txt.T` (f32 BLAS order and f64) and its top-k with
+ * `np.argsort(row)[::-1][:k]` as class TEXTS on the full 42,759-class layout; they
+ * are identical wherever the reference's own adjacent score gaps exceed the
+ * summation-order error (the test reports how few rows are not decided).
+ *
  * Build: gcc -O2 -ffp-contract=off -shared -fPIC -o oracle/_build/libscan_ref.so oracle/scan_ref.c -lm
  */
 #include <math.h>
@@ -28,6 +34,12 @@ float vidil_ref_score(const float* t, const float* f, int D) {
     }
   }
   return s;
+}
+
+/* dense scores out[f][c] = score(txt[c], img[f]) — for the comparison with numpy's matmul */
+void vidil_ref_scores(const float* img, const float* txt, int NF, int D, int NC, float* out) {
+  for (int f = 0; f < NF; ++f)
+    for (int c = 0; c < NC; ++c) out[(size_t)f * NC + c] = vidil_ref_score(txt + (size_t)c * D, img + (size_t)f * D, D);
 }
 
 static int better(float s1, int i1, float s2, int i2) { return s1 > s2 || (s1 == s2 && i1 < i2); }
