@@ -117,7 +117,9 @@ def test_load_checkpoint_semantics(tmp_path):
     from vidil_amd.blip import BLIP_Decoder, blip_decoder
     from vidil_amd.tokenizer import SyntheticBertTokenizer
 
-    tok = SyntheticBertTokenizer()
+    with pytest.raises(RuntimeError):        # a checkpoint + the stand-in vocabulary is refused unless asked for
+        blip_decoder(pretrained=os.path.join(tmp_path, "x.pth"), image_size=64, vit="base", tokenizer=SyntheticBertTokenizer())
+    tok = SyntheticBertTokenizer(allow_pretrained=True)
     src = BLIP_Decoder(image_size=64, vit="base", tokenizer=tok)
     sd = {k: v.clone() for k, v in src.state_dict().items()}
     big = torch.randn(1, 1 + 36, 768)          # a checkpoint trained at 96x96 (6x6 grid)
@@ -171,3 +173,64 @@ def test_balanced_shards_cover_everything_in_order():
         sizes = [e - s for s, e in bounds]
         assert max(sizes) - min(sizes) <= 1
     assert [e - s for s, e in (vdist.shard_bounds(16, 8, r) for r in range(8))] == [2] * 8
+
+
+def test_init_tokenizer_never_falls_back_silently(monkeypatch, tmp_path):
+    from vidil_amd import tokenizer as T
+
+    monkeypatch.setenv("VIDIL_TOKENIZER", "synthetic")
+    assert isinstance(T.init_tokenizer(), T.SyntheticBertTokenizer)
+    monkeypatch.delenv("VIDIL_TOKENIZER")
+    monkeypatch.setenv("VIDIL_BERT_VOCAB", str(tmp_path / "missing_vocab.txt"))
+    with pytest.raises(FileNotFoundError):
+        T.init_tokenizer()
+    monkeypatch.delenv("VIDIL_BERT_VOCAB")
+    monkeypatch.setenv("HF_HUB_OFFLINE", "1")
+    try:
+        tok = T.init_tokenizer()              # a box with the vocabulary cached gets the real tokenizer
+        assert not getattr(tok, "is_synthetic", False)
+    except RuntimeError as e:                 # no vocabulary anywhere: loud, and names the explicit opt-in
+        assert "VIDIL_TOKENIZER=synthetic" in str(e)
+    # a real vocab file works and carries the two added special tokens at the reference's ids
+    vocab = tmp_path / "vocab.txt"
+    words = ["[PAD]"] + [f"[unused{i}]" for i in range(99)] + ["[UNK]", "[CLS]", "[SEP]", "[MASK]"] + ["a", "picture", "of", "dog"]
+    vocab.write_text("\n".join(words) + "\n")
+    tok = T.init_tokenizer(str(vocab))
+    assert tok.bos_token_id == len(words) and tok.enc_token_id == len(words) + 1 and tok.sep_token_id == 102
+
+
+def test_capfilt_config_is_validated_up_front():
+    from vidil_amd.capfilt import validate_config
+
+    good = dict(caption=True, filter=True, filter_generated_only=True, keep_original_caption=False, threshold=0.4)
+    validate_config(good)
+    for k in ("caption", "filter", "threshold", "filter_generated_only", "keep_original_caption"):
+        bad = dict(good); bad.pop(k)
+        with pytest.raises(KeyError):
+            validate_config(bad)
+    with pytest.raises(ValueError):    # would keep every original caption unfiltered
+        validate_config(dict(caption=False, filter=True, filter_generated_only=True, threshold=0.4))
+    validate_config(dict(caption=False, filter=True, filter_generated_only=False, threshold=0.4))
+
+
+def test_split_sentences_requires_spacy_or_an_explicit_opt_in(monkeypatch):
+    from vidil_amd import capfilt
+
+    capfilt.split_sentences.__dict__.pop("_nlp", None)
+    try:
+        import spacy  # noqa: F401
+        spacy.load("en_core_web_sm")
+        have = True
+    except Exception:
+        have = False
+    if not have:
+        monkeypatch.delenv("VIDIL_SENTENCE_SPLIT", raising=False)
+        with pytest.raises(RuntimeError):
+            capfilt.split_sentences(["One sentence here. Another one there."])
+        monkeypatch.setenv("VIDIL_SENTENCE_SPLIT", "naive")
+        with pytest.warns(UserWarning):
+            out = capfilt.split_sentences(["One sentence here. Another one there."])
+        assert out == ["One sentence here", "Another one there."]
+        capfilt.split_sentences.__dict__.pop("_nlp", None)
+    assert capfilt.split_sentences(["a\nb"], do_sentence_tokenization=False) == ["a. b"]
+    assert capfilt.split_sentences([]) == []

@@ -623,6 +623,41 @@ def test_scan_topk_full_vg_ontology_config1_size_bit_exact():
         assert got_i[:, c].min() >= 0 and got_i[:, c].max() < L
 
 
+def test_scan_topk_config1_equals_the_reference_form_argsort_of_f32_matmul():
+    """The DEVICE scan against the reference form itself (run_visual_tokenization.py:276,298-308), not against the
+    oracle: 128 frames (config 1) x the 42,759-class vg layout, `img @ txt.T` in numpy f32 and
+    `np.argsort(score)[::-1][:5]` -> texts.  100 % of the (frame, category) lists must be equal wherever the
+    reference's own ranking is decided at the summation-order resolution; the number of undecided lists is printed."""
+    import scan_cases as sc
+
+    k = _k()
+    NF, D, topk = 128, 512, 5
+    emb, texts = sc.vg_layout(D)
+    img = sc.frames(NF, D, emb=emb, near=32)
+    ref_texts, s32, s64 = sc.reference_form(img, emb, texts, topk)
+    mat, seg_start, seg_len = sc.packed(emb)
+    oi, os_ = k.scan_topk(torch.from_numpy(img).to(DEV), torch.from_numpy(mat).to(DEV), seg_start, seg_len, topk)
+    gi, gs = oi.cpu().numpy(), os_.cpu().numpy()
+    err_dev = err_np = 0.0
+    for c, key in enumerate(sc.CATS):
+        ref_at = np.take_along_axis(s64[key], gi[:, c].astype(np.int64), axis=1)
+        err_dev = max(err_dev, float(np.abs(gs[:, c] - ref_at).max()))
+        err_np = max(err_np, float(np.abs(s32[key] - s64[key]).max()))
+    assert err_dev < 3e-6 and err_np < 3e-6, (err_dev, err_np)
+    tau = 2.0 * (err_dev + err_np)
+    masked = bad = 0
+    for f in range(NF):
+        for c, key in enumerate(sc.CATS):
+            if sc.undecided(s64[key][f], tau, topk):
+                masked += 1
+                continue
+            bad += int([texts[key][int(i)] for i in gi[f, c]] != ref_texts[key][f])
+    print(f"device scan vs numpy reference form: max|score err| {err_dev:.2e} (numpy f32 {err_np:.2e}), tau {tau:.2e}, "
+          f"undecided lists {masked}/{NF * 4}, mismatches outside the mask {bad}")
+    assert bad == 0
+    assert masked <= NF * 4 // 20
+
+
 @pytest.mark.parametrize("D", [512, 768])     # CLIP-B/32 and CLIP-L/14 projection widths
 def test_scan_topk_bit_exact_vs_oracle(D):
     k = _k()

@@ -590,6 +590,38 @@ def test_device_beam_search_random_tables_match_oracle():
         assert score[b].item() == pytest.approx(scores[b], rel=1e-5)
 
 
+@pytest.mark.parametrize("nb,max_len,min_len", [(3, 20, 5), (3, 12, 6), (2, 9, 5)])
+def test_device_beam_search_equals_installed_transformers_when_nothing_ends_early(nb, max_len, min_len):
+    """The device beam kernels (HF 4.15 rule) against EXECUTABLE third-party code: the installed transformers'
+    generate(num_beams=...) on a full-vocabulary table LM whose [SEP] is never in reach — the regime of the random-weight
+    benchmark, where the 4.15 and 5.x rules rank identically (tests/test_beam_hf.py).  Token ids must be identical."""
+    from oracle import hf_beam
+
+    K = _K()
+    B, V, EOS, PAD = 3, 30524, 102, 0
+    fn = hf_beam.table_logits_fn(V, 7 + nb, EOS, eos_boost=0.0, ban=(PAD,), scale=3.0)
+    prompt = np.array([[30522, 1037, 3861, 1997]] * B, dtype=np.int64)
+    prompt[:, 1] += np.arange(B)
+    hseqs, hscores = hf_beam.hf_generate(fn, prompt, V, num_beams=nb, max_length=max_len, min_length=min_len,
+                                         eos_token_id=EOS, pad_token_id=PAD)
+    bufs = K.BeamBuffers(B, nb, max_len, DEV)
+    bufs.reset(torch.from_numpy(prompt).to(torch.int32).to(DEV))
+    cur_len = 4
+    while True:
+        ids = bufs.seqs[:, :cur_len].cpu().numpy().astype(np.int64)
+        cs, ci = K.logsoftmax_topk(torch.from_numpy(fn(ids)).to(DEV), bufs.beam_scores, B, nb, EOS if cur_len < min_len else -1)
+        K.beam_update(bufs, cs, ci, V, cur_len, EOS, PAD)
+        cur_len += 1
+        if cur_len >= max_len or int(bufs.n_done.item()) == B:
+            break
+    tok, ln, score = K.beam_finalize(bufs, cur_len, EOS, PAD)
+    tok = tok.cpu().numpy()
+    for b in range(B):
+        # (5.x pads its output with EOS when pad_token_id == 0: compare the max_len real tokens)
+        assert tok[b][:max_len].tolist() == hseqs[b][:max_len].tolist(), (b, tok[b], hseqs[b])
+        assert score[b].item() * max_len == pytest.approx(hscores[b] * (max_len - 4), rel=1e-4)
+
+
 # =============================================================== end to end vs the oracle pipeline
 def _ontology(dim=512, seed=3):
     g = torch.Generator().manual_seed(seed)

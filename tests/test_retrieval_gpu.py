@@ -84,7 +84,10 @@ def test_blip_retrieval_features_rerank_and_tokenizer_vs_oracle(tmp_path):
     x = clip_ref.preprocess_u8(u8)
     texts = {key: [f"w{1000 + 37 * c + j} w{2000 + j}" if j % 3 else f"w{3000 + 11 * c + j}" for j in range(n)]
              for c, (key, n) in enumerate(zip(CATEGORIES, (23, 17, 9, 12)))}
-    tok = BlipVisualTokenizer(dict(topk_visualize=topk, k_test=k_test, image_size=64), m, texts, DEV)
+    # the reference embeds / re-ranks the PROMPTED strings ('v1': "A photo of {x}", run_visual_tokenization.py:199-201)
+    # for encoder_version blip too, and emits the raw class strings
+    tok = BlipVisualTokenizer(dict(topk_visualize=topk, k_test=k_test, image_size=64,
+                                   prompt_version_visual_tokenization="v1"), m, texts, DEV)
     with torch.no_grad():
         y_ref, img_ref = retrieval_ref.image_features(sd, x, depth=2, heads=4)
     y16, img = m.image_features_u8(torch.from_numpy(u8).to(DEV))
@@ -92,7 +95,7 @@ def test_blip_retrieval_features_rerank_and_tokenizer_vs_oracle(tmp_path):
     idx, score = tok.frame_topk(torch.from_numpy(u8).to(DEV))
     idx, score = idx.cpu().numpy(), score.cpu().numpy()
     for c, key in enumerate(CATEGORIES):
-        ids, lens = m.tokenize(texts[key])
+        ids, lens = m.tokenize([f"A photo of {t}" for t in texts[key]])
         mask = (torch.arange(35)[None] < lens[:, None]).long()
         with torch.no_grad():
             txt_ref = retrieval_ref.text_features(sd, ids.long(), mask, layers=2, H=4)
@@ -114,3 +117,5 @@ def test_blip_retrieval_features_rerank_and_tokenizer_vs_oracle(tmp_path):
                 assert list(idx[f, c]) == list(order), (key, f, idx[f, c], order)
     out = tok.process(["v0"], torch.from_numpy(u8[None]).to(DEV), [["cap"]])
     assert set(out["v0"]["frame_tokens"][0].keys()) == set(CATEGORIES) and len(out["v0"]["frame_tokens"]) == NF
+    for key in CATEGORIES:                                       # emitted tokens are the unprompted class strings
+        assert all(t in texts[key] for fr in out["v0"]["frame_tokens"] for t in fr[key])

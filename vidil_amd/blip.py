@@ -18,7 +18,7 @@ import torch.nn as nn
 from . import kernels as K
 from .med import BeamArena, BertConfig, BertLMHeadModel
 from .packing import require_cuda
-from .tokenizer import init_tokenizer  # noqa: F401  (re-exported, reference API)
+from .tokenizer import init_tokenizer, refuse_synthetic_with_checkpoint  # noqa: F401  (init_tokenizer re-exported, reference API)
 from .vit import VisionTransformer, interpolate_pos_embed
 
 _DEFAULT_MED_CONFIG = os.path.join(os.path.dirname(os.path.abspath(__file__)), "configs", "med_config.json")
@@ -320,6 +320,7 @@ def blip_decoder(pretrained="", **kwargs):
     """Reference: models/blip.py:269-274."""
     model = BLIP_Decoder(**kwargs)
     if pretrained:
+        refuse_synthetic_with_checkpoint(model.tokenizer, pretrained)
         model, msg = load_checkpoint(model, pretrained)
         assert len(msg.missing_keys) == 0
     return model

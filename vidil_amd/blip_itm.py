@@ -17,7 +17,7 @@ from . import kernels as K
 from .blip import create_vit, load_checkpoint, resolve_med_config
 from .med import BertConfig, BertModel
 from .packing import PackedCache, require_cuda, v32, w16
-from .tokenizer import init_tokenizer
+from .tokenizer import init_tokenizer, refuse_synthetic_with_checkpoint
 
 ITM_MAX_LENGTH = 35  # models/blip_itm.py:46
 
@@ -105,6 +105,7 @@ def blip_itm(pretrained="", **kwargs):
     """Reference: models/blip_itm.py:70-75."""
     model = BLIP_ITM(**kwargs)
     if pretrained:
+        refuse_synthetic_with_checkpoint(model.tokenizer, pretrained)
         model, msg = load_checkpoint(model, pretrained)
         assert len(msg.missing_keys) == 0
     return model

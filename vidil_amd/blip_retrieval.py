@@ -20,6 +20,7 @@ from . import kernels as K
 from .blip import CLIP_MEAN, CLIP_STD, load_checkpoint
 from .blip_itm import ITM_MAX_LENGTH, BLIP_ITM
 from .packing import require_cuda, v32, w16
+from .tokenizer import refuse_synthetic_with_checkpoint
 
 
 class BLIP_Retrieval(BLIP_ITM):
@@ -105,6 +106,7 @@ def blip_retrieval(pretrained="", **kwargs):
     """Reference: models/blip_retrieval.py:567-573 (prints, does not assert, the missing keys)."""
     model = BLIP_Retrieval(**kwargs)
     if pretrained:
+        refuse_synthetic_with_checkpoint(model.tokenizer, pretrained)
         model, msg = load_checkpoint(model, pretrained)
         print("missing keys:")
         print(msg.missing_keys)

@@ -59,31 +59,65 @@ def dedup(captions):
 
 
 def split_sentences(texts, do_sentence_tokenization=True):
-    """run_video_CapFilt.py:166-175.  spaCy when installed; otherwise newline/period splitting."""
+    """run_video_CapFilt.py:166-175: spaCy ``doc.sents`` of every original caption.
+
+    Without spaCy (or its ``en_core_web_sm`` model) the sentence boundaries — hence which original-caption sentences
+    become candidates — would differ from the reference, so that is an error unless the plain '. ' splitter is
+    requested explicitly with VIDIL_SENTENCE_SPLIT=naive (a one-time warning is printed then)."""
     if not texts:
         return []
     if not do_sentence_tokenization:
         return [t.replace("\n", ". ").strip() for t in texts]
-    try:
-        import spacy
+    nlp = split_sentences.__dict__.get("_nlp")
+    if nlp is None:
+        try:
+            import spacy
 
-        nlp = split_sentences.__dict__.get("_nlp")
-        if nlp is None:
             nlp = spacy.load("en_core_web_sm", disable=["ner", "tagger", "lemmatizer"])
-            split_sentences._nlp = nlp
-        out = []
-        for t in texts:
-            for sent in nlp(t.replace("\n", ". ")).sents:
-                if len(sent.text) > 3:
-                    out.append(sent.text.strip())
-        return out
-    except ImportError:
-        out = []
-        for t in texts:
-            for s in t.replace("\n", ". ").split(". "):
-                if len(s) > 3:
-                    out.append(s.strip())
-        return out
+        except (ImportError, OSError) as e:
+            if os.environ.get("VIDIL_SENTENCE_SPLIT", "") != "naive":
+                raise RuntimeError(
+                    "do_sentence_tokenization needs spaCy with en_core_web_sm (as the reference, run_video_CapFilt.py:"
+                    "166-175); set VIDIL_SENTENCE_SPLIT=naive to accept plain '. ' splitting instead, or "
+                    "do_sentence_tokenization: false") from e
+            import warnings
+
+            warnings.warn("vidil_amd.capfilt: spaCy/en_core_web_sm not available; splitting original captions on '. ' "
+                          "(VIDIL_SENTENCE_SPLIT=naive) — sentence boundaries may differ from the reference")
+            nlp = "naive"
+        split_sentences._nlp = nlp
+    out = []
+    for t in texts:
+        if nlp == "naive":
+            sents = t.replace("\n", ". ").split(". ")
+        else:
+            sents = [sent.text for sent in nlp(t.replace("\n", ". ")).sents]
+        for sent in sents:
+            if len(sent) > 3:
+                out.append(sent.strip())
+    return out
+
+
+_REQUIRED_KEYS = ("caption", "filter")
+
+
+def validate_config(cfg):
+    """The reference indexes its YAML directly (run_video_CapFilt.py:141-204): a missing key is a KeyError there, and
+    some combinations cannot work.  Check up front instead of defaulting silently."""
+    for k in _REQUIRED_KEYS:
+        if k not in cfg:
+            raise KeyError(f"CapFilt config lacks '{k}' (the reference's pipeline YAMLs set it)")
+    if cfg["filter"]:
+        for k in ("threshold", "filter_generated_only"):
+            if k not in cfg:
+                raise KeyError(f"CapFilt config lacks '{k}' (required when filter is on)")
+    if cfg["caption"] and "keep_original_caption" not in cfg:
+        raise KeyError("CapFilt config lacks 'keep_original_caption' (required when caption is on)")
+    if cfg["filter"] and not cfg["caption"] and cfg["filter_generated_only"]:
+        raise ValueError("caption=False with filter=True and filter_generated_only=True filters an empty list and keeps "
+                         "every original caption unfiltered; set filter_generated_only=False to filter the originals")
+    if cfg.get("filter_mode", "max_filter") not in ("max_filter", "avg_filter"):
+        raise ValueError(f"unknown filter_mode {cfg['filter_mode']!r}")
 
 
 class CapFiltEngine:
@@ -95,6 +129,7 @@ class CapFiltEngine:
     """
 
     def __init__(self, config, device, captioner=None, filterer=None):
+        validate_config(config)
         self.config = config
         self.device = torch.device(device)
         S, vit = config.get("image_size", 224), config.get("vit", "base")
@@ -116,7 +151,7 @@ class CapFiltEngine:
         Nv, F = frames_u8.shape[0], frames_u8.shape[1]
         flat = blip_frames(frames_u8.reshape(Nv * F, *frames_u8.shape[2:]), cfg.get("image_size", 224))
         generated = [[] for _ in range(Nv)]
-        if cfg.get("caption", True):
+        if cfg["caption"]:
             _, y16 = self.captioner.visual_encoder.forward_u8(flat, CLIP_MEAN, CLIP_STD)
             if cfg.get("generation_mode", "beam") == "beam":
                 out_tok, _ = self.captioner.generate_ids(y16, Nv * F, num_beams=3, max_length=20, min_length=5)
@@ -130,28 +165,28 @@ class CapFiltEngine:
         to_filter = []
         for v, item in enumerate(items):
             orig = split_sentences(item.get("text", []), cfg.get("do_sentence_tokenization", True))
-            if not cfg.get("caption", True):
+            if not cfg["caption"]:
                 cand = orig
                 item["unfiltered_text"] = cand
                 gen = []
             else:
                 gen = generated[v]
-                if cfg.get("keep_original_caption", False):
+                if cfg["keep_original_caption"]:
                     cand = orig + gen
                 else:
                     item["text"] = []
                     cand = gen
                 item["unfiltered_text"] = cand
-            if cfg.get("filter", True):
-                to_filter.append(gen if cfg.get("filter_generated_only", True) else cand)
+            if cfg["filter"]:
+                to_filter.append(gen if cfg["filter_generated_only"] else cand)
             else:
                 item["text"] = cand
                 to_filter.append(None)
         n_pairs = 0
-        if cfg.get("filter", True):
+        if cfg["filter"]:
             kept = self._filter_batch(flat, Nv, F, to_filter)
             for v, item in enumerate(items):
-                if cfg.get("filter_generated_only", True):
+                if cfg["filter_generated_only"]:
                     item["text"] = list(item.get("text", [])) + kept[v]
                 else:
                     item["text"] = kept[v]
@@ -199,7 +234,7 @@ class CapFiltEngine:
             # rows of this video: F consecutive blocks of len(caps) pairs -> [F, C] -> per caption over frames
             pv = prob[gs[v * F]: gs[v * F] + F * len(caps)].reshape(F, len(caps))
             for ci, c in enumerate(caps):
-                if keep_caption(pv[:, ci], cfg.get("threshold", 0.4), cfg.get("filter_mode", "max_filter")):
+                if keep_caption(pv[:, ci], cfg["threshold"], cfg.get("filter_mode", "max_filter")):
                     kept[v].append(c)
         return kept
 

@@ -97,23 +97,33 @@ def _comm_device():
 
 
 def gather_json(obj):
-    """Gather one JSON-serialisable object per rank; rank 0 gets the list in rank order, others None."""
+    """Gather one JSON-serialisable object per rank TO RANK 0 (rank order); other ranks get None.
+
+    Sizes first (all_gather of one int64), then the payloads: rank 0 posts one receive per peer sized to that peer's
+    payload and the peers send — nothing is padded, nothing lands on ranks that do not need it.  RCCL (backend 'nccl')
+    moves device buffers over xGMI; Gloo moves host buffers."""
     if not is_dist_avail_and_initialized():
         return [obj]
     dev = _comm_device()
-    payload = torch.frombuffer(bytearray(json.dumps(obj).encode("utf-8")), dtype=torch.uint8).to(dev)
-    world = dist.get_world_size()
-    size = torch.tensor([payload.numel()], dtype=torch.int64, device=dev)
+    raw = json.dumps(obj).encode("utf-8")
+    world, rank = dist.get_world_size(), dist.get_rank()
+    size = torch.tensor([len(raw)], dtype=torch.int64, device=dev)
     sizes = [torch.zeros(1, dtype=torch.int64, device=dev) for _ in range(world)]
     dist.all_gather(sizes, size)
-    mx = int(max(int(s.item()) for s in sizes))
-    buf = torch.zeros(mx, dtype=torch.uint8, device=dev)
-    buf[: payload.numel()] = payload
-    bufs = [torch.zeros(mx, dtype=torch.uint8, device=dev) for _ in range(world)]
-    dist.all_gather(bufs, buf)
-    if dist.get_rank() != 0:
+    sizes = [int(s.item()) for s in sizes]
+    if rank != 0:
+        if sizes[rank]:
+            dist.send(torch.frombuffer(bytearray(raw), dtype=torch.uint8).to(dev), dst=0)
         return None
-    return [json.loads(bytes(b[: int(s.item())].cpu().tolist()).decode("utf-8")) for b, s in zip(bufs, sizes)]
+    parts = [obj]
+    for r in range(1, world):
+        if sizes[r] == 0:
+            parts.append(json.loads("null"))
+            continue
+        buf = torch.empty(sizes[r], dtype=torch.uint8, device=dev)
+        dist.recv(buf, src=r)
+        parts.append(json.loads(buf.cpu().numpy().tobytes().decode("utf-8")))
+    return parts
 
 
 def merge_rank_dicts(parts):

@@ -1,12 +1,18 @@
 """Tokenizers at the text <-> id boundary.
 
 The reference uses HuggingFace ``BertTokenizer('bert-base-uncased')`` plus two added
-special tokens (models/blip.py:290-295).  Its vocabulary file is a download; when it
-is not available (no network on the GPU box) ``init_tokenizer`` falls back to
-``SyntheticBertTokenizer``, an id-preserving stand-in: token id N <-> the word
-``wN`` (and the three prompt words keep their real bert-base-uncased ids), so the
-whole string-level pipeline — decode, prompt stripping, exact-match dedup,
-re-tokenisation for the ITM filter — still runs and round-trips ids exactly.
+special tokens (models/blip.py:290-295).  ``init_tokenizer`` builds exactly that (from
+``vocab_file`` / $VIDIL_BERT_VOCAB, a local HF cache, or the hub) and RAISES when it
+cannot: a real checkpoint decoded through a stand-in vocabulary would write garbage
+captions without any error.
+
+``SyntheticBertTokenizer`` is an id-preserving stand-in for benchmarks and tests on
+boxes without the vocabulary (token id N <-> the word ``wN``; the three prompt words
+keep their real bert-base-uncased ids), so the whole string-level pipeline — decode,
+prompt stripping, exact-match dedup, re-tokenisation for the ITM filter — still runs
+and round-trips ids exactly.  It is used only on explicit request: pass
+``tokenizer=SyntheticBertTokenizer()`` to the model constructors, or set
+``VIDIL_TOKENIZER=synthetic``; the factories refuse it together with ``pretrained=``.
 """
 from __future__ import annotations
 
@@ -42,6 +48,10 @@ class SyntheticBertTokenizer:
     enc_token_id = ENC
     additional_special_tokens_ids = [ENC]
     is_synthetic = True
+
+    def __init__(self, allow_pretrained=False):
+        # allow_pretrained: tests that exercise load_checkpoint on synthetic checkpoints; never for real ones
+        self.allow_pretrained = allow_pretrained
 
     def add_special_tokens(self, mapping):
         return 0
@@ -99,22 +109,48 @@ class SyntheticBertTokenizer:
 
 
 def init_tokenizer(vocab_file=None):
-    """Reference: models/blip.py:290-295.  Real BertTokenizer when its vocabulary can be found
-    (``vocab_file``, $VIDIL_BERT_VOCAB, or a local HF cache), SyntheticBertTokenizer otherwise."""
-    vocab_file = vocab_file or os.environ.get("VIDIL_BERT_VOCAB")
-    tok = None
-    try:
-        from transformers import BertTokenizer
+    """Reference: models/blip.py:290-295 — BertTokenizer('bert-base-uncased') + '[DEC]' (bos) + '[ENC]'.
 
-        if vocab_file:
-            tok = BertTokenizer(vocab_file=vocab_file)
-        elif os.environ.get("VIDIL_TOKENIZER", "") != "synthetic":
-            tok = BertTokenizer.from_pretrained("bert-base-uncased", local_files_only=True)
-    except Exception:
-        tok = None
-    if tok is None:
+    Sources, in order: ``vocab_file`` / $VIDIL_BERT_VOCAB (a vocab.txt; a wrong path raises), the local HF cache,
+    the hub (as the reference's ``from_pretrained`` does).  ``VIDIL_TOKENIZER=synthetic`` selects the stand-in
+    explicitly.  Anything else that fails raises: there is no silent fallback."""
+    if os.environ.get("VIDIL_TOKENIZER", "") == "synthetic":
         return SyntheticBertTokenizer()
+    vocab_file = vocab_file or os.environ.get("VIDIL_BERT_VOCAB")
+    from transformers import BertTokenizer
+
+    if vocab_file:
+        if not os.path.isfile(vocab_file):
+            raise FileNotFoundError(f"init_tokenizer: vocabulary file {vocab_file!r} does not exist")
+        with open(vocab_file, encoding="utf-8") as f:
+            vocab = {w.rstrip("\n"): i for i, w in enumerate(f)}
+        try:
+            tok = BertTokenizer(vocab=vocab)               # transformers 5.x (vocab_file= is silently ignored there)
+        except TypeError:
+            tok = BertTokenizer(vocab_file=vocab_file)     # transformers 4.x, the reference's API
+        if len(tok) != len(vocab):
+            raise RuntimeError(f"init_tokenizer: BertTokenizer holds {len(tok)} entries, {vocab_file!r} has {len(vocab)}")
+    else:
+        try:
+            tok = BertTokenizer.from_pretrained("bert-base-uncased", local_files_only=True)
+        except Exception:
+            try:
+                tok = BertTokenizer.from_pretrained("bert-base-uncased")
+            except Exception as e:
+                raise RuntimeError(
+                    "init_tokenizer: the bert-base-uncased vocabulary is not available (no local HF cache, no network). "
+                    "Point $VIDIL_BERT_VOCAB at a vocab.txt, or — for benchmarks / tests with random weights only — "
+                    "request the id-preserving stand-in explicitly: tokenizer=SyntheticBertTokenizer() or "
+                    "VIDIL_TOKENIZER=synthetic.") from e
     tok.add_special_tokens({"bos_token": "[DEC]"})
     tok.add_special_tokens({"additional_special_tokens": ["[ENC]"]})
-    tok.enc_token_id = tok.additional_special_tokens_ids[0]
+    tok.enc_token_id = tok.convert_tokens_to_ids("[ENC]")     # (== additional_special_tokens_ids[0] of the 4.x API)
     return tok
+
+
+def refuse_synthetic_with_checkpoint(tokenizer, pretrained):
+    """A real checkpoint with the stand-in vocabulary decodes to pseudo-words that the ITM filter re-tokenises
+    consistently — garbage written to video_text_CapFilt.json without an error.  Refuse the combination."""
+    if pretrained and getattr(tokenizer, "is_synthetic", False) and not getattr(tokenizer, "allow_pretrained", False):
+        raise RuntimeError("a pretrained checkpoint needs the real bert-base-uncased tokenizer, not SyntheticBertTokenizer "
+                           "(unset VIDIL_TOKENIZER=synthetic / pass a real tokenizer, or set $VIDIL_BERT_VOCAB)")
