@@ -234,3 +234,57 @@ def test_split_sentences_requires_spacy_or_an_explicit_opt_in(monkeypatch):
         capfilt.split_sentences.__dict__.pop("_nlp", None)
     assert capfilt.split_sentences(["a\nb"], do_sentence_tokenization=False) == ["a. b"]
     assert capfilt.split_sentences([]) == []
+
+
+def test_clip_model_from_pretrained_reads_the_hf_directory_layout(tmp_path):
+    """run_visual_tokenization.py:347-348 `CLIPModel.from_pretrained(name)`: a directory written by the installed
+    transformers' save_pretrained (config.json + model.safetensors) loads key for key."""
+    transformers = pytest.importorskip("transformers")
+    from vidil_amd.clip import CLIPModel
+
+    hc = transformers.CLIPConfig(
+        text_config=dict(hidden_size=128, intermediate_size=256, num_hidden_layers=2, num_attention_heads=2, vocab_size=300,
+                         max_position_embeddings=16, eos_token_id=299, bos_token_id=298),
+        vision_config=dict(hidden_size=192, intermediate_size=384, num_hidden_layers=2, num_attention_heads=3, image_size=64,
+                           patch_size=16),
+        projection_dim=96)
+    torch.manual_seed(3)
+    hf = transformers.CLIPModel(hc).eval()
+    hf.save_pretrained(str(tmp_path))
+    m = CLIPModel.from_pretrained(str(tmp_path))
+    assert m.config.projection_dim == 96 and m.config.vision_config.patch_size == 16 and m.config.text_config.vocab_size == 300
+    assert m.config.text_config.eos_token_id == 299
+    ref = {k: v for k, v in hf.state_dict().items() if not k.endswith("position_ids")}
+    own = m.state_dict()
+    assert set(ref) == set(own)
+    assert all(torch.equal(own[k], ref[k]) for k in ref)
+    # state_dict= form, and a checkpoint that lacks a tensor is an error, not a silent random init
+    m2 = CLIPModel.from_pretrained(str(tmp_path), state_dict=ref)
+    assert torch.equal(m2.state_dict()["visual_projection.weight"], ref["visual_projection.weight"])
+    bad = dict(ref); bad.pop("logit_scale")
+    with pytest.raises(RuntimeError):
+        CLIPModel.from_pretrained(str(tmp_path), state_dict=bad)
+
+
+def test_clip_processor_text_side_and_no_cpu_fallback_for_images():
+    from vidil_amd.clip import CLIPProcessor
+    from vidil_amd.tokenizer import Encoding
+
+    def fake_bpe(texts, return_tensors="pt", padding=True, truncation=True, **_):
+        L = max(len(t.split()) for t in texts) + 2
+        ids = torch.full((len(texts), L), 49407, dtype=torch.long)
+        mask = torch.zeros((len(texts), L), dtype=torch.long)
+        for i, t in enumerate(texts):
+            n = len(t.split())
+            ids[i, 0] = 49406
+            ids[i, 1:1 + n] = torch.tensor([1000 + len(w) for w in t.split()])
+            mask[i, :n + 2] = 1
+        return Encoding(input_ids=ids, attention_mask=mask)
+
+    proc = CLIPProcessor(tokenizer=fake_bpe)
+    enc = proc(text=["A photo of dog", "A photo of a big cat"], return_tensors="pt", padding=True, truncation=True)
+    assert tuple(enc["input_ids"].shape) == (2, 8) and "pixel_values" not in enc
+    assert enc.to("cpu")["attention_mask"].sum().item() == 6 + 8
+    if not torch.cuda.is_available():
+        with pytest.raises(Exception):
+            proc(images=[np.zeros((10, 12, 3), np.uint8)], return_tensors="pt")

@@ -77,3 +77,43 @@ def test_engines_accept_non_square_frames_end_to_end():
     assert torch.equal(y1, y2)
     clip = CLIPModel().eval().to(DEV)
     assert torch.equal(clip.encode_image_u8(clip_frames(x, 224)), clip.encode_image_u8(ref_c))
+
+
+def test_clip_processor_and_model_call_signatures_of_the_reference():
+    """run_visual_tokenization.py:138-142: processor(text=..., images=[PIL ...], return_tensors='pt', padding=True)
+    .to(device) -> model(**inputs).image_embeds; images of mixed sizes, resized on the GPU like CLIPImageProcessor."""
+    from PIL import Image
+
+    from vidil_amd.clip import CLIPConfig, CLIPModel, CLIPProcessor, CLIPTextConfig, CLIPVisionConfig
+    from vidil_amd.tokenizer import Encoding
+
+    rng = np.random.default_rng(5)
+    imgs = [rng.integers(0, 256, size=s, dtype=np.uint8) for s in ((90, 160, 3), (120, 100, 3), (90, 160, 3), (64, 64, 3))]
+
+    def fake_bpe(texts, return_tensors="pt", padding=True, truncation=True, **_):
+        ids = torch.full((len(texts), 6), 299, dtype=torch.long)
+        ids[:, 0] = 298
+        ids[:, 1] = torch.arange(len(texts)) + 5
+        return Encoding(input_ids=ids, attention_mask=torch.ones_like(ids))
+
+    proc = CLIPProcessor(tokenizer=fake_bpe, image_size=64)
+    inputs = proc(text=["hello world"], images=[Image.fromarray(a) for a in imgs], return_tensors="pt", padding=True).to(DEV)
+    pv = inputs["pixel_values"]
+    assert pv.dtype == torch.uint8 and tuple(pv.shape) == (4, 64, 64, 3) and pv.is_cuda
+    for i, a in enumerate(imgs):           # byte-identical with the Pillow path of HF's CLIPImageProcessor
+        assert np.array_equal(pv[i].cpu().numpy(), R.clip_process_frame_u8(a, 64)), i
+    torch.manual_seed(0)
+    cfg = CLIPConfig(CLIPVisionConfig(hidden_size=128, intermediate_size=256, num_hidden_layers=1, num_attention_heads=2,
+                                      image_size=64, patch_size=16),
+                     CLIPTextConfig(vocab_size=300, hidden_size=128, intermediate_size=256, num_hidden_layers=1,
+                                    num_attention_heads=2, max_position_embeddings=16, eos_token_id=299), 64)
+    model = CLIPModel(cfg).eval().to(DEV)
+    out = model(**inputs)
+    assert tuple(out.image_embeds.shape) == (4, 64) and tuple(out.text_embeds.shape) == (1, 64)
+    assert torch.allclose(out.image_embeds.norm(dim=-1), torch.ones(4, device=DEV), atol=1e-5)
+    assert torch.equal(out.image_embeds[0], out.image_embeds[2])        # identical frames -> identical embeddings
+    # the HF-style f32 NCHW pixel_values entry point gives the same embeddings up to the f16 rounding of the input
+    x = (pv.float().permute(0, 3, 1, 2) / 255.0 - torch.tensor((0.48145466, 0.4578275, 0.40821073), device=DEV).view(1, 3, 1, 1)) \
+        / torch.tensor((0.26862954, 0.26130258, 0.27577711), device=DEV).view(1, 3, 1, 1)
+    out2 = model(pixel_values=x.contiguous())
+    assert (out2.image_embeds - out.image_embeds).abs().max().item() < 2e-3

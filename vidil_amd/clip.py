@@ -1,6 +1,8 @@
 """CLIP towers on the HIP kernels — stand-in for the HuggingFace ``CLIPModel`` /
 ``CLIPProcessor`` objects the reference drives in run_visual_tokenization.py
-(:83-96 text embeddings, :135-143 image embeddings, :347-350 construction).
+(:83-96 text embeddings, :135-143 image embeddings, :347-350 construction), with the same call signatures:
+``CLIPModel.from_pretrained(name)``, ``CLIPProcessor.from_pretrained(name)``, ``processor(text=..., images=...,
+return_tensors='pt', padding=True).to(device)``, ``model(**inputs)``.
 
 Same parameter names as HF's ``CLIPModel.state_dict()`` (so ``openai/clip-vit-*``
 weights load with ``load_state_dict``), same outputs (``.image_embeds`` /
@@ -172,6 +174,46 @@ class CLIPModel(PackedCache, nn.Module):
         self.logit_scale = nn.Parameter(torch.tensor(2.6592))
         self.apply(self._init)
 
+    @classmethod
+    def from_pretrained(cls, name_or_path, state_dict=None, **kw):
+        """``CLIPModel.from_pretrained(name)`` of the reference (run_visual_tokenization.py:347-348).  ``name_or_path``: a
+        directory holding ``config.json`` + ``model.safetensors`` / ``pytorch_model.bin`` (the layout ``save_pretrained``
+        and the hub use), or a hub id, resolved through the local HF cache / the hub with ``huggingface_hub``.
+        ``state_dict``: load these tensors instead of the files (config still from ``name_or_path`` if it is a
+        directory, else the ViT-B/32 defaults)."""
+        import json
+        import os
+
+        path = str(name_or_path)
+        if not os.path.isdir(path) and state_dict is None:
+            from huggingface_hub import snapshot_download
+
+            path = snapshot_download(path, allow_patterns=["config.json", "preprocessor_config.json", "model.safetensors",
+                                                           "pytorch_model.bin"], **kw)
+        cfg = None
+        cj = os.path.join(path, "config.json")
+        if os.path.isfile(cj):
+            with open(cj) as f:
+                c = json.load(f)
+            cfg = CLIPConfig(CLIPVisionConfig(**c.get("vision_config", {})), CLIPTextConfig(**c.get("text_config", {})),
+                             c.get("projection_dim", 512))
+        model = cls(cfg)
+        if state_dict is None:
+            st = os.path.join(path, "model.safetensors")
+            if os.path.isfile(st):
+                from safetensors.torch import load_file
+
+                state_dict = load_file(st)
+            else:
+                state_dict = torch.load(os.path.join(path, "pytorch_model.bin"), map_location="cpu")
+        state_dict = {k: v for k, v in state_dict.items() if not k.endswith("position_ids")}    # buffers of older HF versions
+        msg = model.load_state_dict(state_dict, strict=False)
+        if msg.missing_keys:
+            raise RuntimeError(f"CLIPModel.from_pretrained: checkpoint lacks {msg.missing_keys[:5]} ...")
+        if msg.unexpected_keys:
+            raise RuntimeError(f"CLIPModel.from_pretrained: unexpected keys {msg.unexpected_keys[:5]} ...")
+        return model.eval()
+
     @staticmethod
     def _init(m):
         if isinstance(m, (nn.Linear, nn.Embedding)):
@@ -272,29 +314,97 @@ class CLIPModel(PackedCache, nn.Module):
 
     def forward(self, input_ids=None, pixel_values=None, attention_mask=None, **_):
         out = SimpleNamespace(image_embeds=None, text_embeds=None)
-        if pixel_values is not None:
-            out.image_embeds = self.encode_image(pixel_values)
+        if pixel_values is not None:      # uint8 [F,S,S,3] from CLIPProcessor (rescale + normalise fused), or HF-style f32 [F,3,S,S]
+            out.image_embeds = (self.encode_image_u8(pixel_values) if pixel_values.dtype == torch.uint8
+                                else self.encode_image(pixel_values))
         if input_ids is not None:
             out.text_embeds = self.encode_text(input_ids, attention_mask)
         return out
 
 
-class CLIPFrameProcessor:
-    """The image half of HF ``CLIPProcessor`` for frames that are already S x S uint8 (the BASELINE
-    workload): resize / centre-crop are the identity, leaving x/255 and (x-mean)/std, which the
-    ``patchify_u8`` kernel fuses.  Non-S x S input is the 'next' row (GPU bicubic resize)."""
+class CLIPProcessor:
+    """Look-alike of HF ``CLIPProcessor`` as the reference drives it (run_visual_tokenization.py:90-93,138-142,347-350):
 
-    def __init__(self, size=224):
-        self.size = size
+        processor = CLIPProcessor.from_pretrained(name)
+        inputs = processor(text=[...], images=[PIL or HWC uint8 ...], return_tensors="pt", padding=True).to(device)
+        out = model(**inputs)            # .image_embeds / .text_embeds
 
-    def __call__(self, images=None, text=None, return_tensors="pt", **_):
+    Text goes through the CLIP BPE tokenizer (HF ``CLIPTokenizer`` loaded from ``name``, or any injected callable with
+    the same call signature — the vocabulary is a download).  Images of ANY size are uploaded as uint8, resized on the
+    GPU exactly as ``CLIPImageProcessor`` does with Pillow (shortest edge -> S bicubic, centre crop; bit-exact, see
+    preprocess.clip_frames) and handed over as ``pixel_values`` = uint8 [F,S,S,3]; rescale (1/255) and mean/std
+    normalisation are fused into the model's patch-extraction kernel (``CLIPModel.forward`` dispatches on the dtype), so
+    no f32 image is ever materialised.  There is no CPU fallback: without a GPU the image side raises."""
+
+    def __init__(self, tokenizer=None, image_size=224, device=None):
+        self.tokenizer = tokenizer
+        self.image_size = image_size
+        self.device = device
+
+    @classmethod
+    def from_pretrained(cls, name_or_path, tokenizer=None, device=None, **kw):
+        import json
+        import os
+
+        size = 224
+        cfg = os.path.join(str(name_or_path), "preprocessor_config.json")
+        if os.path.isfile(cfg):
+            with open(cfg) as f:
+                pc = json.load(f)
+            sz = pc.get("crop_size", pc.get("size", 224))
+            size = sz if isinstance(sz, int) else sz.get("height", sz.get("shortest_edge", 224))
+        if tokenizer is None:
+            from transformers import CLIPTokenizer
+
+            tokenizer = CLIPTokenizer.from_pretrained(name_or_path, **kw)   # raises when the vocabulary is unavailable
+        return cls(tokenizer=tokenizer, image_size=size, device=device)
+
+    def _frames(self, images):
         import numpy as np
 
-        frames = images if isinstance(images, (list, tuple)) else [images]
-        arr = np.stack([np.asarray(f) for f in frames])
-        if arr.shape[1] != self.size or arr.shape[2] != self.size:
-            raise NotImplementedError(f"CLIPFrameProcessor: frames must be {self.size}x{self.size} (got {arr.shape})")
-        x = torch.from_numpy(arr).permute(0, 3, 1, 2).to(torch.float32) / 255.0
-        mean = torch.tensor(CLIP_MEAN).view(1, 3, 1, 1)
-        std = torch.tensor(CLIP_STD).view(1, 3, 1, 1)
-        return {"pixel_values": (x - mean) / std}
+        from .preprocess import clip_frames
+
+        dev = torch.device(self.device) if self.device is not None else torch.device("cuda", torch.cuda.current_device()) \
+            if torch.cuda.is_available() else None
+        if dev is None or dev.type != "cuda":
+            raise K.VidilHipError("CLIPProcessor: the image side runs on the GPU (no CPU fallback); no HIP device visible")
+        frames = list(images) if isinstance(images, (list, tuple)) else [images]
+        arrs = []
+        for f in frames:
+            if torch.is_tensor(f):
+                a = f
+            else:
+                if hasattr(f, "convert"):                       # PIL image: convert RGB as CLIPImageProcessor does
+                    f = f.convert("RGB")
+                a = torch.from_numpy(np.ascontiguousarray(np.asarray(f)))
+            if a.dtype != torch.uint8 or a.dim() != 3 or a.shape[-1] != 3:
+                raise K.VidilHipError(f"CLIPProcessor: images must be HWC uint8 RGB, got {a.dtype} {tuple(a.shape)}")
+            arrs.append(a)
+        out = [None] * len(arrs)
+        by_shape = {}
+        for i, a in enumerate(arrs):
+            by_shape.setdefault(tuple(a.shape), []).append(i)
+        for shape, idx in by_shape.items():                     # one batched resize per frame geometry
+            batch = torch.stack([arrs[i] for i in idx]).to(dev)
+            res = clip_frames(batch, self.image_size)
+            for j, i in enumerate(idx):
+                out[i] = res[j]
+        return torch.stack(out)
+
+    def __call__(self, text=None, images=None, return_tensors="pt", padding=True, truncation=True, **kw):
+        from .tokenizer import Encoding
+
+        if return_tensors != "pt":
+            raise ValueError("CLIPProcessor: only return_tensors='pt' is supported")
+        enc = Encoding()
+        if text is not None:
+            if self.tokenizer is None:
+                raise K.VidilHipError("CLIPProcessor: no tokenizer (from_pretrained could not load one and none was injected)")
+            t = self.tokenizer([text] if isinstance(text, str) else list(text), return_tensors="pt", padding=padding,
+                               truncation=truncation, **kw)
+            enc["input_ids"] = t["input_ids"]
+            if "attention_mask" in t:
+                enc["attention_mask"] = t["attention_mask"]
+        if images is not None:
+            enc["pixel_values"] = self._frames(images)
+        return enc
