@@ -1,0 +1,111 @@
+"""The N>1 PRODUCT path on real kernels: two ranks (both on cuda:0 — the GPU box has one device; Gloo rendezvous)
+shard a video list through CapFiltEngine + VisualTokenizer + the two write_outputs() and must produce the same three
+JSON files, byte for byte, as one process handling all videos (run_video_CapFilt.py:237-291,
+run_visual_tokenization.py:427-463).  Also smokes `bench.py --gpus 2` in its one-device mode."""
+import json
+import os
+import socket
+import subprocess
+import sys
+
+import pytest
+
+from common import ROOT
+
+pytestmark = pytest.mark.gpu
+
+WORKER = r"""
+import json, os, sys
+sys.path.insert(0, {root!r})
+sys.path.insert(0, os.path.join({root!r}, "tests"))
+import numpy as np, torch
+from common import synthetic_frames
+from vidil_amd import dist as vdist, capfilt, visual_tokenization as vt
+from vidil_amd.blip import BLIP_Decoder
+from vidil_amd.blip_itm import BLIP_ITM
+from vidil_amd.clip import CLIPModel
+from vidil_amd.tokenizer import SyntheticBertTokenizer
+
+rank, world, _ = vdist.init_distributed_mode(backend="gloo")
+torch.cuda.set_device(0)
+dev = torch.device("cuda", 0)
+torch.manual_seed(0)
+tok = SyntheticBertTokenizer()
+cap = BLIP_Decoder(image_size=224, vit="base", tokenizer=tok).eval()
+itm = BLIP_ITM(image_size=224, vit="base", tokenizer=tok).eval()
+clip = CLIPModel().eval()
+cfg = dict(caption=True, filter=True, filter_generated_only=True, keep_original_caption=False, threshold=0.4,
+           filter_mode="max_filter", generation_mode="beam", do_sentence_tokenization=False, image_size=224, vit="base",
+           topk_visualize=5)
+NV, F = 5, 4
+g = torch.Generator().manual_seed(3)
+sizes = dict(objects=500, attributes=300, scenes=65, verbs=96)
+emb = {{k: torch.nn.functional.normalize(torch.randn(n, 512, generator=g), dim=-1) for k, n in sizes.items()}}
+texts = {{k: [f"{{k}}{{i}}" for i in range(n)] for k, n in sizes.items()}}
+eng = capfilt.CapFiltEngine(cfg, dev, captioner=cap, filterer=itm)
+vtk = vt.VisualTokenizer(cfg, clip, texts, emb, dev)
+videos = [f"video{{i}}" for i in range(NV)]
+s, e = vdist.shard_bounds(NV)
+items = [dict(video_id=v, text=[]) for v in videos[s:e]]
+toks = {{}}
+if e > s:
+    u8 = torch.from_numpy(synthetic_frames(e - s, F, first_video=s)).to(dev)
+    eng.process(items, u8)
+    toks = vtk.process([it["video_id"] for it in items], u8, [it["unfiltered_text"] for it in items])
+f, u = capfilt.collect_outputs(items)
+capfilt.write_outputs({out!r}, f, u)
+vt.write_outputs({out!r}, toks)
+vdist.barrier()
+"""
+
+
+def _free_port():
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def _run(world, out):
+    port = _free_port()
+    script = WORKER.format(root=ROOT, out=out)
+    procs = []
+    for r in range(world):
+        env = dict(os.environ, RANK=str(r), WORLD_SIZE=str(world), LOCAL_RANK="0", MASTER_ADDR="127.0.0.1",
+                   MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY="0")
+        procs.append(subprocess.Popen([sys.executable, "-c", script], env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT))
+    for p in procs:
+        o, _ = p.communicate(timeout=900)
+        assert p.returncode == 0, o.decode()[-4000:]
+
+
+def test_two_ranks_on_one_gpu_through_the_engines_equal_single_process(tmp_path):
+    out1, out2 = str(tmp_path / "w1"), str(tmp_path / "w2")
+    _run(1, out1)
+    _run(2, out2)
+    for name in ("video_text_CapFilt.json", "video_text_Cap.json", "visual_tokens.json"):
+        a = open(os.path.join(out1, name)).read()
+        b = open(os.path.join(out2, name)).read()
+        assert a == b, name
+    caps = json.load(open(os.path.join(out2, "video_text_Cap.json")))
+    assert list(caps.keys()) == [f"video{i}" for i in range(5)]
+    toks = json.load(open(os.path.join(out2, "visual_tokens.json")))
+    assert list(toks.keys()) == [f"video{i}" for i in range(5)] and len(toks["video4"]["frame_tokens"]) == 4
+
+
+def test_bench_gpus_2_one_device_smoke(tmp_path):
+    """`bench.py --gpus 2` as the driver launches it (torch.distributed.run, one JSON line from rank 0), with both
+    ranks on the box's single GPU (VIDIL_BENCH_SMOKE_ONE_DEVICE=1 -> Gloo).  The log is kept under gpurun_out/."""
+    env = dict(os.environ, VIDIL_BENCH_SMOKE_ONE_DEVICE="1", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+           "--master-port", str(_free_port()), os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "0",
+           "--videos-per-step", "16"]
+    r = subprocess.run(cmd, env=env, cwd=ROOT, capture_output=True, text=True, timeout=1200)
+    assert r.returncode == 0, (r.stdout[-2000:], r.stderr[-4000:])
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, r.stdout
+    rec = json.loads(lines[0])
+    assert rec["n_gpus"] == 2 and rec["scaling"] == "weak" and rec["value"] > 0
+    assert "roofline" not in rec and "cpu_baseline" not in rec        # rank 0 at N=1 only
+    os.makedirs(os.path.join(ROOT, "gpurun_out"), exist_ok=True)
+    with open(os.path.join(ROOT, "gpurun_out", "bench_gpus2_one_device_smoke.log"), "w") as f:
+        f.write("$ VIDIL_BENCH_SMOKE_ONE_DEVICE=1 " + " ".join(cmd[1:]) + "\n" + r.stdout + "\n---- stderr ----\n" + r.stderr[-3000:])

@@ -103,10 +103,10 @@ def test_clip_processor_and_model_call_signatures_of_the_reference():
     for i, a in enumerate(imgs):           # byte-identical with the Pillow path of HF's CLIPImageProcessor
         assert np.array_equal(pv[i].cpu().numpy(), R.clip_process_frame_u8(a, 64)), i
     torch.manual_seed(0)
-    cfg = CLIPConfig(CLIPVisionConfig(hidden_size=128, intermediate_size=256, num_hidden_layers=1, num_attention_heads=2,
+    cfg = CLIPConfig(CLIPVisionConfig(hidden_size=256, intermediate_size=512, num_hidden_layers=1, num_attention_heads=4,
                                       image_size=64, patch_size=16),
-                     CLIPTextConfig(vocab_size=300, hidden_size=128, intermediate_size=256, num_hidden_layers=1,
-                                    num_attention_heads=2, max_position_embeddings=16, eos_token_id=299), 64)
+                     CLIPTextConfig(vocab_size=300, hidden_size=256, intermediate_size=512, num_hidden_layers=1,
+                                    num_attention_heads=4, max_position_embeddings=16, eos_token_id=299), 64)
     model = CLIPModel(cfg).eval().to(DEV)
     out = model(**inputs)
     assert tuple(out.image_embeds.shape) == (4, 64) and tuple(out.text_embeds.shape) == (1, 64)

@@ -376,7 +376,7 @@ class CLIPProcessor:
             else:
                 if hasattr(f, "convert"):                       # PIL image: convert RGB as CLIPImageProcessor does
                     f = f.convert("RGB")
-                a = torch.from_numpy(np.ascontiguousarray(np.asarray(f)))
+                a = torch.from_numpy(np.array(f))            # (a copy: PIL hands out read-only buffers)
             if a.dtype != torch.uint8 or a.dim() != 3 or a.shape[-1] != 3:
                 raise K.VidilHipError(f"CLIPProcessor: images must be HWC uint8 RGB, got {a.dtype} {tuple(a.shape)}")
             arrs.append(a)
