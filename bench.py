@@ -29,9 +29,35 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 VG_SIZES = dict(objects=19958, attributes=15026, scenes=365, verbs=7410)
-GFLOP_PER_FRAME = dict(vit_caption=35.13, vit_filter=35.13, decode=20.05, itm_kv=5.58, itm_per_caption=7.24,
-                       clip=8.82, scan=0.044)
-MFMA_F16_PEAK_TFLOPS = 2500.0   # dense, /opt/skills/guides/MI355X_MICROARCH.md
+MFMA_F16_PEAK_TFLOPS = 2500.0   # dense f16 / bf16, /opt/skills/guides/MI355X_MICROARCH.md
+
+
+def gflop_per_frame(vit="base", size=224, clip="b32", n_classes=42759, proj=512):
+    """Algorithmic GFLOP per frame of every component (BASELINE.md §4 / SURVEY.md §8d), computed from the geometry so
+    that the alternates (ViT-L/16 — config 4 —, 384^2, CLIP ViT-L/14) get their own figures: 2 x MACs of the Linear
+    layers and of the two attention matmuls, exactly the terms BASELINE.md counts (35.13 for ViT-B/16 @224)."""
+    def tower(D, L, T, mlp=4, K_patch=None):
+        per_tok = 2 * (4 * D * D + 2 * mlp * D * D)            # qkv + proj + fc1 + fc2
+        attn = 2 * 2 * T * D                                   # QK^T and PV per token
+        f = L * T * (per_tok + attn)
+        if K_patch is not None:
+            f += 2 * (T - 1) * K_patch * D
+        return f / 1e9
+    D, L = (768, 12) if vit == "base" else (1024, 24)
+    T = (size // 16) ** 2 + 1
+    vit_f = tower(D, L, T, K_patch=768)
+    C = 768                                                    # MED hidden size
+    cross_kv = 2 * 12 * T * 2 * D * C / 1e9                    # K|V of 12 layers, once per image
+    # per (sequence, token) and layer: self q|k|v + out, cross q + out, FFN; attention over the image + the text keys
+    med_tok = 2 * (4 * C * C + 2 * C * C + 8 * C * C)
+    lm = 2 * (C * C + C * 30524)
+    tok_fwd = 12 * (med_tok + 2 * 2 * (T + 10) * C) + lm        # BASELINE.md: 0.254 GFLOP per token-forward at B/16@224
+    decode = cross_kv + 57 * tok_fwd / 1e9                      # 3 beams x (4 prompt + 15 generated) token-forwards
+    itm_cap = 35 * 12 * (med_tok + 2 * 2 * (T + 35) * C) / 1e9  # one caption padded to 35 tokens (the reference's count)
+    cd, cl, ct, cp = (768, 12, 50, 32 * 32 * 3) if clip == "b32" else (1024, 24, 257, 14 * 14 * 3)
+    clip_f = tower(cd, cl, ct, K_patch=cp) + 2 * cd * proj / 1e9
+    return dict(vit_caption=vit_f, vit_filter=vit_f, decode=decode, itm_kv=cross_kv, itm_per_caption=itm_cap, clip=clip_f,
+                scan=2 * proj * n_classes / 1e9)
 
 
 def synthetic_frames(n_videos, frames, size, first_video=0):
@@ -57,40 +83,28 @@ def synthetic_ontology(dim=512, seed=0):
     return embeds, texts
 
 
-def build_models(device, size=224, clip_name="b32"):
+def build_models(device, size=224, clip_name="b32", vit="base", dtype="f16"):
     from vidil_amd.blip import BLIP_Decoder
     from vidil_amd.blip_itm import BLIP_ITM
     from vidil_amd.clip import CLIPConfig, CLIPModel
+    from vidil_amd.packing import set_compute_dtype
     from vidil_amd.tokenizer import SyntheticBertTokenizer
 
     torch.manual_seed(0)
     tok = SyntheticBertTokenizer()
-    cap = BLIP_Decoder(image_size=size, vit="base", tokenizer=tok).eval()
-    flt = BLIP_ITM(image_size=size, vit="base", tokenizer=tok).eval()
+    cap = BLIP_Decoder(image_size=size, vit=vit, tokenizer=tok).eval()
+    flt = BLIP_ITM(image_size=size, vit=vit, tokenizer=tok).eval()
     clip = CLIPModel(CLIPConfig.vit_l14() if clip_name == "l14" else None).eval()
+    set_compute_dtype(dtype, cap, flt, clip)
     return cap, flt, clip, tok
 
 
 class GemmTimer:
-    """Times every GEMM launch of one step with HIP events on the launch stream."""
+    """Times every GEMM launch of one step with HIP events on the launch stream; kernels are named by the library
+    itself (vidil_gemm_kernel_name: the dispatch is not restated here)."""
 
     def __init__(self):
         self.records = []
-
-    @staticmethod
-    def tile_of(M, N, K=768, f16_out=True):
-        """Mirror of the dispatch in csrc/gemm.hip::pick_tile / gemm256.hip::vidil_gemm256_eligible."""
-        t256 = ((M + 255) // 256) * ((N + 255) // 256)
-        if t256 >= 160 and K >= 128 and N % (8 if f16_out else 4) == 0:
-            return "256x256"
-        n128 = ((M + 127) // 128) * ((N + 127) // 128)
-        if n128 >= 200 and N <= 1024:
-            return "128x128x2" if n128 > 256 else "128x128x3"
-        if ((M + 63) // 64) * ((N + 63) // 64) <= 1280:
-            return "64x64x3"
-        if ((M + 127) // 128) * ((N + 63) // 64) <= 2560:
-            return "128x64x2"
-        return "128x128x2"
 
     def install(self):
         from vidil_amd import kernels as K
@@ -105,13 +119,9 @@ class GemmTimer:
             e0.record()
             r = timer._orig(a, w, bias, **kw)
             e1.record()
-            epi = "heads" if kw.get("heads") else "patch" if kw.get("patch") else "arena" if kw.get("arena") else \
-                ("f32" if (kw.get("out") is not None and kw["out"].dtype == torch.float32) or kw.get("out_dtype") == torch.float32 else "f16")
-            tile = timer.tile_of(M, N, Kd, epi in ("f16", "heads"))
-            if epi == "arena" and tile == "256x256":      # EPI_ARENA is served by the small-tile kernel only
-                tile = timer.tile_of(M, N, 0)
-            timer.records.append((tile, epi, kw.get("act", 0),
-                                  2.0 * M * N * Kd, e0, e1))
+            if "out" not in kw and not (kw.get("heads") or kw.get("patch") or kw.get("arena")):
+                kw = dict(kw, out=r)
+            timer.records.append((K.gemm_kernel_name(a, w, bias, **kw), 2.0 * M * N * Kd, e0, e1))
             return r
 
         K.gemm = timed
@@ -124,43 +134,47 @@ class GemmTimer:
     def summary(self):
         torch.cuda.synchronize()
         agg = {}
-        epi_id = dict(f16=0, f32=1, heads=2, patch=3, arena=4)
-        for tile, epi, act, flops, e0, e1 in self.records:
-            # same spelling as the kernel names in the rocprofv3 trace (profiles/*.md)
-            if tile == "256x256":
-                key = f"gemm256_kernel<{epi_id[epi]}, {act}>"
-            else:
-                bm, bn, st = tile.split("x")
-                key = f"gemm_kernel<{bm}, {bn}, {st}, {epi_id[epi]}, {act}>"
-            a = agg.setdefault(key, [0, 0.0, 0.0])
+        for name, flops, e0, e1 in self.records:
+            a = agg.setdefault(name, [0, 0.0, 0.0])
             a[0] += 1
             a[1] += flops
             a[2] += e0.elapsed_time(e1) * 1e-3
         return agg
 
 
-def cpu_baseline(cap, flt, clip, tok, onto_embeds, onto_texts, n_videos, frames, size):
-    """The CPU oracle in the reference's schedule on a bounded sample (rank 0, N=1 only)."""
+def cpu_baseline(cap, flt, clip, tok, onto_embeds, onto_texts, n_videos, frames, size, vit="base"):
+    """The CPU oracle on a bounded sample (rank 0, N=1 only), on ALL host cores the process may use, in both schedules
+    SURVEY.md §8d asks for: the reference's (ViT per caption, cross K/V per decoder call — `value`) and the
+    de-duplicated one the GPU path uses (`dedup_value`).  Same frames, same weights."""
     from oracle import clip_ref, pipeline_ref
 
-    ncpu = min(len(os.sched_getaffinity(0)), int(os.environ.get("VIDIL_CPU_THREADS", "64")))
-    torch.set_num_threads(ncpu)
+    ncpu = len(os.sched_getaffinity(0))
+    nthreads = int(os.environ.get("VIDIL_CPU_THREADS", ncpu))
+    torch.set_num_threads(nthreads)
+    depth, heads = (12, 12) if vit == "base" else (24, 16)
     sd_cap = {k: v.detach().float().cpu() for k, v in cap.state_dict().items()}
     sd_itm = {k: v.detach().float().cpu() for k, v in flt.state_dict().items()}
     sd_clip = {k: v.detach().float().cpu() for k, v in clip.state_dict().items()}
     prompt = cap.prompt_ids(1, "cpu")[0].long().numpy()
     fr = synthetic_frames(n_videos, frames, size)
-    t0 = time.time()
-    n_caps = 0
-    for v in range(n_videos):
-        x = clip_ref.preprocess_u8(fr[v])
-        kept, caps = pipeline_ref.capfilt_video(sd_cap, sd_itm, x, prompt, tok, cap.prompt, threshold=0.4)
-        n_caps += len(caps)
-        pipeline_ref.visual_tokens_video(sd_clip, x, onto_embeds, onto_texts, topk=5)
-    dt = time.time() - t0
-    return dict(value=round(n_videos * frames / dt, 4), unit="frames/s", cores=ncpu, kind="port",
-                sample=f"{n_videos} video(s) x {frames} frames, oracle (PyTorch fp32, {torch.get_num_threads()} threads) in the "
-                       f"reference's schedule incl. {n_caps} ITM caption passes, {dt:.1f} s")
+    out = {}
+    for label, dedup in (("reference", False), ("dedup", True)):
+        t0 = time.time()
+        n_caps = 0
+        for v in range(n_videos):
+            x = clip_ref.preprocess_u8(fr[v])
+            kept, caps = pipeline_ref.capfilt_video(sd_cap, sd_itm, x, prompt, tok, cap.prompt, threshold=0.4, dedup=dedup,
+                                                    depth=depth, heads=heads)
+            n_caps += len(caps)
+            pipeline_ref.visual_tokens_video(sd_clip, x, onto_embeds, onto_texts, topk=5)
+        out[label] = (time.time() - t0, n_caps)
+    dt, n_caps = out["reference"]
+    dt2, _ = out["dedup"]
+    return dict(value=round(n_videos * frames / dt, 4), unit="frames/s", cores=ncpu, threads=torch.get_num_threads(),
+                os_cpu_count=os.cpu_count(), kind="port", dedup_value=round(n_videos * frames / dt2, 4),
+                sample=f"{n_videos} video(s) x {frames} frames, oracle (PyTorch fp32, {torch.get_num_threads()} threads on "
+                       f"{ncpu} usable cores of {os.cpu_count()}): reference schedule incl. {n_caps} ITM caption passes "
+                       f"{dt:.1f} s; de-duplicated schedule (filter ViT once per frame, cross K/V once per image) {dt2:.1f} s")
 
 
 def main():
@@ -172,7 +186,9 @@ def main():
     # workgroups on the N = 768 GEMMs (98.9 % of the last round filled; 128 videos give 9.23 rounds = 92 %), and
     # 9216 beam rows per decode step (measured: 128 -> 3.7k, 192 -> 3.8-3.95k, 384 -> 4.1k, 576 -> 3.9k frames/s)
     ap.add_argument("--videos-per-step", type=int, default=384)
-    ap.add_argument("--frames", type=int, default=8)
+    ap.add_argument("--frames", type=int, default=8, help="frames per video (config 4: 16)")
+    ap.add_argument("--dtype", choices=["f16", "bf16"], default="f16", help="MFMA operand type (config 2: bf16)")
+    ap.add_argument("--vit", choices=["base", "large"], default="base", help="BLIP vision tower (config 4: large = ViT-L/16)")
     ap.add_argument("--size", type=int, default=224, help="frame / BLIP image size (the headline metric is 224)")
     ap.add_argument("--clip", choices=["b32", "l14"], default="b32", help="CLIP tower (headline metric: ViT-B/32)")
     ap.add_argument("--cpu-sample-videos", type=int, default=1)
@@ -199,12 +215,11 @@ def main():
     dev = torch.device("cuda", local)
 
     t_start = time.perf_counter()
-    cap, flt, clip, tok = build_models(dev, args.size, args.clip)
+    cap, flt, clip, tok = build_models(dev, args.size, args.clip, args.vit, args.dtype)
     onto_embeds, onto_texts = synthetic_ontology(dim=clip.config.projection_dim)
-    headline = args.size == 224 and args.clip == "b32"
     config = dict(caption=True, filter=True, filter_generated_only=True, keep_original_caption=False,
-                  threshold=0.4, filter_mode="max_filter", generation_mode="beam", do_sentence_tokenization=True,
-                  image_size=args.size, vit="base", topk_visualize=5)
+                  threshold=0.4, filter_mode="max_filter", generation_mode="beam", do_sentence_tokenization=False,
+                  image_size=args.size, vit=args.vit, topk_visualize=5)
     engine = CapFiltEngine(config, dev, captioner=cap, filterer=flt)
     vtok = VisualTokenizer(config, clip, onto_texts, onto_embeds, dev)
 
@@ -261,21 +276,21 @@ def main():
         total_frames = world * Nv * F * args.steps
         fps = total_frames / dt
         c_mean = stats["unique_captions"] / max(1, stats["videos"])
-        gf = GFLOP_PER_FRAME
+        gf = gflop_per_frame(args.vit, args.size, args.clip, sum(VG_SIZES.values()), clip.config.projection_dim)
         gflop_frame = (gf["vit_caption"] + gf["vit_filter"] + gf["decode"] + gf["itm_kv"] + gf["itm_per_caption"] * c_mean
                        + gf["clip"] + gf["scan"])
         result = {
             "metric": f"frames/sec whole-node (BLIP caption+filt + CLIP visual-token) {args.size}^2 8f/video",
             "value": round(fps, 2), "unit": "frames/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(dt / args.steps * 1e3, 3), "higher_is_better": True, "scaling": "weak",
-            "vs_baseline": None, "dtype": "f16", "data": "synthetic",
-            "config": {"workload": f"{Nv} synthetic videos x {F} frames {args.size}^2 per GPU per step, BLIP ViT-B/16 caption "
+            "vs_baseline": None, "dtype": args.dtype, "data": "synthetic, resident in HBM (same frames every step; H2D outside the timed region)",
+            "config": {"workload": f"{Nv} synthetic videos x {F} frames {args.size}^2 per GPU per step, BLIP ViT-{'B' if args.vit == 'base' else 'L'}/16 caption "
                                    f"(beam 3, 16 decode steps) + CapFilt ITM + CLIP {'ViT-B/32' if args.clip == 'b32' else 'ViT-L/14'} visual tokens vs 42,759-class "
                                    f"vg-sized ontology; random-init weights (seed 0)",
                        "videos_per_step_per_gpu": Nv, "frames_per_video": F,
                        "unique_captions_per_video": round(c_mean, 2), "itm_pairs_per_step": stats["itm_pairs"],
-                       "algorithmic_gflop_per_frame": round(gflop_frame, 2) if headline else None,
-                       "whole_path_mfma_frac": round(fps / world * gflop_frame / 1e3 / MFMA_F16_PEAK_TFLOPS, 4) if headline else None,
+                       "algorithmic_gflop_per_frame": round(gflop_frame, 2),
+                       "whole_path_mfma_frac": round(fps / world * gflop_frame / 1e3 / MFMA_F16_PEAK_TFLOPS, 4),
                        "parallelism": f"dp{world} (videos sharded, no data-path collective)"},
         }
     if rank == 0 and world == 1 and not args.no_roofline:
@@ -295,7 +310,7 @@ def main():
         n, flops, secs = agg[key]
         ach = flops / secs / 1e12
         # HBM bytes per launch of that kernel from the committed PMC passes of this same command
-        # (tools/profile_bench.sh -> profiles/pmc_traffic.json); null when no profile has been taken.
+        # (tools/profile_bench.sh -> profiles/pmc_traffic.json); null when no profile of this dtype has been taken.
         traffic = None
         try:
             pmc = json.load(open(os.path.join(ROOT, "profiles", "pmc_traffic.json")))
@@ -310,7 +325,8 @@ def main():
                                                "ms": round(v[2] * 1e3, 3)} for k, v in agg.items()}}
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         log("cpu baseline...")
-        result["cpu_baseline"] = cpu_baseline(cap, flt, clip, tok, onto_embeds, onto_texts, args.cpu_sample_videos, F, args.size)
+        result["cpu_baseline"] = cpu_baseline(cap, flt, clip, tok, onto_embeds, onto_texts, args.cpu_sample_videos, F, args.size,
+                                              args.vit)
     if rank == 0:
         print(json.dumps(result), flush=True)
 

@@ -15,8 +15,10 @@
  *   - `stream` is a hipStream_t passed as void* (torch.cuda.current_stream()
  *     .cuda_stream on the Python side).  Nothing here allocates, frees or
  *     synchronises; workspaces are caller-owned.
- *   - "f16" = IEEE half (the MFMA input type), "f32" = float.  Accumulation,
- *     LayerNorm statistics, softmax and the residual stream are f32.
+ *   - 16-bit operand type: every entry point that touches MFMA operands takes a
+ *     `dtype` code, VIDIL_DT_F16 (IEEE half) or VIDIL_DT_BF16 (bfloat16); "T16"
+ *     below means "that type".  Accumulation, LayerNorm statistics, softmax and
+ *     the residual stream are f32 for both.
  *   - head_dim is 64 everywhere on this path (ViT-B/L, MED/BERT, CLIP B/32 and
  *     L/14 towers all use 64).
  */
@@ -28,6 +30,10 @@
 #ifdef __cplusplus
 extern "C" {
 #endif
+
+/* operand types (the `dtype` arguments) */
+#define VIDIL_DT_F16 0
+#define VIDIL_DT_BF16 1
 
 #define VIDIL_OK 0
 #define VIDIL_EINVAL (-1)   /* bad argument (shape, alignment, null pointer)  */
@@ -42,11 +48,11 @@ int vidil_num_entry_points(void);
 
 /* ------------------------------------------------------------------------ */
 /* GEMM  C[M,N] = A[M,K] · W[N,K]^T  (+bias) with a fused epilogue.           */
-/* A and W are f16 row-major with K contiguous (torch nn.Linear layout).      */
+/* A and W are T16 row-major with K contiguous (torch nn.Linear layout).      */
 /* K must be a multiple of 64.  M, N arbitrary (>0).                          */
 /* ------------------------------------------------------------------------ */
 enum {
-  VIDIL_EPI_F16 = 0,   /* out f16 [M,ldo]   = act(acc + bias)                              */
+  VIDIL_EPI_F16 = 0,   /* out T16 [M,ldo]   = act(acc + bias)                              */
   VIDIL_EPI_F32 = 1,   /* out f32 [M,ldo]   = act(acc + bias) + resid (resid may alias out)*/
   VIDIL_EPI_HEADS = 2, /* scatter into per-head Q / K / V^T buffers (see below)            */
   VIDIL_EPI_PATCH = 3, /* out f32 row (m + m/tpi + 1) = acc + bias + pos[(m%tpi)+1]        */
@@ -55,21 +61,21 @@ enum {
 enum { VIDIL_ACT_NONE = 0, VIDIL_ACT_GELU_ERF = 1, VIDIL_ACT_QUICK_GELU = 2 };
 
 typedef struct vidil_gemm_args {
-  const void* A;      /* f16 [M,K], row stride lda                             */
-  const void* W;      /* f16 [N,K]                                             */
+  const void* A;      /* T16 [M,K], row stride lda                             */
+  const void* W;      /* T16 [N,K]                                             */
   const float* bias;  /* f32 [N] or NULL                                       */
   int32_t M, N, K;
   int32_t lda;        /* A row stride in elements; 0 = K; multiple of 8        */
   int32_t epi;        /* VIDIL_EPI_*                                           */
   int32_t act;        /* VIDIL_ACT_* (EPI_F16 / EPI_F32 only)                  */
-  void* out;          /* EPI_F16: f16, EPI_F32/PATCH: f32, row stride ldo      */
+  void* out;          /* EPI_F16: T16, EPI_F32/PATCH: f32, row stride ldo      */
   int32_t ldo;
   const float* resid; /* EPI_F32: f32 [M,ldo] added after act, or NULL         */
   /* EPI_HEADS: column n -> part = part0 + n/(H*64), h = (n%(H*64))/64, d=n%64;
    * row m -> b = m/T, t = m%T.
-   *   part 0: Q [b][h][t][64]            f16, value * q_scale, row capacity Tq_cap
-   *   part 1: K [b][h][t_off+t][64]      f16, row capacity Tk_cap
-   *   part 2: VT[b][h][d][vt(t_off+t)]   f16, row stride NP (multiple of 16); keys of
+   *   part 0: Q [b][h][t][64]            T16, value * q_scale, row capacity Tq_cap
+   *   part 1: K [b][h][t_off+t][64]      T16, row capacity Tk_cap
+   *   part 2: VT[b][h][d][vt(t_off+t)]   T16, row stride NP (multiple of 16); keys of
    *           every 16-key block are stored in the order 0-3, 8-11, 4-7, 12-15:
    *           vt(t) = t ^ 12 when bits 2 and 3 of t differ, else t (see vidil_attention)
    *   NP == 0: part 2 is stored ROW-MAJOR instead, V [b][h][t_off+t][64] in `vt` with row capacity Tk_cap
@@ -82,9 +88,9 @@ typedef struct vidil_gemm_args {
   /* EPI_ARENA: same column / row decomposition as EPI_HEADS (T, H, part0, t_off, q_scale), but the
    * destinations are row-major with all heads of a token contiguous (no transposition, no per-head
    * scatter — the layout vidil_beam_attention reads):
-   *   part 0: Q     [m][H*64]                                   f16, value * q_scale
-   *   part 1: K     [t_off+t][b*slot_stride][H*64]  (arena `k`)  f16, arena_rows slots per position
-   *   part 2: V     [t_off+t][b*slot_stride][H*64]  (arena `vt`) f16 (NOT transposed)
+   *   part 0: Q     [m][H*64]                                   T16, value * q_scale
+   *   part 1: K     [t_off+t][b*slot_stride][H*64]  (arena `k`)  T16, arena_rows slots per position
+   *   part 2: V     [t_off+t][b*slot_stride][H*64]  (arena `vt`) T16 (NOT transposed)
    * decode step: T = 1, slot_stride = 1 (row m appends position t_off of slot m);
    * shared prompt pass: T = P, slot_stride = nb (image b's prompt lives in slot b*nb). */
   int32_t arena_rows, slot_stride;
@@ -92,32 +98,36 @@ typedef struct vidil_gemm_args {
   const float* pos;   /* f32 [(tpi+1), N]                                      */
   int32_t tpi;        /* patches per image                                     */
   /* EPI_HEADS, parts 1 and 2: non-zero = FRAGMENT-TILED K and V (NP ignored, Tk_cap a multiple of 32): every
-   * (b, h) owns Tk_cap/32 tiles of 32 keys x 64 dims (2048 f16) in the operand order of the direct attention kernel,
+   * (b, h) owns Tk_cap/32 tiles of 32 keys x 64 dims (2048 T16) in the operand order of the direct attention kernel,
    *   K tile [c/8][key%32][c%8];  V tile [key%32/16][d/32][g%2][d%32][(g/2)*4 + key%4], g = (key%16)/4,
    * so each of that kernel's wave loads is one contiguous KiB.  Consumer: vidil_attention(kv_tiled = 1). */
   int32_t kv_tiled;
+  int32_t dtype;      /* VIDIL_DT_*: type of A, W and of every 16-bit output (out, q, k, vt)   */
 } vidil_gemm_args;
 
 /* replaces: nn.Linear calls of models/vit.py:35-41,72,84; models/med.py:153-171,
  * 236,301,314,512,534; timm PatchEmbed conv (models/vit.py:144-145,182) as an
  * im2col-free GEMM; HF CLIP q/k/v/out/fc1/fc2/projection Linears. */
-int vidil_gemm_f16(const vidil_gemm_args* args, void* stream);
+int vidil_gemm(const vidil_gemm_args* args, void* stream);
+/* Name of the kernel instantiation vidil_gemm would launch for `args` (the spelling rocprofv3 prints, e.g.
+ * "gemm256_kernel<f16, 1, 0>"), written NUL-terminated into buf[0..n).  For profilers / bench.py. */
+int vidil_gemm_kernel_name(const vidil_gemm_args* args, char* buf_host, int32_t n);
 
 /* ------------------------------------------------------------------------ */
 /* LayerNorm over the last dim.  x f32 rows of length D at stride x_stride    */
-/* (elements); writes f16 and/or f32 outputs (either may be NULL), dense.     */
+/* (elements); writes T16 (dtype16) and/or f32 outputs (either may be NULL), dense. */
 /* D must be a multiple of 64 and <= 1024... (768, 512, 1024 on this path)    */
 /* replaces: nn.LayerNorm at models/vit.py:108-109,192 (eps 1e-6),            */
 /* models/med.py:92,238,316,514 (eps 1e-12), HF CLIP layer norms (eps 1e-5).  */
 /* ------------------------------------------------------------------------ */
 int vidil_layernorm(const float* x, int64_t x_stride, const float* gamma,
                     const float* beta, float eps, int32_t M, int32_t D,
-                    void* out_f16, float* out_f32, void* stream);
+                    void* out16, int32_t dtype16, float* out_f32, void* stream);
 
 /* ------------------------------------------------------------------------ */
 /* Attention for short sequences (Nk <= 768): softmax(Q K^T [+mask]) V.       */
-/* Q  f16 [Bq][H][Tq_cap][64] (already scaled by 1/sqrt(64)),                 */
-/* K  f16 [Bk][H][Tk_cap][64], VT f16 [Bk][H][64][NP] with NP % 16 == 0 and    */
+/* Q  T16 [Bq][H][Tq_cap][64] (already scaled by 1/sqrt(64)),                 */
+/* K  T16 [Bk][H][Tk_cap][64], VT T16 [Bk][H][64][NP] with NP % 16 == 0 and    */
 /* the key axis of every 16-key block permuted to 0-3, 8-11, 4-7, 12-15 (the   */
 /* order the transposed-score MFMA layout consumes; written by EPI_HEADS).     */
 /* NP == 0: `vt` holds V ROW-MAJOR [Bk][H][Tk_cap][64] (like K) and is          */
@@ -139,7 +149,7 @@ int vidil_layernorm(const float* x, int64_t x_stride, const float* gamma,
 /*                         (j+1)*kv_group-1.                                  */
 /* Keys >= kv_len[b] (or >= Nk when kv_len==NULL) are excluded; causal!=0     */
 /* additionally excludes key > q + causal_off.                                */
-/* out f16 row (b*Nq + q), column h*64+d, row stride ldo (multiple of 8).     */
+/* out T16 row (b*Nq + q), column h*64+d, row stride ldo (multiple of 8).     */
 /* replaces: models/vit.py:75-83; models/med.py:178-220 (self, cross, cached);*/
 /* HF CLIPAttention.                                                          */
 /* ------------------------------------------------------------------------ */
@@ -149,7 +159,7 @@ int vidil_attention(const void* q, const void* k, const void* vt, void* out,
                     int32_t Bq, int32_t H, int32_t Nq,
                     int32_t Nk, int32_t Tq_cap, int32_t Tk_cap, int32_t NP,
                     int32_t kv_group, int32_t causal, int32_t causal_off,
-                    int32_t ldo, int32_t kv_tiled, void* stream);
+                    int32_t ldo, int32_t kv_tiled, int32_t dtype, void* stream);
 
 /* ------------------------------------------------------------------------ */
 /* One separable pass of Pillow's antialiased resize on 8-bit interleaved RGB */
@@ -175,18 +185,18 @@ int vidil_resample_u8(const uint8_t* src, uint8_t* dst, int32_t B, int32_t in_h,
 
 /* ------------------------------------------------------------------------ */
 /* Frame -> patch rows (im2col for stride==kernel conv), fused with dtype     */
-/* conversion.  out f16 [B*(S/ps)^2, 3*ps*ps], column = c*ps*ps + py*ps + px  */
+/* conversion.  out T16 [B*(S/ps)^2, 3*ps*ps], column = c*ps*ps + py*ps + px  */
 /* (the flattening of a conv weight [N,3,ps,ps]).                             */
 /* replaces: timm PatchEmbed / HF CLIPVisionEmbeddings conv input read.       */
 /* ------------------------------------------------------------------------ */
 int vidil_patchify_f32(const float* img /*[B,3,S,S]*/, void* out, int32_t B,
-                       int32_t S, int32_t ps, void* stream);
+                       int32_t S, int32_t ps, int32_t dtype, void* stream);
 /* uint8 HWC frames, fused (x/255 - mean[c]) / std[c]:                        */
 /* replaces run_video_CapFilt.py:128-137 (ToTensor+Normalize) and HF          */
 /* CLIPImageProcessor rescale+normalize for frames already at S x S.          */
 int vidil_patchify_u8(const uint8_t* img /*[B,S,S,3]*/, void* out, int32_t B,
                       int32_t S, int32_t ps, const float* mean3_host,
-                      const float* std3_host, void* stream);
+                      const float* std3_host, int32_t dtype, void* stream);
 /* x[b*T + 0, :] = cls[:] + pos[0, :]   (models/vit.py:184-187)               */
 int vidil_set_cls_row(float* x, const float* cls, const float* pos0, int32_t B,
                       int32_t T, int32_t D, void* stream);
@@ -198,6 +208,12 @@ int vidil_set_cls_row(float* x, const float* cls, const float* pos0, int32_t B,
 int vidil_embed_tokens(const int32_t* ids, const float* word, const float* pos,
                        float* out, int32_t M, int32_t T, int32_t pos_off,
                        int32_t D, int32_t vocab, void* stream);
+
+/* Error-compensated operand rows for a GEMM with K tripled (the "precise LM head", see vidil_amd/med.py):  */
+/* out T16 [M, 3D] = [hi | lo | hi] with hi = T16(x), lo = T16(x - hi): against a weight [N, 3D] =           */
+/* [W_hi | W_hi | W_lo] one GEMM yields x_hi·W_hi + x_lo·W_hi + x_hi·W_lo, i.e. x·W to ~2^-20 relative.      */
+int vidil_split3_f32(const float* x, void* out16, int32_t M, int32_t D,
+                     int32_t dtype, void* stream);
 
 /* out[i,:] = x[idx[i],:]   (f32 rows of length D)                            */
 int vidil_gather_rows_f32(const float* x, const int32_t* idx, float* out,
@@ -250,7 +266,7 @@ int vidil_beam_finalize(const vidil_beam_state* st, int32_t B, int32_t nb,
                         int32_t pad_id, int32_t* out_tokens, int32_t* out_len,
                         float* out_score, void* stream);
 /* KV-cache reorder (models/med.py:951-955): for every layer l, row s:        */
-/* dst[l][s] = src[l][beam_idx[s]]; a row is row_halfs f16 values.            */
+/* dst[l][s] = src[l][beam_idx[s]]; a row is row_halfs 16-bit values.         */
 int vidil_kv_reorder(const void* src, void* dst, const int32_t* beam_idx,
                      int32_t L, int32_t rows, int64_t row_halfs, void* stream);
 
@@ -263,10 +279,10 @@ int vidil_kv_reorder(const void* src, void* dst, const int32_t* beam_idx,
 /* position t of the sequence that beam row r currently continues.            */
 /*   vidil_beam_ancestry: dst[r][t] = src[beam_idx[r]][t] for t < cur_pos,    */
 /*                        dst[r][cur_pos] = r  (where row r's next K/V go).   */
-/*   vidil_beam_attention: one query token per beam row r (q f16 [rows][H*64],*/
+/*   vidil_beam_attention: one query token per beam row r (q T16 [rows][H*64],*/
 /*     pre-scaled) over positions 0..n_keys-1 of its ancestry:                */
 /*     out[r][h*64+d] = softmax_t(q_rh . K[t][anc[r][t]][h]) V[t][anc[r][t]][h]*/
-/*     f32 scores / softmax / accumulation, f16 output (row stride ldo).      */
+/*     f32 scores / softmax / accumulation, T16 output (row stride ldo).      */
 /*     n_keys <= 64.  Replaces the cached self-attention of models/med.py:    */
 /*     178-220 on decode steps (past_key_values + _reorder_cache).            */
 /* ------------------------------------------------------------------------ */
@@ -276,7 +292,7 @@ int vidil_beam_ancestry(const int32_t* anc_src, int32_t* anc_dst,
 int vidil_beam_attention(const void* q, const void* k_arena, const void* v_arena,
                          const int32_t* anc, void* out, int32_t rows, int32_t H,
                          int32_t n_keys, int32_t arena_rows, int32_t Tcap,
-                         int32_t ldo, void* stream);
+                         int32_t ldo, int32_t dtype, void* stream);
 
 /* ------------------------------------------------------------------------ */
 /* One nucleus-sampling step (HF transformers 4.15 sample() as configured by  */

@@ -30,7 +30,7 @@ def test_library_exports_every_declared_symbol():
         assert hasattr(lib, n), f"{n} declared in include/vidil_hip.h but not exported"
     assert set(names) == set(_lib.SIGNATURES), set(names) ^ set(_lib.SIGNATURES)
     assert lib.vidil_num_entry_points() == len(names)
-    assert lib.vidil_abi_version() == 3
+    assert lib.vidil_abi_version() == 4
 
 
 def test_gemm_args_struct_matches_header_field_order():
@@ -55,19 +55,30 @@ def test_argument_validation_without_a_gpu():
 
     lib = _lib.load()
     g = _lib.GemmArgs()
-    assert lib.vidil_gemm_f16(ctypes.byref(g), None) == -1
+    assert lib.vidil_gemm(ctypes.byref(g), None) == -1
     assert b"null operand" in lib.vidil_last_error()
     g.A, g.W, g.M, g.N, g.K = 16, 16, 8, 8, 100
-    assert lib.vidil_gemm_f16(ctypes.byref(g), None) == -1
+    assert lib.vidil_gemm(ctypes.byref(g), None) == -1
     assert b"multiple of 64" in lib.vidil_last_error()
-    assert lib.vidil_attention(16, 16, 16, 16, None, None, None, 0, 0, 1, 12, 4, 800, 4, 800, 800, 1, 0, 0, 768, 0, None) == -3
+    assert lib.vidil_attention(16, 16, 16, 16, None, None, None, 0, 0, 1, 12, 4, 800, 4, 800, 800, 1, 0, 0, 768, 0, 0, None) == -3
     assert b"not supported" in lib.vidil_last_error()
     # fragment-tiled K/V: key capacity a multiple of 32, at most 32 query rows per unit
-    assert lib.vidil_attention(16, 16, 16, 16, None, None, None, 0, 0, 3, 12, 1, 197, 1, 200, 0, 3, 0, 0, 768, 1, None) == -1
+    assert lib.vidil_attention(16, 16, 16, 16, None, None, None, 0, 0, 3, 12, 1, 197, 1, 200, 0, 3, 0, 0, 768, 1, 0, None) == -1
     assert b"multiple of 32" in lib.vidil_last_error()
-    assert lib.vidil_attention(16, 16, 16, 16, None, None, None, 0, 0, 40, 12, 1, 197, 1, 224, 0, 40, 0, 0, 768, 1, None) == -1
+    assert lib.vidil_attention(16, 16, 16, 16, None, None, None, 0, 0, 40, 12, 1, 197, 1, 224, 0, 40, 0, 0, 768, 1, 0, None) == -1
     assert b"at most 32 query rows" in lib.vidil_last_error()
     assert lib.vidil_scan_topk_ws_bytes(128, 42784, 5) > 0
+    # unknown operand type codes are argument errors; the kernel-name query follows the dispatch without launching
+    assert lib.vidil_attention(16, 16, 16, 16, None, None, None, 0, 0, 1, 12, 4, 64, 4, 64, 64, 1, 0, 0, 768, 0, 7, None) == -1
+    assert b"unknown dtype" in lib.vidil_last_error()
+    g = _lib.GemmArgs()
+    g.A, g.W, g.out, g.M, g.N, g.K, g.ldo, g.epi, g.dtype = 16, 16, 16, 201728, 768, 768, 768, 1, 1
+    buf = ctypes.create_string_buffer(128)
+    assert lib.vidil_gemm_kernel_name(ctypes.byref(g), buf, 128) == 0 and buf.value == b"gemm256_kernel<__bf16, 1, 0>"
+    g.M, g.dtype = 3072, 0
+    assert lib.vidil_gemm_kernel_name(ctypes.byref(g), buf, 128) == 0 and buf.value.startswith(b"gemm_kernel<_Float16, ")
+    g.dtype = 5
+    assert lib.vidil_gemm(ctypes.byref(g), None) == -1 and b"unknown dtype" in lib.vidil_last_error()
 
 
 def test_product_path_refuses_cpu_tensors():
@@ -288,3 +299,21 @@ def test_clip_processor_text_side_and_no_cpu_fallback_for_images():
     if not torch.cuda.is_available():
         with pytest.raises(Exception):
             proc(images=[np.zeros((10, 12, 3), np.uint8)], return_tensors="pt")
+
+
+def test_bench_gflop_model_reproduces_baseline_md_section_4():
+    """bench.py derives the algorithmic GFLOP/frame from the geometry (so ViT-L/16, 384^2 and CLIP-L/14 get their own
+    figures); at the headline geometry it must reproduce BASELINE.md §4 / SURVEY.md §8d."""
+    import importlib.util
+
+    spec = importlib.util.spec_from_file_location("bench_mod", os.path.join(ROOT, "bench.py"))
+    b = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(b)
+    g = b.gflop_per_frame("base", 224, "b32")
+    for key, want in dict(vit_caption=35.13, decode=20.05, itm_kv=5.58, itm_per_caption=7.24, clip=8.82, scan=0.044).items():
+        assert abs(g[key] - want) <= 0.005 * want + 0.002, (key, g[key], want)
+    total8 = 2 * g["vit_caption"] + g["decode"] + g["itm_kv"] + 8 * g["itm_per_caption"] + g["clip"] + g["scan"]
+    assert abs(total8 - 162.6) < 0.5
+    assert abs(b.gflop_per_frame("large", 224, "b32")["vit_caption"] - 123.11) < 0.1       # config 4
+    assert abs(b.gflop_per_frame("base", 384, "l14")["vit_caption"] - 110.97) < 0.1
+    assert abs(b.gflop_per_frame("base", 384, "l14")["clip"] - 162.03) < 0.2

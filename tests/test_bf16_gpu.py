@@ -1,0 +1,290 @@
+"""The bf16 variant of the path (BASELINE config 2, "1 x MI355X bf16"): the same kernels instantiated on
+v_mfma_f32_32x32x16_bf16, selected per model with packing.set_compute_dtype.
+
+Kernel level: bf16 inputs are exactly representable in f32, so against an fp32 torch reference fed the SAME bf16
+values the only differences are summation order and the final rounding to bf16 (2^-9 relative).
+Model level: tolerances are the f16 ones scaled by the mantissa ratio 2^11 / 2^8 = 8 (measured values in the
+asserts' comments); integer outputs keep their exactness requirements (device beam == oracle beam on the device's
+own logits; batch-composition invariance)."""
+import numpy as np
+import pytest
+import torch
+
+from common import load_golden, load_into, perturb_, synthetic_frames
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda"
+BF = torch.bfloat16
+
+
+def _k():
+    from vidil_amd import kernels
+    return kernels
+
+
+def _rand(*shape, scale=1.0, seed=0):
+    g = torch.Generator(device="cpu").manual_seed(seed)
+    return torch.randn(*shape, generator=g) * scale
+
+
+# ------------------------------------------------------------------------------- GEMM
+@pytest.mark.parametrize("M,N,K", [(197 * 4, 768, 768), (300, 3072, 768), (513, 768, 3072), (7, 2, 768),
+                                   (197 * 300, 768, 768)])        # the last one runs on the 256x256 kernel
+def test_gemm_bf16(M, N, K):
+    k = _k()
+    a = _rand(M, K, seed=1).to(BF)
+    w = _rand(N, K, scale=0.05, seed=2).to(BF)
+    bias = _rand(N, seed=3)
+    ref = a.float() @ w.float().t() + bias
+    out16 = k.gemm(a.to(DEV), w.to(DEV), bias.to(DEV))
+    out32 = k.gemm(a.to(DEV), w.to(DEV), bias.to(DEV), out_dtype=torch.float32)
+    assert out16.dtype == BF
+    assert torch.allclose(out32.cpu(), ref, rtol=1e-4, atol=1e-3)              # exact products, f32 accumulate
+    assert torch.allclose(out16.float().cpu(), ref, rtol=8e-3, atol=8e-3)      # + one rounding to bf16
+    with pytest.raises(k.VidilHipError):                                        # operand types must agree
+        k.gemm(a.to(DEV), w.half().to(DEV), None)
+
+
+def test_gemm_bf16_big_and_small_kernels_agree_bit_for_bit():
+    """Outputs must not depend on which kernel a batch size selects — for bf16 as for f16."""
+    k = _k()
+    M, N, K = 197 * 330, 768, 768
+    a = _rand(M, K, seed=4).to(BF).to(DEV)
+    w = _rand(N, K, scale=0.05, seed=5).to(BF).to(DEV)
+    bias = _rand(N, seed=6).to(DEV)
+    assert k.gemm_kernel_name(a, w, bias, act=k.ACT_GELU_ERF).startswith("gemm256_kernel<__bf16")
+    assert k.gemm_kernel_name(a[:1000], w, bias, act=k.ACT_GELU_ERF).startswith("gemm_kernel<__bf16")
+    big = k.gemm(a, w, bias, act=k.ACT_GELU_ERF)
+    small = k.gemm(a[:1000].contiguous(), w, bias, act=k.ACT_GELU_ERF)
+    assert torch.equal(big[:1000], small)
+    x = _rand(M, N, seed=7).to(DEV)
+    big32 = k.gemm(a, w, bias, out=x.clone(), resid=x)
+    small32 = k.gemm(a[:1000].contiguous(), w, bias, out=x[:1000].clone(), resid=x[:1000].contiguous())
+    assert torch.equal(big32[:1000], small32)
+
+
+@pytest.mark.parametrize("B", [3, 330])     # small-tile kernel and the 256x256 kernel
+def test_gemm_bf16_heads_rowmajor_v_then_staged_attention(B):
+    """QKV GEMM (per-head scatter, V row-major) -> LDS-staged attention, the ViT block's first half, in bf16."""
+    k = _k()
+    T, H = 197, 12
+    M, K, N = B * T, 768, 3 * H * 64
+    a = _rand(M, K, seed=8).to(BF)
+    w = _rand(N, K, scale=0.05, seed=9).to(BF)
+    bias = _rand(N, seed=10)
+    q = torch.zeros(B, H, T, 64, dtype=BF, device=DEV)
+    kk = torch.zeros_like(q)
+    v = torch.zeros_like(q)
+    k.gemm(a.to(DEV), w.to(DEV), bias.to(DEV),
+           heads=dict(q=q, k=kk, vt=v, T=T, H=H, part0=0, t_off=0, Tq_cap=T, Tk_cap=T, NP=0, q_scale=0.125))
+    nb = min(B, 3)
+    ref = (a[:nb * T].float() @ w.float().t() + bias).view(nb, T, 3, H, 64)
+    tol = dict(rtol=8e-3, atol=8e-3)
+    assert torch.allclose(q[:nb].float().cpu(), ref[:, :, 0].permute(0, 2, 1, 3) * 0.125, **tol)
+    assert torch.allclose(kk[:nb].float().cpu(), ref[:, :, 1].permute(0, 2, 1, 3), **tol)
+    assert torch.allclose(v[:nb].float().cpu(), ref[:, :, 2].permute(0, 2, 1, 3), **tol)
+    o = torch.zeros(M, H * 64, dtype=BF, device=DEV)
+    k.attention(q, kk, v, o, Bq=B, H=H, Nq=T, Nk=T, Tq_cap=T, Tk_cap=T, NP=0)
+    qf, kf, vf = q[:nb].float().cpu(), kk[:nb].float().cpu(), v[:nb].float().cpu()
+    p = torch.softmax(qf @ kf.transpose(-1, -2), dim=-1)
+    oref = (p @ vf).permute(0, 2, 1, 3).reshape(nb * T, H * 64)
+    assert torch.allclose(o[:nb * T].float().cpu(), oref, rtol=1e-2, atol=6e-3)     # P and the output rounded to bf16
+
+
+def test_bf16_decode_step_kernels_arena_tiled_cross_and_beam_attention():
+    k = _k()
+    H, C, K_ = 12, 768, 768
+    Tcap, R, nb, B = 8, 12, 3, 4
+    w = _rand(3 * C, K_, scale=0.05, seed=20).to(BF)
+    bias = _rand(3 * C, seed=21)
+    ka = torch.zeros(Tcap, R, C, dtype=BF, device=DEV)
+    va = torch.zeros_like(ka)
+    tol = dict(rtol=8e-3, atol=8e-3)
+    # decode step: append position 5 of every row, then attend over 6 positions through an ancestry table
+    for pos in range(6):
+        a1 = _rand(R, K_, seed=30 + pos).to(BF)
+        q = torch.zeros(R, C, dtype=BF, device=DEV)
+        k.gemm(a1.to(DEV), w.to(DEV), bias.to(DEV),
+               arena=dict(q=q, k=ka, v=va, T=1, H=H, part0=0, t_off=pos, Tcap=Tcap, arena_rows=R, slot_stride=1, q_scale=0.125))
+    r1 = (a1.float() @ w.float().t() + bias).view(R, 3, C)
+    assert torch.allclose(q.float().cpu(), r1[:, 0] * 0.125, **tol) and torch.allclose(ka[5].float().cpu(), r1[:, 1], **tol)
+    g = torch.Generator().manual_seed(5)
+    anc = torch.randint(0, R, (R, Tcap), generator=g, dtype=torch.int32)
+    out = torch.zeros(R, C, dtype=BF, device=DEV)
+    k.beam_attention(q, ka, va, anc.to(DEV), out, rows=R, H=H, n_keys=6)
+    t = torch.arange(6)
+    kg = ka.cpu()[t[None, :], anc[:, :6].long()].float().view(R, 6, H, 64)
+    vg = va.cpu()[t[None, :], anc[:, :6].long()].float().view(R, 6, H, 64)
+    s = torch.einsum("rhd,rthd->rht", q.float().cpu().view(R, H, 64), kg)
+    ref = torch.einsum("rht,rthd->rhd", torch.softmax(s, dim=-1), vg).reshape(R, C)
+    assert torch.allclose(out.float().cpu(), ref, rtol=1e-2, atol=6e-3)
+    # cross K|V in fragment tiles -> direct attention with the 3 beams of an image as one unit
+    T = 197
+    Tc = (T + 31) // 32 * 32
+    enc = _rand(B * T, K_, seed=40).to(BF)
+    wkv = _rand(2 * C, K_, scale=0.05, seed=41).to(BF)
+    bkv = _rand(2 * C, seed=42)
+    kt = torch.zeros(B, H, Tc, 64, dtype=BF, device=DEV)
+    vt = torch.zeros_like(kt)
+    k.gemm(enc.to(DEV), wkv.to(DEV), bkv.to(DEV), heads=dict(k=kt, vt=vt, T=T, H=H, part0=1, t_off=0, Tk_cap=Tc, tiled=True))
+    qx = (_rand(B * nb, H, 1, 64, seed=43) * 0.125).to(BF).to(DEV)
+    ox = torch.zeros(B * nb, C, dtype=BF, device=DEV)
+    k.attention(qx, kt, vt, ox, Bq=B * nb, H=H, Nq=1, Nk=T, Tq_cap=1, Tk_cap=Tc, NP=0, kv_group=nb, kv_tiled=True)
+    kv = (enc.float() @ wkv.float().t() + bkv).to(BF).float().view(B, T, 2, H, 64)
+    kr, vr = kv[:, :, 0].permute(0, 2, 1, 3), kv[:, :, 1].permute(0, 2, 1, 3)                    # [B,H,T,64]
+    qq = qx.float().cpu().view(B, nb, H, 64)
+    s = torch.einsum("bnhd,bhtd->bnht", qq, kr)
+    oref = torch.einsum("bnht,bhtd->bnhd", torch.softmax(s, dim=-1), vr).reshape(B * nb, C)
+    assert torch.allclose(ox.float().cpu(), oref, rtol=1e-2, atol=6e-3)
+
+
+def test_layernorm_patchify_split3_bf16():
+    k = _k()
+    x = _rand(37, 768, seed=50) * 3 + 0.5
+    g, b = _rand(768, seed=51) * 0.1 + 1, _rand(768, seed=52) * 0.1
+    o16 = torch.zeros(37, 768, dtype=BF, device=DEV)
+    o32 = torch.zeros(37, 768, dtype=torch.float32, device=DEV)
+    k.layernorm(x.to(DEV), g.to(DEV), b.to(DEV), 1e-6, out16=o16, out32=o32)
+    ref = torch.nn.functional.layer_norm(x, (768,), g, b, 1e-6)
+    assert torch.allclose(o32.cpu(), ref, rtol=1e-5, atol=1e-5)
+    assert torch.equal(o16.cpu(), o32.cpu().to(BF))                              # round to nearest even of the f32 result
+    u8 = torch.from_numpy(synthetic_frames(1, 2, size=64)[0]).to(DEV)
+    p16 = k.patchify_u8(u8, 16, (0.5, 0.4, 0.3), (0.2, 0.25, 0.3), dtype=BF)
+    ph = k.patchify_u8(u8, 16, (0.5, 0.4, 0.3), (0.2, 0.25, 0.3), dtype=torch.float16)
+    assert p16.dtype == BF and (p16.float() - ph.float()).abs().max().item() < 2e-2
+    for dt in (BF, torch.float16):
+        s3 = torch.zeros(37, 3 * 768, dtype=dt, device=DEV)
+        k.split3(x.to(DEV), s3)
+        hi, lo = s3[:, :768].float().cpu(), s3[:, 768:1536].float().cpu()
+        assert torch.equal(s3[:, :768], s3[:, 1536:]) and torch.equal(s3[:, :768].cpu(), x.to(dt))
+        # hi + lo carries ~2x the mantissa bits of one T16 value
+        assert ((hi + lo) - x).abs().max().item() <= (2.0 ** -15 if dt == BF else 2.0 ** -20) * x.abs().max().item()
+
+
+# ------------------------------------------------------------------------------- models
+def test_vit_small_vs_golden_bf16():
+    from vidil_amd.packing import set_compute_dtype
+    from vidil_amd.vit import VisionTransformer
+
+    sd, g = load_golden("vit_small.npz")
+    m = VisionTransformer(img_size=64, patch_size=16, embed_dim=256, depth=2, num_heads=4)
+    load_into(m, sd, "visual_encoder.")
+    set_compute_dtype("bf16", m)
+    y = m.to(DEV)(torch.from_numpy(g["x"]).to(DEV)).cpu()
+    d = (y - torch.from_numpy(g["y"])).abs()
+    assert d.max().item() < 4e-2 and d.mean().item() < 4e-3          # f16: 5e-3 / 5e-4 (x8)
+    set_compute_dtype("f16", m)                                       # the same module re-packs for f16
+    y2 = m(torch.from_numpy(g["x"]).to(DEV)).cpu()
+    assert (y2 - torch.from_numpy(g["y"])).abs().max().item() < 5e-3
+
+
+@pytest.fixture(scope="module")
+def bf16_models():
+    from vidil_amd.blip import BLIP_Decoder
+    from vidil_amd.blip_itm import BLIP_ITM
+    from vidil_amd.clip import CLIPModel
+    from vidil_amd.packing import set_compute_dtype
+    from vidil_amd.tokenizer import SyntheticBertTokenizer
+
+    torch.manual_seed(0)
+    tok = SyntheticBertTokenizer()
+    cap = BLIP_Decoder(image_size=224, vit="base", tokenizer=tok).eval()
+    itm = BLIP_ITM(image_size=224, vit="base", tokenizer=tok).eval()
+    clip = CLIPModel().eval()
+    for i, m in enumerate((cap, itm, clip)):
+        perturb_(m, 100 + i)
+    sds = [{k: v.clone() for k, v in m.state_dict().items()} for m in (cap, itm, clip)]
+    set_compute_dtype("bf16", cap, itm, clip)
+    return dict(tok=tok, cap=cap.to(DEV), itm=itm.to(DEV), clip=clip.to(DEV), sd_cap=sds[0], sd_itm=sds[1], sd_clip=sds[2])
+
+
+def test_full_blip_caption_logits_and_beam_bf16_vs_fp32_oracle(bf16_models):
+    from oracle import beam_ref, clip_ref, med_ref, vit_ref
+    from vidil_amd.blip import DecoderSession
+
+    fm = bf16_models
+    cap, sd = fm["cap"], fm["sd_cap"]
+    B, nb = 2, 3
+    u8 = synthetic_frames(1, B)[0]
+    x = clip_ref.preprocess_u8(u8)
+    with torch.no_grad():
+        y_ref = vit_ref.vit_forward(sd, x)
+    y32, y16 = cap.visual_encoder.forward_u8(torch.from_numpy(u8).to(DEV), clip_ref.CLIP_MEAN, clip_ref.CLIP_STD)
+    assert y16.dtype == BF
+    d = (y32.cpu() - y_ref).abs()
+    assert d.max().item() < 8e-2 and d.mean().item() < 8e-3           # f16: 1e-2 / 1e-3
+    prompt = cap.prompt_ids(B, "cpu").long()
+    with torch.no_grad():
+        ref0, _ = med_ref.decoder_logits(sd, prompt, y_ref, None)
+    sess = DecoderSession(cap.text_decoder, y16, B, nb, 20)
+    lg = sess.prefill(prompt.to(torch.int32).reshape(-1).to(DEV), prompt.shape[1], shared=True)
+    dl = (lg.cpu() - ref0).abs()
+    scale = max(1.0, ref0.abs().max().item())
+    print(f"bf16 caption logits (prompt pass): max|d| {dl.max().item():.3e} mean {dl.mean().item():.3e} scale {scale:.2f}")
+    assert dl.max().item() <= 8e-3 * scale and dl.mean().item() <= 4e-3 * scale       # f16: 1e-3 / 5e-4 of the scale
+    # free-running device beam search == the oracle's beam search driven by the DEVICE's bf16 logits (bit-identical ids)
+    out_tok, _ = cap.generate_ids(y16, B, num_beams=nb, max_length=20, min_length=5)
+    sess2 = DecoderSession(cap.text_decoder, y16, B, nb, 20)
+
+    def dev_step(ids, beam_idx):
+        if beam_idx is None:
+            l = sess2.prefill(torch.from_numpy(ids).to(torch.int32).reshape(-1).to(DEV), ids.shape[1])
+        else:
+            l = sess2.step(torch.from_numpy(ids[:, -1].copy()).to(torch.int32).to(DEV),
+                           torch.from_numpy(beam_idx).to(torch.int32).to(DEV), ids.shape[1] - 1)
+        return l.cpu().numpy()
+
+    seqs, _ = beam_ref.beam_search(dev_step, prompt.numpy(), num_beams=nb, max_length=20, min_length=5, eos_token_id=102,
+                                   pad_token_id=0)
+    toks = out_tok.cpu().numpy()
+    for b in range(B):
+        assert np.array_equal(toks[b][: len(seqs[b])], seqs[b])
+
+
+def test_itm_and_clip_bf16_vs_fp32_oracle(bf16_models):
+    from oracle import clip_ref, med_ref, vit_ref
+
+    fm = bf16_models
+    u8 = synthetic_frames(1, 3, first_video=3)[0]
+    x = clip_ref.preprocess_u8(u8)
+    caps = ["w2000 w2001 w2002", "a picture of w77 w78 w79 w80", "w5 w6"]
+    ids, lens = fm["itm"].tokenize(caps)
+    am = (torch.arange(35)[None] < lens[:, None]).long()
+    with torch.no_grad():
+        ref = med_ref.itm_logits(fm["sd_itm"], vit_ref.vit_forward(fm["sd_itm"], x), ids.long(), am)
+        ie_ref = clip_ref.image_embeds(fm["sd_clip"], x)
+    got = fm["itm"](x.to(DEV), caps).cpu()
+    assert (got - ref).abs().max().item() < 1.6e-2                    # f16: 2e-3
+    p_ref, p_got = torch.softmax(ref, 1)[:, 1], torch.softmax(got, 1)[:, 1]
+    assert (p_got - p_ref).abs().max().item() < 8e-3                  # f16: 1e-3
+    ie = fm["clip"].encode_image_u8(torch.from_numpy(u8).to(DEV)).cpu()
+    assert (ie - ie_ref).abs().max().item() < 4e-3                    # f16: 5e-4 (unit-norm embeddings)
+
+
+def test_bf16_results_do_not_depend_on_batch_composition(bf16_models):
+    from vidil_amd.capfilt import CapFiltEngine
+    from vidil_amd.visual_tokenization import VisualTokenizer
+
+    fm = bf16_models
+    Nv, F = 3, 8
+    u8 = torch.from_numpy(synthetic_frames(Nv, F, first_video=21)).to(DEV)
+    cfg = dict(caption=True, filter=True, filter_generated_only=True, keep_original_caption=False, threshold=0.4,
+               filter_mode="max_filter", generation_mode="beam", image_size=224, vit="base", topk_visualize=5)
+    eng = CapFiltEngine(cfg, DEV, captioner=fm["cap"], filterer=fm["itm"])
+    g = torch.Generator().manual_seed(3)
+    sizes = dict(objects=700, attributes=333, scenes=65, verbs=96)
+    emb = {k: torch.nn.functional.normalize(torch.randn(n, 512, generator=g), dim=-1) for k, n in sizes.items()}
+    texts = {k: [f"{k}{i}" for i in range(n)] for k, n in sizes.items()}
+    vt = VisualTokenizer(cfg, fm["clip"], texts, emb, DEV)
+
+    def run(lo, hi):
+        items = [dict(video_id=f"video{v}", text=[]) for v in range(lo, hi)]
+        eng.process(items, u8[lo:hi])
+        return items, vt.process([it["video_id"] for it in items], u8[lo:hi], [[] for _ in items])
+
+    all_items, all_t = run(0, Nv)
+    assert all(len(it["unfiltered_text"]) > 0 for it in all_items)
+    for v in range(Nv):
+        it, t = run(v, v + 1)
+        assert it[0]["unfiltered_text"] == all_items[v]["unfiltered_text"] and it[0]["text"] == all_items[v]["text"]
+        assert t[f"video{v}"] == all_t[f"video{v}"]

@@ -330,6 +330,32 @@ def test_full_vit_and_caption_logits_and_beam_tokens_vs_oracle(full_models):
     print(f"free-running captions equal to the fp32 oracle: {agree}/{B}")
 
 
+def test_error_compensated_lm_head_removes_the_heads_own_rounding(full_models):
+    """VIDIL_PRECISE_LM_HEAD: fed the ORACLE's exact hidden states, the hi+lo split head reproduces the fp32 logits to
+    ~1e-5 where the plain f16 head is off by several 1e-4 — i.e. what remains in the full path is the trunk's operand
+    rounding, not the head's (DESIGN.md §4 budget)."""
+    from oracle import med_ref
+
+    cap, sd = full_models["cap"], full_models["sd_cap"]
+    dec = cap.text_decoder
+    g = torch.Generator().manual_seed(11)
+    h = torch.randn(12, 768, generator=g)                         # post-LayerNorm-like hidden states
+    with torch.no_grad():
+        ref = med_ref.lm_head(sd, "text_decoder.cls.", h)
+    h32 = h.to(DEV)
+    was = dec.precise_head
+    try:
+        dec.precise_head = False
+        plain = dec.lm_logits(h32.half(), 12, 1, h32=h32).cpu()
+        dec.precise_head = True
+        precise = dec.lm_logits(h32.half(), 12, 1, h32=h32).cpu()
+    finally:
+        dec.precise_head = was
+    e_plain, e_prec = (plain - ref).abs().max().item(), (precise - ref).abs().max().item()
+    print(f"LM head alone vs fp32: plain f16 operands max|d| {e_plain:.2e}, error-compensated {e_prec:.2e}")
+    assert e_prec < 3e-5 and e_prec < e_plain / 10
+
+
 def test_full_itm_vs_oracle(full_models):
     from oracle import clip_ref, med_ref, vit_ref
 

@@ -138,3 +138,31 @@ def test_ontology_filter_replayed_on_reference_files():
             if key in attrs:
                 attrs.remove(key)
         assert ont["attributes"] == attrs
+
+
+def test_deduplicated_cpu_schedule_gives_the_reference_schedule_results():
+    """bench.py times the oracle in the reference's redundant schedule AND in the de-duplicated one (cross K/V once per
+    image, filter ViT once per frame): same function, so identical captions / filter probabilities."""
+    import numpy as np
+    import torch
+
+    from oracle import pipeline_ref
+    from vidil_amd.blip import BLIP_Decoder
+    from vidil_amd.blip_itm import BLIP_ITM
+    from vidil_amd.tokenizer import SyntheticBertTokenizer
+
+    torch.manual_seed(1)
+    tok = SyntheticBertTokenizer()
+    cap = BLIP_Decoder(image_size=32, vit="base", tokenizer=tok).eval()        # 5 image tokens: fast on the CPU
+    itm = BLIP_ITM(image_size=32, vit="base", tokenizer=tok).eval()
+    sd_cap = {k: v.clone() for k, v in cap.state_dict().items()}
+    sd_itm = {k: v.clone() for k, v in itm.state_dict().items()}
+    x = torch.randn(2, 3, 32, 32)
+    prompt = cap.prompt_ids(1, "cpu")[0].long().numpy()
+    kw = dict(max_length=8, min_length=5)
+    caps_ref = pipeline_ref.caption_video(sd_cap, x, prompt, tok, cap.prompt, **kw)
+    caps_dd = pipeline_ref.caption_video(sd_cap, x, prompt, tok, cap.prompt, dedup=True, **kw)
+    assert caps_ref == caps_dd and len(caps_ref) == 2
+    _, p_ref = pipeline_ref.filter_video(sd_itm, x, caps_ref, tok, 0.4, return_probs=True)
+    _, p_dd = pipeline_ref.filter_video(sd_itm, x, caps_ref, tok, 0.4, return_probs=True, dedup=True)
+    assert all(np.array_equal(a, b) for a, b in zip(p_ref, p_dd))

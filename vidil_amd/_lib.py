@@ -17,6 +17,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("VIDIL_HIP_LIB") or os.path.join(_HERE, "csrc", "libvidil_hip.so")
 
 EPI_F16, EPI_F32, EPI_HEADS, EPI_PATCH, EPI_ARENA = 0, 1, 2, 3, 4
+DT_F16, DT_BF16 = 0, 1
 ACT_NONE, ACT_GELU_ERF, ACT_QUICK_GELU = 0, 1, 2
 
 
@@ -34,7 +35,7 @@ class GemmArgs(C.Structure):
         ("Tq_cap", C.c_int32), ("Tk_cap", C.c_int32), ("NP", C.c_int32),
         ("q_scale", C.c_float),
         ("arena_rows", C.c_int32), ("slot_stride", C.c_int32),
-        ("pos", C.c_void_p), ("tpi", C.c_int32), ("kv_tiled", C.c_int32),
+        ("pos", C.c_void_p), ("tpi", C.c_int32), ("kv_tiled", C.c_int32), ("dtype", C.c_int32),
     ]
 
 
@@ -53,11 +54,13 @@ SIGNATURES = {
     "vidil_last_error": (C.c_char_p, []),
     "vidil_abi_version": (_i32, []),
     "vidil_num_entry_points": (_i32, []),
-    "vidil_gemm_f16": (_i32, [C.POINTER(GemmArgs), _p]),
-    "vidil_layernorm": (_i32, [_p, _i64, _p, _p, _f32, _i32, _i32, _p, _p, _p]),
-    "vidil_attention": (_i32, [_p, _p, _p, _p, _p, _p, _p] + [_i32] * 14 + [_p]),
-    "vidil_patchify_f32": (_i32, [_p, _p, _i32, _i32, _i32, _p]),
-    "vidil_patchify_u8": (_i32, [_p, _p, _i32, _i32, _i32, C.POINTER(_f32), C.POINTER(_f32), _p]),
+    "vidil_gemm": (_i32, [C.POINTER(GemmArgs), _p]),
+    "vidil_gemm_kernel_name": (_i32, [C.POINTER(GemmArgs), C.c_char_p, _i32]),
+    "vidil_layernorm": (_i32, [_p, _i64, _p, _p, _f32, _i32, _i32, _p, _i32, _p, _p]),
+    "vidil_split3_f32": (_i32, [_p, _p, _i32, _i32, _i32, _p]),
+    "vidil_attention": (_i32, [_p, _p, _p, _p, _p, _p, _p] + [_i32] * 15 + [_p]),
+    "vidil_patchify_f32": (_i32, [_p, _p, _i32, _i32, _i32, _i32, _p]),
+    "vidil_patchify_u8": (_i32, [_p, _p, _i32, _i32, _i32, C.POINTER(_f32), C.POINTER(_f32), _i32, _p]),
     "vidil_resample_u8": (_i32, [_p, _p] + [_i32] * 6 + [_p, _p, _i32, _i32, _p]),
     "vidil_set_cls_row": (_i32, [_p, _p, _p, _i32, _i32, _i32, _p]),
     "vidil_embed_tokens": (_i32, [_p, _p, _p, _p, _i32, _i32, _i32, _i32, _i32, _p]),
@@ -68,7 +71,7 @@ SIGNATURES = {
     "vidil_beam_finalize": (_i32, [C.POINTER(BeamState)] + [_i32] * 6 + [_p, _p, _p, _p]),
     "vidil_kv_reorder": (_i32, [_p, _p, _p, _i32, _i32, _i64, _p]),
     "vidil_beam_ancestry": (_i32, [_p, _p, _p, _i32, _i32, _i32, _p]),
-    "vidil_beam_attention": (_i32, [_p, _p, _p, _p, _p] + [_i32] * 6 + [_p]),
+    "vidil_beam_attention": (_i32, [_p, _p, _p, _p, _p] + [_i32] * 7 + [_p]),
     "vidil_sample_top_k_top_p": (_i32, [_p, _p, _p, _p, _p] + [_i32] * 8 + [_f32, _f32, C.c_uint64, _i32, _i32, _p]),
     "vidil_scan_scores": (_i32, [_p, _p, _i32, _i32, _i32, _p, _p]),
     "vidil_topk_rows": (_i32, [_p, _i64, _i32, _i32, _i32, _p, _p, _p]),

@@ -101,7 +101,7 @@ class DecoderSession:
         self.tiled_cross = tiled_cross
         self.cross = self.bert.project_cross_kv(enc16, B, Te, tiled=tiled_cross)
         self.Tcap = max_length
-        self.arena = BeamArena(self.L, self.Tcap, self.R, cfg.hidden_size, dev)
+        self.arena = BeamArena(self.L, self.Tcap, self.R, cfg.hidden_size, dev, dtype=enc16.dtype)
         self.ws_prefill, self.ws_step = {}, {}
         self.logits = None
 
@@ -121,15 +121,16 @@ class DecoderSession:
         rows = self.B if shared else self.R
         dev = ids_i32.device
         h32, h16 = self.bert.embed(ids_i32, P, 0)
+        cdt = h16.dtype
         NPp = (P + 15) // 16 * 16
         # the prompt block attends to itself through one scratch K / V^T pair shared by all layers
-        sk = torch.empty((1, rows, self.H, P, 64), dtype=torch.float16, device=dev).expand(self.L, -1, -1, -1, -1)
-        sv = torch.empty((1, rows, self.H, 64, NPp), dtype=torch.float16, device=dev).expand(self.L, -1, -1, -1, -1)
+        sk = torch.empty((1, rows, self.H, P, 64), dtype=cdt, device=dev).expand(self.L, -1, -1, -1, -1)
+        sv = torch.empty((1, rows, self.H, 64, NPp), dtype=cdt, device=dev).expand(self.L, -1, -1, -1, -1)
         self.arena.init_prompt(P, self.nb if shared else 1)
         self.bert.run_layers(h32, h16, rows=rows, T=P, self_k=sk, self_vt=sv, t_off=0, Tk_cap=P, NPs=NPp, causal=True,
                              kv_len=None, cross=self.cross, cross_group=1 if shared else self.nb, ws=self.ws_prefill,
                              arena=self.arena, arena_slot_stride=self.nb if shared else 1)
-        return self.dec.lm_logits(h16, rows, P)
+        return self.dec.lm_logits(h16, rows, P, h32=h32)
 
     def step(self, next_tok_i32, beam_idx_i32, past_len):
         """Re-point the beams at their new histories (``beam_idx``: models/med.py:951-955 _reorder_cache, here a
@@ -140,7 +141,7 @@ class DecoderSession:
         self.bert.run_layers(h32, h16, rows=self.R, T=1, self_k=None, self_vt=None, t_off=past_len, Tk_cap=self.Tcap,
                              NPs=0, causal=False, kv_len=None, cross=self.cross, cross_group=self.nb, ws=self.ws_step,
                              arena=self.arena)
-        self.logits = self.dec.lm_logits(h16, self.R, 1, out=self.logits)
+        self.logits = self.dec.lm_logits(h16, self.R, 1, out=self.logits, h32=h32)
         return self.logits
 
 

@@ -37,7 +37,7 @@ class BLIP_ITM(PackedCache, nn.Module):
         self.itm_head = nn.Linear(text_width, 2)
 
     def _pack(self):
-        return dict(itm_w=w16(self.itm_head.weight), itm_b=v32(self.itm_head.bias))
+        return dict(itm_w=w16(self.itm_head.weight, dtype=self.cdt), itm_b=v32(self.itm_head.bias))
 
     def parameters_for_fingerprint(self):
         return [self.itm_head.weight, self.itm_head.bias]

@@ -34,8 +34,8 @@ class BLIP_Retrieval(BLIP_ITM):
 
     def _pack(self):
         p = super()._pack()
-        p.update(vp_w=w16(self.vision_proj.weight), vp_b=v32(self.vision_proj.bias),
-                 tp_w=w16(self.text_proj.weight), tp_b=v32(self.text_proj.bias))
+        p.update(vp_w=w16(self.vision_proj.weight, dtype=self.cdt), vp_b=v32(self.vision_proj.bias),
+                 tp_w=w16(self.text_proj.weight, dtype=self.cdt), tp_b=v32(self.text_proj.bias))
         return p
 
     def parameters_for_fingerprint(self):

@@ -119,18 +119,18 @@ class _TextModel(nn.Module):
         self.final_layer_norm = nn.LayerNorm(cfg.hidden_size, eps=cfg.layer_norm_eps)
 
 
-def _pack_layers(encoder):
+def _pack_layers(encoder, c):
     out = []
     for l in encoder.layers:
         a = l.self_attn
         out.append(dict(
             n1g=v32(l.layer_norm1.weight), n1b=v32(l.layer_norm1.bias),
-            qkv_w=w16(a.q_proj.weight, a.k_proj.weight, a.v_proj.weight),
+            qkv_w=w16(a.q_proj.weight, a.k_proj.weight, a.v_proj.weight, dtype=c),
             qkv_b=v32(a.q_proj.bias, a.k_proj.bias, a.v_proj.bias),
-            o_w=w16(a.out_proj.weight), o_b=v32(a.out_proj.bias),
+            o_w=w16(a.out_proj.weight, dtype=c), o_b=v32(a.out_proj.bias),
             n2g=v32(l.layer_norm2.weight), n2b=v32(l.layer_norm2.bias),
-            fc1_w=w16(l.mlp.fc1.weight), fc1_b=v32(l.mlp.fc1.bias),
-            fc2_w=w16(l.mlp.fc2.weight), fc2_b=v32(l.mlp.fc2.bias)))
+            fc1_w=w16(l.mlp.fc1.weight, dtype=c), fc1_b=v32(l.mlp.fc1.bias),
+            fc2_w=w16(l.mlp.fc2.weight, dtype=c), fc2_b=v32(l.mlp.fc2.bias)))
     return out
 
 
@@ -138,15 +138,16 @@ def _run_layers(layers, x, B, T, H, eps, *, causal=False, kv_len=None):
     """Pre-LN CLIP encoder layers on the f32 residual stream x [B*T, D] (in place)."""
     dev = x.device
     M, D = x.shape
+    cdt = layers[0]["qkv_w"].dtype
     # more than 32 rows -> LDS-staged attention, which takes V row-major (NP = 0: plain 16-B stores from the QKV GEMM);
     # short text batches go through the direct kernels, which read V^T fragments straight from memory
     NP = 0 if T > 32 else (T + 15) // 16 * 16
-    xn = torch.empty((M, D), dtype=torch.float16, device=dev)
-    q = torch.empty((B, H, T, 64), dtype=torch.float16, device=dev)
-    k = torch.empty((B, H, T, 64), dtype=torch.float16, device=dev)
-    vt = torch.empty((B, H, T, 64) if NP == 0 else (B, H, 64, NP), dtype=torch.float16, device=dev)
-    o = torch.empty((M, D), dtype=torch.float16, device=dev)
-    hid = torch.empty((M, layers[0]["fc1_w"].shape[0]), dtype=torch.float16, device=dev)
+    xn = torch.empty((M, D), dtype=cdt, device=dev)
+    q = torch.empty((B, H, T, 64), dtype=cdt, device=dev)
+    k = torch.empty((B, H, T, 64), dtype=cdt, device=dev)
+    vt = torch.empty((B, H, T, 64) if NP == 0 else (B, H, 64, NP), dtype=cdt, device=dev)
+    o = torch.empty((M, D), dtype=cdt, device=dev)
+    hid = torch.empty((M, layers[0]["fc1_w"].shape[0]), dtype=cdt, device=dev)
     heads = dict(q=q, k=k, vt=vt, T=T, H=H, part0=0, t_off=0, Tq_cap=T, Tk_cap=T, NP=NP, q_scale=0.125)
     for l in layers:
         K.layernorm(x, l["n1g"], l["n1b"], eps, out16=xn)
@@ -224,16 +225,17 @@ class CLIPModel(PackedCache, nn.Module):
     def _pack(self):
         vm, tm = self.vision_model, self.text_model
         D = self.config.vision_config.hidden_size
+        c = self.cdt
         return dict(
-            pe_w=w16_patch(vm.embeddings.patch_embedding.weight),
+            pe_w=w16_patch(vm.embeddings.patch_embedding.weight, c),
             cls=v32(vm.embeddings.class_embedding), pos=v32(vm.embeddings.position_embedding.weight).view(-1, D),
             pre_g=v32(vm.pre_layrnorm.weight), pre_b=v32(vm.pre_layrnorm.bias),
             post_g=v32(vm.post_layernorm.weight), post_b=v32(vm.post_layernorm.bias),
-            vproj=w16(self.visual_projection.weight), vlayers=_pack_layers(vm.encoder),
+            vproj=w16(self.visual_projection.weight, dtype=c), vlayers=_pack_layers(vm.encoder, c),
             tok=v32(tm.embeddings.token_embedding.weight).view(self.config.text_config.vocab_size, -1),
             tpos=v32(tm.embeddings.position_embedding.weight).view(self.config.text_config.max_position_embeddings, -1),
             fin_g=v32(tm.final_layer_norm.weight), fin_b=v32(tm.final_layer_norm.bias),
-            tproj=w16(self.text_projection.weight), tlayers=_pack_layers(tm.encoder))
+            tproj=w16(self.text_projection.weight, dtype=c), tlayers=_pack_layers(tm.encoder, c))
 
     # ------------------------------------------------------------------ vision tower
     def _vision_from_patches(self, patches16, B, pooled=False):
@@ -243,12 +245,13 @@ class CLIPModel(PackedCache, nn.Module):
         P = (vc.image_size // vc.patch_size) ** 2
         T = P + 1
         dev = patches16.device
+        cdt = patches16.dtype
         x = torch.empty((B * T, D), dtype=torch.float32, device=dev)
         K.gemm(patches16, p["pe_w"], None, patch=dict(out=x, pos=p["pos"], tpi=P))
         K.set_cls_row(x, p["cls"], p["pos"], B, T, D)
         K.layernorm(x, p["pre_g"], p["pre_b"], vc.layer_norm_eps, out32=x)
         _run_layers(p["vlayers"], x, B, T, H, vc.layer_norm_eps)
-        pooled16 = torch.empty((B, D), dtype=torch.float16, device=dev)
+        pooled16 = torch.empty((B, D), dtype=cdt, device=dev)
         pooled32 = torch.empty((B, D), dtype=torch.float32, device=dev) if pooled else None
         K.layernorm(x, p["post_g"], p["post_b"], vc.layer_norm_eps, M=B, D=D, x_stride=T * D, out16=pooled16,
                     out32=pooled32)
@@ -262,7 +265,7 @@ class CLIPModel(PackedCache, nn.Module):
         """pixel_values f32 [F,3,S,S] (already normalised) -> unit-norm f32 [F,P]."""
         require_cuda(pixel_values, "CLIPModel.encode_image")
         ps = self.config.vision_config.patch_size
-        patches = K.patchify_f32(pixel_values.contiguous().float(), ps)
+        patches = K.patchify_f32(pixel_values.contiguous().float(), ps, dtype=self.cdt)
         return self._vision_from_patches(patches, pixel_values.shape[0])
 
     @torch.no_grad()
@@ -270,7 +273,7 @@ class CLIPModel(PackedCache, nn.Module):
         """uint8 [F,S,S,3] frames already at the model resolution; fused /255 + CLIP normalisation."""
         require_cuda(frames_u8, "CLIPModel.encode_image_u8")
         ps = self.config.vision_config.patch_size
-        patches = K.patchify_u8(frames_u8.contiguous(), ps, CLIP_MEAN, CLIP_STD)
+        patches = K.patchify_u8(frames_u8.contiguous(), ps, CLIP_MEAN, CLIP_STD, dtype=self.cdt)
         return self._vision_from_patches(patches, frames_u8.shape[0])
 
     @torch.no_grad()
@@ -280,7 +283,7 @@ class CLIPModel(PackedCache, nn.Module):
         (data/video_pretrain_dataset.py:199-202)."""
         require_cuda(frames_u8, "CLIPModel.pooled_image_u8")
         ps = self.config.vision_config.patch_size
-        patches = K.patchify_u8(frames_u8.contiguous(), ps, CLIP_MEAN, CLIP_STD)
+        patches = K.patchify_u8(frames_u8.contiguous(), ps, CLIP_MEAN, CLIP_STD, dtype=self.cdt)
         return self._vision_from_patches(patches, frames_u8.shape[0], pooled=True)
 
     # ------------------------------------------------------------------ text tower
@@ -295,6 +298,7 @@ class CLIPModel(PackedCache, nn.Module):
         N, L = input_ids.shape
         dev = input_ids.device
         ids32 = input_ids.to(torch.int32).contiguous()
+        cdt = p["tproj"].dtype
         x = torch.empty((N * L, D), dtype=torch.float32, device=dev)
         K.embed_tokens(ids32.view(-1), p["tok"], p["tpos"], x, T=L, pos_off=0)
         kv_len = None
@@ -307,7 +311,7 @@ class CLIPModel(PackedCache, nn.Module):
             pos = (ids32 == tc.eos_token_id).to(torch.int32).argmax(dim=-1)
         rows = (torch.arange(N, device=dev) * L + pos).to(torch.int32)
         sel = K.gather_rows(x, rows)
-        pooled16 = torch.empty((N, D), dtype=torch.float16, device=dev)
+        pooled16 = torch.empty((N, D), dtype=cdt, device=dev)
         K.layernorm(sel, p["fin_g"], p["fin_b"], tc.layer_norm_eps, out16=pooled16)
         emb = K.gemm(pooled16, p["tproj"], None, out_dtype=torch.float32)
         return K.l2_normalize_rows(emb)

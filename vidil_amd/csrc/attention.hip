@@ -33,11 +33,12 @@
 
 namespace {
 
+template <typename T>
 struct AttnP {
-  const f16* q;
-  const f16* k;
-  const f16* vt;
-  f16* out;
+  const T* q;
+  const T* k;
+  const T* vt;
+  T* out;
   const int32_t* kv_len;       // per query batch, or null
   const int32_t* kv_index;     // per query batch -> kv batch (only with kv_group == 1 semantics), or null
   const int32_t* group_start;  // [n_kv+1] prefix of query batches per kv batch, or null
@@ -56,7 +57,8 @@ struct RowInfo {
 };
 
 // Resolve the work unit: kv batch + [first, first+count) query batches.
-__device__ __forceinline__ void resolve_unit(const AttnP& p, int z, int& bk, int& first, int& count) {
+template <typename P>
+__device__ __forceinline__ void resolve_unit(const P& p, int z, int& bk, int& first, int& count) {
   if (p.group_start != nullptr) {
     bk = z;
     first = p.group_start[z];
@@ -72,7 +74,8 @@ __device__ __forceinline__ void resolve_unit(const AttnP& p, int z, int& bk, int
   }
 }
 
-__device__ __forceinline__ RowInfo row_info(const AttnP& p, int v, int first, int rows) {
+template <typename P>
+__device__ __forceinline__ RowInfo row_info(const P& p, int v, int first, int rows) {
   RowInfo r;
   r.valid = v < rows;
   const int vc = r.valid ? v : rows - 1;
@@ -94,7 +97,7 @@ __device__ __forceinline__ RowInfo row_info(const AttnP& p, int v, int first, in
 
 // One key tile of online softmax + P·V for the 32 rows of a wave.
 // S: scores of this tile (S^T layout: lane = row, 16 keys per half-wave).
-template <typename VFrag>
+template <typename T, typename VFrag>
 __device__ __forceinline__ void softmax_pv_tile(f32x16& S, int key0, int klim, bool need_mask, float& m, float& l,
                                                 f32x16 (&O)[2], VFrag&& vfrag) {
   const int hi = (threadIdx.x & 63) >> 5;
@@ -127,20 +130,23 @@ __device__ __forceinline__ void softmax_pv_tile(f32x16& S, int key0, int klim, b
     for (int r = 0; r < 16; ++r) O[dt][r] *= alpha;
 #pragma unroll
   for (int hb = 0; hb < 2; ++hb) {
-    f16x8 pf;
+    typename Elt<T>::x8 pf;
 #pragma unroll
-    for (int j = 0; j < 8; ++j) pf[j] = (f16)S[hb * 8 + j];
+    for (int j = 0; j < 8; ++j) pf[j] = (T)S[hb * 8 + j];
 #pragma unroll
     for (int dt = 0; dt < 2; ++dt) {
-      const f16x8 vf = vfrag(dt, hb);
+      const typename Elt<T>::x8 vf = vfrag(dt, hb);
       // O^T[d][q] += V^T[d][keys] · P^T[keys][q]
-      O[dt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(vf, pf, O[dt], 0, 0, 0);
+      O[dt] = Elt<T>::mfma32(vf, pf, O[dt]);
     }
   }
 }
 
 // O[dt][r] is (d = dt*32 + (r&3) + 8*(r>>2) + 4*hi, row = lane&31): 4 contiguous d per register quad.
-__device__ __forceinline__ void store_rows(const AttnP& p, const RowInfo& ri, int h, const f32x16 (&O)[2], float inv) {
+template <typename T>
+__device__ __forceinline__ void store_rows(const AttnP<T>& p, const RowInfo& ri, int h, const f32x16 (&O)[2], float inv) {
+  using f16x4 = typename Elt<T>::x4;
+  using f16 = T;
   if (!ri.valid) return;
   const int hi = (threadIdx.x & 63) >> 5;
   f16* og = p.out + ((size_t)ri.qb * p.Nq + ri.t) * p.ldo + h * 64 + 4 * hi;
@@ -155,8 +161,10 @@ __device__ __forceinline__ void store_rows(const AttnP& p, const RowInfo& ri, in
 }
 
 // ------------------------------------------------------------------ LDS-staged kernel
-template <int NKT, int NW>
-__global__ __launch_bounds__(NW * 64) void attn_lds_kernel(const AttnP p) {
+template <typename T, int NKT, int NW>
+__global__ __launch_bounds__(NW * 64) void attn_lds_kernel(const AttnP<T> p) {
+  using f16 = T;                       // (the body below is written in terms of "the 16-bit operand type")
+  using f16x8 = typename Elt<T>::x8;
   constexpr int NKEY = NKT * 32;
   constexpr int VROW = NKEY + 8;  // halfs per V^T row in LDS: 16-B aligned rows, (2*NKEY+16)/16 odd ->
                                   // the ds_read_b128 of 16 different rows hit 16 different 16-B bank slots
@@ -187,7 +195,7 @@ __global__ __launch_bounds__(NW * 64) void attn_lds_kernel(const AttnP p) {
     // ---- stage K rows k0 .. k0+NKEY-1 (rows >= Nk zero) ------------------------------------------------
     for (int q = tid; q < NKEY * 8; q += NT) {
       const int row = q >> 3, c = q & 7;
-      f16x8 v = {0, 0, 0, 0, 0, 0, 0, 0};
+      f16x8 v = zero8<T>();
       if (k0 + row < nk) v = *(const f16x8*)(kg + (size_t)(k0 + row) * 64 + c * 8);
       *(f16x8*)(Ks + row * KROW + c * 8) = v;
     }
@@ -199,7 +207,7 @@ __global__ __launch_bounds__(NW * 64) void attn_lds_kernel(const AttnP p) {
       const f16* vrow = p.vt + ((size_t)bk * p.H + h) * p.Tk_cap * 64;
       for (int q = tid; q < NKEY * 8; q += NT) {
         const int c = q / NKEY, r = q - c * NKEY;
-        f16x8 v = {0, 0, 0, 0, 0, 0, 0, 0};
+        f16x8 v = zero8<T>();
         if (k0 + r < nk) v = *(const f16x8*)(vrow + (size_t)(k0 + r) * 64 + c * 8);
         const int col = vt_pos(r);
 #pragma unroll
@@ -211,7 +219,7 @@ __global__ __launch_bounds__(NW * 64) void attn_lds_kernel(const AttnP p) {
       const int d = q / (NKT * 4), kc = q - d * (NKT * 4);
       const int pos0 = k0 + kc * 8;           // storage columns pos0..pos0+7 (key = vt_pos(column))
       const int blk_end = (pos0 | 15) + 1;    // end of the 16-key block this chunk belongs to
-      f16x8 v = {0, 0, 0, 0, 0, 0, 0, 0};
+      f16x8 v = zero8<T>();
       if (blk_end <= nk) {
         v = *(const f16x8*)(vg + (size_t)d * p.NP + pos0);
       } else if ((pos0 & ~15) < nk && pos0 + 8 <= p.NP) {
@@ -274,10 +282,10 @@ __global__ __launch_bounds__(NW * 64) void attn_lds_kernel(const AttnP p) {
 #pragma unroll
         for (int ks = 0; ks < 4; ++ks) {
           const f16x8 kf = *(const f16x8*)(Ks + (kt * 32 + l31) * KROW + ks * 16 + hi * 8);
-          S = __builtin_amdgcn_mfma_f32_32x32x16_f16(kf, qf[ks], S, 0, 0, 0);
+          S = Elt<T>::mfma32(kf, qf[ks], S);
         }
         const bool need_mask = (k0 + kt * 32 + 32) > kmin;
-        softmax_pv_tile(S, k0 + kt * 32, ri.klim, need_mask, m, l, O, [&](int dt, int hb) {
+        softmax_pv_tile<T>(S, k0 + kt * 32, ri.klim, need_mask, m, l, O, [&](int dt, int hb) {
           return *(const f16x8*)(Vs + (dt * 32 + l31) * VROW + (kt * 2 + hb) * 16 + 8 * hi);
         });
       }
@@ -290,8 +298,10 @@ __global__ __launch_bounds__(NW * 64) void attn_lds_kernel(const AttnP p) {
 
 // ------------------------------------------------------------------ direct (no K/V staging) kernel
 // rows <= 32.  4 waves; wave w handles key tiles w, w+4, ...; partials merged by wave 0.
-template <int NKT>
-__global__ __launch_bounds__(256) void attn_direct_kernel(const AttnP p) {
+template <typename T, int NKT>
+__global__ __launch_bounds__(256) void attn_direct_kernel(const AttnP<T> p) {
+  using f16 = T;
+  using f16x8 = typename Elt<T>::x8;
   __shared__ float part_m[4][32];
   __shared__ float part_l[4][32];
   __shared__ float part_o[4][64][33];  // [wave][d][row] (+1 pad)
@@ -345,11 +355,11 @@ __global__ __launch_bounds__(256) void attn_direct_kernel(const AttnP p) {
     for (int i = 0; i < NI; ++i) {
       const int kt = kt0 + 4 * i;
 #pragma unroll
-      for (int ks = 0; ks < 4; ++ks) kf[i][ks] = f16x8{0, 0, 0, 0, 0, 0, 0, 0};
+      for (int ks = 0; ks < 4; ++ks) kf[i][ks] = zero8<T>();
 #pragma unroll
       for (int dt = 0; dt < 2; ++dt)
 #pragma unroll
-        for (int hb = 0; hb < 2; ++hb) vf[i][dt][hb] = f16x8{0, 0, 0, 0, 0, 0, 0, 0};
+        for (int hb = 0; hb < 2; ++hb) vf[i][dt][hb] = zero8<T>();
       if (kt < ntiles && p.tiled) {
         // fragment tiles: each instruction of the wave reads one contiguous KiB; rows / key groups past the
         // last key are not fetched (they stay zero and are masked below)
@@ -391,10 +401,10 @@ __global__ __launch_bounds__(256) void attn_direct_kernel(const AttnP p) {
 #pragma unroll
       for (int r = 0; r < 16; ++r) S[r] = 0.f;
 #pragma unroll
-      for (int ks = 0; ks < 4; ++ks) S = __builtin_amdgcn_mfma_f32_32x32x16_f16(kf[i][ks], qf[ks], S, 0, 0, 0);
+      for (int ks = 0; ks < 4; ++ks) S = Elt<T>::mfma32(kf[i][ks], qf[ks], S);
       const bool tail = (kt * 32 + 32) > nk;  // tile reaches past the last key: V^T needs zeroing too
       const bool need_mask = (kt * 32 + 32) > kmin;
-      softmax_pv_tile(S, kt * 32, ri.klim, need_mask, m, l, O, [&](int dt, int hb) {
+      softmax_pv_tile<T>(S, kt * 32, ri.klim, need_mask, m, l, O, [&](int dt, int hb) {
         const int blk0 = (kt * 2 + hb) * 16;
         f16x8 v = vf[i][dt][hb];
         if (tail) {
@@ -448,7 +458,10 @@ __global__ __launch_bounds__(256) void attn_direct_kernel(const AttnP p) {
 // ------------------------------------------------------------------ one wave, one key tile
 // rows <= 32 and Nk <= 32 (decoder self-attention over the cached tokens): a single wave per (unit, head),
 // operands straight from memory, no LDS and no barrier.
-__global__ __launch_bounds__(64) void attn_wave_kernel(const AttnP p) {
+template <typename T>
+__global__ __launch_bounds__(64) void attn_wave_kernel(const AttnP<T> p) {
+  using f16 = T;
+  using f16x8 = typename Elt<T>::x8;
   const int lane = threadIdx.x & 63;
   const int hi = lane >> 5, l31 = lane & 31;
   const int h = blockIdx.y;
@@ -468,16 +481,16 @@ __global__ __launch_bounds__(64) void attn_wave_kernel(const AttnP p) {
   for (int r = 0; r < 16; ++r) S[r] = 0.f;
 #pragma unroll
   for (int ks = 0; ks < 4; ++ks)
-    S = __builtin_amdgcn_mfma_f32_32x32x16_f16(*(const f16x8*)(kr + ks * 16), *(const f16x8*)(qg + ks * 16), S, 0, 0, 0);
+    S = Elt<T>::mfma32(*(const f16x8*)(kr + ks * 16), *(const f16x8*)(qg + ks * 16), S);
   float m = -INFINITY, l = 0.f;
   f32x16 O[2];
 #pragma unroll
   for (int dt = 0; dt < 2; ++dt)
 #pragma unroll
     for (int r = 0; r < 16; ++r) O[dt][r] = 0.f;
-  softmax_pv_tile(S, 0, ri.klim, true, m, l, O, [&](int dt, int hb) {
+  softmax_pv_tile<T>(S, 0, ri.klim, true, m, l, O, [&](int dt, int hb) {
     const int blk0 = hb * 16;
-    f16x8 v = {0, 0, 0, 0, 0, 0, 0, 0};
+    f16x8 v = zero8<T>();
     if (blk0 < nk) {
       v = *(const f16x8*)(vg + (size_t)(dt * 32 + l31) * p.NP + blk0 + 8 * hi);
 #pragma unroll
@@ -490,11 +503,11 @@ __global__ __launch_bounds__(64) void attn_wave_kernel(const AttnP p) {
   store_rows(p, ri, h, O, l > 0.f ? 1.0f / l : 0.f);
 }
 
-template <int NKT, int NW>
-int launch_lds(const AttnP& p, int max_rows, hipStream_t s) {
+template <typename T, int NKT, int NW>
+int launch_lds(const AttnP<T>& p, int max_rows, hipStream_t s) {
   constexpr int smem = NKT * 32 * KROW * 2 + 64 * (NKT * 32 + 8) * 2;
   static bool attr_set = false;
-  auto kern = attn_lds_kernel<NKT, NW>;
+  auto kern = attn_lds_kernel<T, NKT, NW>;
   if (!attr_set) {
     hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, smem);
     if (e != hipSuccess) {
@@ -506,7 +519,7 @@ int launch_lds(const AttnP& p, int max_rows, hipStream_t s) {
   // rows a little over one round of NW blocks (the ITM cross-attention: 8 captions x 35 tokens = 280 rows per
   // image with NW = 8): a second round in the same workgroup instead of a second workgroup that would stage the
   // unit's K/V again for a handful of rows
-  AttnP q = p;
+  AttnP<T> q = p;
   q.rb = (p.Nk <= NKT * 32 && max_rows > NW * 32 && max_rows <= NW * 32 + NW * 16) ? 2 : 1;
   dim3 grid((max_rows + NW * 32 * q.rb - 1) / (NW * 32 * q.rb), p.H, p.n_kv);
   hipLaunchKernelGGL(kern, grid, dim3(NW * 64), smem, s, q);
@@ -514,20 +527,49 @@ int launch_lds(const AttnP& p, int max_rows, hipStream_t s) {
   return VIDIL_OK;
 }
 
-template <int NKT>
-int launch_any(const AttnP& p, int max_rows, hipStream_t s) {
+template <typename T, int NKT>
+int launch_any(const AttnP<T>& p, int max_rows, hipStream_t s) {
   if (max_rows <= 32 && NKT == 1 && !p.tiled) {
-    hipLaunchKernelGGL(attn_wave_kernel, dim3(1, p.H, p.n_kv), dim3(64), 0, s, p);
+    hipLaunchKernelGGL(attn_wave_kernel<T>, dim3(1, p.H, p.n_kv), dim3(64), 0, s, p);
     VIDIL_CHECK_LAUNCH("attention/wave");
     return VIDIL_OK;
   }
   if (max_rows <= 32) {
-    hipLaunchKernelGGL(attn_direct_kernel<NKT>, dim3(1, p.H, p.n_kv), dim3(256), 0, s, p);
+    hipLaunchKernelGGL((attn_direct_kernel<T, NKT>), dim3(1, p.H, p.n_kv), dim3(256), 0, s, p);
     VIDIL_CHECK_LAUNCH("attention/direct");
     return VIDIL_OK;
   }
-  if (max_rows > 128) return launch_lds<NKT, 8>(p, max_rows, s);
-  return launch_lds<NKT, 4>(p, max_rows, s);
+  if (max_rows > 128) return launch_lds<T, NKT, 8>(p, max_rows, s);
+  return launch_lds<T, NKT, 4>(p, max_rows, s);
+}
+
+template <typename T>
+int attention_dispatch(const AttnP<T>& p, int nkt, int max_rows, int Nk, hipStream_t s) {
+  switch (nkt) {
+    case 1: return launch_any<T, 1>(p, max_rows, s);
+    case 2: return launch_any<T, 2>(p, max_rows, s);
+    case 3: return launch_any<T, 3>(p, max_rows, s);
+    case 4: return launch_any<T, 4>(p, max_rows, s);
+    case 5: return launch_any<T, 5>(p, max_rows, s);
+    case 6: return launch_any<T, 6>(p, max_rows, s);
+    case 7: return launch_any<T, 7>(p, max_rows, s);
+    case 8: return launch_any<T, 8>(p, max_rows, s);
+    case 9: return launch_any<T, 9>(p, max_rows, s);
+    default: break;
+  }
+  // longer sequences (577 tokens of a 384^2 ViT-B/16, 257+ of others): rounds of key tiles in the direct
+  // kernel, 224-key chunks re-staged through LDS in the staged kernel
+  if (nkt <= 24) {
+    if (max_rows <= 32) {
+      hipLaunchKernelGGL((attn_direct_kernel<T, 24>), dim3(1, p.H, p.n_kv), dim3(256), 0, s, p);
+      VIDIL_CHECK_LAUNCH("attention/direct");
+      return VIDIL_OK;
+    }
+    if (max_rows > 128) return launch_lds<T, 7, 8>(p, max_rows, s);
+    return launch_lds<T, 7, 4>(p, max_rows, s);
+  }
+  vidil_set_error("attention: Nk=%d > 768 not supported by these kernels", Nk);
+  return VIDIL_EUNSUP;
 }
 
 }  // namespace
@@ -536,7 +578,7 @@ extern "C" int vidil_attention(const void* q, const void* k, const void* vt, voi
                                const int32_t* kv_index, const int32_t* group_start, int32_t n_kv, int32_t max_group,
                                int32_t Bq, int32_t H, int32_t Nq, int32_t Nk, int32_t Tq_cap, int32_t Tk_cap, int32_t NP,
                                int32_t kv_group, int32_t causal, int32_t causal_off, int32_t ldo, int32_t kv_tiled,
-                               void* stream) {
+                               int32_t dtype, void* stream) {
   VIDIL_REQUIRE(q && k && vt && out, "attention: null pointer");
   VIDIL_REQUIRE(Bq > 0 && H > 0 && Nq > 0 && Nk > 0, "attention: bad shape Bq=%d H=%d Nq=%d Nk=%d", Bq, H, Nq, Nk);
   if (kv_tiled) {
@@ -563,37 +605,14 @@ extern "C" int vidil_attention(const void* q, const void* k, const void* vt, voi
     max_rows = kv_group * Nq;
   }
   VIDIL_REQUIRE(H <= 65535 && units <= 65535, "attention: grid too large (H=%d units=%d)", H, units);
-  AttnP p{(const f16*)q, (const f16*)k, (const f16*)vt, (f16*)out, kv_len, kv_index, group_start, Bq, H, Nq, Nk,
-          Tq_cap, Tk_cap, NP, kv_group, causal, causal_off, ldo, units, kv_tiled ? 1 : 0, 1};
-  hipStream_t s = (hipStream_t)stream;
   const int nkt = (Nk + 31) / 32;
   VIDIL_REQUIRE(!kv_tiled || max_rows <= 32, "attention: tiled K/V serve at most 32 query rows per unit (got %d)", max_rows);
   // NP == 0: `vt` holds V row-major [Bk][H][Tk_cap][64]; only the LDS-staged kernel transposes on the way in
   VIDIL_REQUIRE(NP != 0 || max_rows > 32, "attention: row-major V (NP == 0) needs more than 32 query rows per unit (got %d)",
                 max_rows);
-  switch (nkt) {
-    case 1: return launch_any<1>(p, max_rows, s);
-    case 2: return launch_any<2>(p, max_rows, s);
-    case 3: return launch_any<3>(p, max_rows, s);
-    case 4: return launch_any<4>(p, max_rows, s);
-    case 5: return launch_any<5>(p, max_rows, s);
-    case 6: return launch_any<6>(p, max_rows, s);
-    case 7: return launch_any<7>(p, max_rows, s);
-    case 8: return launch_any<8>(p, max_rows, s);
-    case 9: return launch_any<9>(p, max_rows, s);
-    default: break;
-  }
-  // longer sequences (577 tokens of a 384^2 ViT-B/16, 257+ of others): rounds of key tiles in the direct
-  // kernel, 224-key chunks re-staged through LDS in the staged kernel
-  if (nkt <= 24) {
-    if (max_rows <= 32) {
-      hipLaunchKernelGGL(attn_direct_kernel<24>, dim3(1, p.H, p.n_kv), dim3(256), 0, s, p);
-      VIDIL_CHECK_LAUNCH("attention/direct");
-      return VIDIL_OK;
-    }
-    if (max_rows > 128) return launch_lds<7, 8>(p, max_rows, s);
-    return launch_lds<7, 4>(p, max_rows, s);
-  }
-  vidil_set_error("attention: Nk=%d > 768 not supported by these kernels", Nk);
-  return VIDIL_EUNSUP;
+  VIDIL_DISPATCH_DTYPE(dtype, "attention", {
+    const AttnP<T> p{(const T*)q, (const T*)k, (const T*)vt, (T*)out, kv_len, kv_index, group_start, Bq, H, Nq, Nk,
+                     Tq_cap, Tk_cap, NP, kv_group, causal, causal_off, ldo, units, kv_tiled ? 1 : 0, 1};
+    return attention_dispatch<T>(p, nkt, max_rows, Nk, (hipStream_t)stream);
+  });
 }

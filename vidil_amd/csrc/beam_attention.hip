@@ -18,17 +18,20 @@
 
 namespace {
 
+template <typename T>
 struct BeamAttnP {
-  const f16* q;
-  const f16* k;
-  const f16* v;
+  const T* q;
+  const T* k;
+  const T* v;
   const int32_t* anc;
-  f16* out;
+  T* out;
   int rows, H, n_keys, arena_rows, Tcap, ldo;
 };
 
-template <int MAXJ>
-__global__ __launch_bounds__(256) void beam_attn_kernel(const BeamAttnP p) {
+template <typename T, int MAXJ>
+__global__ __launch_bounds__(256) void beam_attn_kernel(const BeamAttnP<T> p) {
+  using f16 = T;
+  using f16x8 = typename Elt<T>::x8;
   const int lane = threadIdx.x & 63;
   const int w = blockIdx.x * 4 + (threadIdx.x >> 6);   // (row, head) unit of this wave
   if (w >= p.rows * p.H) return;
@@ -113,7 +116,7 @@ __global__ __launch_bounds__(256) void beam_attn_kernel(const BeamAttnP p) {
   const float send = b0 ? o2[0] : o2[1];
   const float od = keep + __shfl_xor(send, 8, 64);
   const int d = 8 * c + (b2 ? 4 : 0) + (b1 ? 2 : 0) + (b0 ? 1 : 0);
-  p.out[(size_t)r * p.ldo + h * 64 + d] = to_f16(od * (1.0f / l));
+  p.out[(size_t)r * p.ldo + h * 64 + d] = Elt<T>::from_f32(od * (1.0f / l));
 }
 
 __global__ __launch_bounds__(256) void beam_ancestry_kernel(const int32_t* __restrict__ src, int32_t* __restrict__ dst,
@@ -149,7 +152,7 @@ extern "C" int vidil_beam_ancestry(const int32_t* anc_src, int32_t* anc_dst, con
 
 extern "C" int vidil_beam_attention(const void* q, const void* k_arena, const void* v_arena, const int32_t* anc, void* out,
                                     int32_t rows, int32_t H, int32_t n_keys, int32_t arena_rows, int32_t Tcap, int32_t ldo,
-                                    void* stream) {
+                                    int32_t dtype, void* stream) {
   VIDIL_REQUIRE(q && k_arena && v_arena && anc && out, "beam_attention: null pointer");
   VIDIL_REQUIRE(rows > 0 && H > 0 && n_keys > 0, "beam_attention: bad shape rows=%d H=%d n_keys=%d", rows, H, n_keys);
   VIDIL_REQUIRE(n_keys <= Tcap, "beam_attention: n_keys=%d exceeds the ancestry capacity Tcap=%d", n_keys, Tcap);
@@ -157,18 +160,18 @@ extern "C" int vidil_beam_attention(const void* q, const void* k_arena, const vo
   VIDIL_REQUIRE(ldo >= H * 64, "beam_attention: ldo=%d must be >= H*64", ldo);
   VIDIL_REQUIRE(((uintptr_t)q & 15) == 0 && ((uintptr_t)k_arena & 15) == 0 && ((uintptr_t)v_arena & 15) == 0,
                 "beam_attention: q / arenas must be 16-B aligned");
-  const BeamAttnP p{(const f16*)q, (const f16*)k_arena, (const f16*)v_arena, anc, (f16*)out, rows, H, n_keys, arena_rows, Tcap, ldo};
+  VIDIL_REQUIRE(n_keys <= 64, "beam_attention: n_keys=%d > 64 not supported by this kernel", n_keys);
   const long units = (long)rows * H;
   const dim3 grid((unsigned)((units + 3) / 4));
   hipStream_t s = (hipStream_t)stream;
-  if (n_keys <= 32) {
-    hipLaunchKernelGGL(beam_attn_kernel<4>, grid, dim3(256), 0, s, p);
-  } else if (n_keys <= 64) {
-    hipLaunchKernelGGL(beam_attn_kernel<8>, grid, dim3(256), 0, s, p);
-  } else {
-    vidil_set_error("beam_attention: n_keys=%d > 64 not supported by this kernel", n_keys);
-    return VIDIL_EUNSUP;
-  }
+  VIDIL_DISPATCH_DTYPE(dtype, "beam_attention", {
+    const BeamAttnP<T> p{(const T*)q, (const T*)k_arena, (const T*)v_arena, anc, (T*)out, rows, H, n_keys, arena_rows, Tcap, ldo};
+    if (n_keys <= 32) {
+      hipLaunchKernelGGL((beam_attn_kernel<T, 4>), grid, dim3(256), 0, s, p);
+    } else {
+      hipLaunchKernelGGL((beam_attn_kernel<T, 8>), grid, dim3(256), 0, s, p);
+    }
+  });
   VIDIL_CHECK_LAUNCH("beam_attention");
   return VIDIL_OK;
 }

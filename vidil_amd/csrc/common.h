@@ -8,6 +8,9 @@
 typedef _Float16 f16;
 typedef _Float16 f16x4 __attribute__((ext_vector_type(4)));
 typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+typedef __bf16 bf16;
+typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 
@@ -76,6 +79,42 @@ __device__ __forceinline__ f16 to_f16(float v) {
   asm volatile("" : "+v"(v));
   return (f16)v;
 }
+
+// The 16-bit operand type of a kernel instantiation (VIDIL_DT_F16 / VIDIL_DT_BF16): vector types, the dense
+// v_mfma_f32_32x32x16 of that type, and the pinned f32 -> T rounding (round to nearest even in both cases;
+// bf16 through v_cvt_pk_bf16_f32).  Everything else in the kernels — accumulation, softmax, LayerNorm
+// statistics, the residual stream — is f32 for both.
+template <typename T> struct Elt;
+template <> struct Elt<f16> {
+  typedef f16x4 x4;
+  typedef f16x8 x8;
+  static constexpr int kDtype = VIDIL_DT_F16;
+  static __device__ __forceinline__ f32x16 mfma32(x8 a, x8 b, f32x16 c) { return __builtin_amdgcn_mfma_f32_32x32x16_f16(a, b, c, 0, 0, 0); }
+  static __device__ __forceinline__ f16 from_f32(float v) { return to_f16(v); }
+};
+template <> struct Elt<bf16> {
+  typedef bf16x4 x4;
+  typedef bf16x8 x8;
+  static constexpr int kDtype = VIDIL_DT_BF16;
+  static __device__ __forceinline__ f32x16 mfma32(x8 a, x8 b, f32x16 c) { return __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c, 0, 0, 0); }
+  static __device__ __forceinline__ bf16 from_f32(float v) {
+    asm volatile("" : "+v"(v));
+    return (bf16)v;
+  }
+};
+template <typename T> __device__ __forceinline__ typename Elt<T>::x8 zero8() {
+  typename Elt<T>::x8 z;
+#pragma unroll
+  for (int e = 0; e < 8; ++e) z[e] = (T)0.f;
+  return z;
+}
+// run `fn(T{})` for the operand type a dtype code names; unknown codes are an argument error
+#define VIDIL_DISPATCH_DTYPE(dtype, what, ...)                                         \
+  do {                                                                                 \
+    if ((dtype) == VIDIL_DT_F16) { using T = f16; __VA_ARGS__; }                       \
+    else if ((dtype) == VIDIL_DT_BF16) { using T = bf16; __VA_ARGS__; }                \
+    else { vidil_set_error("%s: unknown dtype %d", what, (int)(dtype)); return VIDIL_EINVAL; } \
+  } while (0)
 
 // erf by Abramowitz & Stegun 7.1.26 (|error| <= 1.5e-7, far below the f16 rounding of the value it
 // feeds): 1 v_rcp + 1 v_exp + 5 fma instead of libm's branchy erff.  The GELU epilogue runs on 3072 columns

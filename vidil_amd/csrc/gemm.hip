@@ -36,8 +36,10 @@ __device__ __forceinline__ void wait_vm() {
 // already overlaps LDS-DMA issue with MFMAs; the smaller tiles use 4 waves (2 x 2) and rely on co-resident workgroups
 constexpr int waves_n(int bm, int bn) { return (bm == 128 && bn == 128) ? 4 : 2; }
 
-template <int BM, int BN, int ST, int EPI, int ACT>
+template <typename T, int BM, int BN, int ST, int EPI, int ACT>
 __global__ __launch_bounds__(2 * waves_n(BM, BN) * 64) void gemm_kernel(const vidil_gemm_args p) {
+  using f16 = T;                        // (the body is written in terms of "the 16-bit operand type")
+  using f16x8 = typename Elt<T>::x8;
   constexpr int NWN = waves_n(BM, BN);
   constexpr int NT = 2 * NWN * 64;   // threads
   constexpr int WN = BN / NWN;       // output columns per wave
@@ -172,7 +174,7 @@ __global__ __launch_bounds__(2 * waves_n(BM, BN) * 64) void gemm_kernel(const vi
       for (int i = 0; i < TM; ++i)
 #pragma unroll
         for (int j = 0; j < TN; ++j)
-          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(af[ks][i], bf[ks][j], acc[i][j], 0, 0, 0);
+          acc[i][j] = Elt<T>::mfma32(af[ks][i], bf[ks][j], acc[i][j]);
   }
 
   // ---------------------------------------------------------------- epilogue
@@ -248,7 +250,7 @@ __global__ __launch_bounds__(2 * waves_n(BM, BN) * 64) void gemm_kernel(const vi
           float v = acc[i][j][rq * 4 + rr];
           const bool ok = col_ok && row < M;
           if constexpr (EPI == VIDIL_EPI_F16) {
-            if (ok) ((f16*)p.out)[(size_t)row * p.ldo + col] = to_f16(v);
+            if (ok) ((f16*)p.out)[(size_t)row * p.ldo + col] = Elt<T>::from_f32(v);
           } else if constexpr (EPI == VIDIL_EPI_F32) {
             if (ok) {
               ((float*)p.out)[(size_t)row * p.ldo + col] = v;
@@ -258,15 +260,15 @@ __global__ __launch_bounds__(2 * waves_n(BM, BN) * 64) void gemm_kernel(const vi
               const int h = hcol >> 6, d = hcol & 63;
               const size_t bh = (size_t)b * p.H + h;
               if (part == 0) {
-                ((f16*)p.q)[(bh * p.Tq_cap + t) * 64 + d] = to_f16(v * p.q_scale);
+                ((f16*)p.q)[(bh * p.Tq_cap + t) * 64 + d] = Elt<T>::from_f32(v * p.q_scale);
               } else if (p.kv_tiled) {               // fragment tiles (common.h)
                 const size_t base = bh * (size_t)p.Tk_cap * 64;
-                if (part == 1) ((f16*)p.k)[base + ktile_off(p.t_off + t, d)] = to_f16(v);
-                else ((f16*)p.vt)[base + vtile_off(p.t_off + t, d)] = to_f16(v);
+                if (part == 1) ((f16*)p.k)[base + ktile_off(p.t_off + t, d)] = Elt<T>::from_f32(v);
+                else ((f16*)p.vt)[base + vtile_off(p.t_off + t, d)] = Elt<T>::from_f32(v);
               } else if (part == 1 || p.NP == 0) {   // NP == 0: V row-major, laid out like K
-                ((f16*)(part == 1 ? p.k : p.vt))[(bh * p.Tk_cap + p.t_off + t) * 64 + d] = to_f16(v);
+                ((f16*)(part == 1 ? p.k : p.vt))[(bh * p.Tk_cap + p.t_off + t) * 64 + d] = Elt<T>::from_f32(v);
               } else {
-                ((f16*)p.vt)[(bh * 64 + d) * (size_t)p.NP + vt_pos(p.t_off + t)] = to_f16(v);
+                ((f16*)p.vt)[(bh * 64 + d) * (size_t)p.NP + vt_pos(p.t_off + t)] = Elt<T>::from_f32(v);
               }
             }
             if (++t == p.T) { t = 0; ++b; }
@@ -274,10 +276,10 @@ __global__ __launch_bounds__(2 * waves_n(BM, BN) * 64) void gemm_kernel(const vi
             if (ok) {
               const size_t hd = (size_t)p.H * 64;
               if (part == 0) {
-                ((f16*)p.q)[(size_t)row * hd + hcol] = to_f16(v * p.q_scale);
+                ((f16*)p.q)[(size_t)row * hd + hcol] = Elt<T>::from_f32(v * p.q_scale);
               } else {
                 f16* dst = (f16*)(part == 1 ? p.k : p.vt);
-                dst[((size_t)(p.t_off + t) * p.arena_rows + (size_t)b * p.slot_stride) * hd + hcol] = to_f16(v);
+                dst[((size_t)(p.t_off + t) * p.arena_rows + (size_t)b * p.slot_stride) * hd + hcol] = Elt<T>::from_f32(v);
               }
             }
             if (++t == p.T) { t = 0; ++b; }
@@ -294,11 +296,11 @@ __global__ __launch_bounds__(2 * waves_n(BM, BN) * 64) void gemm_kernel(const vi
   }
 }
 
-template <int BM, int BN, int ST, int EPI, int ACT>
+template <typename T, int BM, int BN, int ST, int EPI, int ACT>
 int launch(const vidil_gemm_args& a, hipStream_t s) {
   constexpr int smem = ST * (BM + BN) * BK * 2;
   static bool attr_set = false;
-  auto kern = gemm_kernel<BM, BN, ST, EPI, ACT>;
+  auto kern = gemm_kernel<T, BM, BN, ST, EPI, ACT>;
   if (!attr_set) {
     hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, smem);
     if (e != hipSuccess) {
@@ -313,28 +315,20 @@ int launch(const vidil_gemm_args& a, hipStream_t s) {
   return VIDIL_OK;
 }
 
-template <int EPI, int ACT>
-int pick_tile(const vidil_gemm_args& a, hipStream_t s) {
-  // Fill 256 CUs (2 workgroups each at 128x128): shrink the tile when the
-  // grid would otherwise be too small (decode-step GEMMs with M of a few
-  // hundred rows).
+// Which kernel serves a problem.  big != 0: the 256x256 kernel of gemm256.hip; else the small-tile kernel <bm, bn, st>.
+struct TileChoice { int big, bm, bn, st; };
+
+TileChoice choose_tile(const vidil_gemm_args& a) {
   static const bool allow256 = []() {
     const char* e = getenv("VIDIL_GEMM256");
     return !(e && e[0] == '0');
   }();
-  if (allow256 && vidil_gemm256_eligible(a)) return vidil_gemm256_launch(a, s);
+  if (allow256 && a.epi != VIDIL_EPI_ARENA && vidil_gemm256_eligible(a)) return {1, 256, 256, 2};
 #ifdef VIDIL_GEMM_TUNE
   // developer builds only: VIDIL_GEMM_TILE=<BM>x<BN>x<ST> forces one configuration
   if (const char* e = getenv("VIDIL_GEMM_TILE")) {
     int bm = 0, bn = 0, st = 0;
-    if (sscanf(e, "%dx%dx%d", &bm, &bn, &st) == 3) {
-#define VIDIL_TRY(BM_, BN_, ST_) \
-  if (bm == BM_ && bn == BN_ && st == ST_) return launch<BM_, BN_, ST_, EPI, ACT>(a, s);
-      VIDIL_TRY(128, 128, 2) VIDIL_TRY(128, 128, 3) VIDIL_TRY(128, 128, 4)
-      VIDIL_TRY(128, 64, 2) VIDIL_TRY(128, 64, 3) VIDIL_TRY(128, 64, 4)
-      VIDIL_TRY(64, 64, 2) VIDIL_TRY(64, 64, 3) VIDIL_TRY(64, 64, 4)
-#undef VIDIL_TRY
-    }
+    if (sscanf(e, "%dx%dx%d", &bm, &bn, &st) == 3) return {0, bm, bn, st};
   }
 #endif
   // Problems too small for gemm256 run one or two rounds of workgroups, so what matters is how many waves
@@ -345,41 +339,43 @@ int pick_tile(const vidil_gemm_args& a, hipStream_t s) {
   // ~200 128x128 tiles: the 8-wave 128x128 tile, 2-deep ring when two workgroups share a CU, 3-deep when alone
   // (M = 9216, K = 3072: 61 us against 74 us on 128x64; M = 4608: 33 against 43)
   const long n128 = (long)((a.M + 127) / 128) * ((a.N + 127) / 128);
-  if (n128 >= 200 && a.N <= 1024) {
-    if (n128 > 256) return launch<128, 128, 2, EPI, ACT>(a, s);
-    return launch<128, 128, 3, EPI, ACT>(a, s);
-  }
+  if (n128 >= 200 && a.N <= 1024) return {0, 128, 128, n128 > 256 ? 2 : 3};
   const long n64 = (long)((a.M + 63) / 64) * ((a.N + 63) / 64);
-  if (n64 <= 1280) return launch<64, 64, ST_64x64, EPI, ACT>(a, s);
+  if (n64 <= 1280) return {0, 64, 64, ST_64x64};
   const long n128x64 = (long)((a.M + 127) / 128) * ((a.N + 63) / 64);
-  if (n128x64 <= 2560) return launch<128, 64, ST_128x64, EPI, ACT>(a, s);
-  return launch<128, 128, ST_128x128, EPI, ACT>(a, s);
+  if (n128x64 <= 2560) return {0, 128, 64, ST_128x64};
+  return {0, 128, 128, ST_128x128};
 }
 
-}  // namespace
+template <typename T, int EPI, int ACT>
+int pick_tile(const vidil_gemm_args& a, hipStream_t s) {
+  const TileChoice c = choose_tile(a);
+  if (c.big) return vidil_gemm256_launch(a, s);
+#define VIDIL_TRY(BM_, BN_, ST_) \
+  if (c.bm == BM_ && c.bn == BN_ && c.st == ST_) return launch<T, BM_, BN_, ST_, EPI, ACT>(a, s);
+  VIDIL_TRY(128, 128, 2) VIDIL_TRY(128, 128, 3) VIDIL_TRY(128, 64, 2) VIDIL_TRY(64, 64, 3)
+#ifdef VIDIL_GEMM_TUNE
+  VIDIL_TRY(128, 128, 4) VIDIL_TRY(128, 64, 3) VIDIL_TRY(128, 64, 4) VIDIL_TRY(64, 64, 2) VIDIL_TRY(64, 64, 4)
+#endif
+#undef VIDIL_TRY
+  vidil_set_error("gemm: no kernel for tile %dx%dx%d", c.bm, c.bn, c.st);
+  return VIDIL_EUNSUP;
+}
 
-extern "C" int vidil_gemm_f16(const vidil_gemm_args* args, void* stream) {
-  VIDIL_REQUIRE(args != nullptr, "gemm: null args");
-  const vidil_gemm_args& a = *args;
+// argument checks shared by vidil_gemm and vidil_gemm_kernel_name
+int check_args(const vidil_gemm_args& a) {
   VIDIL_REQUIRE(a.A && a.W, "gemm: null operand");
+  VIDIL_REQUIRE(a.dtype == VIDIL_DT_F16 || a.dtype == VIDIL_DT_BF16, "gemm: unknown dtype %d", a.dtype);
   VIDIL_REQUIRE(a.M > 0 && a.N > 0 && a.K > 0, "gemm: bad shape M=%d N=%d K=%d", a.M, a.N, a.K);
   VIDIL_REQUIRE(a.K % BK == 0, "gemm: K=%d must be a multiple of %d", a.K, BK);
   VIDIL_REQUIRE(a.lda == 0 || (a.lda >= a.K && a.lda % 8 == 0), "gemm: lda=%d must be 0 or >= K and a multiple of 8", a.lda);
   VIDIL_REQUIRE(((uintptr_t)a.A & 15) == 0 && ((uintptr_t)a.W & 15) == 0, "gemm: operands must be 16-B aligned");
-  hipStream_t s = (hipStream_t)stream;
   switch (a.epi) {
     case VIDIL_EPI_F16:
-      VIDIL_REQUIRE(a.out && a.ldo >= a.N, "gemm/f16: bad out/ldo");
-      if (a.act == VIDIL_ACT_NONE) return pick_tile<VIDIL_EPI_F16, VIDIL_ACT_NONE>(a, s);
-      if (a.act == VIDIL_ACT_GELU_ERF) return pick_tile<VIDIL_EPI_F16, VIDIL_ACT_GELU_ERF>(a, s);
-      if (a.act == VIDIL_ACT_QUICK_GELU) return pick_tile<VIDIL_EPI_F16, VIDIL_ACT_QUICK_GELU>(a, s);
-      break;
     case VIDIL_EPI_F32:
-      VIDIL_REQUIRE(a.out && a.ldo >= a.N, "gemm/f32: bad out/ldo");
-      if (a.act == VIDIL_ACT_NONE) return pick_tile<VIDIL_EPI_F32, VIDIL_ACT_NONE>(a, s);
-      if (a.act == VIDIL_ACT_GELU_ERF) return pick_tile<VIDIL_EPI_F32, VIDIL_ACT_GELU_ERF>(a, s);
-      if (a.act == VIDIL_ACT_QUICK_GELU) return pick_tile<VIDIL_EPI_F32, VIDIL_ACT_QUICK_GELU>(a, s);
-      break;
+      VIDIL_REQUIRE(a.out && a.ldo >= a.N, "gemm: bad out/ldo");
+      VIDIL_REQUIRE(a.act >= VIDIL_ACT_NONE && a.act <= VIDIL_ACT_QUICK_GELU, "gemm: unknown act %d", a.act);
+      return VIDIL_OK;
     case VIDIL_EPI_HEADS: {
       VIDIL_REQUIRE(a.act == VIDIL_ACT_NONE, "gemm/heads: no activation");
       VIDIL_REQUIRE(a.H > 0 && a.T > 0 && a.N % (a.H * 64) == 0, "gemm/heads: N=%d not a multiple of H*64 (H=%d)", a.N, a.H);
@@ -399,7 +395,7 @@ extern "C" int vidil_gemm_f16(const vidil_gemm_args* args, void* stream) {
           VIDIL_REQUIRE(a.vt && a.Tk_cap >= a.t_off + a.T, "gemm/heads: bad v / Tk_cap");
       }
       VIDIL_REQUIRE(a.M % a.T == 0, "gemm/heads: M=%d not a multiple of T=%d", a.M, a.T);
-      return pick_tile<VIDIL_EPI_HEADS, VIDIL_ACT_NONE>(a, s);
+      return VIDIL_OK;
     }
     case VIDIL_EPI_ARENA: {
       VIDIL_REQUIRE(a.act == VIDIL_ACT_NONE, "gemm/arena: no activation");
@@ -416,15 +412,54 @@ extern "C" int vidil_gemm_f16(const vidil_gemm_args* args, void* stream) {
                       "gemm/arena: %d sequences at slot stride %d do not fit %d arena rows", a.M / a.T, a.slot_stride,
                       a.arena_rows);
       }
-      return pick_tile<VIDIL_EPI_ARENA, VIDIL_ACT_NONE>(a, s);
+      return VIDIL_OK;
     }
     case VIDIL_EPI_PATCH:
       VIDIL_REQUIRE(a.act == VIDIL_ACT_NONE, "gemm/patch: no activation");
       VIDIL_REQUIRE(a.out && a.pos && a.tpi > 0 && a.M % a.tpi == 0 && a.ldo >= a.N, "gemm/patch: bad args");
-      return pick_tile<VIDIL_EPI_PATCH, VIDIL_ACT_NONE>(a, s);
+      return VIDIL_OK;
     default:
       break;
   }
   vidil_set_error("gemm: unsupported epi=%d act=%d", a.epi, a.act);
   return VIDIL_EUNSUP;
+}
+
+template <typename T>
+int dispatch(const vidil_gemm_args& a, hipStream_t s) {
+  switch (a.epi) {
+    case VIDIL_EPI_F16:
+      if (a.act == VIDIL_ACT_NONE) return pick_tile<T, VIDIL_EPI_F16, VIDIL_ACT_NONE>(a, s);
+      if (a.act == VIDIL_ACT_GELU_ERF) return pick_tile<T, VIDIL_EPI_F16, VIDIL_ACT_GELU_ERF>(a, s);
+      return pick_tile<T, VIDIL_EPI_F16, VIDIL_ACT_QUICK_GELU>(a, s);
+    case VIDIL_EPI_F32:
+      if (a.act == VIDIL_ACT_NONE) return pick_tile<T, VIDIL_EPI_F32, VIDIL_ACT_NONE>(a, s);
+      if (a.act == VIDIL_ACT_GELU_ERF) return pick_tile<T, VIDIL_EPI_F32, VIDIL_ACT_GELU_ERF>(a, s);
+      return pick_tile<T, VIDIL_EPI_F32, VIDIL_ACT_QUICK_GELU>(a, s);
+    case VIDIL_EPI_HEADS: return pick_tile<T, VIDIL_EPI_HEADS, VIDIL_ACT_NONE>(a, s);
+    case VIDIL_EPI_ARENA: return pick_tile<T, VIDIL_EPI_ARENA, VIDIL_ACT_NONE>(a, s);
+    default: return pick_tile<T, VIDIL_EPI_PATCH, VIDIL_ACT_NONE>(a, s);
+  }
+}
+
+}  // namespace
+
+extern "C" int vidil_gemm(const vidil_gemm_args* args, void* stream) {
+  VIDIL_REQUIRE(args != nullptr, "gemm: null args");
+  const int rc = check_args(*args);
+  if (rc != VIDIL_OK) return rc;
+  if (args->dtype == VIDIL_DT_BF16) return dispatch<bf16>(*args, (hipStream_t)stream);
+  return dispatch<f16>(*args, (hipStream_t)stream);
+}
+
+extern "C" int vidil_gemm_kernel_name(const vidil_gemm_args* args, char* buf_host, int32_t n) {
+  VIDIL_REQUIRE(args != nullptr && buf_host != nullptr && n > 0, "gemm_kernel_name: bad args");
+  const int rc = check_args(*args);
+  if (rc != VIDIL_OK) return rc;
+  const TileChoice c = choose_tile(*args);
+  const char* t = args->dtype == VIDIL_DT_BF16 ? "__bf16" : "_Float16";     // the spelling rocprofv3 demangles to
+  const int act = (args->epi == VIDIL_EPI_F16 || args->epi == VIDIL_EPI_F32) ? args->act : 0;
+  if (c.big) snprintf(buf_host, n, "gemm256_kernel<%s, %d, %d>", t, args->epi, act);
+  else snprintf(buf_host, n, "gemm_kernel<%s, %d, %d, %d, %d, %d>", t, c.bm, c.bn, c.st, args->epi, act);
+  return VIDIL_OK;
 }

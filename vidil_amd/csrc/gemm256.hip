@@ -38,7 +38,7 @@ constexpr int SLOT = 16384;      // one half-tile: 128 rows x 64 halfs
 constexpr int BUF = 4 * SLOT;     // one K-tile: A0, A1, W0, W1
 constexpr int LDS_BYTES = 2 * BUF;
 
-__device__ __forceinline__ void glds16(const f16* g, char* lds) {
+__device__ __forceinline__ void glds16(const void* g, char* lds) {
   __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)g,
                                    (__attribute__((address_space(3))) void*)lds, 16, 0, 0);
 }
@@ -64,8 +64,11 @@ struct Probe {
 };
 #endif
 
-template <int EPI, int ACT>
+template <typename T, int EPI, int ACT>
 __global__ __launch_bounds__(512) void gemm256_kernel(const vidil_gemm_args p) {
+  using f16 = T;                        // (the body is written in terms of "the 16-bit operand type")
+  using f16x4 = typename Elt<T>::x4;
+  using f16x8 = typename Elt<T>::x8;
   extern __shared__ __attribute__((aligned(16))) char smem[];
 #ifdef VIDIL_GEMM_PROBE
   Probe probe;
@@ -201,7 +204,7 @@ __global__ __launch_bounds__(512) void gemm256_kernel(const vidil_gemm_args p) {
       for (int i = 0; i < 2; ++i)
 #pragma unroll
         for (int j = 0; j < 2; ++j)
-          acc[RH * 2 + i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wf[j][ks], a[ks][i], acc[RH * 2 + i][j], 0, 0, 0);
+          acc[RH * 2 + i][j] = Elt<T>::mfma32(wf[j][ks], a[ks][i], acc[RH * 2 + i][j]);
       if (ks < 3) dma_piece(h, ks);
     }
   };
@@ -320,8 +323,8 @@ __global__ __launch_bounds__(512) void gemm256_kernel(const vidil_gemm_args p) {
         for (int j = 0; j < 2; ++j)
 #pragma unroll
           for (int rq = 0; rq < 4; ++rq) {
-            const f16x4 v = {to_f16(value(it, j, rq, 0)), to_f16(value(it, j, rq, 1)), to_f16(value(it, j, rq, 2)),
-                             to_f16(value(it, j, rq, 3))};
+            const f16x4 v = {Elt<T>::from_f32(value(it, j, rq, 0)), Elt<T>::from_f32(value(it, j, rq, 1)), Elt<T>::from_f32(value(it, j, rq, 2)),
+                             Elt<T>::from_f32(value(it, j, rq, 3))};
             *(f16x4*)(ep + l31 * ROWB + (j * 32 + rq * 8 + hi * 4) * 2) = v;
           }
         int b = mb / p.T, t = mb - b * p.T;
@@ -358,7 +361,7 @@ __global__ __launch_bounds__(512) void gemm256_kernel(const vidil_gemm_args p) {
 #pragma unroll
             for (int rq = 0; rq < 4; ++rq)
 #pragma unroll
-              for (int e = 0; e < 4; ++e) dst[(size_t)(j * 32 + rq * 8 + hi * 4 + e) * p.NP] = to_f16(value(it, j, rq, e));
+              for (int e = 0; e < 4; ++e) dst[(size_t)(j * 32 + rq * 8 + hi * 4 + e) * p.NP] = Elt<T>::from_f32(value(it, j, rq, e));
         }
       }
       break;
@@ -378,8 +381,8 @@ __global__ __launch_bounds__(512) void gemm256_kernel(const vidil_gemm_args p) {
         for (int j = 0; j < 2; ++j)
 #pragma unroll
           for (int rq = 0; rq < 4; ++rq) {
-            const f16x4 v = {to_f16(value(it, j, rq, 0) * scale), to_f16(value(it, j, rq, 1) * scale),
-                             to_f16(value(it, j, rq, 2) * scale), to_f16(value(it, j, rq, 3) * scale)};
+            const f16x4 v = {Elt<T>::from_f32(value(it, j, rq, 0) * scale), Elt<T>::from_f32(value(it, j, rq, 1) * scale),
+                             Elt<T>::from_f32(value(it, j, rq, 2) * scale), Elt<T>::from_f32(value(it, j, rq, 3) * scale)};
             *(f16x4*)(ep + row * 128 + (((j * 4 + rq) ^ (row & 7)) << 4) + hi * 8) = v;
           }
       }
@@ -474,10 +477,10 @@ __global__ __launch_bounds__(512) void gemm256_kernel(const vidil_gemm_args p) {
   }  // tile loop
 }
 
-template <int EPI, int ACT>
+template <typename T, int EPI, int ACT>
 int launch256(const vidil_gemm_args& a, hipStream_t s) {
   static bool attr_set = false;
-  auto kern = gemm256_kernel<EPI, ACT>;
+  auto kern = gemm256_kernel<T, EPI, ACT>;
   if (!attr_set) {
     hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES);
     if (e != hipSuccess) {
@@ -532,19 +535,25 @@ bool vidil_gemm256_eligible(const vidil_gemm_args& a) {
   }
 }
 
-int vidil_gemm256_launch(const vidil_gemm_args& a, hipStream_t s) {
+template <typename T>
+static int launch256_dispatch(const vidil_gemm_args& a, hipStream_t s) {
   switch (a.epi) {
     case VIDIL_EPI_F16:
-      if (a.act == VIDIL_ACT_NONE) return launch256<VIDIL_EPI_F16, VIDIL_ACT_NONE>(a, s);
-      if (a.act == VIDIL_ACT_GELU_ERF) return launch256<VIDIL_EPI_F16, VIDIL_ACT_GELU_ERF>(a, s);
-      return launch256<VIDIL_EPI_F16, VIDIL_ACT_QUICK_GELU>(a, s);
+      if (a.act == VIDIL_ACT_NONE) return launch256<T, VIDIL_EPI_F16, VIDIL_ACT_NONE>(a, s);
+      if (a.act == VIDIL_ACT_GELU_ERF) return launch256<T, VIDIL_EPI_F16, VIDIL_ACT_GELU_ERF>(a, s);
+      return launch256<T, VIDIL_EPI_F16, VIDIL_ACT_QUICK_GELU>(a, s);
     case VIDIL_EPI_F32:
-      if (a.act == VIDIL_ACT_NONE) return launch256<VIDIL_EPI_F32, VIDIL_ACT_NONE>(a, s);
-      if (a.act == VIDIL_ACT_GELU_ERF) return launch256<VIDIL_EPI_F32, VIDIL_ACT_GELU_ERF>(a, s);
-      return launch256<VIDIL_EPI_F32, VIDIL_ACT_QUICK_GELU>(a, s);
+      if (a.act == VIDIL_ACT_NONE) return launch256<T, VIDIL_EPI_F32, VIDIL_ACT_NONE>(a, s);
+      if (a.act == VIDIL_ACT_GELU_ERF) return launch256<T, VIDIL_EPI_F32, VIDIL_ACT_GELU_ERF>(a, s);
+      return launch256<T, VIDIL_EPI_F32, VIDIL_ACT_QUICK_GELU>(a, s);
     case VIDIL_EPI_HEADS:
-      return launch256<VIDIL_EPI_HEADS, VIDIL_ACT_NONE>(a, s);
+      return launch256<T, VIDIL_EPI_HEADS, VIDIL_ACT_NONE>(a, s);
     default:
-      return launch256<VIDIL_EPI_PATCH, VIDIL_ACT_NONE>(a, s);
+      return launch256<T, VIDIL_EPI_PATCH, VIDIL_ACT_NONE>(a, s);
   }
+}
+
+int vidil_gemm256_launch(const vidil_gemm_args& a, hipStream_t s) {
+  if (a.dtype == VIDIL_DT_BF16) return launch256_dispatch<bf16>(a, s);
+  return launch256_dispatch<f16>(a, s);
 }

@@ -8,11 +8,12 @@ namespace {
 
 // One wave per row; D/64 elements per lane, processed as float4 where D%256==0
 // is not required: lane handles elements lane*4 + 256*i (+0..3).
-template <int VPL>  // float4 vectors per lane: D = 256*VPL
+template <typename T, int VPL>  // float4 vectors per lane: D = 256*VPL
 __global__ __launch_bounds__(256) void layernorm_kernel(const float* __restrict__ x, int64_t x_stride,
                                                         const float* __restrict__ gamma,
                                                         const float* __restrict__ beta, float eps, int M,
-                                                        f16* __restrict__ out16, float* __restrict__ out32) {
+                                                        T* __restrict__ out16, float* __restrict__ out32) {
+  using x4 = typename Elt<T>::x4;
   constexpr int D = 256 * VPL;
   const int lane = threadIdx.x & 63;
   const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
@@ -47,14 +48,38 @@ __global__ __launch_bounds__(256) void layernorm_kernel(const float* __restrict_
     for (int e = 0; e < 4; ++e) y[e] = (v[i][e] - mean) * rstd * g[e] + b[e];
     if (out32 != nullptr) *(f32x4*)(out32 + (size_t)row * D + c) = y;
     if (out16 != nullptr)
-      __builtin_nontemporal_store(f16x4{(f16)y[0], (f16)y[1], (f16)y[2], (f16)y[3]}, (f16x4*)(out16 + (size_t)row * D + c));
+      __builtin_nontemporal_store(x4{(T)y[0], (T)y[1], (T)y[2], (T)y[3]}, (x4*)(out16 + (size_t)row * D + c));
+  }
+}
+
+// out[m][0:D] = hi, out[m][D:2D] = lo, out[m][2D:3D] = hi   with hi = T(x), lo = T(x - hi)
+template <typename T>
+__global__ __launch_bounds__(256) void split3_kernel(const float* __restrict__ x, T* __restrict__ out, int M, int D) {
+  using x4 = typename Elt<T>::x4;
+  const size_t total = (size_t)M * (D / 4);
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+    const size_t m = i / (D / 4);
+    const int c = (int)(i - m * (D / 4)) * 4;
+    const f32x4 v = *(const f32x4*)(x + m * D + c);
+    x4 hi, lo;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      hi[e] = Elt<T>::from_f32(v[e]);
+      lo[e] = Elt<T>::from_f32(v[e] - (float)hi[e]);
+    }
+    T* o = out + m * 3 * D + c;
+    *(x4*)o = hi;
+    *(x4*)(o + D) = lo;
+    *(x4*)(o + 2 * D) = hi;
   }
 }
 
 // out[(b*P + py*G + px), c*ps*ps + y*ps + x] = img[b, c, py*ps + y, px*ps + x]
 // one thread = 8 consecutive x of one (patch, c, y) line.
-__global__ __launch_bounds__(256) void patchify_f32_kernel(const float* __restrict__ img, f16* __restrict__ out,
+template <typename T>
+__global__ __launch_bounds__(256) void patchify_f32_kernel(const float* __restrict__ img, T* __restrict__ out,
                                                            int B, int S, int ps) {
+  using x8 = typename Elt<T>::x8;
   const int G = S / ps;
   const int xch = ps / 8;                      // 8-pixel chunks per patch line
   const size_t total = (size_t)B * G * G * 3 * ps * xch;
@@ -68,9 +93,9 @@ __global__ __launch_bounds__(256) void patchify_f32_kernel(const float* __restri
     const int b = (int)r;
     const float* src = img + (((size_t)b * 3 + c) * S + (py * ps + y)) * S + px * ps + xc * 8;
     const f32x4 a0 = *(const f32x4*)(src), a1 = *(const f32x4*)(src + 4);
-    f16x8 o = {(f16)a0[0], (f16)a0[1], (f16)a0[2], (f16)a0[3], (f16)a1[0], (f16)a1[1], (f16)a1[2], (f16)a1[3]};
-    f16* dst = out + ((size_t)(b * G + py) * G + px) * (3 * ps * ps) + (c * ps + y) * ps + xc * 8;
-    *(f16x8*)dst = o;
+    x8 o = {(T)a0[0], (T)a0[1], (T)a0[2], (T)a0[3], (T)a1[0], (T)a1[1], (T)a1[2], (T)a1[3]};
+    T* dst = out + ((size_t)(b * G + py) * G + px) * (3 * ps * ps) + (c * ps + y) * ps + xc * 8;
+    *(x8*)dst = o;
   }
 }
 
@@ -78,8 +103,10 @@ struct Norm3 { float scale[3]; float shift[3]; };  // y = x*scale + shift
 
 // uint8 HWC -> normalised f16 patch rows.  One thread = 8 consecutive pixels
 // (24 B read, three 16-B stores to the three channel planes of the patch row).
-__global__ __launch_bounds__(256) void patchify_u8_kernel(const uint8_t* __restrict__ img, f16* __restrict__ out,
+template <typename T>
+__global__ __launch_bounds__(256) void patchify_u8_kernel(const uint8_t* __restrict__ img, T* __restrict__ out,
                                                           int B, int S, int ps, Norm3 nm) {
+  using x8 = typename Elt<T>::x8;
   const int G = S / ps;
   const int xch = ps / 8;
   const size_t total = (size_t)B * G * G * ps * xch;
@@ -95,13 +122,13 @@ __global__ __launch_bounds__(256) void patchify_u8_kernel(const uint8_t* __restr
     const uint2 w0 = *(const uint2*)(src), w1 = *(const uint2*)(src + 8), w2 = *(const uint2*)(src + 16);
     uint8_t bytes[24];
     *(uint2*)(bytes) = w0; *(uint2*)(bytes + 8) = w1; *(uint2*)(bytes + 16) = w2;
-    f16* dst = out + ((size_t)(b * G + py) * G + px) * (3 * ps * ps) + y * ps + xc * 8;
+    T* dst = out + ((size_t)(b * G + py) * G + px) * (3 * ps * ps) + y * ps + xc * 8;
 #pragma unroll
     for (int c = 0; c < 3; ++c) {
-      f16x8 o;
+      x8 o;
 #pragma unroll
-      for (int e = 0; e < 8; ++e) o[e] = (f16)((float)bytes[e * 3 + c] * nm.scale[c] + nm.shift[c]);
-      *(f16x8*)(dst + c * ps * ps) = o;
+      for (int e = 0; e < 8; ++e) o[e] = (T)((float)bytes[e * 3 + c] * nm.scale[c] + nm.shift[c]);
+      *(x8*)(dst + c * ps * ps) = o;
     }
   }
 }
@@ -109,8 +136,8 @@ __global__ __launch_bounds__(256) void patchify_u8_kernel(const uint8_t* __restr
 // Any patch size (CLIP ViT-L/14: ps = 14, 588 columns): one thread per output element; rows are ldk =
 // round_up(3*ps*ps, 64) halfs long and zero padded so the patch-embedding GEMM keeps its K % 64 == 0 contract
 // (the weight is zero padded the same way by the host packing: exact).
-template <bool U8>
-__global__ __launch_bounds__(256) void patchify_any_kernel(const void* __restrict__ img, f16* __restrict__ out, int B, int S,
+template <typename T, bool U8>
+__global__ __launch_bounds__(256) void patchify_any_kernel(const void* __restrict__ img, T* __restrict__ out, int B, int S,
                                                            int ps, int ldk, Norm3 nm) {
   const int G = S / ps;
   const int pp = ps * ps;
@@ -132,7 +159,7 @@ __global__ __launch_bounds__(256) void patchify_any_kernel(const void* __restric
         v = ((const float*)img)[(((size_t)b * 3 + c) * S + row) * S + cx];
       }
     }
-    out[i] = (f16)v;
+    out[i] = (T)v;
   }
 }
 
@@ -194,19 +221,16 @@ inline int grid_for(size_t total, int block) {
 
 }  // namespace
 
-extern "C" int vidil_layernorm(const float* x, int64_t x_stride, const float* gamma, const float* beta, float eps,
-                               int32_t M, int32_t D, void* out_f16, float* out_f32, void* stream) {
-  VIDIL_REQUIRE(x && gamma && beta && (out_f16 || out_f32), "layernorm: null pointer");
-  VIDIL_REQUIRE(M > 0, "layernorm: M=%d", M);
-  VIDIL_REQUIRE(x_stride % 4 == 0, "layernorm: x_stride must be a multiple of 4");
-  hipStream_t s = (hipStream_t)stream;
+template <typename T>
+static int layernorm_launch(const float* x, int64_t x_stride, const float* gamma, const float* beta, float eps, int M, int D,
+                            T* out16, float* out32, hipStream_t s) {
   dim3 grid((M + 3) / 4), block(256);
   switch (D) {
-    case 256: hipLaunchKernelGGL(layernorm_kernel<1>, grid, block, 0, s, x, x_stride, gamma, beta, eps, M, (f16*)out_f16, out_f32); break;
-    case 512: hipLaunchKernelGGL(layernorm_kernel<2>, grid, block, 0, s, x, x_stride, gamma, beta, eps, M, (f16*)out_f16, out_f32); break;
-    case 768: hipLaunchKernelGGL(layernorm_kernel<3>, grid, block, 0, s, x, x_stride, gamma, beta, eps, M, (f16*)out_f16, out_f32); break;
-    case 1024: hipLaunchKernelGGL(layernorm_kernel<4>, grid, block, 0, s, x, x_stride, gamma, beta, eps, M, (f16*)out_f16, out_f32); break;
-    case 1280: hipLaunchKernelGGL(layernorm_kernel<5>, grid, block, 0, s, x, x_stride, gamma, beta, eps, M, (f16*)out_f16, out_f32); break;
+    case 256: hipLaunchKernelGGL((layernorm_kernel<T, 1>), grid, block, 0, s, x, x_stride, gamma, beta, eps, M, out16, out32); break;
+    case 512: hipLaunchKernelGGL((layernorm_kernel<T, 2>), grid, block, 0, s, x, x_stride, gamma, beta, eps, M, out16, out32); break;
+    case 768: hipLaunchKernelGGL((layernorm_kernel<T, 3>), grid, block, 0, s, x, x_stride, gamma, beta, eps, M, out16, out32); break;
+    case 1024: hipLaunchKernelGGL((layernorm_kernel<T, 4>), grid, block, 0, s, x, x_stride, gamma, beta, eps, M, out16, out32); break;
+    case 1280: hipLaunchKernelGGL((layernorm_kernel<T, 5>), grid, block, 0, s, x, x_stride, gamma, beta, eps, M, out16, out32); break;
     default:
       vidil_set_error("layernorm: D=%d not supported (256/512/768/1024/1280)", D);
       return VIDIL_EUNSUP;
@@ -215,25 +239,47 @@ extern "C" int vidil_layernorm(const float* x, int64_t x_stride, const float* ga
   return VIDIL_OK;
 }
 
-extern "C" int vidil_patchify_f32(const float* img, void* out, int32_t B, int32_t S, int32_t ps, void* stream) {
+extern "C" int vidil_layernorm(const float* x, int64_t x_stride, const float* gamma, const float* beta, float eps,
+                               int32_t M, int32_t D, void* out16, int32_t dtype16, float* out_f32, void* stream) {
+  VIDIL_REQUIRE(x && gamma && beta && (out16 || out_f32), "layernorm: null pointer");
+  VIDIL_REQUIRE(M > 0, "layernorm: M=%d", M);
+  VIDIL_REQUIRE(x_stride % 4 == 0, "layernorm: x_stride must be a multiple of 4");
+  VIDIL_DISPATCH_DTYPE(out16 ? dtype16 : VIDIL_DT_F16, "layernorm",
+                       return layernorm_launch<T>(x, x_stride, gamma, beta, eps, M, D, (T*)out16, out_f32, (hipStream_t)stream));
+}
+
+extern "C" int vidil_split3_f32(const float* x, void* out16, int32_t M, int32_t D, int32_t dtype, void* stream) {
+  VIDIL_REQUIRE(x && out16 && M > 0 && D > 0 && D % 8 == 0, "split3: bad args (D %% 8 == 0)");
+  const size_t total = (size_t)M * (D / 4);
+  VIDIL_DISPATCH_DTYPE(dtype, "split3",
+                       hipLaunchKernelGGL(split3_kernel<T>, dim3(grid_for(total, 256)), dim3(256), 0, (hipStream_t)stream, x,
+                                          (T*)out16, M, D));
+  VIDIL_CHECK_LAUNCH("split3");
+  return VIDIL_OK;
+}
+
+extern "C" int vidil_patchify_f32(const float* img, void* out, int32_t B, int32_t S, int32_t ps, int32_t dtype, void* stream) {
   VIDIL_REQUIRE(img && out && B > 0, "patchify_f32: bad args");
   VIDIL_REQUIRE(ps > 0 && S % ps == 0, "patchify_f32: S=%d ps=%d (S%%ps==0 required)", S, ps);
   if (ps % 8 != 0) {
     const int ldk = (3 * ps * ps + 63) / 64 * 64;
     const size_t n = (size_t)B * (S / ps) * (S / ps) * ldk;
-    hipLaunchKernelGGL(patchify_any_kernel<false>, dim3(grid_for(n, 256)), dim3(256), 0, (hipStream_t)stream, (const void*)img,
-                       (f16*)out, B, S, ps, ldk, Norm3{});
+    VIDIL_DISPATCH_DTYPE(dtype, "patchify_f32",
+                         hipLaunchKernelGGL((patchify_any_kernel<T, false>), dim3(grid_for(n, 256)), dim3(256), 0,
+                                            (hipStream_t)stream, (const void*)img, (T*)out, B, S, ps, ldk, Norm3{}));
     VIDIL_CHECK_LAUNCH("patchify_f32");
     return VIDIL_OK;
   }
   const size_t total = (size_t)B * (S / ps) * (S / ps) * 3 * ps * (ps / 8);
-  hipLaunchKernelGGL(patchify_f32_kernel, dim3(grid_for(total, 256)), dim3(256), 0, (hipStream_t)stream, img, (f16*)out, B, S, ps);
+  VIDIL_DISPATCH_DTYPE(dtype, "patchify_f32",
+                       hipLaunchKernelGGL(patchify_f32_kernel<T>, dim3(grid_for(total, 256)), dim3(256), 0, (hipStream_t)stream,
+                                          img, (T*)out, B, S, ps));
   VIDIL_CHECK_LAUNCH("patchify_f32");
   return VIDIL_OK;
 }
 
 extern "C" int vidil_patchify_u8(const uint8_t* img, void* out, int32_t B, int32_t S, int32_t ps,
-                                 const float* mean3_host, const float* std3_host, void* stream) {
+                                 const float* mean3_host, const float* std3_host, int32_t dtype, void* stream) {
   VIDIL_REQUIRE(img && out && mean3_host && std3_host && B > 0, "patchify_u8: bad args");
   VIDIL_REQUIRE(ps > 0 && S % ps == 0, "patchify_u8: S=%d ps=%d (S%%ps==0 required)", S, ps);
   Norm3 nm;
@@ -245,13 +291,16 @@ extern "C" int vidil_patchify_u8(const uint8_t* img, void* out, int32_t B, int32
   if (ps % 8 != 0) {
     const int ldk = (3 * ps * ps + 63) / 64 * 64;
     const size_t n = (size_t)B * (S / ps) * (S / ps) * ldk;
-    hipLaunchKernelGGL(patchify_any_kernel<true>, dim3(grid_for(n, 256)), dim3(256), 0, (hipStream_t)stream, (const void*)img,
-                       (f16*)out, B, S, ps, ldk, nm);
+    VIDIL_DISPATCH_DTYPE(dtype, "patchify_u8",
+                         hipLaunchKernelGGL((patchify_any_kernel<T, true>), dim3(grid_for(n, 256)), dim3(256), 0,
+                                            (hipStream_t)stream, (const void*)img, (T*)out, B, S, ps, ldk, nm));
     VIDIL_CHECK_LAUNCH("patchify_u8");
     return VIDIL_OK;
   }
   const size_t total = (size_t)B * (S / ps) * (S / ps) * ps * (ps / 8);
-  hipLaunchKernelGGL(patchify_u8_kernel, dim3(grid_for(total, 256)), dim3(256), 0, (hipStream_t)stream, img, (f16*)out, B, S, ps, nm);
+  VIDIL_DISPATCH_DTYPE(dtype, "patchify_u8",
+                       hipLaunchKernelGGL(patchify_u8_kernel<T>, dim3(grid_for(total, 256)), dim3(256), 0, (hipStream_t)stream,
+                                          img, (T*)out, B, S, ps, nm));
   VIDIL_CHECK_LAUNCH("patchify_u8");
   return VIDIL_OK;
 }

@@ -11,7 +11,7 @@ import ctypes as C
 import torch
 
 from . import _lib
-from ._lib import (ACT_GELU_ERF, ACT_NONE, ACT_QUICK_GELU, EPI_ARENA, EPI_F16, EPI_F32,
+from ._lib import (ACT_GELU_ERF, ACT_NONE, ACT_QUICK_GELU, DT_BF16, DT_F16, EPI_ARENA, EPI_F16, EPI_F32,
                    EPI_HEADS, EPI_PATCH, BeamState, GemmArgs, VidilHipError, check)
 
 __all__ = [
@@ -44,6 +44,17 @@ def kv_tile_offsets(n: int):
     return k_off, v_off
 
 
+_DT = {torch.float16: DT_F16, torch.bfloat16: DT_BF16}
+
+
+def _dt(t, name="tensor") -> int:
+    """VIDIL_DT_* code of a 16-bit operand tensor (float16 / bfloat16)."""
+    code = _DT.get(t if isinstance(t, torch.dtype) else t.dtype)
+    if code is None:
+        raise VidilHipError(f"{name}: expected a float16 or bfloat16 tensor, got {t if isinstance(t, torch.dtype) else t.dtype}")
+    return code
+
+
 def _stream() -> int:
     return torch.cuda.current_stream().cuda_stream
 
@@ -61,18 +72,31 @@ def _ptr(t, dtype=None, name="tensor"):
 
 
 # --------------------------------------------------------------------------- GEMM
-def gemm(a, w, bias=None, *, out=None, out_dtype=torch.float16, act=ACT_NONE, resid=None,
-         heads=None, patch=None, arena=None, M=None, lda=None):
+def gemm(a, w, bias=None, **kw):
     """C = A · W^T with a fused epilogue.
 
-    a [M,K] f16, w [N,K] f16, bias f32 [N] or None.
-      * default: returns/fills ``out`` [M,N] (f16 or f32 by ``out_dtype``); f32 may add ``resid``.
+    a [M,K], w [N,K] in the same 16-bit type T16 (float16 or bfloat16), bias f32 [N] or None.
+      * default: returns/fills ``out`` [M,N] (T16, or f32 with ``out_dtype=torch.float32``); f32 may add ``resid``.
       * heads=dict(q=,k=,vt=,T=,H=,part0=,t_off=,Tq_cap=,Tk_cap=,NP=,q_scale=,tiled=): per-head scatter.
       * patch=dict(out=,pos=,tpi=): patch-embedding epilogue (row remap + pos embed).
       * arena=dict(q=,k=,v=,T=,H=,part0=,t_off=,arena_rows=,slot_stride=,Tcap=,q_scale=): Q rows + K/V rows
         appended to a beam-search KV arena [position][slot][H*64] (see vidil_beam_attention).
     """
-    lib = _lib.load()
+    g, ret = _gemm_build(a, w, bias, **kw)
+    check(_lib.load().vidil_gemm(C.byref(g), _stream()), "gemm")
+    return ret
+
+
+def gemm_kernel_name(a, w, bias=None, **kw):
+    """The kernel instantiation ``gemm`` would launch for these arguments, as rocprofv3 spells it."""
+    g, _ = _gemm_build(a, w, bias, **kw)
+    buf = C.create_string_buffer(128)
+    check(_lib.load().vidil_gemm_kernel_name(C.byref(g), buf, 128), "gemm_kernel_name")
+    return buf.value.decode()
+
+
+def _gemm_build(a, w, bias=None, *, out=None, out_dtype=None, act=ACT_NONE, resid=None,
+                heads=None, patch=None, arena=None, M=None, lda=None):
     K_ = w.shape[1]
     if lda is None:
         M, Ka = a.shape
@@ -83,8 +107,10 @@ def gemm(a, w, bias=None, *, out=None, out_dtype=torch.float16, act=ACT_NONE, re
     K = K_
     N = w.shape[0]
     g = GemmArgs()
-    g.A = _ptr(a, torch.float16, "gemm.A")
-    g.W = _ptr(w, torch.float16, "gemm.W")
+    t16 = a.dtype
+    g.dtype = _dt(a, "gemm.A")
+    g.A = _ptr(a, t16, "gemm.A")
+    g.W = _ptr(w, t16, "gemm.W")
     g.bias = _ptr(bias, torch.float32, "gemm.bias")
     g.M, g.N, g.K = M, N, K
     g.lda = 0 if lda is None else lda
@@ -92,9 +118,9 @@ def gemm(a, w, bias=None, *, out=None, out_dtype=torch.float16, act=ACT_NONE, re
     ret = None
     if heads is not None:
         g.epi = EPI_HEADS
-        g.q = _ptr(heads.get("q"), torch.float16, "gemm.q")
-        g.k = _ptr(heads.get("k"), torch.float16, "gemm.k")
-        g.vt = _ptr(heads.get("vt"), torch.float16, "gemm.vt")
+        g.q = _ptr(heads.get("q"), t16, "gemm.q")
+        g.k = _ptr(heads.get("k"), t16, "gemm.k")
+        g.vt = _ptr(heads.get("vt"), t16, "gemm.vt")
         g.T, g.H = heads["T"], heads["H"]
         g.part0 = heads.get("part0", 0)
         g.t_off = heads.get("t_off", 0)
@@ -105,9 +131,9 @@ def gemm(a, w, bias=None, *, out=None, out_dtype=torch.float16, act=ACT_NONE, re
         g.kv_tiled = 1 if heads.get("tiled") else 0
     elif arena is not None:
         g.epi = EPI_ARENA
-        g.q = _ptr(arena.get("q"), torch.float16, "gemm.arena.q")
-        g.k = _ptr(arena.get("k"), torch.float16, "gemm.arena.k")
-        g.vt = _ptr(arena.get("v"), torch.float16, "gemm.arena.v")
+        g.q = _ptr(arena.get("q"), t16, "gemm.arena.q")
+        g.k = _ptr(arena.get("k"), t16, "gemm.arena.k")
+        g.vt = _ptr(arena.get("v"), t16, "gemm.arena.v")
         g.T, g.H = arena["T"], arena["H"]
         g.part0 = arena.get("part0", 0)
         g.t_off = arena.get("t_off", 0)
@@ -124,17 +150,18 @@ def gemm(a, w, bias=None, *, out=None, out_dtype=torch.float16, act=ACT_NONE, re
         g.tpi = patch["tpi"]
     else:
         if out is None:
-            out = torch.empty((M, N), dtype=out_dtype, device=a.device)
+            out = torch.empty((M, N), dtype=out_dtype or t16, device=a.device)
         ret = out
-        g.epi = EPI_F16 if out.dtype == torch.float16 else EPI_F32
+        if out.dtype not in (t16, torch.float32):
+            raise VidilHipError(f"gemm: out must be {t16} (the operand type) or float32, got {out.dtype}")
+        g.epi = EPI_F32 if out.dtype == torch.float32 else EPI_F16
         g.out = _ptr(out, None, "gemm.out")
         g.ldo = out.shape[-1]
         if resid is not None:
             if out.dtype != torch.float32:
                 raise VidilHipError("gemm: resid needs an f32 output")
             g.resid = _ptr(resid, torch.float32, "gemm.resid")
-    check(lib.vidil_gemm_f16(C.byref(g), _stream()), "gemm")
-    return ret
+    return g, ret
 
 
 # ---------------------------------------------------------------------- row kernels
@@ -146,8 +173,16 @@ def layernorm(x, gamma, beta, eps, *, M=None, D=None, x_stride=None, out16=None,
     x_stride = x_stride if x_stride is not None else D
     check(lib.vidil_layernorm(_ptr(x, torch.float32, "ln.x"), x_stride, _ptr(gamma, torch.float32, "ln.gamma"),
                               _ptr(beta, torch.float32, "ln.beta"), float(eps), M, D,
-                              _ptr(out16, torch.float16, "ln.out16"), _ptr(out32, torch.float32, "ln.out32"),
-                              _stream()), "layernorm")
+                              _ptr(out16, None, "ln.out16"), _dt(out16, "ln.out16") if out16 is not None else DT_F16,
+                              _ptr(out32, torch.float32, "ln.out32"), _stream()), "layernorm")
+
+
+def split3(x32, out16):
+    """out16 [M,3D] = [hi | lo | hi] of f32 x [M,D] (hi = T16(x), lo = T16(x - hi)): error-compensated GEMM operand rows."""
+    M, D = x32.shape
+    check(_lib.load().vidil_split3_f32(_ptr(x32, torch.float32, "split3.x"), _ptr(out16, None, "split3.out"), M, D,
+                                       _dt(out16, "split3.out"), _stream()), "split3")
+    return out16
 
 
 def attention(q, k, vt, out, *, Bq, H, Nq, Nk, Tq_cap, Tk_cap, NP, kv_group=1, causal=False,
@@ -157,12 +192,14 @@ def attention(q, k, vt, out, *, Bq, H, Nq, Nk, Tq_cap, Tk_cap, NP, kv_group=1, c
     lib = _lib.load()
     ldo = ldo if ldo is not None else H * 64
     n_kv = 0 if group_start is None else group_start.numel() - 1
-    check(lib.vidil_attention(_ptr(q, torch.float16, "attn.q"), _ptr(k, torch.float16, "attn.k"),
-                              _ptr(vt, torch.float16, "attn.vt"), _ptr(out, torch.float16, "attn.out"),
+    t16 = q.dtype
+    check(lib.vidil_attention(_ptr(q, t16, "attn.q"), _ptr(k, t16, "attn.k"),
+                              _ptr(vt, t16, "attn.vt"), _ptr(out, t16, "attn.out"),
                               _ptr(kv_len, torch.int32, "attn.kv_len"), _ptr(kv_index, torch.int32, "attn.kv_index"),
                               _ptr(group_start, torch.int32, "attn.group_start"), n_kv, max_group,
                               Bq, H, Nq, Nk, Tq_cap, Tk_cap, NP,
-                              kv_group, int(bool(causal)), causal_off, ldo, int(bool(kv_tiled)), _stream()), "attention")
+                              kv_group, int(bool(causal)), causal_off, ldo, int(bool(kv_tiled)), _dt(q, "attn.q"),
+                              _stream()), "attention")
     return out
 
 
@@ -183,31 +220,31 @@ def patch_row_halfs(ps: int) -> int:
     return (3 * ps * ps + 63) // 64 * 64
 
 
-def patchify_f32(img, ps, out=None):
+def patchify_f32(img, ps, out=None, dtype=torch.float16):
     lib = _lib.load()
     B, Cc, S, S2 = img.shape
     if Cc != 3 or S != S2:
         raise VidilHipError(f"patchify_f32: expected [B,3,S,S], got {tuple(img.shape)}")
     G = S // ps
     if out is None:
-        out = torch.empty((B * G * G, patch_row_halfs(ps)), dtype=torch.float16, device=img.device)
-    check(lib.vidil_patchify_f32(_ptr(img, torch.float32, "patchify.img"), _ptr(out, torch.float16, "patchify.out"),
-                                 B, S, ps, _stream()), "patchify_f32")
+        out = torch.empty((B * G * G, patch_row_halfs(ps)), dtype=dtype, device=img.device)
+    check(lib.vidil_patchify_f32(_ptr(img, torch.float32, "patchify.img"), _ptr(out, None, "patchify.out"),
+                                 B, S, ps, _dt(out, "patchify.out"), _stream()), "patchify_f32")
     return out
 
 
-def patchify_u8(img, ps, mean, std, out=None):
+def patchify_u8(img, ps, mean, std, out=None, dtype=torch.float16):
     lib = _lib.load()
     B, S, S2, Cc = img.shape
     if Cc != 3 or S != S2:
         raise VidilHipError(f"patchify_u8: expected [B,S,S,3], got {tuple(img.shape)}")
     G = S // ps
     if out is None:
-        out = torch.empty((B * G * G, patch_row_halfs(ps)), dtype=torch.float16, device=img.device)
+        out = torch.empty((B * G * G, patch_row_halfs(ps)), dtype=dtype, device=img.device)
     m3 = (C.c_float * 3)(*[float(v) for v in mean])
     s3 = (C.c_float * 3)(*[float(v) for v in std])
-    check(lib.vidil_patchify_u8(_ptr(img, torch.uint8, "patchify.img"), _ptr(out, torch.float16, "patchify.out"),
-                                B, S, ps, m3, s3, _stream()), "patchify_u8")
+    check(lib.vidil_patchify_u8(_ptr(img, torch.uint8, "patchify.img"), _ptr(out, None, "patchify.out"),
+                                B, S, ps, m3, s3, _dt(out, "patchify.out"), _stream()), "patchify_u8")
     return out
 
 
@@ -320,7 +357,7 @@ def beam_finalize(bufs: BeamBuffers, cur_len, eos_id, pad_id):
 
 def kv_reorder(src, dst, beam_idx, L, rows):
     row_halfs = src.numel() // (L * rows)
-    check(_lib.load().vidil_kv_reorder(_ptr(src, torch.float16), _ptr(dst, torch.float16),
+    check(_lib.load().vidil_kv_reorder(_ptr(src, None), _ptr(dst, src.dtype),
                                        _ptr(beam_idx, torch.int32), L, rows, row_halfs, _stream()), "kv_reorder")
 
 
@@ -346,10 +383,11 @@ def beam_attention(q, k_arena, v_arena, anc, out, *, rows, H, n_keys, ldo=None):
     """Decode-step self-attention over the KV arena: q f16 [rows,H*64]; arenas f16 [Tcap,arena_rows,H*64];
     anc i32 [rows,Tcap]; out f16 [rows,ldo]."""
     Tcap, arena_rows = k_arena.shape[0], k_arena.shape[1]
-    check(_lib.load().vidil_beam_attention(_ptr(q, torch.float16), _ptr(k_arena, torch.float16),
-                                           _ptr(v_arena, torch.float16), _ptr(anc, torch.int32),
-                                           _ptr(out, torch.float16), rows, H, n_keys, arena_rows, anc.shape[1],
-                                           ldo if ldo is not None else out.shape[-1], _stream()), "beam_attention")
+    t16 = q.dtype
+    check(_lib.load().vidil_beam_attention(_ptr(q, t16), _ptr(k_arena, t16), _ptr(v_arena, t16), _ptr(anc, torch.int32),
+                                           _ptr(out, t16), rows, H, n_keys, arena_rows, anc.shape[1],
+                                           ldo if ldo is not None else out.shape[-1], _dt(q, "beam_attention.q"), _stream()),
+          "beam_attention")
 
 
 def scan_scores(img, txt):

@@ -140,10 +140,10 @@ class BeamArena:
     [position][slot = producing beam row]; ``anc`` i32 [rows][Tcap] maps (beam row, position) -> slot and is the
     only thing reordered per step (vidil_beam_ancestry) — the reference's _reorder_cache without moving the cache."""
 
-    def __init__(self, L, Tcap, rows, C, device):
+    def __init__(self, L, Tcap, rows, C, device, dtype=torch.float16):
         self.L, self.Tcap, self.rows = L, Tcap, rows
-        self.k = torch.empty((L, Tcap, rows, C), dtype=torch.float16, device=device)
-        self.v = torch.empty((L, Tcap, rows, C), dtype=torch.float16, device=device)
+        self.k = torch.empty((L, Tcap, rows, C), dtype=dtype, device=device)
+        self.v = torch.empty((L, Tcap, rows, C), dtype=dtype, device=device)
         self._anc = [torch.zeros((rows, Tcap), dtype=torch.int32, device=device) for _ in range(2)]
         self._cur = 0
 
@@ -179,23 +179,24 @@ class BertModel(PackedCache, nn.Module):
     # ------------------------------------------------------------------ packing
     def _pack(self):
         e = self.embeddings
+        c = self.cdt
         p = dict(word=v32(e.word_embeddings.weight).view(self.config.vocab_size, -1),
                  pos=v32(e.position_embeddings.weight).view(self.config.max_position_embeddings, -1),
                  emb_g=v32(e.LayerNorm.weight), emb_b=v32(e.LayerNorm.bias), layers=[])
         for l in self.encoder.layer:
             a, o = l.attention.self, l.attention.output
-            d = dict(qkv_w=w16(a.query.weight, a.key.weight, a.value.weight),
+            d = dict(qkv_w=w16(a.query.weight, a.key.weight, a.value.weight, dtype=c),
                      qkv_b=v32(a.query.bias, a.key.bias, a.value.bias),
-                     ao_w=w16(o.dense.weight), ao_b=v32(o.dense.bias),
+                     ao_w=w16(o.dense.weight, dtype=c), ao_b=v32(o.dense.bias),
                      ao_g=v32(o.LayerNorm.weight), ao_bt=v32(o.LayerNorm.bias),
-                     i_w=w16(l.intermediate.dense.weight), i_b=v32(l.intermediate.dense.bias),
-                     o_w=w16(l.output.dense.weight), o_b=v32(l.output.dense.bias),
+                     i_w=w16(l.intermediate.dense.weight, dtype=c), i_b=v32(l.intermediate.dense.bias),
+                     o_w=w16(l.output.dense.weight, dtype=c), o_b=v32(l.output.dense.bias),
                      o_g=v32(l.output.LayerNorm.weight), o_bt=v32(l.output.LayerNorm.bias))
             if hasattr(l, "crossattention"):
-                c, co = l.crossattention.self, l.crossattention.output
-                d.update(cq_w=w16(c.query.weight), cq_b=v32(c.query.bias),
-                         ckv_w=w16(c.key.weight, c.value.weight), ckv_b=v32(c.key.bias, c.value.bias),
-                         co_w=w16(co.dense.weight), co_b=v32(co.dense.bias),
+                ca, co = l.crossattention.self, l.crossattention.output
+                d.update(cq_w=w16(ca.query.weight, dtype=c), cq_b=v32(ca.query.bias),
+                         ckv_w=w16(ca.key.weight, ca.value.weight, dtype=c), ckv_b=v32(ca.key.bias, ca.value.bias),
+                         co_w=w16(co.dense.weight, dtype=c), co_b=v32(co.dense.bias),
                          co_g=v32(co.LayerNorm.weight), co_bt=v32(co.LayerNorm.bias))
             p["layers"].append(d)
         return p
@@ -212,6 +213,7 @@ class BertModel(PackedCache, nn.Module):
         image and which re-read the K/V from HBM many times (the decode steps of the captioner)."""
         p = self.packed()
         H = self.config.num_attention_heads
+        cdt = enc16.dtype
         if tiled:
             Tc = (Te + 31) // 32 * 32
             L = len(p["layers"])
@@ -219,8 +221,8 @@ class BertModel(PackedCache, nn.Module):
             if out is not None and out.tiled and (out.B, out.Te) == (B, Te) and out.k.device == dev:
                 k, v = out.k, out.vt
             else:
-                k = torch.empty((L, B, H, Tc, 64), dtype=torch.float16, device=dev)
-                v = torch.empty((L, B, H, Tc, 64), dtype=torch.float16, device=dev)
+                k = torch.empty((L, B, H, Tc, 64), dtype=cdt, device=dev)
+                v = torch.empty((L, B, H, Tc, 64), dtype=cdt, device=dev)
             for i, d in enumerate(p["layers"]):
                 K.gemm(enc16, d["ckv_w"], d["ckv_b"],
                        heads=dict(k=k[i], vt=v[i], T=Te, H=H, part0=1, t_off=0, Tk_cap=Tc, tiled=True))
@@ -232,11 +234,11 @@ class BertModel(PackedCache, nn.Module):
         if out is not None and not out.tiled and (out.B, out.Te, out.NP) == (B, Te, NP) and out.k.device == dev:
             k, vt = out.k, out.vt
         else:
-            k = torch.empty((L, B, H, Te, 64), dtype=torch.float16, device=dev)
-            vt = torch.empty((L, B, H, Te, 64) if v_rowmajor else (L, B, H, 64, NP), dtype=torch.float16, device=dev)
+            k = torch.empty((L, B, H, Te, 64), dtype=cdt, device=dev)
+            vt = torch.empty((L, B, H, Te, 64) if v_rowmajor else (L, B, H, 64, NP), dtype=cdt, device=dev)
         last_vt = None
         if v_rowmajor and last_layer_vt:
-            last_vt = torch.empty((B, H, 64, NPt), dtype=torch.float16, device=dev)
+            last_vt = torch.empty((B, H, 64, NPt), dtype=cdt, device=dev)
         for i, d in enumerate(p["layers"]):
             if last_vt is not None and i == L - 1:
                 K.gemm(enc16, d["ckv_w"], d["ckv_b"],
@@ -267,15 +269,16 @@ class BertModel(PackedCache, nn.Module):
         eps = cfg.layer_norm_eps
         M = rows * T
         dev = h32.device
+        cdt = h16.dtype
         if ws is None:
             ws = {}
         q = ws.get("q")
         if q is None or q.shape[0] < rows or q.shape[2] != T:
-            q = torch.empty((rows, H, T, 64), dtype=torch.float16, device=dev)
+            q = torch.empty((rows, H, T, 64), dtype=cdt, device=dev)
             ws["q"] = q
-        o = torch.empty((M, C), dtype=torch.float16, device=dev)
+        o = torch.empty((M, C), dtype=cdt, device=dev)
         tmp = torch.empty((M, C), dtype=torch.float32, device=dev)
-        inter = torch.empty((M, cfg.intermediate_size), dtype=torch.float16, device=dev)
+        inter = torch.empty((M, cfg.intermediate_size), dtype=cdt, device=dev)
         Nk = t_off + T
         if arena is not None and T > 1 and t_off != 0:
             raise K.VidilHipError("run_layers: a multi-token block can only be appended to a beam arena at position 0")
@@ -325,10 +328,11 @@ class BertModel(PackedCache, nn.Module):
         C = self.config.hidden_size
         M = ids_i32.numel()
         dev = ids_i32.device
+        cdt = p["layers"][0]["qkv_w"].dtype
         raw = torch.empty((M, C), dtype=torch.float32, device=dev)
         K.embed_tokens(ids_i32, p["word"], p["pos"], raw, T=T, pos_off=pos_off)
         h32 = torch.empty((M, C), dtype=torch.float32, device=dev)
-        h16 = torch.empty((M, C), dtype=torch.float16, device=dev)
+        h16 = torch.empty((M, C), dtype=cdt, device=dev)
         K.layernorm(raw, p["emb_g"], p["emb_b"], self.config.layer_norm_eps, out16=h16, out32=h32)
         return h32, h16
 
@@ -343,8 +347,9 @@ class BertModel(PackedCache, nn.Module):
         dev = ids_i32.device
         NPs = (T + 15) // 16 * 16
         h32, h16 = self.embed(ids_i32.reshape(-1), T, 0)
-        sk = torch.empty((1, P, H, T, 64), dtype=torch.float16, device=dev).expand(L, -1, -1, -1, -1)
-        sv = torch.empty((1, P, H, 64, NPs), dtype=torch.float16, device=dev).expand(L, -1, -1, -1, -1)
+        cdt = h16.dtype
+        sk = torch.empty((1, P, H, T, 64), dtype=cdt, device=dev).expand(L, -1, -1, -1, -1)
+        sv = torch.empty((1, P, H, 64, NPs), dtype=cdt, device=dev).expand(L, -1, -1, -1, -1)
         # (one scratch K / V^T buffer is reused by every layer: the encoder keeps no cache)
         self.run_layers(h32, h16, rows=P, T=T, self_k=sk, self_vt=sv, t_off=0, Tk_cap=T, NPs=NPs, causal=False,
                         kv_len=kv_len_i32, cross=cross, cross_index=cross_index, cross_groups=cross_groups,
@@ -373,13 +378,14 @@ class BertModel(PackedCache, nn.Module):
         H, C, L = cfg.num_attention_heads, cfg.hidden_size, cfg.num_hidden_layers
         eps = cfg.layer_norm_eps
         dev = ids_i32.device
+        cdt = p["layers"][0]["qkv_w"].dtype
         NPs = (T + 15) // 16 * 16
         if cross is not None and cross.NP == 0 and cross.last_vt is None:
             raise K.VidilHipError("encode_cls: row-major cross values need project_cross_kv(last_layer_vt=True)")
 
         def scratch(rows):
-            k = torch.empty((rows, H, T, 64), dtype=torch.float16, device=dev)
-            v = torch.empty((rows, H, 64, NPs), dtype=torch.float16, device=dev)
+            k = torch.empty((rows, H, T, 64), dtype=cdt, device=dev)
+            v = torch.empty((rows, H, 64, NPs), dtype=cdt, device=dev)
             return k, v, k.unsqueeze(0).expand(L, -1, -1, -1, -1), v.unsqueeze(0).expand(L, -1, -1, -1, -1)
 
         h32, h16 = self.embed(ids_i32.reshape(-1), T, 0)
@@ -402,10 +408,10 @@ class BertModel(PackedCache, nn.Module):
                         kv_len=kv_len_i32, cross=cross, cross_index=cross_index, cross_groups=cross_groups,
                         cross_max_group=cross_max_group, n_layers=L - 1, self_done_first=shared)
         d = p["layers"][L - 1]
-        q1 = torch.empty((P, H, 1, 64), dtype=torch.float16, device=dev)
-        o1 = torch.empty((P, C), dtype=torch.float16, device=dev)
+        q1 = torch.empty((P, H, 1, 64), dtype=cdt, device=dev)
+        o1 = torch.empty((P, C), dtype=cdt, device=dev)
         tmp = torch.empty((P, C), dtype=torch.float32, device=dev)
-        c16 = torch.empty((P, C), dtype=torch.float16, device=dev)
+        c16 = torch.empty((P, C), dtype=cdt, device=dev)
         c32 = h32.view(P, T, C)[:, 0].contiguous()
         # self-attention: keys / values of every token, query of token 0 (A rows p*T of h16: strided operand)
         K.gemm(h16, d["qkv_w"][C:], d["qkv_b"][C:], heads=dict(k=sk, vt=sv, T=T, H=H, part0=1, t_off=0, Tk_cap=T, NP=NPs))
@@ -453,11 +459,30 @@ class _LMHead(nn.Module):
         self.predictions = _LMPredictions(cfg)
 
 
+def _w3(weight, dtype):
+    """[N,K] f32 -> 16-bit [N,3K] = [W_hi | W_hi | W_lo] (hi = T16(W), lo = T16(W - hi)): the weight side of an
+    error-compensated GEMM whose activation rows are [x_hi | x_lo | x_hi] (vidil_split3_f32)."""
+    w = weight.detach().float()
+    hi = w.to(dtype)
+    lo = (w - hi.float()).to(dtype)
+    return torch.cat([hi, hi, lo], dim=1).contiguous()
+
+
 class BertLMHeadModel(PackedCache, nn.Module):
-    """Caption decoder: ``bert`` trunk + ``cls`` LM head (models/med.py:811-955)."""
+    """Caption decoder: ``bert`` trunk + ``cls`` LM head (models/med.py:811-955).
+
+    ``precise_head`` (default: $VIDIL_PRECISE_LM_HEAD == "1"): run the two GEMMs of the LM head with
+    error-compensated operands — activations and weights split into hi + lo 16-bit parts, the three significant
+    cross terms accumulated by ONE GEMM with K tripled — so that the head adds ~2^-20 instead of ~2^-11 (f16) /
+    2^-8 (bf16) relative rounding to the logits.  It is what the "caption logits within 1e-3" budget can afford
+    to spend on precision: the head is 19 % of a decode step's FLOPs (x3 here), the trunk's operand rounding is
+    untouched (DESIGN.md §4 has the measured split)."""
 
     def __init__(self, config):
         super().__init__()
+        import os
+
+        self.precise_head = os.environ.get("VIDIL_PRECISE_LM_HEAD", "0") == "1"
         self.config = config
         self.bert = BertModel(config, add_pooling_layer=False)
         self.cls = _LMHead(config)
@@ -465,22 +490,46 @@ class BertLMHeadModel(PackedCache, nn.Module):
 
     def _pack(self):
         pr = self.cls.predictions
-        return dict(t_w=w16(pr.transform.dense.weight), t_b=v32(pr.transform.dense.bias),
-                    t_g=v32(pr.transform.LayerNorm.weight), t_bt=v32(pr.transform.LayerNorm.bias),
-                    dec_w=w16(pr.decoder.weight), dec_b=v32(pr.bias))
+        c = self.cdt
+        p = dict(t_w=w16(pr.transform.dense.weight, dtype=c), t_b=v32(pr.transform.dense.bias),
+                 t_g=v32(pr.transform.LayerNorm.weight), t_bt=v32(pr.transform.LayerNorm.bias),
+                 dec_w=w16(pr.decoder.weight, dtype=c), dec_b=v32(pr.bias), precise=self.precise_head)
+        if self.precise_head:
+            p.update(t_w3=_w3(pr.transform.dense.weight, c), dec_w3=_w3(pr.decoder.weight, c))
+        return p
 
-    def lm_logits(self, h16, rows, T, out=None):
+    def packed(self):
+        cache = self.__dict__.get("_packed_cache")
+        if cache is not None and cache[1].get("precise") != self.precise_head:
+            self.__dict__.pop("_packed_cache")          # the flag was flipped after packing
+        return super().packed()
+
+    def lm_logits(self, h16, rows, T, out=None, h32=None):
         """LM head (models/med.py:501-545) on the LAST token of each of ``rows`` sequences of length T:
-        dense -> erf-GELU -> LayerNorm -> decoder(+bias).  h16: f16 [rows*T, C].  Returns f32 [rows, V].
+        dense -> erf-GELU -> LayerNorm -> decoder(+bias).  h16: T16 [rows*T, C]; h32: the same hidden states in f32
+        (used by the precise head).  Returns f32 [rows, V].
         (The reference computes logits for all T positions and HF generate() keeps only the last.)"""
         p = self.packed()
         cfg = self.config
         C = cfg.hidden_size
         dev = h16.device
+        cdt = h16.dtype
+        if self.precise_head and h32 is not None:
+            last32 = h32.view(rows, T, C)[:, T - 1].contiguous()
+            a3 = K.split3(last32, torch.empty((rows, 3 * C), dtype=cdt, device=dev))
+            t32 = torch.empty((rows, C), dtype=torch.float32, device=dev)
+            K.gemm(a3, p["t_w3"], p["t_b"], out=t32, act=K.ACT_GELU_ERF)
+            tn32 = torch.empty((rows, C), dtype=torch.float32, device=dev)
+            K.layernorm(t32, p["t_g"], p["t_bt"], cfg.layer_norm_eps, out32=tn32)
+            K.split3(tn32, a3)
+            if out is None:
+                out = torch.empty((rows, cfg.vocab_size), dtype=torch.float32, device=dev)
+            K.gemm(a3, p["dec_w3"], p["dec_b"], out=out)
+            return out
         last = h16.view(-1)[(T - 1) * C:]  # row r of the strided view = token T-1 of sequence r
         t32 = torch.empty((rows, C), dtype=torch.float32, device=dev)
         K.gemm(last, p["t_w"], p["t_b"], out=t32, act=K.ACT_GELU_ERF, M=rows, lda=T * C)
-        t16 = torch.empty((rows, C), dtype=torch.float16, device=dev)
+        t16 = torch.empty((rows, C), dtype=cdt, device=dev)
         K.layernorm(t32, p["t_g"], p["t_bt"], cfg.layer_norm_eps, out16=t16)
         if out is None:
             out = torch.empty((rows, cfg.vocab_size), dtype=torch.float32, device=dev)

@@ -3,23 +3,61 @@ device-resident f16 GEMM operands + f32 vectors the HIP kernels read.  Packing i
 one-time per weight version (cached by a data_ptr/_version fingerprint)."""
 from __future__ import annotations
 
+import os
+
 import torch
+
+_DTYPES = {"f16": torch.float16, "fp16": torch.float16, "float16": torch.float16, "half": torch.float16,
+           "bf16": torch.bfloat16, "bfloat16": torch.bfloat16}
+
+
+def as_compute_dtype(d):
+    """'f16' / 'bf16' / torch dtype -> torch.float16 or torch.bfloat16 (the two MFMA operand types of the kernels)."""
+    if isinstance(d, str):
+        if d.lower() not in _DTYPES:
+            raise ValueError(f"unknown compute dtype {d!r} (f16 or bf16)")
+        d = _DTYPES[d.lower()]
+    if d not in (torch.float16, torch.bfloat16):
+        raise ValueError(f"compute dtype must be float16 or bfloat16, got {d}")
+    return d
+
+
+_default = [as_compute_dtype(os.environ.get("VIDIL_DTYPE", "f16"))]
+
+
+def set_compute_dtype(dtype, *modules):
+    """Select the 16-bit MFMA operand type — weights are re-packed and every activation buffer follows them.
+    Without modules: the process-wide default ($VIDIL_DTYPE, f16 if unset) used by models that were not set
+    individually.  With modules: those models (and all their sub-modules) only."""
+    dtype = as_compute_dtype(dtype)
+    if not modules:
+        _default[0] = dtype
+        return dtype
+    for m in modules:
+        for sub in m.modules():
+            sub.__dict__["_compute_dtype"] = dtype
+    return dtype
+
+
+def compute_dtype(module=None):
+    d = None if module is None else module.__dict__.get("_compute_dtype")
+    return d if d is not None else _default[0]
 
 
 def fingerprint(module) -> tuple:
-    return tuple((p.data_ptr(), p._version, p.device.index) for p in module.parameters())
+    return tuple((p.data_ptr(), p._version, p.device.index) for p in module.parameters()) + (compute_dtype(module),)
 
 
-def w16(*weights):
-    """Concatenate nn.Linear weights along N and cast to contiguous f16 [N,K]."""
+def w16(*weights, dtype=None):
+    """Concatenate nn.Linear weights along N and cast to the contiguous 16-bit GEMM operand [N,K]."""
     w = weights[0] if len(weights) == 1 else torch.cat(list(weights), dim=0)
-    return w.detach().to(torch.float16).contiguous()
+    return w.detach().to(dtype or _default[0]).contiguous()
 
 
-def w16_patch(conv_weight):
+def w16_patch(conv_weight, dtype=None):
     """Patch-embedding conv weight [N,3,ps,ps] -> f16 [N, round_up(3*ps*ps, 64)], zero padded along K so the GEMM's
     K % 64 == 0 contract holds for any patch size (CLIP ViT-L/14: 588 -> 640; the patch rows are padded alike)."""
-    w = conv_weight.detach().reshape(conv_weight.shape[0], -1).to(torch.float16)
+    w = conv_weight.detach().reshape(conv_weight.shape[0], -1).to(dtype or _default[0])
     K = w.shape[1]
     Kp = (K + 63) // 64 * 64
     if Kp != K:
@@ -40,7 +78,12 @@ def v32(*vecs):
 
 
 class PackedCache:
-    """Mixin: ``self.packed()`` returns the cached result of ``self._pack()``."""
+    """Mixin: ``self.packed()`` returns the cached result of ``self._pack()`` (re-packed when a parameter or the
+    compute dtype changes); ``self.cdt`` is the model's 16-bit operand type."""
+
+    @property
+    def cdt(self):
+        return compute_dtype(self)
 
     def packed(self):
         fp = fingerprint(self)

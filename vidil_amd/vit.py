@@ -12,7 +12,7 @@ unchanged: ``patch_embed.proj.weight``, ``cls_token``, ``pos_embed``,
         fc1 GEMM (+erf-GELU) -> fc2 GEMM (+residual) ] -> LN
 
 with the residual stream, LayerNorm statistics and softmax in f32 and the MFMA
-operands in f16.
+operands in the model's compute dtype (f16 or bf16, packing.set_compute_dtype).
 """
 from __future__ import annotations
 
@@ -101,18 +101,19 @@ class VisionTransformer(PackedCache, nn.Module):
     def _pack(self):
         D = self.embed_dim
         pe = self.patch_embed.proj
+        c = self.cdt
         p = dict(
-            pe_w=w16_patch(pe.weight), pe_b=v32(pe.bias),
+            pe_w=w16_patch(pe.weight, c), pe_b=v32(pe.bias),
             cls=v32(self.cls_token), pos=v32(self.pos_embed).view(-1, D),
             norm_g=v32(self.norm.weight), norm_b=v32(self.norm.bias), blocks=[])
         for b in self.blocks:
             p["blocks"].append(dict(
                 n1g=v32(b.norm1.weight), n1b=v32(b.norm1.bias),
-                qkv_w=w16(b.attn.qkv.weight), qkv_b=v32(b.attn.qkv.bias),
-                proj_w=w16(b.attn.proj.weight), proj_b=v32(b.attn.proj.bias),
+                qkv_w=w16(b.attn.qkv.weight, dtype=c), qkv_b=v32(b.attn.qkv.bias),
+                proj_w=w16(b.attn.proj.weight, dtype=c), proj_b=v32(b.attn.proj.bias),
                 n2g=v32(b.norm2.weight), n2b=v32(b.norm2.bias),
-                fc1_w=w16(b.mlp.fc1.weight), fc1_b=v32(b.mlp.fc1.bias),
-                fc2_w=w16(b.mlp.fc2.weight), fc2_b=v32(b.mlp.fc2.bias)))
+                fc1_w=w16(b.mlp.fc1.weight, dtype=c), fc1_b=v32(b.mlp.fc1.bias),
+                fc2_w=w16(b.mlp.fc2.weight, dtype=c), fc2_b=v32(b.mlp.fc2.bias)))
         return p
 
     # ------------------------------------------------------------------ forward
@@ -136,12 +137,13 @@ class VisionTransformer(PackedCache, nn.Module):
         NP = 0 if T > 32 else (T + 15) // 16 * 16     # (tiny test geometries fall back to V^T + the direct kernels)
         dev = x.device
         M = B * T
-        xn = torch.empty((M, D), dtype=torch.float16, device=dev)
-        q = torch.empty((B, H, T, 64), dtype=torch.float16, device=dev)
-        k = torch.empty((B, H, T, 64), dtype=torch.float16, device=dev)
-        vt = torch.empty((B, H, T, 64) if NP == 0 else (B, H, 64, NP), dtype=torch.float16, device=dev)
-        o = torch.empty((M, D), dtype=torch.float16, device=dev)
-        hid = torch.empty((M, p["blocks"][0]["fc1_w"].shape[0]), dtype=torch.float16, device=dev)
+        cdt = p["pe_w"].dtype
+        xn = torch.empty((M, D), dtype=cdt, device=dev)
+        q = torch.empty((B, H, T, 64), dtype=cdt, device=dev)
+        k = torch.empty((B, H, T, 64), dtype=cdt, device=dev)
+        vt = torch.empty((B, H, T, 64) if NP == 0 else (B, H, 64, NP), dtype=cdt, device=dev)
+        o = torch.empty((M, D), dtype=cdt, device=dev)
+        hid = torch.empty((M, p["blocks"][0]["fc1_w"].shape[0]), dtype=cdt, device=dev)
         heads = dict(q=q, k=k, vt=vt, T=T, H=H, part0=0, t_off=0, Tq_cap=T, Tk_cap=T, NP=NP, q_scale=0.125)
         for b in p["blocks"]:
             K.layernorm(x, b["n1g"], b["n1b"], self.ln_eps, out16=xn)
@@ -161,7 +163,7 @@ class VisionTransformer(PackedCache, nn.Module):
         require_cuda(x, "VisionTransformer.forward")
         B = x.shape[0]
         ps = self.patch_embed.patch_size[0]
-        patches = K.patchify_f32(x.contiguous().float(), ps)
+        patches = K.patchify_f32(x.contiguous().float(), ps, dtype=self.cdt)
         xr = self.embed_patches(patches, B)
         y32, y16 = self.run_blocks(xr, B)
         return y32.view(B, -1, self.embed_dim), y16
@@ -171,7 +173,7 @@ class VisionTransformer(PackedCache, nn.Module):
         require_cuda(frames_u8, "VisionTransformer.forward_u8")
         B = frames_u8.shape[0]
         ps = self.patch_embed.patch_size[0]
-        patches = K.patchify_u8(frames_u8.contiguous(), ps, mean, std)
+        patches = K.patchify_u8(frames_u8.contiguous(), ps, mean, std, dtype=self.cdt)
         xr = self.embed_patches(patches, B)
         y32, y16 = self.run_blocks(xr, B)
         return y32.view(B, -1, self.embed_dim), y16
