@@ -103,6 +103,21 @@ typedef struct vidil_gemm_args {
    * so each of that kernel's wave loads is one contiguous KiB.  Consumer: vidil_attention(kv_tiled = 1). */
   int32_t kv_tiled;
   int32_t dtype;      /* VIDIL_DT_*: type of A, W and of every 16-bit output (out, q, k, vt)   */
+  /* ---- LayerNorm folded into the GEMMs of a pre-LN block (models/vit.py:107-110 `x + attn(norm1(x))`,
+   * `x + mlp(norm2(x))`; HF CLIPEncoderLayer) -----------------------------------------------------
+   * producer (EPI_F32, the residual GEMM that writes the stream x): out16 != NULL additionally stores
+   *   T16(x) [M, ldo16] — the RAW stream in the operand type — for the consumer below;
+   * consumer (EPI_F16 / EPI_HEADS with ln_fold != 0; needs K == the LayerNorm width D): A is that raw T16(x),
+   *   W is W' = T16(gamma (.) W) (gamma scales the K axis), bias is b' = b + W·beta, ln_colsum[n] = sum_k W'[n][k];
+   *   the kernel accumulates every row's sum and sum of squares from the A fragments it streams anyway and
+   *   applies  y[m][n] = rstd_m * (acc[m][n] - mean_m * ln_colsum[n]) + b'[n]  in its epilogue (then act / the
+   *   per-head scatter), which equals LayerNorm(x)·W^T + b with the rounding point moved from LN(x) to x.
+   * Both run on the 256x256 kernel whatever M is (results never depend on the batch size). */
+  void* out16;
+  int32_t ldo16;
+  int32_t ln_fold;
+  const float* ln_colsum; /* f32 [N] */
+  float ln_eps;
 } vidil_gemm_args;
 
 /* replaces: nn.Linear calls of models/vit.py:35-41,72,84; models/med.py:153-171,

@@ -687,3 +687,83 @@ def test_scan_topk_bit_exact_vs_oracle(D):
     assert np.array_equal(oi.cpu().numpy(), ri)
     assert np.array_equal(os_.cpu().numpy().view(np.uint32), rs.view(np.uint32))  # bit-exact scores
     assert list(ri[3, 2, :3]) == [7, 40, 41]
+
+
+# ------------------------------------------------------------------------ LayerNorm folded into the GEMMs
+@pytest.mark.parametrize("dtype", [torch.float16, torch.bfloat16])
+@pytest.mark.parametrize("M,D,N,act", [(197 * 3, 768, 3072, "gelu"), (197 * 330, 768, 3072, "gelu"), (50 * 7, 768, 3072, "quick"),
+                                       (197 * 2, 1024, 4096, "gelu"), (333, 768, 768, "none")])
+def test_gemm_layernorm_fold_consumer_vs_torch(dtype, M, D, N, act):
+    """y = act(LayerNorm(x) W^T + b) computed as the LN-folded GEMM on the RAW 16-bit stream: statistics from the A
+    fragments, normalisation on the accumulators (vidil_gemm_args.ln_fold).  Rows with a large mean / outlier channels
+    included (the cancellation-prone case of the algebraic fold)."""
+    from vidil_amd.packing import fold_layernorm
+
+    k = _k()
+    x = _rand(M, D, seed=70) * 1.5
+    x[:, 5] += 9.0                                   # an outlier channel (as ViT residual streams have)
+    x[::7] += 2.0                                    # rows with a mean of ~2 sigma
+    g, bt = _rand(D, seed=71) * 0.2 + 1.0, _rand(D, seed=72) * 0.2
+    w, b = _rand(N, D, scale=0.03, seed=73), _rand(N, seed=74) * 0.1
+    x16 = x.to(dtype)
+    wf, bf, cs = fold_layernorm(w, b, g, bt, dtype)
+    code = dict(gelu=k.ACT_GELU_ERF, quick=k.ACT_QUICK_GELU, none=k.ACT_NONE)[act]
+    out = k.gemm(x16.to(DEV), wf.to(DEV), bf.to(DEV), act=code, ln=(cs.to(DEV), 1e-6))
+    assert k.gemm_kernel_name(x16.to(DEV), wf.to(DEV), bf.to(DEV), act=code, ln=(cs.to(DEV), 1e-6)).startswith("gemm256_kernel")
+    # reference: exact LayerNorm of the SAME 16-bit stream values, fp32 weights
+    pre = torch.nn.functional.layer_norm(x16.float(), (D,), g, bt, 1e-6) @ w.t() + b
+    ref = dict(gelu=torch.nn.functional.gelu(pre), quick=pre * torch.sigmoid(1.702 * pre), none=pre)[act]
+    n = min(M, 1200)
+    tol = 4e-3 if dtype == torch.float16 else 3e-2    # one operand rounding of W' (2^-11 / 2^-8) through K terms + the output's
+    d = (out[:n].float().cpu() - ref[:n]).abs()
+    assert d.max().item() < tol * max(1.0, ref[:n].abs().max().item()), (d.max().item(), ref[:n].abs().max().item())
+    assert d.mean().item() < tol / 8
+
+
+@pytest.mark.parametrize("dtype", [torch.float16, torch.bfloat16])
+def test_gemm_layernorm_fold_heads_consumer_and_out16_producer(dtype):
+    from vidil_amd.packing import fold_layernorm
+
+    k = _k()
+    B, T, H, D = 4, 197, 12, 768
+    M, N = B * T, 3 * H * 64
+    # producer: the residual GEMM writes the f32 stream AND its 16-bit copy
+    a = _rand(M, D, seed=80).to(dtype)
+    wp, bp = _rand(D, D, scale=0.03, seed=81).to(dtype), _rand(D, seed=82) * 0.1
+    x0 = _rand(M, D, seed=83) * 1.5
+    x = x0.to(DEV).clone()
+    x16 = torch.zeros(M, D, dtype=dtype, device=DEV)
+    k.gemm(a.to(DEV), wp.to(DEV), bp.to(DEV), out=x, resid=x, out16=x16)
+    ref_x = a.float() @ wp.float().t() + bp + x0
+    assert torch.allclose(x.cpu(), ref_x, rtol=1e-4, atol=1e-3)
+    assert torch.equal(x16.cpu(), x.cpu().to(dtype))            # exactly the rounded stream
+    plain = x0.to(DEV).clone()
+    k.gemm(a.to(DEV), wp.to(DEV), bp.to(DEV), out=plain, resid=plain)     # (small-tile kernel) same bits
+    assert torch.equal(plain, x)
+    # consumer: LN + QKV with the per-head scatter
+    g, bt = _rand(D, seed=84) * 0.2 + 1.0, _rand(D, seed=85) * 0.2
+    w, b = _rand(N, D, scale=0.03, seed=86), _rand(N, seed=87) * 0.1
+    wf, bf, cs = fold_layernorm(w, b, g, bt, dtype)
+    q = torch.zeros(B, H, T, 64, dtype=dtype, device=DEV)
+    kk, v = torch.zeros_like(q), torch.zeros_like(q)
+    k.gemm(x16, wf.to(DEV), bf.to(DEV), ln=(cs.to(DEV), 1e-6),
+           heads=dict(q=q, k=kk, vt=v, T=T, H=H, part0=0, t_off=0, Tq_cap=T, Tk_cap=T, NP=0, q_scale=0.125))
+    ref = (torch.nn.functional.layer_norm(x16.float().cpu(), (D,), g, bt, 1e-6) @ w.t() + b).view(B, T, 3, H, 64)
+    tol = dict(rtol=4e-3, atol=4e-3) if dtype == torch.float16 else dict(rtol=3e-2, atol=3e-2)
+    assert torch.allclose(q.float().cpu(), ref[:, :, 0].permute(0, 2, 1, 3) * 0.125, **tol)
+    assert torch.allclose(kk.float().cpu(), ref[:, :, 1].permute(0, 2, 1, 3), **tol)
+    assert torch.allclose(v.float().cpu(), ref[:, :, 2].permute(0, 2, 1, 3), **tol)
+
+
+def test_layernorm_fold_does_not_depend_on_the_batch_size():
+    """The folded GEMMs always run on the 256x256 kernel: a row's result is the same bits in a 3-frame and a 330-frame batch."""
+    from vidil_amd.packing import fold_layernorm
+
+    k = _k()
+    D, N = 768, 3072
+    x16 = (_rand(197 * 330, D, seed=90) * 1.5).half().to(DEV)
+    g, bt = _rand(D, seed=91) * 0.2 + 1.0, _rand(D, seed=92) * 0.2
+    wf, bf, cs = fold_layernorm(_rand(N, D, scale=0.03, seed=93), _rand(N, seed=94) * 0.1, g, bt, torch.float16)
+    big = k.gemm(x16, wf.to(DEV), bf.to(DEV), act=k.ACT_GELU_ERF, ln=(cs.to(DEV), 1e-6))
+    small = k.gemm(x16[:591].contiguous(), wf.to(DEV), bf.to(DEV), act=k.ACT_GELU_ERF, ln=(cs.to(DEV), 1e-6))
+    assert torch.equal(big[:591], small)

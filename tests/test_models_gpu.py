@@ -761,3 +761,30 @@ def test_results_do_not_depend_on_batch_composition(full_models):
         assert it[0]["unfiltered_text"] == all_items[v]["unfiltered_text"]
         assert it[0]["text"] == all_items[v]["text"]
         assert t[f"video{v}"] == all_t[f"video{v}"]
+
+
+def test_vit_with_fused_layernorm_matches_the_unfused_path_and_the_oracle():
+    """fuse_layernorm moves the rounding point of the GEMM operand from LN(x) to x; both variants must sit within the
+    same tolerance of the fp32 oracle, and within ~2x the f16 tolerance of each other."""
+    from oracle import vit_ref
+    from vidil_amd.vit import VisionTransformer
+
+    torch.manual_seed(4)
+    m = VisionTransformer(img_size=224, patch_size=16, embed_dim=768, depth=12, num_heads=12).eval()
+    perturb_(m, 31)
+    sd = {"visual_encoder." + k: v.clone() for k, v in m.state_dict().items()}
+    x = torch.randn(3, 3, 224, 224)
+    with torch.no_grad():
+        ref = vit_ref.vit_forward(sd, x)
+    m = m.to(DEV)
+    assert m.fuse_layernorm
+    y_f = m(x.to(DEV)).cpu()
+    m.fuse_layernorm = False
+    y_u = m(x.to(DEV)).cpu()
+    m.fuse_layernorm = True
+    e_f, e_u = (y_f - ref).abs(), (y_u - ref).abs()
+    print(f"ViT-B/16 vs fp32 oracle: fused LN max {e_f.max().item():.2e} mean {e_f.mean().item():.2e}; "
+          f"unfused max {e_u.max().item():.2e} mean {e_u.mean().item():.2e}")
+    assert e_f.max().item() < 1e-2 and e_f.mean().item() < 1e-3
+    assert e_u.max().item() < 1e-2 and e_u.mean().item() < 1e-3
+    assert (y_f - y_u).abs().max().item() < 1.5e-2

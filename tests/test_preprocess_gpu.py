@@ -89,6 +89,7 @@ def test_clip_processor_and_model_call_signatures_of_the_reference():
 
     rng = np.random.default_rng(5)
     imgs = [rng.integers(0, 256, size=s, dtype=np.uint8) for s in ((90, 160, 3), (120, 100, 3), (90, 160, 3), (64, 64, 3))]
+    imgs[2] = imgs[0].copy()
 
     def fake_bpe(texts, return_tensors="pt", padding=True, truncation=True, **_):
         ids = torch.full((len(texts), 6), 299, dtype=torch.long)

@@ -19,7 +19,7 @@ import torch
 import torch.nn as nn
 
 from . import kernels as K
-from .packing import PackedCache, require_cuda, v32, w16, w16_patch
+from .packing import PackedCache, fold_layernorm, require_cuda, v32, w16, w16_patch
 
 CLIP_MEAN = (0.48145466, 0.4578275, 0.40821073)
 CLIP_STD = (0.26862954, 0.26130258, 0.27577711)
@@ -119,11 +119,20 @@ class _TextModel(nn.Module):
         self.final_layer_norm = nn.LayerNorm(cfg.hidden_size, eps=cfg.layer_norm_eps)
 
 
-def _pack_layers(encoder, c):
+def _pack_layers(encoder, c, fuse=False):
+    """fuse: LayerNorm folded into the QKV / fc1 GEMMs (layer_norm2 everywhere, layer_norm1 from layer 1 on: layer
+    0's input is written by a stand-alone LayerNorm / embedding kernel, not by a residual GEMM)."""
     out = []
-    for l in encoder.layers:
+    for i, l in enumerate(encoder.layers):
         a = l.self_attn
-        out.append(dict(
+        extra = {}
+        if fuse:
+            extra["fc1_f"] = fold_layernorm(l.mlp.fc1.weight, l.mlp.fc1.bias, l.layer_norm2.weight, l.layer_norm2.bias, c)
+            if i > 0:
+                qkv_w = torch.cat([a.q_proj.weight, a.k_proj.weight, a.v_proj.weight], dim=0)
+                qkv_b = torch.cat([a.q_proj.bias, a.k_proj.bias, a.v_proj.bias], dim=0)
+                extra["qkv_f"] = fold_layernorm(qkv_w, qkv_b, l.layer_norm1.weight, l.layer_norm1.bias, c)
+        out.append(dict(extra, 
             n1g=v32(l.layer_norm1.weight), n1b=v32(l.layer_norm1.bias),
             qkv_w=w16(a.q_proj.weight, a.k_proj.weight, a.v_proj.weight, dtype=c),
             qkv_b=v32(a.q_proj.bias, a.k_proj.bias, a.v_proj.bias),
@@ -149,14 +158,26 @@ def _run_layers(layers, x, B, T, H, eps, *, causal=False, kv_len=None):
     o = torch.empty((M, D), dtype=cdt, device=dev)
     hid = torch.empty((M, layers[0]["fc1_w"].shape[0]), dtype=cdt, device=dev)
     heads = dict(q=q, k=k, vt=vt, T=T, H=H, part0=0, t_off=0, Tq_cap=T, Tk_cap=T, NP=NP, q_scale=0.125)
-    for l in layers:
-        K.layernorm(x, l["n1g"], l["n1b"], eps, out16=xn)
-        K.gemm(xn, l["qkv_w"], l["qkv_b"], heads=heads)
+    n = len(layers)
+    for i, l in enumerate(layers):
+        fused = "fc1_f" in l      # LayerNorm folded into the consuming GEMMs (see vit.VisionTransformer.run_blocks)
+        if fused and i > 0:
+            w_, b_, cs = l["qkv_f"]
+            K.gemm(xn, w_, b_, heads=heads, ln=(cs, eps))
+        else:
+            K.layernorm(x, l["n1g"], l["n1b"], eps, out16=xn)
+            K.gemm(xn, l["qkv_w"], l["qkv_b"], heads=heads)
         K.attention(q, k, vt, o, Bq=B, H=H, Nq=T, Nk=T, Tq_cap=T, Tk_cap=T, NP=NP, causal=causal, kv_len=kv_len)
-        K.gemm(o, l["o_w"], l["o_b"], out=x, resid=x)
-        K.layernorm(x, l["n2g"], l["n2b"], eps, out16=xn)
-        K.gemm(xn, l["fc1_w"], l["fc1_b"], out=hid, act=K.ACT_QUICK_GELU)
-        K.gemm(hid, l["fc2_w"], l["fc2_b"], out=x, resid=x)
+        if fused:
+            K.gemm(o, l["o_w"], l["o_b"], out=x, resid=x, out16=xn)
+            w_, b_, cs = l["fc1_f"]
+            K.gemm(xn, w_, b_, out=hid, act=K.ACT_QUICK_GELU, ln=(cs, eps))
+            K.gemm(hid, l["fc2_w"], l["fc2_b"], out=x, resid=x, out16=xn if i + 1 < n else None)
+        else:
+            K.gemm(o, l["o_w"], l["o_b"], out=x, resid=x)
+            K.layernorm(x, l["n2g"], l["n2b"], eps, out16=xn)
+            K.gemm(xn, l["fc1_w"], l["fc1_b"], out=hid, act=K.ACT_QUICK_GELU)
+            K.gemm(hid, l["fc2_w"], l["fc2_b"], out=x, resid=x)
     return x
 
 
@@ -173,6 +194,8 @@ class CLIPModel(PackedCache, nn.Module):
         self.visual_projection = nn.Linear(vc.hidden_size, self.config.projection_dim, bias=False)
         self.text_projection = nn.Linear(tc.hidden_size, self.config.projection_dim, bias=False)
         self.logit_scale = nn.Parameter(torch.tensor(2.6592))
+        import os
+        self.fuse_layernorm = os.environ.get("VIDIL_FUSE_LN", "1") != "0"   # vision tower only (the text tower runs once per ontology)
         self.apply(self._init)
 
     @classmethod
@@ -222,6 +245,9 @@ class CLIPModel(PackedCache, nn.Module):
             if isinstance(m, nn.Linear) and m.bias is not None:
                 nn.init.zeros_(m.bias)
 
+    def pack_flags(self):
+        return (self.fuse_layernorm,)
+
     def _pack(self):
         vm, tm = self.vision_model, self.text_model
         D = self.config.vision_config.hidden_size
@@ -231,7 +257,7 @@ class CLIPModel(PackedCache, nn.Module):
             cls=v32(vm.embeddings.class_embedding), pos=v32(vm.embeddings.position_embedding.weight).view(-1, D),
             pre_g=v32(vm.pre_layrnorm.weight), pre_b=v32(vm.pre_layrnorm.bias),
             post_g=v32(vm.post_layernorm.weight), post_b=v32(vm.post_layernorm.bias),
-            vproj=w16(self.visual_projection.weight, dtype=c), vlayers=_pack_layers(vm.encoder, c),
+            vproj=w16(self.visual_projection.weight, dtype=c), vlayers=_pack_layers(vm.encoder, c, self.fuse_layernorm),
             tok=v32(tm.embeddings.token_embedding.weight).view(self.config.text_config.vocab_size, -1),
             tpos=v32(tm.embeddings.position_embedding.weight).view(self.config.text_config.max_position_embeddings, -1),
             fin_g=v32(tm.final_layer_norm.weight), fin_b=v32(tm.final_layer_norm.bias),

@@ -11,6 +11,7 @@ typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
 typedef __bf16 bf16;
 typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef float f32x2 __attribute__((ext_vector_type(2)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 
@@ -20,7 +21,7 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 void vidil_set_error(const char* fmt, ...);
 
 // gemm256.hip: the 256x256 8-wave kernel for large problems (dispatched from vidil_gemm_f16)
-bool vidil_gemm256_eligible(const vidil_gemm_args& a);
+bool vidil_gemm256_eligible(const vidil_gemm_args& a, bool any_size = false);
 int vidil_gemm256_launch(const vidil_gemm_args& a, hipStream_t s);
 
 #define VIDIL_REQUIRE(cond, ...)                \
@@ -124,7 +125,6 @@ template <typename T> __device__ __forceinline__ typename Elt<T>::x8 zero8() {
 // Every step is an explicit operation (no contraction, no IEEE-division expansion: v_rcp_f32 is 1 ulp and one
 // instruction instead of ten) so the instruction sequence, hence every bit of the result, is the same in
 // every kernel instantiation: outputs must not depend on which GEMM kernel a batch size selects.
-typedef float f32x2 __attribute__((ext_vector_type(2)));
 __device__ __forceinline__ f32x2 pk_fma(f32x2 a, f32x2 b, f32x2 c) { return __builtin_elementwise_fma(a, b, c); }
 __device__ __forceinline__ f32x2 pk_splat(float v) { return f32x2{v, v}; }
 __device__ __forceinline__ f32x2 gelu_erf2(f32x2 x) {

@@ -323,6 +323,7 @@ TileChoice choose_tile(const vidil_gemm_args& a) {
     const char* e = getenv("VIDIL_GEMM256");
     return !(e && e[0] == '0');
   }();
+  if (a.ln_fold || a.out16) return {1, 256, 256, 2};     // LN-folded pair: always the 256x256 kernel (check_args)
   if (allow256 && a.epi != VIDIL_EPI_ARENA && vidil_gemm256_eligible(a)) return {1, 256, 256, 2};
 #ifdef VIDIL_GEMM_TUNE
   // developer builds only: VIDIL_GEMM_TILE=<BM>x<BN>x<ST> forces one configuration
@@ -370,6 +371,17 @@ int check_args(const vidil_gemm_args& a) {
   VIDIL_REQUIRE(a.K % BK == 0, "gemm: K=%d must be a multiple of %d", a.K, BK);
   VIDIL_REQUIRE(a.lda == 0 || (a.lda >= a.K && a.lda % 8 == 0), "gemm: lda=%d must be 0 or >= K and a multiple of 8", a.lda);
   VIDIL_REQUIRE(((uintptr_t)a.A & 15) == 0 && ((uintptr_t)a.W & 15) == 0, "gemm: operands must be 16-B aligned");
+  if (a.ln_fold) {
+    VIDIL_REQUIRE(a.epi == VIDIL_EPI_F16 || a.epi == VIDIL_EPI_HEADS, "gemm/ln_fold: only EPI_F16 / EPI_HEADS consume a folded LayerNorm");
+    VIDIL_REQUIRE(a.ln_colsum != nullptr && a.ln_eps >= 0.f, "gemm/ln_fold: null ln_colsum");
+    VIDIL_REQUIRE(a.lda == 0 || a.lda == a.K, "gemm/ln_fold: A rows must be dense (K = the LayerNorm width)");
+  }
+  if (a.out16) {
+    VIDIL_REQUIRE(a.epi == VIDIL_EPI_F32, "gemm/out16: only the f32 residual epilogue writes the 16-bit copy");
+    VIDIL_REQUIRE(a.ldo16 >= a.N, "gemm/out16: ldo16=%d < N=%d", a.ldo16, a.N);
+  }
+  if (a.ln_fold || a.out16)
+    VIDIL_REQUIRE(vidil_gemm256_eligible(a, true), "gemm: this LN-folded problem does not meet the 256x256 kernel's alignment / size rules (N %% 4, 16-B aligned vectors, K >= 128)");
   switch (a.epi) {
     case VIDIL_EPI_F16:
     case VIDIL_EPI_F32:

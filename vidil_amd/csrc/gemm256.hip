@@ -37,6 +37,7 @@ namespace {
 constexpr int SLOT = 16384;      // one half-tile: 128 rows x 64 halfs
 constexpr int BUF = 4 * SLOT;     // one K-tile: A0, A1, W0, W1
 constexpr int LDS_BYTES = 2 * BUF;
+constexpr int STATS_BYTES = 2 * 4 * 128 * 8;   // LN-fold consumers: [group][wave column][row] (sum, sum of squares)
 
 __device__ __forceinline__ void glds16(const void* g, char* lds) {
   __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)g,
@@ -64,7 +65,34 @@ struct Probe {
 };
 #endif
 
-template <typename T, int EPI, int ACT>
+// row sum / sum of squares of one A fragment (8 operand values of a row) in f32: v_dot2c_f32_{f16,bf16}
+__device__ __forceinline__ void frag_stats(f16x8 a, float& s, float& ss) {
+  typedef _Float16 h2 __attribute__((ext_vector_type(2)));
+  const h2 one = {(_Float16)1.f, (_Float16)1.f};
+#pragma unroll
+  for (int e = 0; e < 8; e += 2) {
+    const h2 v = {a[e], a[e + 1]};
+    s = __builtin_amdgcn_fdot2(v, one, s, false);
+    ss = __builtin_amdgcn_fdot2(v, v, ss, false);
+  }
+}
+__device__ __forceinline__ void frag_stats(bf16x8 a, float& s, float& ss) {
+  typedef __bf16 b2 __attribute__((ext_vector_type(2)));
+  const b2 one = {(__bf16)1.f, (__bf16)1.f};
+#pragma unroll
+  for (int e = 0; e < 8; e += 2) {
+    const b2 v = {a[e], a[e + 1]};
+    s = __builtin_amdgcn_fdot2_f32_bf16(v, one, s, false);
+    ss = __builtin_amdgcn_fdot2_f32_bf16(v, v, ss, false);
+  }
+}
+
+// FOLD: LayerNorm folded into this GEMM (vidil_gemm_args.ln_fold, include/vidil_hip.h).  A holds the RAW residual
+// stream in the operand type; every wave accumulates sum / sum of squares of its 128 rows from the A fragments of the
+// k-steps it owns (k-step ks belongs to the wave with wc == ks: the four waves that read the same rows split the
+// work), the partials meet in LDS after the main loop, and the epilogue applies
+//   y = rstd * acc - (rstd * mean) * colsum[n] + b'[n].
+template <typename T, int EPI, int ACT, bool FOLD>
 __global__ __launch_bounds__(512) void gemm256_kernel(const vidil_gemm_args p) {
   using f16 = T;                        // (the body is written in terms of "the 16-bit operand type")
   using f16x4 = typename Elt<T>::x4;
@@ -140,6 +168,7 @@ __global__ __launch_bounds__(512) void gemm256_kernel(const vidil_gemm_args p) {
   };
 
   f32x16 acc[4][2];
+  float st_s[4], st_ss[4];   // FOLD: per row tile `it` — partial sum / sum of squares, later rstd / mean*rstd
 
   const int sw = (l31 >> 1) & 7;
   const int a_off = grp * SLOT + l31 * 128;
@@ -205,6 +234,12 @@ __global__ __launch_bounds__(512) void gemm256_kernel(const vidil_gemm_args p) {
 #pragma unroll
         for (int j = 0; j < 2; ++j)
           acc[RH * 2 + i][j] = Elt<T>::mfma32(wf[j][ks], a[ks][i], acc[RH * 2 + i][j]);
+      if constexpr (FOLD) {
+        if (wc == ks) {   // wave-uniform
+#pragma unroll
+          for (int i = 0; i < 2; ++i) frag_stats(a[ks][i], st_s[RH * 2 + i], st_ss[RH * 2 + i]);
+        }
+      }
       if (ks < 3) dma_piece(h, ks);
     }
   };
@@ -225,6 +260,10 @@ __global__ __launch_bounds__(512) void gemm256_kernel(const vidil_gemm_args p) {
     for (int j = 0; j < 2; ++j)
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[it][j][r] = 0.f;
+  if constexpr (FOLD) {
+#pragma unroll
+    for (int it = 0; it < 4; ++it) st_s[it] = st_ss[it] = 0.f;
+  }
 
   // Both groups run the same straight-line [first half, second half] body per K-tile (so the accumulators
   // never pass through a branch); group 1 simply starts one half-period later and group 0 idles in the last.
@@ -247,6 +286,38 @@ __global__ __launch_bounds__(512) void gemm256_kernel(const vidil_gemm_args p) {
   asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
   __builtin_amdgcn_s_barrier();
 
+  if constexpr (FOLD) {
+    // LayerNorm statistics of this tile's rows: every wave holds, per row, the sums over the k-steps it owns (and a
+    // half-wave over its 8 of the step's 16 k) -> combine the half-waves, meet the other three waves of the group in
+    // LDS (a region past the ring: nothing else touches it), then rstd and mean*rstd per row in fixed wave order.
+    f32x2* stats = (f32x2*)(smem + LDS_BYTES);
+#pragma unroll
+    for (int it = 0; it < 4; ++it) {
+      const float s = st_s[it] + __shfl_xor(st_s[it], 32, 64);
+      const float ss = st_ss[it] + __shfl_xor(st_ss[it], 32, 64);
+      if (hi == 0) stats[(grp * 4 + wc) * 128 + it * 32 + l31] = f32x2{s, ss};
+    }
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    const float inv_k = 1.0f / (float)K;
+#pragma unroll
+    for (int it = 0; it < 4; ++it) {
+      float s = 0.f, ss = 0.f;
+#pragma unroll
+      for (int w = 0; w < 4; ++w) {
+        const f32x2 v = stats[(grp * 4 + w) * 128 + it * 32 + l31];
+        s += v[0];
+        ss += v[1];
+      }
+      const float mean = s * inv_k;
+      float var = ss * inv_k - mean * mean;
+      var = var > 0.f ? var : 0.f;
+      const float rstd = 1.0f / sqrtf(var + p.ln_eps);
+      st_s[it] = rstd;
+      st_ss[it] = mean * rstd;
+    }
+  }
+
   // ================================================================================ epilogue
   // acc[it][j][rq*4+e]: row = m_w + it*32 + l31 ; col = n_w + j*32 + rq*8 + hi*4 + e
   const int m_w = m0 + grp * 128;
@@ -266,6 +337,25 @@ __global__ __launch_bounds__(512) void gemm256_kernel(const vidil_gemm_args p) {
   if (n_w >= N) break;
   char* ep = smem + BUF + wave * 8192;  // private 8 KiB transposition buffer of this wave, inside K-tile buffer 1
 
+  if constexpr (FOLD) {
+    // y = rstd * acc + (b' - (mean * rstd) * colsum): LayerNorm applied to the accumulators (see the kernel comment)
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int rq = 0; rq < 4; ++rq) {
+        const int col = n_w + j * 32 + rq * 8 + hi * 4;
+        if (col + 4 <= N) {
+          const f32x4 c4 = *(const f32x4*)(p.ln_colsum + col);
+          f32x4 b4 = {0.f, 0.f, 0.f, 0.f};
+          if (p.bias != nullptr) b4 = *(const f32x4*)(p.bias + col);
+#pragma unroll
+          for (int it = 0; it < 4; ++it)
+#pragma unroll
+            for (int e = 0; e < 4; ++e)
+              acc[it][j][rq * 4 + e] = __builtin_fmaf(acc[it][j][rq * 4 + e], st_s[it], __builtin_fmaf(-st_ss[it], c4[e], b4[e]));
+        }
+      }
+  } else
   // bias folded into the accumulators once (4 consecutive columns per register quad)
   if (p.bias != nullptr) {
 #pragma unroll
@@ -460,6 +550,10 @@ __global__ __launch_bounds__(512) void gemm256_kernel(const vidil_gemm_args p) {
           v += add[iter];
           if constexpr (EPI == VIDIL_EPI_F32) {
             *(f32x4*)((float*)p.out + (size_t)m * p.ldo + col) = v;
+            if (p.out16 != nullptr) {   // the raw stream in the operand type, for the LN-folded consumer GEMM
+              const f16x4 h4 = {Elt<T>::from_f32(v[0]), Elt<T>::from_f32(v[1]), Elt<T>::from_f32(v[2]), Elt<T>::from_f32(v[3])};
+              *(f16x4*)((f16*)p.out16 + (size_t)m * p.ldo16 + col) = h4;
+            }
           } else {  // EPI_PATCH
             const int b = m / p.tpi;
             *(f32x4*)((float*)p.out + ((size_t)m + b + 1) * p.ldo + col) = v;
@@ -477,12 +571,13 @@ __global__ __launch_bounds__(512) void gemm256_kernel(const vidil_gemm_args p) {
   }  // tile loop
 }
 
-template <typename T, int EPI, int ACT>
+template <typename T, int EPI, int ACT, bool FOLD = false>
 int launch256(const vidil_gemm_args& a, hipStream_t s) {
   static bool attr_set = false;
-  auto kern = gemm256_kernel<T, EPI, ACT>;
+  auto kern = gemm256_kernel<T, EPI, ACT, FOLD>;
+  constexpr int lds = LDS_BYTES + (FOLD ? STATS_BYTES : 0);
   if (!attr_set) {
-    hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES);
+    hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
     if (e != hipSuccess) {
       vidil_set_error("gemm256: hipFuncSetAttribute failed: %s", hipGetErrorString(e));
       return VIDIL_ELAUNCH;
@@ -499,7 +594,7 @@ int launch256(const vidil_gemm_args& a, hipStream_t s) {
   // persistent grid: one workgroup per CU (a multiple of 8 so every XCD gets the same number), never more than tiles
   const int ntiles = ((a.M + 255) / 256) * ((a.N + 255) / 256);
   const int tiles = !kPersistent<EPI> ? ntiles : ntiles >= num_cu ? num_cu : (ntiles >= 8 ? (ntiles & ~7) : ntiles);
-  hipLaunchKernelGGL(kern, dim3(tiles), dim3(512), LDS_BYTES, s, a);
+  hipLaunchKernelGGL(kern, dim3(tiles), dim3(512), lds, s, a);
   VIDIL_CHECK_LAUNCH("gemm256");
   return VIDIL_OK;
 }
@@ -513,18 +608,21 @@ extern "C" int vidil_debug_gemm_probe(unsigned long long* out2) {
 #endif
 
 // Returns true when the 256x256 kernel can run this problem with vector epilogues (checked by the caller).
-bool vidil_gemm256_eligible(const vidil_gemm_args& a) {
+// any_size: skip the "enough tiles to fill the chip" test (LN-folded GEMMs always run here, whatever M is).
+bool vidil_gemm256_eligible(const vidil_gemm_args& a, bool any_size) {
   const long tiles = (long)((a.M + 255) / 256) * ((a.N + 255) / 256);
-  if (tiles < 160) return false;                   // too few workgroups to fill 256 CUs: small-tile kernel
+  if (tiles < 160 && !any_size) return false;      // too few workgroups to fill 256 CUs: small-tile kernel
   if (a.K < 128) return false;
   const long lda = a.lda > 0 ? a.lda : a.K;
   if ((long)a.M * lda >= (1L << 31) || (long)a.N * a.K >= (1L << 31)) return false;   // 32-bit staging offsets
   auto al16 = [](const void* p) { return ((uintptr_t)p & 15) == 0; };
   if (a.bias && !al16(a.bias)) return false;
+  if (a.ln_fold && !(a.ln_colsum && al16(a.ln_colsum) && a.N % 4 == 0)) return false;
   switch (a.epi) {
     case VIDIL_EPI_F16:
       return a.N % 8 == 0 && a.ldo % 8 == 0 && al16(a.out);
     case VIDIL_EPI_F32:
+      if (a.out16 && !(a.ldo16 % 4 == 0 && ((uintptr_t)a.out16 & 7) == 0)) return false;
       return a.N % 4 == 0 && a.ldo % 4 == 0 && al16(a.out) && (!a.resid || al16(a.resid));
     case VIDIL_EPI_PATCH:
       return a.N % 4 == 0 && a.ldo % 4 == 0 && al16(a.out) && al16(a.pos);
@@ -537,6 +635,12 @@ bool vidil_gemm256_eligible(const vidil_gemm_args& a) {
 
 template <typename T>
 static int launch256_dispatch(const vidil_gemm_args& a, hipStream_t s) {
+  if (a.ln_fold) {
+    if (a.epi == VIDIL_EPI_HEADS) return launch256<T, VIDIL_EPI_HEADS, VIDIL_ACT_NONE, true>(a, s);
+    if (a.act == VIDIL_ACT_NONE) return launch256<T, VIDIL_EPI_F16, VIDIL_ACT_NONE, true>(a, s);
+    if (a.act == VIDIL_ACT_GELU_ERF) return launch256<T, VIDIL_EPI_F16, VIDIL_ACT_GELU_ERF, true>(a, s);
+    return launch256<T, VIDIL_EPI_F16, VIDIL_ACT_QUICK_GELU, true>(a, s);
+  }
   switch (a.epi) {
     case VIDIL_EPI_F16:
       if (a.act == VIDIL_ACT_NONE) return launch256<T, VIDIL_EPI_F16, VIDIL_ACT_NONE>(a, s);

@@ -81,6 +81,9 @@ def gemm(a, w, bias=None, **kw):
       * patch=dict(out=,pos=,tpi=): patch-embedding epilogue (row remap + pos embed).
       * arena=dict(q=,k=,v=,T=,H=,part0=,t_off=,arena_rows=,slot_stride=,Tcap=,q_scale=): Q rows + K/V rows
         appended to a beam-search KV arena [position][slot][H*64] (see vidil_beam_attention).
+      * LayerNorm folded into a pre-LN block's GEMM pair (vidil_gemm_args.ln_fold): the residual GEMM passes
+        ``out16=`` (T16 copy of the f32 stream it writes), the next GEMM passes that copy as ``a`` with
+        ``ln=(colsum, eps)`` and weights / bias folded by ``packing.fold_layernorm``.
     """
     g, ret = _gemm_build(a, w, bias, **kw)
     check(_lib.load().vidil_gemm(C.byref(g), _stream()), "gemm")
@@ -96,7 +99,7 @@ def gemm_kernel_name(a, w, bias=None, **kw):
 
 
 def _gemm_build(a, w, bias=None, *, out=None, out_dtype=None, act=ACT_NONE, resid=None,
-                heads=None, patch=None, arena=None, M=None, lda=None):
+                heads=None, patch=None, arena=None, M=None, lda=None, out16=None, ln=None):
     K_ = w.shape[1]
     if lda is None:
         M, Ka = a.shape
@@ -161,6 +164,14 @@ def _gemm_build(a, w, bias=None, *, out=None, out_dtype=None, act=ACT_NONE, resi
             if out.dtype != torch.float32:
                 raise VidilHipError("gemm: resid needs an f32 output")
             g.resid = _ptr(resid, torch.float32, "gemm.resid")
+    if out16 is not None:      # LN-fold producer: the raw stream in the operand type beside the f32 one
+        g.out16 = _ptr(out16, t16, "gemm.out16")
+        g.ldo16 = out16.shape[-1]
+    if ln is not None:         # LN-fold consumer: (colsum f32 [N], eps); w / bias are the folded W', b'
+        colsum, eps = ln
+        g.ln_fold = 1
+        g.ln_colsum = _ptr(colsum, torch.float32, "gemm.ln_colsum")
+        g.ln_eps = float(eps)
     return g, ret
 
 

@@ -498,11 +498,8 @@ class BertLMHeadModel(PackedCache, nn.Module):
             p.update(t_w3=_w3(pr.transform.dense.weight, c), dec_w3=_w3(pr.decoder.weight, c))
         return p
 
-    def packed(self):
-        cache = self.__dict__.get("_packed_cache")
-        if cache is not None and cache[1].get("precise") != self.precise_head:
-            self.__dict__.pop("_packed_cache")          # the flag was flipped after packing
-        return super().packed()
+    def pack_flags(self):
+        return (self.precise_head,)
 
     def lm_logits(self, h16, rows, T, out=None, h32=None):
         """LM head (models/med.py:501-545) on the LAST token of each of ``rows`` sequences of length T:

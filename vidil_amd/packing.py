@@ -65,6 +65,20 @@ def w16_patch(conv_weight, dtype=None):
     return w.contiguous()
 
 
+def fold_layernorm(weight, bias, gamma, beta, dtype=None):
+    """LayerNorm(x; gamma, beta) followed by Linear(weight, bias), folded for the LN-fused GEMM
+    (vidil_gemm_args.ln_fold): returns (W' = T16(gamma (.) W) [N,K], b' = b + W·beta f32 [N], colsum[n] = sum_k W'[n][k]
+    f32 [N]).  colsum is taken from the ROUNDED W' — the kernel computes rstd * (x16·W'^T - mean * colsum) + b', which
+    centres exactly the values the MFMA multiplies."""
+    w = weight.detach().float()
+    wf = (w * gamma.detach().float()[None, :]).to(dtype or _default[0]).contiguous()
+    b = w @ beta.detach().float()
+    if bias is not None:
+        b = b + bias.detach().float()
+    colsum = wf.double().sum(dim=1).float()
+    return wf, b.contiguous(), colsum.contiguous()
+
+
 def v32(*vecs):
     """Concatenate bias/LN vectors, contiguous f32 (None if every part is None)."""
     if all(v is None for v in vecs):
@@ -85,8 +99,12 @@ class PackedCache:
     def cdt(self):
         return compute_dtype(self)
 
+    def pack_flags(self):
+        """Host-side switches that change what ``_pack`` produces (overridden by the models that have any)."""
+        return ()
+
     def packed(self):
-        fp = fingerprint(self)
+        fp = fingerprint(self) + tuple(self.pack_flags())
         cache = self.__dict__.get("_packed_cache")
         if cache is None or cache[0] != fp:
             cache = (fp, self._pack())

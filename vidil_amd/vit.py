@@ -6,10 +6,14 @@ unchanged: ``patch_embed.proj.weight``, ``cls_token``, ``pos_embed``,
 ``blocks.N.{norm1,attn.qkv,attn.proj,norm2,mlp.fc1,mlp.fc2}``, ``norm``), same
 ``forward(x[B,3,S,S]) -> [B,1+P,width]`` fp32 contract.  The arithmetic is:
 
-    patchify (f32->f16 im2col) -> GEMM(+bias+pos, row remap) -> 12 x [
-        LN -> QKV GEMM (per-head Q/K/V^T scatter, q pre-scaled) -> in-register
-        softmax attention -> proj GEMM (+residual, in place) -> LN ->
-        fc1 GEMM (+erf-GELU) -> fc2 GEMM (+residual) ] -> LN
+    patchify (f32->T16 im2col) -> GEMM(+bias+pos, row remap) -> 12 x [
+        [LN+]QKV GEMM (per-head Q/K/V scatter, q pre-scaled) -> softmax attention ->
+        proj GEMM (+residual, in place, + T16 copy of the stream) ->
+        [LN+]fc1 GEMM (+erf-GELU) -> fc2 GEMM (+residual, + T16 copy) ] -> LN
+
+where "[LN+]" is the block's LayerNorm folded into the GEMM (statistics from the A fragments the GEMM streams,
+normalisation applied to the accumulators; ``fuse_layernorm``) — only block 0's norm1 and the final norm run as
+stand-alone LayerNorm kernels —
 
 with the residual stream, LayerNorm statistics and softmax in f32 and the MFMA
 operands in the model's compute dtype (f16 or bf16, packing.set_compute_dtype).
@@ -23,7 +27,7 @@ import torch
 import torch.nn as nn
 
 from . import kernels as K
-from .packing import PackedCache, require_cuda, v32, w16, w16_patch
+from .packing import PackedCache, fold_layernorm, require_cuda, v32, w16, w16_patch
 
 
 class PatchEmbed(nn.Module):
@@ -74,6 +78,9 @@ class VisionTransformer(PackedCache, nn.Module):
         self.num_features = self.embed_dim = embed_dim
         self.num_heads = num_heads
         self.ln_eps = 1e-6  # models/vit.py:142
+        # LayerNorm folded into the QKV / fc1 GEMMs (vidil_gemm_args.ln_fold): on unless VIDIL_FUSE_LN=0
+        import os
+        self.fuse_layernorm = os.environ.get("VIDIL_FUSE_LN", "1") != "0"
         norm_layer = norm_layer or partial(nn.LayerNorm, eps=self.ln_eps)
         self.patch_embed = PatchEmbed(img_size=img_size, patch_size=patch_size, in_chans=in_chans, embed_dim=embed_dim)
         num_patches = self.patch_embed.num_patches
@@ -98,6 +105,9 @@ class VisionTransformer(PackedCache, nn.Module):
             nn.init.constant_(m.weight, 1.0)
 
     # ------------------------------------------------------------------ packing
+    def pack_flags(self):
+        return (self.fuse_layernorm,)
+
     def _pack(self):
         D = self.embed_dim
         pe = self.patch_embed.proj
@@ -106,14 +116,22 @@ class VisionTransformer(PackedCache, nn.Module):
             pe_w=w16_patch(pe.weight, c), pe_b=v32(pe.bias),
             cls=v32(self.cls_token), pos=v32(self.pos_embed).view(-1, D),
             norm_g=v32(self.norm.weight), norm_b=v32(self.norm.bias), blocks=[])
-        for b in self.blocks:
-            p["blocks"].append(dict(
+        for i, b in enumerate(self.blocks):
+            d = dict(
                 n1g=v32(b.norm1.weight), n1b=v32(b.norm1.bias),
                 qkv_w=w16(b.attn.qkv.weight, dtype=c), qkv_b=v32(b.attn.qkv.bias),
                 proj_w=w16(b.attn.proj.weight, dtype=c), proj_b=v32(b.attn.proj.bias),
                 n2g=v32(b.norm2.weight), n2b=v32(b.norm2.bias),
                 fc1_w=w16(b.mlp.fc1.weight, dtype=c), fc1_b=v32(b.mlp.fc1.bias),
-                fc2_w=w16(b.mlp.fc2.weight, dtype=c), fc2_b=v32(b.mlp.fc2.bias)))
+                fc2_w=w16(b.mlp.fc2.weight, dtype=c), fc2_b=v32(b.mlp.fc2.bias))
+            if self.fuse_layernorm:
+                # norm2 folded into fc1 in every block; norm1 folded into qkv from block 1 on (block 0's input comes
+                # from the patch-embedding GEMM, which writes no 16-bit copy of the stream)
+                d["fc1_f"] = fold_layernorm(b.mlp.fc1.weight, b.mlp.fc1.bias, b.norm2.weight, b.norm2.bias, c)
+                if i > 0:
+                    d["qkv_f"] = fold_layernorm(b.attn.qkv.weight, b.attn.qkv.bias, b.norm1.weight, b.norm1.bias, c)
+            p["blocks"].append(d)
+        p["fused"] = self.fuse_layernorm
         return p
 
     # ------------------------------------------------------------------ forward
@@ -145,14 +163,28 @@ class VisionTransformer(PackedCache, nn.Module):
         o = torch.empty((M, D), dtype=cdt, device=dev)
         hid = torch.empty((M, p["blocks"][0]["fc1_w"].shape[0]), dtype=cdt, device=dev)
         heads = dict(q=q, k=k, vt=vt, T=T, H=H, part0=0, t_off=0, Tq_cap=T, Tk_cap=T, NP=NP, q_scale=0.125)
-        for b in p["blocks"]:
-            K.layernorm(x, b["n1g"], b["n1b"], self.ln_eps, out16=xn)
-            K.gemm(xn, b["qkv_w"], b["qkv_b"], heads=heads)
+        # Fused LayerNorm (models/vit.py:107-110): the residual GEMMs (proj, fc2) also store the stream in the operand
+        # type (``xn`` then holds RAW x, not LN(x)) and the next GEMM applies the LayerNorm to its accumulators.
+        fused = p.get("fused", False)
+        nblk = len(p["blocks"])
+        for i, b in enumerate(p["blocks"]):
+            if fused and i > 0:
+                w_, b_, cs = b["qkv_f"]
+                K.gemm(xn, w_, b_, heads=heads, ln=(cs, self.ln_eps))
+            else:
+                K.layernorm(x, b["n1g"], b["n1b"], self.ln_eps, out16=xn)
+                K.gemm(xn, b["qkv_w"], b["qkv_b"], heads=heads)
             K.attention(q, k, vt, o, Bq=B, H=H, Nq=T, Nk=T, Tq_cap=T, Tk_cap=T, NP=NP)
-            K.gemm(o, b["proj_w"], b["proj_b"], out=x, resid=x)
-            K.layernorm(x, b["n2g"], b["n2b"], self.ln_eps, out16=xn)
-            K.gemm(xn, b["fc1_w"], b["fc1_b"], out=hid, act=K.ACT_GELU_ERF)
-            K.gemm(hid, b["fc2_w"], b["fc2_b"], out=x, resid=x)
+            if fused:
+                K.gemm(o, b["proj_w"], b["proj_b"], out=x, resid=x, out16=xn)
+                w_, b_, cs = b["fc1_f"]
+                K.gemm(xn, w_, b_, out=hid, act=K.ACT_GELU_ERF, ln=(cs, self.ln_eps))
+                K.gemm(hid, b["fc2_w"], b["fc2_b"], out=x, resid=x, out16=xn if i + 1 < nblk else None)
+            else:
+                K.gemm(o, b["proj_w"], b["proj_b"], out=x, resid=x)
+                K.layernorm(x, b["n2g"], b["n2b"], self.ln_eps, out16=xn)
+                K.gemm(xn, b["fc1_w"], b["fc1_b"], out=hid, act=K.ACT_GELU_ERF)
+                K.gemm(hid, b["fc2_w"], b["fc2_b"], out=x, resid=x)
         y32 = torch.empty((M, D), dtype=torch.float32, device=dev)
         y16 = xn if want16 else None
         K.layernorm(x, p["norm_g"], p["norm_b"], self.ln_eps, out16=y16, out32=y32)
