@@ -788,3 +788,59 @@ def test_vit_with_fused_layernorm_matches_the_unfused_path_and_the_oracle():
     assert e_f.max().item() < 1e-2 and e_f.mean().item() < 1e-3
     assert e_u.max().item() < 1e-2 and e_u.mean().item() < 1e-3
     assert (y_f - y_u).abs().max().item() < 1.5e-2
+
+
+def test_config4_vit_large_16_frames_end_to_end_vs_oracle_pipeline():
+    """BASELINE config 4: BLIP ViT-L/16 captioner + filter, 16 frames per video, through CapFiltEngine and the visual
+    tokenizer, against the fp32 oracle pipeline (de-duplicated schedule: same results as the reference's, see
+    tests/test_oracle_cpu.py) on the same frames.  Captions must match wherever every beam decision of the oracle was
+    decisive; the filter is compared on the captions the device produced."""
+    from oracle import clip_ref, pipeline_ref
+    from vidil_amd.blip import BLIP_Decoder
+    from vidil_amd.blip_itm import BLIP_ITM
+    from vidil_amd.capfilt import CapFiltEngine
+    from vidil_amd.clip import CLIPModel
+    from vidil_amd.tokenizer import SyntheticBertTokenizer
+    from vidil_amd.visual_tokenization import CATEGORIES, VisualTokenizer
+
+    torch.manual_seed(5)
+    tok = SyntheticBertTokenizer()
+    cap = BLIP_Decoder(image_size=224, vit="large", tokenizer=tok).eval()
+    itm = BLIP_ITM(image_size=224, vit="large", tokenizer=tok).eval()
+    clip = CLIPModel().eval()
+    for i, m in enumerate((cap, itm, clip)):
+        perturb_(m, 300 + i)
+    sd_cap, sd_itm, sd_clip = ({k: v.clone() for k, v in m.state_dict().items()} for m in (cap, itm, clip))
+    F = 16
+    u8 = synthetic_frames(1, F, first_video=40)
+    cfg = dict(caption=True, filter=True, filter_generated_only=True, keep_original_caption=False, threshold=0.5,
+               filter_mode="max_filter", generation_mode="beam", image_size=224, vit="large", topk_visualize=5)
+    eng = CapFiltEngine(cfg, DEV, captioner=cap, filterer=itm)
+    items = [dict(video_id="yc0", text=[])]
+    eng.process(items, torch.from_numpy(u8).to(DEV))
+    emb, texts = _ontology()
+    vt = VisualTokenizer(cfg, clip, texts, emb, DEV)
+    toks = vt.process(["yc0"], torch.from_numpy(u8).to(DEV), [items[0]["unfiltered_text"]])
+    x = clip_ref.preprocess_u8(u8[0])
+    prompt = cap.prompt_ids(1, "cpu")[0].long().numpy()
+    otrace = []
+    caps_ref = pipeline_ref.caption_video(sd_cap, x, prompt, tok, cap.prompt, depth=24, heads=16, trace=otrace, dedup=True)
+    gaps = np.stack([np.min(t["cand_scores"][:, :-1] - t["cand_scores"][:, 1:], axis=1) for t in otrace])
+    decisive = gaps.min(axis=0) > 1.5e-2              # (twice the base model's depth in front of the decoder)
+    dev_caps = eng.last_frame_captions
+    assert len(dev_caps) == F
+    same = sum(int(dev_caps[f] == caps_ref[f]) for f in range(F))
+    for f in range(F):
+        if decisive[f]:
+            assert dev_caps[f] == caps_ref[f], f
+    assert same >= F // 2, same
+    caps = items[0]["unfiltered_text"]
+    kept, probs = pipeline_ref.filter_video(sd_itm, x, caps, tok, 0.5, depth=24, heads=16, return_probs=True, dedup=True)
+    if all(abs(float(np.max(p)) - 0.5) > 4e-3 for p in probs):
+        assert items[0]["text"] == kept
+    ref = pipeline_ref.visual_tokens_video(sd_clip, x, emb, texts, topk=5)
+    got = toks["yc0"]
+    tot = sum(5 for _ in range(F) for _ in CATEGORIES)
+    eq = sum(a == b for f in range(F) for key in CATEGORIES for a, b in zip(got["frame_tokens"][f][key], ref["frame_tokens"][f][key]))
+    assert eq / tot >= 0.97, (eq, tot)
+    assert len(got["frame_tokens"]) == F

@@ -166,3 +166,26 @@ def test_deduplicated_cpu_schedule_gives_the_reference_schedule_results():
     _, p_ref = pipeline_ref.filter_video(sd_itm, x, caps_ref, tok, 0.4, return_probs=True)
     _, p_dd = pipeline_ref.filter_video(sd_itm, x, caps_ref, tok, 0.4, return_probs=True, dedup=True)
     assert all(np.array_equal(a, b) for a, b in zip(p_ref, p_dd))
+
+
+@needs_ref
+def test_youcook2_ontology_mapping_is_the_documented_one():
+    """Config 4 names a 'youcook2 ontology'; the reference ships the files but no loader branch (its YAML keeps 'vg').
+    The build's mapping: cooking nouns -> objects, cooking verbs + relation triples -> verbs, vg attributes / scenes."""
+    root = os.path.join(ref_shim.REFERENCE_ROOT, "visual_token_ontology")
+    from vidil_amd.visual_tokenization import OMIT_KEYWORDS, load_visual_token_texts
+
+    yc = load_visual_token_texts(root, "youcook2")
+    vg = load_visual_token_texts(root, "vg")
+    nouns = json.load(open(os.path.join(root, "youcook2", "cooking_vocabulary_nouns.json")))
+    verbs = json.load(open(os.path.join(root, "youcook2", "cooking_vocabulary_verbs.json")))
+    triples = json.load(open(os.path.join(root, "youcook2", "openimage_relation_triples.json")))
+    assert yc["objects"] == [t for t in nouns if t not in OMIT_KEYWORDS] and len(yc["objects"]) >= 1200
+    assert yc["scenes"] == vg["scenes"]
+    assert yc["verbs"][:len(verbs)] == verbs and set(yc["verbs"]) == set(verbs) | set(triples)
+    assert len(yc["verbs"]) == len(set(yc["verbs"]))
+    # the attribute filter ("drop attributes that are also objects", with the reference's skip quirk) runs against the
+    # cooking nouns here, so the list differs from vg's only by what that filter removes
+    assert set(yc["attributes"]) <= set(json.load(open(os.path.join(root, "vg", "vg_original_attributes_synsets_keys_cleaned_remove_similar0.9.json"))))
+    with pytest.raises(ValueError):
+        load_visual_token_texts(root, "coco")

@@ -31,11 +31,25 @@ OMIT_KEYWORDS = ['media player', 'video', 'playing video', 'audio', 'sound', 'ta
                  'viewed from', 'showing video of', 'are on at', 'shuttlecock', 'shutter', 'shutter is white',
                  'shutters have bones', 'tape is looped', 'bliss wants you', 'thumbnail', 'technique']
 
+# 'youcook2': the reference ships visual_token_ontology/youcook2/ (a cooking vocabulary) but has NO loader branch for it —
+# run_visual_tokenization.py:369-381 knows 'vg' and 'vg_tencent' only and pipeline_config_youcook2_train.yaml:17-18
+# keeps `ontology: 'vg'` with `# ontology: 'youcook2'` commented out.  The category mapping below is therefore this
+# build's own definition (documented in DESIGN.md): the files that exist in that directory fill the categories they
+# describe, the two categories without a cooking-specific list keep the vg ones.
+#   objects    <- youcook2/cooking_vocabulary_nouns.json (1,208)
+#   attributes <- vg attributes (as 'vg')
+#   scenes     <- vg/place365_ontology.json (as 'vg')
+#   verbs      <- youcook2/cooking_vocabulary_verbs.json (504) followed by youcook2/openimage_relation_triples.json
+#                 (1,466 "subject relation object" phrases), duplicates of the first list dropped
 _ONTOLOGY_FILES = {
     "vg": ("vg/openimage_classes_all_cleaned_fictional_characters.json",
            "vg/vg_original_attributes_synsets_keys_cleaned_remove_similar0.9.json",
            "vg/place365_ontology.json",
            "vg/vg_srl_selected_object_synsets_keys_remove_similar0.9.json"),
+    "youcook2": ("youcook2/cooking_vocabulary_nouns.json",
+                 "vg/vg_original_attributes_synsets_keys_cleaned_remove_similar0.9.json",
+                 "vg/place365_ontology.json",
+                 ("youcook2/cooking_vocabulary_verbs.json", "youcook2/openimage_relation_triples.json")),
     "vg_tencent": ("vg_tencent/tencent_ml_images_objects.json",
                    "vg_tencent/vg_original_attributes_synsets_keys_cleaned_remove_similar0.9.json",
                    "vg/place365_ontology.json",
@@ -59,8 +73,21 @@ def load_visual_token_texts(ontology_root, ontology="vg"):
     also objects are removed from the list WHILE it is iterated, so the element after each removal is
     never examined.  Class order defines the index space of the visual tokens, so it is reproduced."""
     if ontology not in _ONTOLOGY_FILES:
-        raise ValueError(f"ontology '{ontology}' has no branch in the reference (vg, vg_tencent)")
-    lists = [json.load(open(os.path.join(ontology_root, f))) for f in _ONTOLOGY_FILES[ontology]]
+        raise ValueError(f"unknown ontology '{ontology}' (vg, vg_tencent: the reference's branches; youcook2: this build's mapping)")
+
+    def _load(spec):
+        if isinstance(spec, str):
+            return json.load(open(os.path.join(ontology_root, spec)))
+        out, seen = [], set()
+        for f in spec:                      # several files concatenated, first occurrence of a string wins
+            items = json.load(open(os.path.join(ontology_root, f)))
+            for t in (list(items.keys()) if isinstance(items, dict) else items):
+                if t not in seen:
+                    seen.add(t)
+                    out.append(t)
+        return out
+
+    lists = [_load(f) for f in _ONTOLOGY_FILES[ontology]]
     objects, attributes, scenes, verbs = lists
     if isinstance(verbs, dict):
         verbs = list(verbs.keys())
