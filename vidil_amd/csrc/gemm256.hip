@@ -117,7 +117,7 @@ __global__ __launch_bounds__(512) void gemm256_kernel(const vidil_gemm_args p) {
   // stride of gridDim/8, so at any moment the 32 CUs of an XCD work on 32 consecutive tiles, as before.  What
   // persistence buys: the first K-tile of the NEXT tile is fetched while this tile's epilogue runs.
   int logical, remaining;
-  const int tile_step = gridDim.x >> 3;
+  const int tile_step = gridDim.x >= 8 ? (gridDim.x >> 3) : 1;   // (grids below 8 workgroups: one tile each, never 0)
   {
     const int nblk = tiles_m * tiles_n;
     const int bid = blockIdx.x;
