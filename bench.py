@@ -187,7 +187,8 @@ def main():
     # 9216 beam rows per decode step (measured: 128 -> 3.7k, 192 -> 3.8-3.95k, 384 -> 4.1k, 576 -> 3.9k frames/s)
     ap.add_argument("--videos-per-step", type=int, default=384)
     ap.add_argument("--frames", type=int, default=8, help="frames per video (config 4: 16)")
-    ap.add_argument("--dtype", choices=["f16", "bf16"], default="f16", help="MFMA operand type (config 2: bf16)")
+    ap.add_argument("--dtype", choices=["f16", "bf16", "fp8"], default="f16",
+                    help="MFMA operand type (config 2: bf16; config 5: fp8 = e4m3 operands in the towers' big GEMMs, f16 elsewhere)")
     ap.add_argument("--vit", choices=["base", "large"], default="base", help="BLIP vision tower (config 4: large = ViT-L/16)")
     ap.add_argument("--size", type=int, default=224, help="frame / BLIP image size (the headline metric is 224)")
     ap.add_argument("--clip", choices=["b32", "l14"], default="b32", help="CLIP tower (headline metric: ViT-B/32)")

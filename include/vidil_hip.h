@@ -34,6 +34,7 @@ extern "C" {
 /* operand types (the `dtype` arguments) */
 #define VIDIL_DT_F16 0
 #define VIDIL_DT_BF16 1
+#define VIDIL_DT_FP8 2      /* OCP e4m3fn: GEMM A / W operands (and the tensors feeding them) of the fp8 tower mode */
 
 #define VIDIL_OK 0
 #define VIDIL_EINVAL (-1)   /* bad argument (shape, alignment, null pointer)  */
@@ -56,7 +57,8 @@ enum {
   VIDIL_EPI_F32 = 1,   /* out f32 [M,ldo]   = act(acc + bias) + resid (resid may alias out)*/
   VIDIL_EPI_HEADS = 2, /* scatter into per-head Q / K / V^T buffers (see below)            */
   VIDIL_EPI_PATCH = 3, /* out f32 row (m + m/tpi + 1) = acc + bias + pos[(m%tpi)+1]        */
-  VIDIL_EPI_ARENA = 4  /* Q rows + K / V rows appended to a beam-search KV arena (below)   */
+  VIDIL_EPI_ARENA = 4, /* Q rows + K / V rows appended to a beam-search KV arena (below)   */
+  VIDIL_EPI_F8 = 5     /* out fp8 (e4m3) [M,ldo] = act(acc * w_scale + bias): the fc1 -> fc2 hand-over of the fp8 mode */
 };
 enum { VIDIL_ACT_NONE = 0, VIDIL_ACT_GELU_ERF = 1, VIDIL_ACT_QUICK_GELU = 2 };
 
@@ -118,6 +120,14 @@ typedef struct vidil_gemm_args {
   int32_t ln_fold;
   const float* ln_colsum; /* f32 [N] */
   float ln_eps;
+  /* ---- fp8 tower mode (dtype == VIDIL_DT_FP8; BASELINE config 5 "fp8 MFMA ViT path") ----------------------------
+   * A and W are OCP e4m3 bytes (K % 128 == 0), multiplied by v_mfma_scale_f32_32x32x64_f8f6f4 (block scales fixed at
+   * 2^0: plain fp8 products at twice the f16 MFMA rate, f32 accumulate).  W is stored as W / w_scale[n] (per output
+   * column, chosen by the host so that the row's largest weight sits well inside e4m3's range); the epilogue
+   * multiplies the accumulator by w_scale[n] before the bias.  dtype16 names the 16-bit type of the 16-bit outputs
+   * (EPI_HEADS q / k / vt); EPI_F8 writes fp8; EPI_F32 / EPI_PATCH as for the 16-bit types.  The 256x256 kernel only. */
+  const float* w_scale;   /* f32 [N] or NULL (= 1) */
+  int32_t dtype16;        /* VIDIL_DT_F16 / VIDIL_DT_BF16 */
 } vidil_gemm_args;
 
 /* replaces: nn.Linear calls of models/vit.py:35-41,72,84; models/med.py:153-171,
@@ -130,7 +140,8 @@ int vidil_gemm_kernel_name(const vidil_gemm_args* args, char* buf_host, int32_t 
 
 /* ------------------------------------------------------------------------ */
 /* LayerNorm over the last dim.  x f32 rows of length D at stride x_stride    */
-/* (elements); writes T16 (dtype16) and/or f32 outputs (either may be NULL), dense. */
+/* (elements); writes T16 (dtype16; VIDIL_DT_FP8 too: the fp8 mode's GEMM operand)   */
+/* and/or f32 outputs (either may be NULL), dense.                                */
 /* D must be a multiple of 64 and <= 1024... (768, 512, 1024 on this path)    */
 /* replaces: nn.LayerNorm at models/vit.py:108-109,192 (eps 1e-6),            */
 /* models/med.py:92,238,316,514 (eps 1e-12), HF CLIP layer norms (eps 1e-5).  */
@@ -164,7 +175,9 @@ int vidil_layernorm(const float* x, int64_t x_stride, const float* gamma,
 /*                         (j+1)*kv_group-1.                                  */
 /* Keys >= kv_len[b] (or >= Nk when kv_len==NULL) are excluded; causal!=0     */
 /* additionally excludes key > q + causal_off.                                */
-/* out T16 row (b*Nq + q), column h*64+d, row stride ldo (multiple of 8).     */
+/* out row (b*Nq + q), column h*64+d, row stride ldo (multiple of 8), in      */
+/* out_dtype: the operand type `dtype`, or VIDIL_DT_FP8 (staged kernel only:  */
+/* the fp8 tower mode feeds the attention output straight to the proj GEMM).  */
 /* replaces: models/vit.py:75-83; models/med.py:178-220 (self, cross, cached);*/
 /* HF CLIPAttention.                                                          */
 /* ------------------------------------------------------------------------ */
@@ -174,7 +187,8 @@ int vidil_attention(const void* q, const void* k, const void* vt, void* out,
                     int32_t Bq, int32_t H, int32_t Nq,
                     int32_t Nk, int32_t Tq_cap, int32_t Tk_cap, int32_t NP,
                     int32_t kv_group, int32_t causal, int32_t causal_off,
-                    int32_t ldo, int32_t kv_tiled, int32_t dtype, void* stream);
+                    int32_t ldo, int32_t kv_tiled, int32_t dtype, int32_t out_dtype,
+                    void* stream);
 
 /* ------------------------------------------------------------------------ */
 /* One separable pass of Pillow's antialiased resize on 8-bit interleaved RGB */

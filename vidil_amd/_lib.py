@@ -16,8 +16,8 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 # VIDIL_HIP_LIB: developer override (A/B-ing two builds of the same ABI on one box)
 LIB_PATH = os.environ.get("VIDIL_HIP_LIB") or os.path.join(_HERE, "csrc", "libvidil_hip.so")
 
-EPI_F16, EPI_F32, EPI_HEADS, EPI_PATCH, EPI_ARENA = 0, 1, 2, 3, 4
-DT_F16, DT_BF16 = 0, 1
+EPI_F16, EPI_F32, EPI_HEADS, EPI_PATCH, EPI_ARENA, EPI_F8 = 0, 1, 2, 3, 4, 5
+DT_F16, DT_BF16, DT_FP8 = 0, 1, 2
 ACT_NONE, ACT_GELU_ERF, ACT_QUICK_GELU = 0, 1, 2
 
 
@@ -37,6 +37,7 @@ class GemmArgs(C.Structure):
         ("arena_rows", C.c_int32), ("slot_stride", C.c_int32),
         ("pos", C.c_void_p), ("tpi", C.c_int32), ("kv_tiled", C.c_int32), ("dtype", C.c_int32),
         ("out16", C.c_void_p), ("ldo16", C.c_int32), ("ln_fold", C.c_int32), ("ln_colsum", C.c_void_p), ("ln_eps", C.c_float),
+        ("w_scale", C.c_void_p), ("dtype16", C.c_int32),
     ]
 
 
@@ -59,7 +60,7 @@ SIGNATURES = {
     "vidil_gemm_kernel_name": (_i32, [C.POINTER(GemmArgs), C.c_char_p, _i32]),
     "vidil_layernorm": (_i32, [_p, _i64, _p, _p, _f32, _i32, _i32, _p, _i32, _p, _p]),
     "vidil_split3_f32": (_i32, [_p, _p, _i32, _i32, _i32, _p]),
-    "vidil_attention": (_i32, [_p, _p, _p, _p, _p, _p, _p] + [_i32] * 15 + [_p]),
+    "vidil_attention": (_i32, [_p, _p, _p, _p, _p, _p, _p] + [_i32] * 16 + [_p]),
     "vidil_patchify_f32": (_i32, [_p, _p, _i32, _i32, _i32, _i32, _p]),
     "vidil_patchify_u8": (_i32, [_p, _p, _i32, _i32, _i32, C.POINTER(_f32), C.POINTER(_f32), _i32, _p]),
     "vidil_resample_u8": (_i32, [_p, _p] + [_i32] * 6 + [_p, _p, _i32, _i32, _p]),

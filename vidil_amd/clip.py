@@ -19,7 +19,7 @@ import torch
 import torch.nn as nn
 
 from . import kernels as K
-from .packing import PackedCache, fold_layernorm, require_cuda, v32, w16, w16_patch
+from .packing import FP8, PackedCache, fold_layernorm, require_cuda, v32, w8, w16, w16_patch
 
 CLIP_MEAN = (0.48145466, 0.4578275, 0.40821073)
 CLIP_STD = (0.26862954, 0.26130258, 0.27577711)
@@ -119,14 +119,19 @@ class _TextModel(nn.Module):
         self.final_layer_norm = nn.LayerNorm(cfg.hidden_size, eps=cfg.layer_norm_eps)
 
 
-def _pack_layers(encoder, c, fuse=False):
+def _pack_layers(encoder, c, fuse=False, fp8=False):
     """fuse: LayerNorm folded into the QKV / fc1 GEMMs (layer_norm2 everywhere, layer_norm1 from layer 1 on: layer
     0's input is written by a stand-alone LayerNorm / embedding kernel, not by a residual GEMM)."""
     out = []
     for i, l in enumerate(encoder.layers):
         a = l.self_attn
         extra = {}
-        if fuse:
+        if fp8:     # fp8 tower mode (see vit.VisionTransformer._run_blocks_fp8)
+            extra["qkv_w8"], extra["qkv_s"] = w8(a.q_proj.weight, a.k_proj.weight, a.v_proj.weight)
+            extra["o_w8"], extra["o_s"] = w8(a.out_proj.weight)
+            extra["fc1_w8"], extra["fc1_s"] = w8(l.mlp.fc1.weight)
+            extra["fc2_w8"], extra["fc2_s"] = w8(l.mlp.fc2.weight)
+        elif fuse:
             extra["fc1_f"] = fold_layernorm(l.mlp.fc1.weight, l.mlp.fc1.bias, l.layer_norm2.weight, l.layer_norm2.bias, c)
             if i > 0:
                 qkv_w = torch.cat([a.q_proj.weight, a.k_proj.weight, a.v_proj.weight], dim=0)
@@ -159,6 +164,19 @@ def _run_layers(layers, x, B, T, H, eps, *, causal=False, kv_len=None):
     hid = torch.empty((M, layers[0]["fc1_w"].shape[0]), dtype=cdt, device=dev)
     heads = dict(q=q, k=k, vt=vt, T=T, H=H, part0=0, t_off=0, Tq_cap=T, Tk_cap=T, NP=NP, q_scale=0.125)
     n = len(layers)
+    if "qkv_w8" in layers[0] and T > 32:
+        xn8 = torch.empty((M, D), dtype=FP8, device=dev)
+        o8 = torch.empty((M, D), dtype=FP8, device=dev)
+        hid8 = torch.empty((M, layers[0]["fc1_w8"].shape[0]), dtype=FP8, device=dev)
+        for l in layers:
+            K.layernorm(x, l["n1g"], l["n1b"], eps, out16=xn8)
+            K.gemm(xn8, l["qkv_w8"], l["qkv_b"], heads=heads, w_scale=l["qkv_s"])
+            K.attention(q, k, vt, o8, Bq=B, H=H, Nq=T, Nk=T, Tq_cap=T, Tk_cap=T, NP=NP, causal=causal, kv_len=kv_len)
+            K.gemm(o8, l["o_w8"], l["o_b"], out=x, resid=x, w_scale=l["o_s"], dtype16=cdt)
+            K.layernorm(x, l["n2g"], l["n2b"], eps, out16=xn8)
+            K.gemm(xn8, l["fc1_w8"], l["fc1_b"], out=hid8, act=K.ACT_QUICK_GELU, w_scale=l["fc1_s"], dtype16=cdt)
+            K.gemm(hid8, l["fc2_w8"], l["fc2_b"], out=x, resid=x, w_scale=l["fc2_s"], dtype16=cdt)
+        return x
     for i, l in enumerate(layers):
         fused = "fc1_f" in l      # LayerNorm folded into the consuming GEMMs (see vit.VisionTransformer.run_blocks)
         if fused and i > 0:
@@ -246,7 +264,7 @@ class CLIPModel(PackedCache, nn.Module):
                 nn.init.zeros_(m.bias)
 
     def pack_flags(self):
-        return (self.fuse_layernorm,)
+        return (self.fuse_layernorm, self.fp8)
 
     def _pack(self):
         vm, tm = self.vision_model, self.text_model
@@ -257,7 +275,7 @@ class CLIPModel(PackedCache, nn.Module):
             cls=v32(vm.embeddings.class_embedding), pos=v32(vm.embeddings.position_embedding.weight).view(-1, D),
             pre_g=v32(vm.pre_layrnorm.weight), pre_b=v32(vm.pre_layrnorm.bias),
             post_g=v32(vm.post_layernorm.weight), post_b=v32(vm.post_layernorm.bias),
-            vproj=w16(self.visual_projection.weight, dtype=c), vlayers=_pack_layers(vm.encoder, c, self.fuse_layernorm),
+            vproj=w16(self.visual_projection.weight, dtype=c), vlayers=_pack_layers(vm.encoder, c, self.fuse_layernorm, self.fp8),
             tok=v32(tm.embeddings.token_embedding.weight).view(self.config.text_config.vocab_size, -1),
             tpos=v32(tm.embeddings.position_embedding.weight).view(self.config.text_config.max_position_embeddings, -1),
             fin_g=v32(tm.final_layer_norm.weight), fin_b=v32(tm.final_layer_norm.bias),

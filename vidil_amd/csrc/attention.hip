@@ -43,6 +43,7 @@ struct AttnP {
   const int32_t* kv_index;     // per query batch -> kv batch (only with kv_group == 1 semantics), or null
   const int32_t* group_start;  // [n_kv+1] prefix of query batches per kv batch, or null
   int Bq, H, Nq, Nk, Tq_cap, Tk_cap, NP, kv_group, causal, causal_off, ldo, n_kv;
+  int out_fp8;                 // `out` holds e4m3 bytes (the fp8 tower mode's proj-GEMM operand); store_rows kernels only
   int tiled;                   // K and V in 32-key fragment tiles (common.h: ktile_off / vtile_off); direct kernel only
   int rb;                      // staged kernel, single key chunk: rounds of NW row blocks per workgroup (launch_lds)
 };
@@ -149,6 +150,16 @@ __device__ __forceinline__ void store_rows(const AttnP<T>& p, const RowInfo& ri,
   using f16 = T;
   if (!ri.valid) return;
   const int hi = (threadIdx.x & 63) >> 5;
+  if (p.out_fp8) {   // wave-uniform
+    uint8_t* o8 = (uint8_t*)p.out + ((size_t)ri.qb * p.Nq + ri.t) * p.ldo + h * 64 + 4 * hi;
+#pragma unroll
+    for (int dt = 0; dt < 2; ++dt)
+#pragma unroll
+      for (int rq = 0; rq < 4; ++rq)
+        *(uint32_t*)(o8 + dt * 32 + rq * 8) = pack4_fp8(O[dt][rq * 4 + 0] * inv, O[dt][rq * 4 + 1] * inv, O[dt][rq * 4 + 2] * inv,
+                                                        O[dt][rq * 4 + 3] * inv);
+    return;
+  }
   f16* og = p.out + ((size_t)ri.qb * p.Nq + ri.t) * p.ldo + h * 64 + 4 * hi;
 #pragma unroll
   for (int dt = 0; dt < 2; ++dt)
@@ -578,7 +589,7 @@ extern "C" int vidil_attention(const void* q, const void* k, const void* vt, voi
                                const int32_t* kv_index, const int32_t* group_start, int32_t n_kv, int32_t max_group,
                                int32_t Bq, int32_t H, int32_t Nq, int32_t Nk, int32_t Tq_cap, int32_t Tk_cap, int32_t NP,
                                int32_t kv_group, int32_t causal, int32_t causal_off, int32_t ldo, int32_t kv_tiled,
-                               int32_t dtype, void* stream) {
+                               int32_t dtype, int32_t out_dtype, void* stream) {
   VIDIL_REQUIRE(q && k && vt && out, "attention: null pointer");
   VIDIL_REQUIRE(Bq > 0 && H > 0 && Nq > 0 && Nk > 0, "attention: bad shape Bq=%d H=%d Nq=%d Nk=%d", Bq, H, Nq, Nk);
   if (kv_tiled) {
@@ -610,9 +621,13 @@ extern "C" int vidil_attention(const void* q, const void* k, const void* vt, voi
   // NP == 0: `vt` holds V row-major [Bk][H][Tk_cap][64]; only the LDS-staged kernel transposes on the way in
   VIDIL_REQUIRE(NP != 0 || max_rows > 32, "attention: row-major V (NP == 0) needs more than 32 query rows per unit (got %d)",
                 max_rows);
+  VIDIL_REQUIRE(out_dtype == dtype || (out_dtype == VIDIL_DT_FP8 && max_rows > 32 && ldo % 16 == 0),
+                "attention: out_dtype=%d must equal dtype=%d, or be fp8 with more than 32 query rows per unit (staged kernel)",
+                out_dtype, dtype);
   VIDIL_DISPATCH_DTYPE(dtype, "attention", {
     const AttnP<T> p{(const T*)q, (const T*)k, (const T*)vt, (T*)out, kv_len, kv_index, group_start, Bq, H, Nq, Nk,
-                     Tq_cap, Tk_cap, NP, kv_group, causal, causal_off, ldo, units, kv_tiled ? 1 : 0, 1};
+                     Tq_cap, Tk_cap, NP, kv_group, causal, causal_off, ldo, units, out_dtype == VIDIL_DT_FP8 ? 1 : 0,
+                     kv_tiled ? 1 : 0, 1};
     return attention_dispatch<T>(p, nkt, max_rows, Nk, (hipStream_t)stream);
   });
 }

@@ -323,7 +323,7 @@ TileChoice choose_tile(const vidil_gemm_args& a) {
     const char* e = getenv("VIDIL_GEMM256");
     return !(e && e[0] == '0');
   }();
-  if (a.ln_fold || a.out16) return {1, 256, 256, 2};     // LN-folded pair: always the 256x256 kernel (check_args)
+  if (a.ln_fold || a.out16 || a.dtype == VIDIL_DT_FP8) return {1, 256, 256, 2};   // always the 256x256 kernel (check_args)
   if (allow256 && a.epi != VIDIL_EPI_ARENA && vidil_gemm256_eligible(a)) return {1, 256, 256, 2};
 #ifdef VIDIL_GEMM_TUNE
   // developer builds only: VIDIL_GEMM_TILE=<BM>x<BN>x<ST> forces one configuration
@@ -366,7 +366,15 @@ int pick_tile(const vidil_gemm_args& a, hipStream_t s) {
 // argument checks shared by vidil_gemm and vidil_gemm_kernel_name
 int check_args(const vidil_gemm_args& a) {
   VIDIL_REQUIRE(a.A && a.W, "gemm: null operand");
-  VIDIL_REQUIRE(a.dtype == VIDIL_DT_F16 || a.dtype == VIDIL_DT_BF16, "gemm: unknown dtype %d", a.dtype);
+  VIDIL_REQUIRE(a.dtype == VIDIL_DT_F16 || a.dtype == VIDIL_DT_BF16 || a.dtype == VIDIL_DT_FP8, "gemm: unknown dtype %d", a.dtype);
+  if (a.dtype == VIDIL_DT_FP8) {
+    VIDIL_REQUIRE(a.K % 128 == 0, "gemm/fp8: K=%d must be a multiple of 128", a.K);
+    VIDIL_REQUIRE(a.dtype16 == VIDIL_DT_F16 || a.dtype16 == VIDIL_DT_BF16, "gemm/fp8: dtype16=%d must name the 16-bit output type", a.dtype16);
+    VIDIL_REQUIRE(!a.ln_fold && !a.out16, "gemm/fp8: the LayerNorm fold is a 16-bit feature");
+    VIDIL_REQUIRE(a.epi != VIDIL_EPI_F16 && a.epi != VIDIL_EPI_ARENA, "gemm/fp8: epilogue %d is not built for fp8 operands", a.epi);
+  } else {
+    VIDIL_REQUIRE(a.epi != VIDIL_EPI_F8, "gemm: EPI_F8 needs fp8 operands");
+  }
   VIDIL_REQUIRE(a.M > 0 && a.N > 0 && a.K > 0, "gemm: bad shape M=%d N=%d K=%d", a.M, a.N, a.K);
   VIDIL_REQUIRE(a.K % BK == 0, "gemm: K=%d must be a multiple of %d", a.K, BK);
   VIDIL_REQUIRE(a.lda == 0 || (a.lda >= a.K && a.lda % 8 == 0), "gemm: lda=%d must be 0 or >= K and a multiple of 8", a.lda);
@@ -380,11 +388,12 @@ int check_args(const vidil_gemm_args& a) {
     VIDIL_REQUIRE(a.epi == VIDIL_EPI_F32, "gemm/out16: only the f32 residual epilogue writes the 16-bit copy");
     VIDIL_REQUIRE(a.ldo16 >= a.N, "gemm/out16: ldo16=%d < N=%d", a.ldo16, a.N);
   }
-  if (a.ln_fold || a.out16)
+  if (a.ln_fold || a.out16 || a.dtype == VIDIL_DT_FP8)
     VIDIL_REQUIRE(vidil_gemm256_eligible(a, true), "gemm: this LN-folded problem does not meet the 256x256 kernel's alignment / size rules (N %% 4, 16-B aligned vectors, K >= 128)");
   switch (a.epi) {
     case VIDIL_EPI_F16:
     case VIDIL_EPI_F32:
+    case VIDIL_EPI_F8:
       VIDIL_REQUIRE(a.out && a.ldo >= a.N, "gemm: bad out/ldo");
       VIDIL_REQUIRE(a.act >= VIDIL_ACT_NONE && a.act <= VIDIL_ACT_QUICK_GELU, "gemm: unknown act %d", a.act);
       return VIDIL_OK;
@@ -460,6 +469,7 @@ extern "C" int vidil_gemm(const vidil_gemm_args* args, void* stream) {
   VIDIL_REQUIRE(args != nullptr, "gemm: null args");
   const int rc = check_args(*args);
   if (rc != VIDIL_OK) return rc;
+  if (args->dtype == VIDIL_DT_FP8) return vidil_gemm256_launch(*args, (hipStream_t)stream);
   if (args->dtype == VIDIL_DT_BF16) return dispatch<bf16>(*args, (hipStream_t)stream);
   return dispatch<f16>(*args, (hipStream_t)stream);
 }
@@ -469,9 +479,10 @@ extern "C" int vidil_gemm_kernel_name(const vidil_gemm_args* args, char* buf_hos
   const int rc = check_args(*args);
   if (rc != VIDIL_OK) return rc;
   const TileChoice c = choose_tile(*args);
-  const char* t = args->dtype == VIDIL_DT_BF16 ? "__bf16" : "_Float16";     // the spelling rocprofv3 demangles to
-  const int act = (args->epi == VIDIL_EPI_F16 || args->epi == VIDIL_EPI_F32) ? args->act : 0;
-  if (c.big) snprintf(buf_host, n, "gemm256_kernel<%s, %d, %d>", t, args->epi, act);
+  const char* t16 = (args->dtype == VIDIL_DT_FP8 ? args->dtype16 : args->dtype) == VIDIL_DT_BF16 ? "__bf16" : "_Float16";
+  const char* t = args->dtype == VIDIL_DT_FP8 ? "fp8" : t16;                 // the spelling rocprofv3 demangles to
+  const int act = (args->epi == VIDIL_EPI_F16 || args->epi == VIDIL_EPI_F32 || args->epi == VIDIL_EPI_F8) ? args->act : 0;
+  if (c.big) snprintf(buf_host, n, "gemm256_kernel<%s, %s, %d, %d, %s>", t, t16, args->epi, act, args->ln_fold ? "true" : "false");
   else snprintf(buf_host, n, "gemm_kernel<%s, %d, %d, %d, %d, %d>", t, c.bm, c.bn, c.st, args->epi, act);
   return VIDIL_OK;
 }

@@ -87,16 +87,54 @@ __device__ __forceinline__ void frag_stats(bf16x8 a, float& s, float& ss) {
   }
 }
 
+// What the main loop needs to know about the operand type: a 128-byte LDS row holds one K-tile (64 x 16-bit or
+// 128 x fp8), consumed in KS MFMA k-steps; a fragment is the lane's share of one k-step of one 32-row tile.
+template <typename T>
+struct Mma {   // f16 / bf16: v_mfma_f32_32x32x16, 16 k per step, one 16-byte slot per lane
+  static constexpr int KS = 4;
+  typedef typename Elt<T>::x8 Frag;
+  static __device__ __forceinline__ Frag load(const char* row, int ks, int hi, int sw) {
+    return *(const Frag*)(row + (((ks * 2 + hi) ^ sw) << 4));
+  }
+  static __device__ __forceinline__ f32x16 mma(Frag w, Frag a, f32x16 c) { return Elt<T>::mfma32(w, a, c); }
+};
+template <>
+struct Mma<fp8> {   // e4m3: v_mfma_scale_f32_32x32x64_f8f6f4 (scales 2^0), 64 k per step, two 16-byte slots per lane
+  static constexpr int KS = 2;
+  typedef i32x8 Frag;
+  static __device__ __forceinline__ Frag load(const char* row, int ks, int hi, int sw) {
+    // operand layout of the 32x32x64 instruction (tools/micro/mx_fp8_layout.hip, measured): lane l holds row l % 32 and
+    // the 32 consecutive k of half l / 32 — two adjacent 16-byte slots of the 128-byte row
+#ifdef VIDIL_FP8_LAYOUT_INTERLEAVED   // alternative layout (16-byte halves interleaved), kept for the probe
+    const i32x4 lo = *(const i32x4*)(row + (((ks * 4 + hi) ^ sw) << 4));
+    const i32x4 hi4 = *(const i32x4*)(row + (((ks * 4 + 2 + hi) ^ sw) << 4));
+#else
+    const i32x4 lo = *(const i32x4*)(row + (((ks * 4 + hi * 2) ^ sw) << 4));
+    const i32x4 hi4 = *(const i32x4*)(row + (((ks * 4 + hi * 2 + 1) ^ sw) << 4));
+#endif
+    return Frag{lo[0], lo[1], lo[2], lo[3], hi4[0], hi4[1], hi4[2], hi4[3]};
+  }
+  static __device__ __forceinline__ f32x16 mma(Frag w, Frag a, f32x16 c) {
+    return __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(w, a, c, 0, 0, 0, 0x7f7f7f7f, 0, 0x7f7f7f7f);
+  }
+};
+
 // FOLD: LayerNorm folded into this GEMM (vidil_gemm_args.ln_fold, include/vidil_hip.h).  A holds the RAW residual
 // stream in the operand type; every wave accumulates sum / sum of squares of its 128 rows from the A fragments of the
 // k-steps it owns (k-step ks belongs to the wave with wc == ks: the four waves that read the same rows split the
 // work), the partials meet in LDS after the main loop, and the epilogue applies
 //   y = rstd * acc - (rstd * mean) * colsum[n] + b'[n].
-template <typename T, int EPI, int ACT, bool FOLD>
+// T: operand type of A and W (f16 / bf16 / fp8); TO: the 16-bit type of 16-bit outputs (== T unless T is fp8).
+template <typename T, typename TO, int EPI, int ACT, bool FOLD>
 __global__ __launch_bounds__(512) void gemm256_kernel(const vidil_gemm_args p) {
-  using f16 = T;                        // (the body is written in terms of "the 16-bit operand type")
-  using f16x4 = typename Elt<T>::x4;
-  using f16x8 = typename Elt<T>::x8;
+  using f16 = TO;                       // (the epilogue is written in terms of "the 16-bit output type")
+  using f16x4 = typename Elt<TO>::x4;
+  using f16x8 = typename Elt<TO>::x8;
+  using Frag = typename Mma<T>::Frag;
+  constexpr int KS = Mma<T>::KS;
+  constexpr int ESZ = sizeof(T);        // bytes per operand element
+  constexpr int KT = 128 / ESZ;         // operand elements per K-tile (one 128-byte LDS row)
+  static_assert(!FOLD || ESZ == 2, "the LayerNorm fold reads 16-bit A fragments");
   extern __shared__ __attribute__((aligned(16))) char smem[];
 #ifdef VIDIL_GEMM_PROBE
   Probe probe;
@@ -126,7 +164,7 @@ __global__ __launch_bounds__(512) void gemm256_kernel(const vidil_gemm_args p) {
     remaining = (xcd < r ? q + 1 : q) - slot;     // tiles from `logical` to the end of the XCD's range
   }
   if (remaining <= 0) return;
-  const int nk = K >> 6;
+  const int nk = K / KT;
 
   // ---- staging sources: half-tile hf of A / W, two 16-B chunks per thread ------------------------
   // (32-bit element offsets from the two uniform base pointers: 8 VGPRs instead of 16 for pointers — this
@@ -150,19 +188,19 @@ __global__ __launch_bounds__(512) void gemm256_kernel(const vidil_gemm_args p) {
         ra = ra < M ? ra : M - 1;
         int rw = n0 + hf * 128 + r;
         rw = rw < N ? rw : N - 1;
-        gA[hf][i] = ra * lda + c * 8;
-        gW[hf][i] = rw * K + c * 8;
+        gA[hf][i] = ra * lda + c * (16 / ESZ);
+        gW[hf][i] = rw * K + c * (16 / ESZ);
       }
   };
   setup_tile(logical);
-  const f16* const baseA = (const f16*)p.A;
-  const f16* const baseW = (const f16*)p.W;
+  const T* const baseA = (const T*)p.A;
+  const T* const baseW = (const T*)p.W;
   // slot ids inside a K-tile buffer: 0 = A0, 1 = A1, 2 = W0, 3 = W1.  Tiles past the end re-fetch the
   // last tile into the slot the schedule says is free, so the counted waits stay uniform.
-  auto issue = [&](const f16* base, const int(&g)[2], int tile, int slot) {
+  auto issue = [&](const T* base, const int(&g)[2], int tile, int slot) {
     const int tt = tile < nk ? tile : nk - 1;
     char* dst = smem + (tile & 1) * BUF + slot * SLOT + wave * 1024;
-    const f16* src = base + tt * 64;
+    const T* src = base + tt * KT;
     glds16(src + g[0], dst);
     glds16(src + g[1], dst + 8192);
   };
@@ -173,11 +211,7 @@ __global__ __launch_bounds__(512) void gemm256_kernel(const vidil_gemm_args p) {
   const int sw = (l31 >> 1) & 7;
   const int a_off = grp * SLOT + l31 * 128;
   const int w_off = (2 + (wc >> 1)) * SLOT + ((wc & 1) * 64 + l31) * 128;
-  int slot_of[4];
-#pragma unroll
-  for (int ks = 0; ks < 4; ++ks) slot_of[ks] = ((ks * 2 + hi) ^ sw) << 4;
-
-  f16x8 wf[2][4];   // W fragments of the current K-tile (both column tiles), resident for both half-periods
+  Frag wf[2][KS];   // W fragments of the current K-tile (both column tiles), resident for both half-periods
 
   const int nhp = 2 * nk;
   // DMA of GLOBAL half-period h, in three pieces so it can be interleaved with MFMAs (an LDS-DMA instruction
@@ -214,33 +248,38 @@ __global__ __launch_bounds__(512) void gemm256_kernel(const vidil_gemm_args p) {
   auto half_period = [&](auto rh_tag, const char* buf, int h) {
     constexpr int RH = decltype(rh_tag)::value;
     const char* ab = buf + a_off + RH * 8192;
-    f16x8 a[4][2];
+    Frag a[KS][2];
 #pragma unroll
-    for (int i = 0; i < 2; ++i) a[0][i] = *(const f16x8*)(ab + i * 4096 + slot_of[0]);
+    for (int i = 0; i < 2; ++i) a[0][i] = Mma<T>::load(ab + i * 4096, 0, hi, sw);
     if constexpr (RH == 0) {
 #pragma unroll
-      for (int ks = 0; ks < 4; ++ks)
+      for (int ks = 0; ks < KS; ++ks)
 #pragma unroll
-        for (int j = 0; j < 2; ++j) wf[j][ks] = *(const f16x8*)(buf + w_off + j * 4096 + slot_of[ks]);
+        for (int j = 0; j < 2; ++j) wf[j][ks] = Mma<T>::load(buf + w_off + j * 4096, ks, hi, sw);
     }
 #pragma unroll
-    for (int ks = 0; ks < 4; ++ks) {
-      if (ks < 3) {
+    for (int ks = 0; ks < KS; ++ks) {
+      if (ks < KS - 1) {
 #pragma unroll
-        for (int i = 0; i < 2; ++i) a[ks + 1][i] = *(const f16x8*)(ab + i * 4096 + slot_of[ks + 1]);
+        for (int i = 0; i < 2; ++i) a[ks + 1][i] = Mma<T>::load(ab + i * 4096, ks + 1, hi, sw);
       }
 #pragma unroll
       for (int i = 0; i < 2; ++i)
 #pragma unroll
         for (int j = 0; j < 2; ++j)
-          acc[RH * 2 + i][j] = Elt<T>::mfma32(wf[j][ks], a[ks][i], acc[RH * 2 + i][j]);
+          acc[RH * 2 + i][j] = Mma<T>::mma(wf[j][ks], a[ks][i], acc[RH * 2 + i][j]);
       if constexpr (FOLD) {
         if (wc == ks) {   // wave-uniform
 #pragma unroll
           for (int i = 0; i < 2; ++i) frag_stats(a[ks][i], st_s[RH * 2 + i], st_ss[RH * 2 + i]);
         }
       }
-      if (ks < 3) dma_piece(h, ks);
+      // this half-period's (up to) three DMA pieces go out behind MFMAs, never right in front of the next barrier
+      if constexpr (KS == 4) {
+        if (ks < 3) dma_piece(h, ks);
+      } else {
+        if (ks == 0) { dma_piece(h, 0); dma_piece(h, 1); dma_piece(h, 2); }
+      }
     }
   };
 
@@ -355,6 +394,23 @@ __global__ __launch_bounds__(512) void gemm256_kernel(const vidil_gemm_args p) {
               acc[it][j][rq * 4 + e] = __builtin_fmaf(acc[it][j][rq * 4 + e], st_s[it], __builtin_fmaf(-st_ss[it], c4[e], b4[e]));
         }
       }
+  } else if (ESZ == 1 && p.w_scale != nullptr) {
+    // fp8 weights are stored as W / w_scale[n]: scale the accumulators back, then the bias
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int rq = 0; rq < 4; ++rq) {
+        const int col = n_w + j * 32 + rq * 8 + hi * 4;
+        if (col + 4 <= N) {
+          const f32x4 w4 = *(const f32x4*)(p.w_scale + col);
+          f32x4 b4 = {0.f, 0.f, 0.f, 0.f};
+          if (p.bias != nullptr) b4 = *(const f32x4*)(p.bias + col);
+#pragma unroll
+          for (int it = 0; it < 4; ++it)
+#pragma unroll
+            for (int e = 0; e < 4; ++e) acc[it][j][rq * 4 + e] = __builtin_fmaf(acc[it][j][rq * 4 + e], w4[e], b4[e]);
+        }
+      }
   } else
   // bias folded into the accumulators once (4 consecutive columns per register quad)
   if (p.bias != nullptr) {
@@ -413,8 +469,8 @@ __global__ __launch_bounds__(512) void gemm256_kernel(const vidil_gemm_args p) {
         for (int j = 0; j < 2; ++j)
 #pragma unroll
           for (int rq = 0; rq < 4; ++rq) {
-            const f16x4 v = {Elt<T>::from_f32(value(it, j, rq, 0)), Elt<T>::from_f32(value(it, j, rq, 1)), Elt<T>::from_f32(value(it, j, rq, 2)),
-                             Elt<T>::from_f32(value(it, j, rq, 3))};
+            const f16x4 v = {Elt<TO>::from_f32(value(it, j, rq, 0)), Elt<TO>::from_f32(value(it, j, rq, 1)), Elt<TO>::from_f32(value(it, j, rq, 2)),
+                             Elt<TO>::from_f32(value(it, j, rq, 3))};
             *(f16x4*)(ep + l31 * ROWB + (j * 32 + rq * 8 + hi * 4) * 2) = v;
           }
         int b = mb / p.T, t = mb - b * p.T;
@@ -451,14 +507,41 @@ __global__ __launch_bounds__(512) void gemm256_kernel(const vidil_gemm_args p) {
 #pragma unroll
             for (int rq = 0; rq < 4; ++rq)
 #pragma unroll
-              for (int e = 0; e < 4; ++e) dst[(size_t)(j * 32 + rq * 8 + hi * 4 + e) * p.NP] = Elt<T>::from_f32(value(it, j, rq, e));
+              for (int e = 0; e < 4; ++e) dst[(size_t)(j * 32 + rq * 8 + hi * 4 + e) * p.NP] = Elt<TO>::from_f32(value(it, j, rq, e));
         }
       }
       break;
     }
   }
 
-  if constexpr (EPI == VIDIL_EPI_F16 || EPI == VIDIL_EPI_HEADS) {
+  if constexpr (EPI == VIDIL_EPI_F8) {
+    // ---- fp8 rows of 64 columns (64 B), two passes of 64 rows: [64][64] bytes, 16-B chunk index XOR ((row>>2)&3) ----
+#pragma unroll
+    for (int pass = 0; pass < 2; ++pass) {
+#pragma unroll
+      for (int i = 0; i < 2; ++i) {
+        const int it = pass * 2 + i;
+        const int row = i * 32 + l31;
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+          for (int rq = 0; rq < 4; ++rq) {
+            const int cb = j * 32 + rq * 8 + hi * 4;      // first of 4 consecutive columns = byte offset in the row
+            *(uint32_t*)(ep + row * 64 + ((((cb >> 4) ^ ((row >> 2) & 3)) << 4) | (cb & 15))) =
+                pack4_fp8(value(it, j, rq, 0), value(it, j, rq, 1), value(it, j, rq, 2), value(it, j, rq, 3));
+          }
+      }
+      const int ch = lane & 3;
+#pragma unroll
+      for (int iter = 0; iter < 4; ++iter) {
+        const int row = iter * 16 + (lane >> 2);
+        const i32x4 v = *(const i32x4*)(ep + row * 64 + ((ch ^ ((row >> 2) & 3)) << 4));
+        const int m = m_w + pass * 64 + row;
+        const int col = n_w + ch * 16;
+        if (m < M && col + 16 <= N) *(i32x4*)((char*)p.out + (size_t)m * p.ldo + col) = v;
+      }
+    }
+  } else if constexpr (EPI == VIDIL_EPI_F16 || EPI == VIDIL_EPI_HEADS) {
     // ---- f16 rows of 64 columns, two passes of 64 rows: [64][64] halfs, 16-B chunk index XOR (row&7) ------
     const float scale = (EPI == VIDIL_EPI_HEADS && part == 0) ? p.q_scale : 1.0f;
 #pragma unroll
@@ -471,8 +554,8 @@ __global__ __launch_bounds__(512) void gemm256_kernel(const vidil_gemm_args p) {
         for (int j = 0; j < 2; ++j)
 #pragma unroll
           for (int rq = 0; rq < 4; ++rq) {
-            const f16x4 v = {Elt<T>::from_f32(value(it, j, rq, 0) * scale), Elt<T>::from_f32(value(it, j, rq, 1) * scale),
-                             Elt<T>::from_f32(value(it, j, rq, 2) * scale), Elt<T>::from_f32(value(it, j, rq, 3) * scale)};
+            const f16x4 v = {Elt<TO>::from_f32(value(it, j, rq, 0) * scale), Elt<TO>::from_f32(value(it, j, rq, 1) * scale),
+                             Elt<TO>::from_f32(value(it, j, rq, 2) * scale), Elt<TO>::from_f32(value(it, j, rq, 3) * scale)};
             *(f16x4*)(ep + row * 128 + (((j * 4 + rq) ^ (row & 7)) << 4) + hi * 8) = v;
           }
       }
@@ -551,7 +634,7 @@ __global__ __launch_bounds__(512) void gemm256_kernel(const vidil_gemm_args p) {
           if constexpr (EPI == VIDIL_EPI_F32) {
             *(f32x4*)((float*)p.out + (size_t)m * p.ldo + col) = v;
             if (p.out16 != nullptr) {   // the raw stream in the operand type, for the LN-folded consumer GEMM
-              const f16x4 h4 = {Elt<T>::from_f32(v[0]), Elt<T>::from_f32(v[1]), Elt<T>::from_f32(v[2]), Elt<T>::from_f32(v[3])};
+              const f16x4 h4 = {Elt<TO>::from_f32(v[0]), Elt<TO>::from_f32(v[1]), Elt<TO>::from_f32(v[2]), Elt<TO>::from_f32(v[3])};
               *(f16x4*)((f16*)p.out16 + (size_t)m * p.ldo16 + col) = h4;
             }
           } else {  // EPI_PATCH
@@ -571,10 +654,10 @@ __global__ __launch_bounds__(512) void gemm256_kernel(const vidil_gemm_args p) {
   }  // tile loop
 }
 
-template <typename T, int EPI, int ACT, bool FOLD = false>
+template <typename T, int EPI, int ACT, bool FOLD = false, typename TO = T>
 int launch256(const vidil_gemm_args& a, hipStream_t s) {
   static bool attr_set = false;
-  auto kern = gemm256_kernel<T, EPI, ACT, FOLD>;
+  auto kern = gemm256_kernel<T, TO, EPI, ACT, FOLD>;
   constexpr int lds = LDS_BYTES + (FOLD ? STATS_BYTES : 0);
   if (!attr_set) {
     hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
@@ -613,12 +696,16 @@ bool vidil_gemm256_eligible(const vidil_gemm_args& a, bool any_size) {
   const long tiles = (long)((a.M + 255) / 256) * ((a.N + 255) / 256);
   if (tiles < 160 && !any_size) return false;      // too few workgroups to fill 256 CUs: small-tile kernel
   if (a.K < 128) return false;
+  if (a.dtype == VIDIL_DT_FP8 && (a.K % 128 != 0 || (a.lda != 0 && a.lda % 16 != 0))) return false;
   const long lda = a.lda > 0 ? a.lda : a.K;
   if ((long)a.M * lda >= (1L << 31) || (long)a.N * a.K >= (1L << 31)) return false;   // 32-bit staging offsets
   auto al16 = [](const void* p) { return ((uintptr_t)p & 15) == 0; };
   if (a.bias && !al16(a.bias)) return false;
   if (a.ln_fold && !(a.ln_colsum && al16(a.ln_colsum) && a.N % 4 == 0)) return false;
+  if (a.w_scale && !al16(a.w_scale)) return false;
   switch (a.epi) {
+    case VIDIL_EPI_F8:
+      return a.dtype == VIDIL_DT_FP8 && a.N % 16 == 0 && a.ldo % 16 == 0 && al16(a.out);
     case VIDIL_EPI_F16:
       return a.N % 8 == 0 && a.ldo % 8 == 0 && al16(a.out);
     case VIDIL_EPI_F32:
@@ -657,7 +744,26 @@ static int launch256_dispatch(const vidil_gemm_args& a, hipStream_t s) {
   }
 }
 
+// fp8 operands: the residual / patch epilogues (f32 out), the per-head scatter into the 16-bit companion type, and the
+// fp8 hand-over (fc1 -> fc2)
+template <typename TO>
+static int launch256_fp8(const vidil_gemm_args& a, hipStream_t s) {
+  switch (a.epi) {
+    case VIDIL_EPI_F32: return launch256<fp8, VIDIL_EPI_F32, VIDIL_ACT_NONE, false, TO>(a, s);
+    case VIDIL_EPI_PATCH: return launch256<fp8, VIDIL_EPI_PATCH, VIDIL_ACT_NONE, false, TO>(a, s);
+    case VIDIL_EPI_HEADS: return launch256<fp8, VIDIL_EPI_HEADS, VIDIL_ACT_NONE, false, TO>(a, s);
+    case VIDIL_EPI_F8:
+      if (a.act == VIDIL_ACT_GELU_ERF) return launch256<fp8, VIDIL_EPI_F8, VIDIL_ACT_GELU_ERF, false, TO>(a, s);
+      if (a.act == VIDIL_ACT_QUICK_GELU) return launch256<fp8, VIDIL_EPI_F8, VIDIL_ACT_QUICK_GELU, false, TO>(a, s);
+      return launch256<fp8, VIDIL_EPI_F8, VIDIL_ACT_NONE, false, TO>(a, s);
+    default:
+      vidil_set_error("gemm/fp8: epilogue %d is not built for fp8 operands", a.epi);
+      return VIDIL_EUNSUP;
+  }
+}
+
 int vidil_gemm256_launch(const vidil_gemm_args& a, hipStream_t s) {
+  if (a.dtype == VIDIL_DT_FP8) return a.dtype16 == VIDIL_DT_BF16 ? launch256_fp8<bf16>(a, s) : launch256_fp8<f16>(a, s);
   if (a.dtype == VIDIL_DT_BF16) return launch256_dispatch<bf16>(a, s);
   return launch256_dispatch<f16>(a, s);
 }

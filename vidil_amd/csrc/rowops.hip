@@ -2,6 +2,8 @@
 // stride==kernel conv, fused with uint8 -> normalised f16), CLS row, token
 // embedding, row gather, L2 normalisation.  All are one wave per row (or per
 // patch), 16-B vector accesses, f32 statistics.
+#include <type_traits>
+
 #include "common.h"
 
 namespace {
@@ -13,7 +15,7 @@ __global__ __launch_bounds__(256) void layernorm_kernel(const float* __restrict_
                                                         const float* __restrict__ gamma,
                                                         const float* __restrict__ beta, float eps, int M,
                                                         T* __restrict__ out16, float* __restrict__ out32) {
-  using x4 = typename Elt<T>::x4;
+  using x4 = typename std::conditional<sizeof(T) == 1, uint32_t, typename Elt<typename std::conditional<sizeof(T) == 1, f16, T>::type>::x4>::type;
   constexpr int D = 256 * VPL;
   const int lane = threadIdx.x & 63;
   const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
@@ -47,8 +49,13 @@ __global__ __launch_bounds__(256) void layernorm_kernel(const float* __restrict_
 #pragma unroll
     for (int e = 0; e < 4; ++e) y[e] = (v[i][e] - mean) * rstd * g[e] + b[e];
     if (out32 != nullptr) *(f32x4*)(out32 + (size_t)row * D + c) = y;
-    if (out16 != nullptr)
-      __builtin_nontemporal_store(x4{(T)y[0], (T)y[1], (T)y[2], (T)y[3]}, (x4*)(out16 + (size_t)row * D + c));
+    if (out16 != nullptr) {
+      if constexpr (sizeof(T) == 1) {
+        __builtin_nontemporal_store(pack4_fp8(y[0], y[1], y[2], y[3]), (uint32_t*)((uint8_t*)out16 + (size_t)row * D + c));
+      } else {
+        __builtin_nontemporal_store(x4{(T)y[0], (T)y[1], (T)y[2], (T)y[3]}, (x4*)(out16 + (size_t)row * D + c));
+      }
+    }
   }
 }
 
@@ -244,6 +251,8 @@ extern "C" int vidil_layernorm(const float* x, int64_t x_stride, const float* ga
   VIDIL_REQUIRE(x && gamma && beta && (out16 || out_f32), "layernorm: null pointer");
   VIDIL_REQUIRE(M > 0, "layernorm: M=%d", M);
   VIDIL_REQUIRE(x_stride % 4 == 0, "layernorm: x_stride must be a multiple of 4");
+  if (out16 && dtype16 == VIDIL_DT_FP8)
+    return layernorm_launch<fp8>(x, x_stride, gamma, beta, eps, M, D, (fp8*)out16, out_f32, (hipStream_t)stream);
   VIDIL_DISPATCH_DTYPE(out16 ? dtype16 : VIDIL_DT_F16, "layernorm",
                        return layernorm_launch<T>(x, x_stride, gamma, beta, eps, M, D, (T*)out16, out_f32, (hipStream_t)stream));
 }

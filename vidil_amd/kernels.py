@@ -11,7 +11,7 @@ import ctypes as C
 import torch
 
 from . import _lib
-from ._lib import (ACT_GELU_ERF, ACT_NONE, ACT_QUICK_GELU, DT_BF16, DT_F16, EPI_ARENA, EPI_F16, EPI_F32,
+from ._lib import (ACT_GELU_ERF, ACT_NONE, ACT_QUICK_GELU, DT_BF16, DT_F16, DT_FP8, EPI_ARENA, EPI_F8, EPI_F16, EPI_F32,
                    EPI_HEADS, EPI_PATCH, BeamState, GemmArgs, VidilHipError, check)
 
 __all__ = [
@@ -44,14 +44,15 @@ def kv_tile_offsets(n: int):
     return k_off, v_off
 
 
-_DT = {torch.float16: DT_F16, torch.bfloat16: DT_BF16}
+_DT = {torch.float16: DT_F16, torch.bfloat16: DT_BF16, torch.float8_e4m3fn: DT_FP8}
 
 
-def _dt(t, name="tensor") -> int:
-    """VIDIL_DT_* code of a 16-bit operand tensor (float16 / bfloat16)."""
-    code = _DT.get(t if isinstance(t, torch.dtype) else t.dtype)
-    if code is None:
-        raise VidilHipError(f"{name}: expected a float16 or bfloat16 tensor, got {t if isinstance(t, torch.dtype) else t.dtype}")
+def _dt(t, name="tensor", fp8_ok=False) -> int:
+    """VIDIL_DT_* code of an operand tensor (float16 / bfloat16; float8_e4m3fn where the entry point takes it)."""
+    d = t if isinstance(t, torch.dtype) else t.dtype
+    code = _DT.get(d)
+    if code is None or (code == DT_FP8 and not fp8_ok):
+        raise VidilHipError(f"{name}: expected a float16 or bfloat16{' or float8_e4m3fn' if fp8_ok else ''} tensor, got {d}")
     return code
 
 
@@ -99,7 +100,7 @@ def gemm_kernel_name(a, w, bias=None, **kw):
 
 
 def _gemm_build(a, w, bias=None, *, out=None, out_dtype=None, act=ACT_NONE, resid=None,
-                heads=None, patch=None, arena=None, M=None, lda=None, out16=None, ln=None):
+                heads=None, patch=None, arena=None, M=None, lda=None, out16=None, ln=None, w_scale=None, dtype16=None):
     K_ = w.shape[1]
     if lda is None:
         M, Ka = a.shape
@@ -110,10 +111,20 @@ def _gemm_build(a, w, bias=None, *, out=None, out_dtype=None, act=ACT_NONE, resi
     K = K_
     N = w.shape[0]
     g = GemmArgs()
+    g.dtype = _dt(a, "gemm.A", fp8_ok=True)
+    g.A = _ptr(a, a.dtype, "gemm.A")
+    g.W = _ptr(w, a.dtype, "gemm.W")
+    fp8 = g.dtype == DT_FP8
+    # fp8 operands (tower mode): 16-bit outputs are written in the companion type (taken from the output buffers)
     t16 = a.dtype
-    g.dtype = _dt(a, "gemm.A")
-    g.A = _ptr(a, t16, "gemm.A")
-    g.W = _ptr(w, t16, "gemm.W")
+    if fp8:
+        t16 = dtype16
+        for cand in ((heads or {}).get("q"), (heads or {}).get("k"), (heads or {}).get("vt")):
+            if t16 is None and cand is not None:
+                t16 = cand.dtype
+        t16 = t16 or torch.float16
+        g.dtype16 = _dt(t16, "gemm.dtype16")
+        g.w_scale = _ptr(w_scale, torch.float32, "gemm.w_scale")
     g.bias = _ptr(bias, torch.float32, "gemm.bias")
     g.M, g.N, g.K = M, N, K
     g.lda = 0 if lda is None else lda
@@ -153,11 +164,11 @@ def _gemm_build(a, w, bias=None, *, out=None, out_dtype=None, act=ACT_NONE, resi
         g.tpi = patch["tpi"]
     else:
         if out is None:
-            out = torch.empty((M, N), dtype=out_dtype or t16, device=a.device)
+            out = torch.empty((M, N), dtype=out_dtype or a.dtype, device=a.device)
         ret = out
-        if out.dtype not in (t16, torch.float32):
-            raise VidilHipError(f"gemm: out must be {t16} (the operand type) or float32, got {out.dtype}")
-        g.epi = EPI_F32 if out.dtype == torch.float32 else EPI_F16
+        if out.dtype not in (a.dtype, torch.float32):
+            raise VidilHipError(f"gemm: out must be {a.dtype} (the operand type) or float32, got {out.dtype}")
+        g.epi = EPI_F32 if out.dtype == torch.float32 else (EPI_F8 if fp8 else EPI_F16)
         g.out = _ptr(out, None, "gemm.out")
         g.ldo = out.shape[-1]
         if resid is not None:
@@ -184,7 +195,7 @@ def layernorm(x, gamma, beta, eps, *, M=None, D=None, x_stride=None, out16=None,
     x_stride = x_stride if x_stride is not None else D
     check(lib.vidil_layernorm(_ptr(x, torch.float32, "ln.x"), x_stride, _ptr(gamma, torch.float32, "ln.gamma"),
                               _ptr(beta, torch.float32, "ln.beta"), float(eps), M, D,
-                              _ptr(out16, None, "ln.out16"), _dt(out16, "ln.out16") if out16 is not None else DT_F16,
+                              _ptr(out16, None, "ln.out16"), _dt(out16, "ln.out16", fp8_ok=True) if out16 is not None else DT_F16,
                               _ptr(out32, torch.float32, "ln.out32"), _stream()), "layernorm")
 
 
@@ -205,12 +216,12 @@ def attention(q, k, vt, out, *, Bq, H, Nq, Nk, Tq_cap, Tk_cap, NP, kv_group=1, c
     n_kv = 0 if group_start is None else group_start.numel() - 1
     t16 = q.dtype
     check(lib.vidil_attention(_ptr(q, t16, "attn.q"), _ptr(k, t16, "attn.k"),
-                              _ptr(vt, t16, "attn.vt"), _ptr(out, t16, "attn.out"),
+                              _ptr(vt, t16, "attn.vt"), _ptr(out, None, "attn.out"),
                               _ptr(kv_len, torch.int32, "attn.kv_len"), _ptr(kv_index, torch.int32, "attn.kv_index"),
                               _ptr(group_start, torch.int32, "attn.group_start"), n_kv, max_group,
                               Bq, H, Nq, Nk, Tq_cap, Tk_cap, NP,
                               kv_group, int(bool(causal)), causal_off, ldo, int(bool(kv_tiled)), _dt(q, "attn.q"),
-                              _stream()), "attention")
+                              _dt(out, "attn.out", fp8_ok=True), _stream()), "attention")
     return out
 
 

@@ -7,19 +7,38 @@ import os
 
 import torch
 
+FP8 = torch.float8_e4m3fn      # OCP e4m3: the fp8 tower mode's GEMM operand type (gfx950's native fp8)
 _DTYPES = {"f16": torch.float16, "fp16": torch.float16, "float16": torch.float16, "half": torch.float16,
-           "bf16": torch.bfloat16, "bfloat16": torch.bfloat16}
+           "bf16": torch.bfloat16, "bfloat16": torch.bfloat16, "fp8": FP8, "f8": FP8, "e4m3": FP8}
 
 
 def as_compute_dtype(d):
-    """'f16' / 'bf16' / torch dtype -> torch.float16 or torch.bfloat16 (the two MFMA operand types of the kernels)."""
+    """'f16' / 'bf16' / 'fp8' / torch dtype -> torch.float16, torch.bfloat16 or torch.float8_e4m3fn.
+    fp8 is a TOWER mode (BASELINE config 5): the four big GEMMs of every ViT / CLIP-vision block run on fp8 operands
+    (2x the MFMA rate); attention, the text stacks and everything else stay in the 16-bit companion type
+    ($VIDIL_FP8_COMPANION, f16 by default)."""
     if isinstance(d, str):
         if d.lower() not in _DTYPES:
-            raise ValueError(f"unknown compute dtype {d!r} (f16 or bf16)")
+            raise ValueError(f"unknown compute dtype {d!r} (f16, bf16 or fp8)")
         d = _DTYPES[d.lower()]
-    if d not in (torch.float16, torch.bfloat16):
-        raise ValueError(f"compute dtype must be float16 or bfloat16, got {d}")
+    if d not in (torch.float16, torch.bfloat16, FP8):
+        raise ValueError(f"compute dtype must be float16, bfloat16 or float8_e4m3fn, got {d}")
     return d
+
+
+def fp8_companion():
+    d = as_compute_dtype(os.environ.get("VIDIL_FP8_COMPANION", "f16"))
+    if d == FP8:
+        raise ValueError("VIDIL_FP8_COMPANION must be f16 or bf16")
+    return d
+
+
+def w8(*weights):
+    """nn.Linear weights (concatenated along N) -> (e4m3 [N,K] = W / scale[n], scale f32 [N]) with the largest weight
+    of every output row at half of e4m3's range (224 of 448): the GEMM epilogue multiplies the accumulator by scale[n]."""
+    w = (weights[0] if len(weights) == 1 else torch.cat(list(weights), dim=0)).detach().float()
+    scale = (w.abs().amax(dim=1) / 224.0).clamp_min(1e-12)
+    return (w / scale[:, None]).to(FP8).contiguous(), scale.contiguous()
 
 
 _default = [as_compute_dtype(os.environ.get("VIDIL_DTYPE", "f16"))]
@@ -97,7 +116,14 @@ class PackedCache:
 
     @property
     def cdt(self):
-        return compute_dtype(self)
+        """The 16-bit operand type of this model (in the fp8 tower mode: the companion type of everything that is not
+        one of the towers' big GEMMs)."""
+        d = compute_dtype(self)
+        return fp8_companion() if d == FP8 else d
+
+    @property
+    def fp8(self):
+        return compute_dtype(self) == FP8
 
     def pack_flags(self):
         """Host-side switches that change what ``_pack`` produces (overridden by the models that have any)."""

@@ -27,7 +27,7 @@ import torch
 import torch.nn as nn
 
 from . import kernels as K
-from .packing import PackedCache, fold_layernorm, require_cuda, v32, w16, w16_patch
+from .packing import FP8, PackedCache, fold_layernorm, require_cuda, v32, w8, w16, w16_patch
 
 
 class PatchEmbed(nn.Module):
@@ -106,7 +106,7 @@ class VisionTransformer(PackedCache, nn.Module):
 
     # ------------------------------------------------------------------ packing
     def pack_flags(self):
-        return (self.fuse_layernorm,)
+        return (self.fuse_layernorm, self.fp8)
 
     def _pack(self):
         D = self.embed_dim
@@ -124,14 +124,20 @@ class VisionTransformer(PackedCache, nn.Module):
                 n2g=v32(b.norm2.weight), n2b=v32(b.norm2.bias),
                 fc1_w=w16(b.mlp.fc1.weight, dtype=c), fc1_b=v32(b.mlp.fc1.bias),
                 fc2_w=w16(b.mlp.fc2.weight, dtype=c), fc2_b=v32(b.mlp.fc2.bias))
-            if self.fuse_layernorm:
+            if self.fp8:
+                # fp8 tower mode: the four big GEMMs on e4m3 operands (weights per-output-row scaled), LayerNorm as
+                # a stand-alone kernel writing fp8 (its output is well scaled; the raw stream is not)
+                for name, lin in (("qkv", b.attn.qkv), ("proj", b.attn.proj), ("fc1", b.mlp.fc1), ("fc2", b.mlp.fc2)):
+                    d[name + "_w8"], d[name + "_s"] = w8(lin.weight)
+            elif self.fuse_layernorm:
                 # norm2 folded into fc1 in every block; norm1 folded into qkv from block 1 on (block 0's input comes
                 # from the patch-embedding GEMM, which writes no 16-bit copy of the stream)
                 d["fc1_f"] = fold_layernorm(b.mlp.fc1.weight, b.mlp.fc1.bias, b.norm2.weight, b.norm2.bias, c)
                 if i > 0:
                     d["qkv_f"] = fold_layernorm(b.attn.qkv.weight, b.attn.qkv.bias, b.norm1.weight, b.norm1.bias, c)
             p["blocks"].append(d)
-        p["fused"] = self.fuse_layernorm
+        p["fused"] = self.fuse_layernorm and not self.fp8
+        p["fp8"] = self.fp8
         return p
 
     # ------------------------------------------------------------------ forward
@@ -163,6 +169,8 @@ class VisionTransformer(PackedCache, nn.Module):
         o = torch.empty((M, D), dtype=cdt, device=dev)
         hid = torch.empty((M, p["blocks"][0]["fc1_w"].shape[0]), dtype=cdt, device=dev)
         heads = dict(q=q, k=k, vt=vt, T=T, H=H, part0=0, t_off=0, Tq_cap=T, Tk_cap=T, NP=NP, q_scale=0.125)
+        if p.get("fp8"):
+            return self._run_blocks_fp8(p, x, B, T, q, k, vt, heads, NP, want16)
         # Fused LayerNorm (models/vit.py:107-110): the residual GEMMs (proj, fc2) also store the stream in the operand
         # type (``xn`` then holds RAW x, not LN(x)) and the next GEMM applies the LayerNorm to its accumulators.
         fused = p.get("fused", False)
@@ -187,6 +195,29 @@ class VisionTransformer(PackedCache, nn.Module):
                 K.gemm(hid, b["fc2_w"], b["fc2_b"], out=x, resid=x)
         y32 = torch.empty((M, D), dtype=torch.float32, device=dev)
         y16 = xn if want16 else None
+        K.layernorm(x, p["norm_g"], p["norm_b"], self.ln_eps, out16=y16, out32=y32)
+        return y32, y16
+
+    def _run_blocks_fp8(self, p, x, B, T, q, k, vt, heads, NP, want16):
+        """fp8 tower mode (BASELINE config 5): LN -> fp8, QKV / proj / fc1 / fc2 on e4m3 operands at twice the 16-bit
+        MFMA rate, attention on the 16-bit companion type writing fp8, f32 residual stream.  NOT a parity mode: e4m3
+        carries 3 mantissa bits (tests/test_fp8_gpu.py states the measured deviation from the fp32 oracle)."""
+        D, H = self.embed_dim, self.num_heads
+        dev = x.device
+        M = B * T
+        xn8 = torch.empty((M, D), dtype=FP8, device=dev)
+        o8 = torch.empty((M, D), dtype=FP8, device=dev)
+        hid8 = torch.empty((M, p["blocks"][0]["fc1_w8"].shape[0]), dtype=FP8, device=dev)
+        for b in p["blocks"]:
+            K.layernorm(x, b["n1g"], b["n1b"], self.ln_eps, out16=xn8)
+            K.gemm(xn8, b["qkv_w8"], b["qkv_b"], heads=heads, w_scale=b["qkv_s"])
+            K.attention(q, k, vt, o8, Bq=B, H=H, Nq=T, Nk=T, Tq_cap=T, Tk_cap=T, NP=NP)
+            K.gemm(o8, b["proj_w8"], b["proj_b"], out=x, resid=x, w_scale=b["proj_s"], dtype16=q.dtype)
+            K.layernorm(x, b["n2g"], b["n2b"], self.ln_eps, out16=xn8)
+            K.gemm(xn8, b["fc1_w8"], b["fc1_b"], out=hid8, act=K.ACT_GELU_ERF, w_scale=b["fc1_s"], dtype16=q.dtype)
+            K.gemm(hid8, b["fc2_w8"], b["fc2_b"], out=x, resid=x, w_scale=b["fc2_s"], dtype16=q.dtype)
+        y32 = torch.empty((M, D), dtype=torch.float32, device=dev)
+        y16 = torch.empty((M, D), dtype=q.dtype, device=dev) if want16 else None
         K.layernorm(x, p["norm_g"], p["norm_b"], self.ln_eps, out16=y16, out32=y32)
         return y32, y16
 
