@@ -6,6 +6,7 @@ ARGS=${@:---steps 2 --warmup 1 --no-cpu-baseline}
 R=$GRAFT_REPO_ROOT
 OUT=$R/gpurun_out/prof_$TAG
 mkdir -p $OUT
+echo "$ARGS" > $OUT/cmdline.txt
 cd /tmp && export TMPDIR=/tmp
 python $R/bench.py $ARGS > $OUT/bench.json 2> $OUT/bench.log
 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace -o t -- python $R/bench.py $ARGS --no-roofline > $OUT/bench_traced.json 2>/dev/null
