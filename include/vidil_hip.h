@@ -108,11 +108,12 @@ typedef struct vidil_gemm_args {
   /* ---- LayerNorm folded into the GEMMs of a pre-LN block (models/vit.py:107-110 `x + attn(norm1(x))`,
    * `x + mlp(norm2(x))`; HF CLIPEncoderLayer) -----------------------------------------------------
    * producer (EPI_F32, the residual GEMM that writes the stream x): out16 != NULL additionally stores
-   *   T16(x) [M, ldo16] — the RAW stream in the operand type — for the consumer below;
+   *   T16(x) [M, ldo16] — the RAW stream in the operand type — and, per row and per 64 output columns, the
+   *   partial (sum, sum of squares) of the f32 values into ln_stats_out f32 [M][N/64][2] (N % 64 == 0);
    * consumer (EPI_F16 / EPI_HEADS with ln_fold != 0; needs K == the LayerNorm width D): A is that raw T16(x),
-   *   W is W' = T16(gamma (.) W) (gamma scales the K axis), bias is b' = b + W·beta, ln_colsum[n] = sum_k W'[n][k];
-   *   the kernel accumulates every row's sum and sum of squares from the A fragments it streams anyway and
-   *   applies  y[m][n] = rstd_m * (acc[m][n] - mean_m * ln_colsum[n]) + b'[n]  in its epilogue (then act / the
+   *   W is W' = T16(gamma (.) W) (gamma scales the K axis), bias is b' = b + W·beta, ln_colsum[n] = sum_k W'[n][k],
+   *   ln_stats = the producer's partials [M][K/64][2]; the kernel combines them into mean_m, rstd_m and applies
+   *   y[m][n] = rstd_m * (acc[m][n] - mean_m * ln_colsum[n]) + b'[n]  in its epilogue (then act / the
    *   per-head scatter), which equals LayerNorm(x)·W^T + b with the rounding point moved from LN(x) to x.
    * Both run on the 256x256 kernel whatever M is (results never depend on the batch size). */
   void* out16;
@@ -120,6 +121,8 @@ typedef struct vidil_gemm_args {
   int32_t ln_fold;
   const float* ln_colsum; /* f32 [N] */
   float ln_eps;
+  float* ln_stats_out;    /* producer: f32 [M][N/64][2] */
+  const float* ln_stats;  /* consumer: f32 [M][K/64][2] */
   /* ---- fp8 tower mode (dtype == VIDIL_DT_FP8; BASELINE config 5 "fp8 MFMA ViT path") ----------------------------
    * A and W are OCP e4m3 bytes (K % 128 == 0), multiplied by v_mfma_scale_f32_32x32x64_f8f6f4 (block scales fixed at
    * 2^0: plain fp8 products at twice the f16 MFMA rate, f32 accumulate).  W is stored as W / w_scale[n] (per output

@@ -690,6 +690,13 @@ def test_scan_topk_bit_exact_vs_oracle(D):
 
 
 # ------------------------------------------------------------------------ LayerNorm folded into the GEMMs
+def _row_partials(x32):
+    """What the producing GEMM leaves for the folded consumer: per row and per 64 columns (sum, sum of squares)."""
+    M, D = x32.shape
+    xs = x32.view(M, D // 64, 64)
+    return torch.stack([xs.sum(-1), (xs * xs).sum(-1)], dim=-1).contiguous()
+
+
 @pytest.mark.parametrize("dtype", [torch.float16, torch.bfloat16])
 @pytest.mark.parametrize("M,D,N,act", [(197 * 3, 768, 3072, "gelu"), (197 * 330, 768, 3072, "gelu"), (50 * 7, 768, 3072, "quick"),
                                        (197 * 2, 1024, 4096, "gelu"), (333, 768, 768, "none")])
@@ -708,8 +715,9 @@ def test_gemm_layernorm_fold_consumer_vs_torch(dtype, M, D, N, act):
     x16 = x.to(dtype)
     wf, bf, cs = fold_layernorm(w, b, g, bt, dtype)
     code = dict(gelu=k.ACT_GELU_ERF, quick=k.ACT_QUICK_GELU, none=k.ACT_NONE)[act]
-    out = k.gemm(x16.to(DEV), wf.to(DEV), bf.to(DEV), act=code, ln=(cs.to(DEV), 1e-6))
-    assert k.gemm_kernel_name(x16.to(DEV), wf.to(DEV), bf.to(DEV), act=code, ln=(cs.to(DEV), 1e-6)).startswith("gemm256_kernel")
+    st = _row_partials(x16.float()).to(DEV)
+    out = k.gemm(x16.to(DEV), wf.to(DEV), bf.to(DEV), act=code, ln=(cs.to(DEV), 1e-6, st))
+    assert k.gemm_kernel_name(x16.to(DEV), wf.to(DEV), bf.to(DEV), act=code, ln=(cs.to(DEV), 1e-6, st)).startswith("gemm256_kernel")
     # reference: exact LayerNorm of the SAME 16-bit stream values, fp32 weights
     pre = torch.nn.functional.layer_norm(x16.float(), (D,), g, bt, 1e-6) @ w.t() + b
     ref = dict(gelu=torch.nn.functional.gelu(pre), quick=pre * torch.sigmoid(1.702 * pre), none=pre)[act]
@@ -733,10 +741,12 @@ def test_gemm_layernorm_fold_heads_consumer_and_out16_producer(dtype):
     x0 = _rand(M, D, seed=83) * 1.5
     x = x0.to(DEV).clone()
     x16 = torch.zeros(M, D, dtype=dtype, device=DEV)
-    k.gemm(a.to(DEV), wp.to(DEV), bp.to(DEV), out=x, resid=x, out16=x16)
+    st = torch.zeros(M, D // 64, 2, dtype=torch.float32, device=DEV)
+    k.gemm(a.to(DEV), wp.to(DEV), bp.to(DEV), out=x, resid=x, out16=x16, ln_stats_out=st)
     ref_x = a.float() @ wp.float().t() + bp + x0
     assert torch.allclose(x.cpu(), ref_x, rtol=1e-4, atol=1e-3)
     assert torch.equal(x16.cpu(), x.cpu().to(dtype))            # exactly the rounded stream
+    assert torch.allclose(st.cpu(), _row_partials(x.cpu()), rtol=1e-5, atol=1e-4)   # row partials of the f32 stream
     plain = x0.to(DEV).clone()
     k.gemm(a.to(DEV), wp.to(DEV), bp.to(DEV), out=plain, resid=plain)     # (small-tile kernel) same bits
     assert torch.equal(plain, x)
@@ -746,7 +756,7 @@ def test_gemm_layernorm_fold_heads_consumer_and_out16_producer(dtype):
     wf, bf, cs = fold_layernorm(w, b, g, bt, dtype)
     q = torch.zeros(B, H, T, 64, dtype=dtype, device=DEV)
     kk, v = torch.zeros_like(q), torch.zeros_like(q)
-    k.gemm(x16, wf.to(DEV), bf.to(DEV), ln=(cs.to(DEV), 1e-6),
+    k.gemm(x16, wf.to(DEV), bf.to(DEV), ln=(cs.to(DEV), 1e-6, st),
            heads=dict(q=q, k=kk, vt=v, T=T, H=H, part0=0, t_off=0, Tq_cap=T, Tk_cap=T, NP=0, q_scale=0.125))
     ref = (torch.nn.functional.layer_norm(x16.float().cpu(), (D,), g, bt, 1e-6) @ w.t() + b).view(B, T, 3, H, 64)
     tol = dict(rtol=4e-3, atol=4e-3) if dtype == torch.float16 else dict(rtol=3e-2, atol=3e-2)
@@ -764,6 +774,7 @@ def test_layernorm_fold_does_not_depend_on_the_batch_size():
     x16 = (_rand(197 * 330, D, seed=90) * 1.5).half().to(DEV)
     g, bt = _rand(D, seed=91) * 0.2 + 1.0, _rand(D, seed=92) * 0.2
     wf, bf, cs = fold_layernorm(_rand(N, D, scale=0.03, seed=93), _rand(N, seed=94) * 0.1, g, bt, torch.float16)
-    big = k.gemm(x16, wf.to(DEV), bf.to(DEV), act=k.ACT_GELU_ERF, ln=(cs.to(DEV), 1e-6))
-    small = k.gemm(x16[:591].contiguous(), wf.to(DEV), bf.to(DEV), act=k.ACT_GELU_ERF, ln=(cs.to(DEV), 1e-6))
+    st = _row_partials(x16.float())
+    big = k.gemm(x16, wf.to(DEV), bf.to(DEV), act=k.ACT_GELU_ERF, ln=(cs.to(DEV), 1e-6, st))
+    small = k.gemm(x16[:591].contiguous(), wf.to(DEV), bf.to(DEV), act=k.ACT_GELU_ERF, ln=(cs.to(DEV), 1e-6, st[:591].contiguous()))
     assert torch.equal(big[:591], small)

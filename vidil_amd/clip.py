@@ -164,6 +164,7 @@ def _run_layers(layers, x, B, T, H, eps, *, causal=False, kv_len=None):
     hid = torch.empty((M, layers[0]["fc1_w"].shape[0]), dtype=cdt, device=dev)
     heads = dict(q=q, k=k, vt=vt, T=T, H=H, part0=0, t_off=0, Tq_cap=T, Tk_cap=T, NP=NP, q_scale=0.125)
     n = len(layers)
+    stats = torch.empty((M, D // 64, 2), dtype=torch.float32, device=dev) if "fc1_f" in layers[0] else None
     if "qkv_w8" in layers[0] and T > 32:
         xn8 = torch.empty((M, D), dtype=FP8, device=dev)
         o8 = torch.empty((M, D), dtype=FP8, device=dev)
@@ -181,16 +182,17 @@ def _run_layers(layers, x, B, T, H, eps, *, causal=False, kv_len=None):
         fused = "fc1_f" in l      # LayerNorm folded into the consuming GEMMs (see vit.VisionTransformer.run_blocks)
         if fused and i > 0:
             w_, b_, cs = l["qkv_f"]
-            K.gemm(xn, w_, b_, heads=heads, ln=(cs, eps))
+            K.gemm(xn, w_, b_, heads=heads, ln=(cs, eps, stats))
         else:
             K.layernorm(x, l["n1g"], l["n1b"], eps, out16=xn)
             K.gemm(xn, l["qkv_w"], l["qkv_b"], heads=heads)
         K.attention(q, k, vt, o, Bq=B, H=H, Nq=T, Nk=T, Tq_cap=T, Tk_cap=T, NP=NP, causal=causal, kv_len=kv_len)
         if fused:
-            K.gemm(o, l["o_w"], l["o_b"], out=x, resid=x, out16=xn)
+            K.gemm(o, l["o_w"], l["o_b"], out=x, resid=x, out16=xn, ln_stats_out=stats)
             w_, b_, cs = l["fc1_f"]
-            K.gemm(xn, w_, b_, out=hid, act=K.ACT_QUICK_GELU, ln=(cs, eps))
-            K.gemm(hid, l["fc2_w"], l["fc2_b"], out=x, resid=x, out16=xn if i + 1 < n else None)
+            K.gemm(xn, w_, b_, out=hid, act=K.ACT_QUICK_GELU, ln=(cs, eps, stats))
+            K.gemm(hid, l["fc2_w"], l["fc2_b"], out=x, resid=x, out16=xn if i + 1 < n else None,
+                   ln_stats_out=stats if i + 1 < n else None)
         else:
             K.gemm(o, l["o_w"], l["o_b"], out=x, resid=x)
             K.layernorm(x, l["n2g"], l["n2b"], eps, out16=xn)

@@ -323,7 +323,7 @@ TileChoice choose_tile(const vidil_gemm_args& a) {
     const char* e = getenv("VIDIL_GEMM256");
     return !(e && e[0] == '0');
   }();
-  if (a.ln_fold || a.out16 || a.dtype == VIDIL_DT_FP8) return {1, 256, 256, 2};   // always the 256x256 kernel (check_args)
+  if (a.ln_fold || a.out16 || a.ln_stats_out || a.dtype == VIDIL_DT_FP8) return {1, 256, 256, 2};   // always the 256x256 kernel (check_args)
   if (allow256 && a.epi != VIDIL_EPI_ARENA && vidil_gemm256_eligible(a)) return {1, 256, 256, 2};
 #ifdef VIDIL_GEMM_TUNE
   // developer builds only: VIDIL_GEMM_TILE=<BM>x<BN>x<ST> forces one configuration
@@ -381,14 +381,15 @@ int check_args(const vidil_gemm_args& a) {
   VIDIL_REQUIRE(((uintptr_t)a.A & 15) == 0 && ((uintptr_t)a.W & 15) == 0, "gemm: operands must be 16-B aligned");
   if (a.ln_fold) {
     VIDIL_REQUIRE(a.epi == VIDIL_EPI_F16 || a.epi == VIDIL_EPI_HEADS, "gemm/ln_fold: only EPI_F16 / EPI_HEADS consume a folded LayerNorm");
-    VIDIL_REQUIRE(a.ln_colsum != nullptr && a.ln_eps >= 0.f, "gemm/ln_fold: null ln_colsum");
+    VIDIL_REQUIRE(a.ln_colsum != nullptr && a.ln_stats != nullptr && a.ln_eps >= 0.f, "gemm/ln_fold: null ln_colsum / ln_stats");
     VIDIL_REQUIRE(a.lda == 0 || a.lda == a.K, "gemm/ln_fold: A rows must be dense (K = the LayerNorm width)");
   }
   if (a.out16) {
     VIDIL_REQUIRE(a.epi == VIDIL_EPI_F32, "gemm/out16: only the f32 residual epilogue writes the 16-bit copy");
     VIDIL_REQUIRE(a.ldo16 >= a.N, "gemm/out16: ldo16=%d < N=%d", a.ldo16, a.N);
   }
-  if (a.ln_fold || a.out16 || a.dtype == VIDIL_DT_FP8)
+  if (a.ln_stats_out) VIDIL_REQUIRE(a.epi == VIDIL_EPI_F32 && a.N % 64 == 0, "gemm/ln_stats_out: f32 residual epilogue, N %% 64 == 0");
+  if (a.ln_fold || a.out16 || a.ln_stats_out || a.dtype == VIDIL_DT_FP8)
     VIDIL_REQUIRE(vidil_gemm256_eligible(a, true), "gemm: this LN-folded problem does not meet the 256x256 kernel's alignment / size rules (N %% 4, 16-B aligned vectors, K >= 128)");
   switch (a.epi) {
     case VIDIL_EPI_F16:

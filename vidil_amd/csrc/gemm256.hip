@@ -65,26 +65,16 @@ struct Probe {
 };
 #endif
 
-// row sum / sum of squares of one A fragment (8 operand values of a row) in f32: v_dot2c_f32_{f16,bf16}
-__device__ __forceinline__ void frag_stats(f16x8 a, float& s, float& ss) {
-  typedef _Float16 h2 __attribute__((ext_vector_type(2)));
-  const h2 one = {(_Float16)1.f, (_Float16)1.f};
-#pragma unroll
-  for (int e = 0; e < 8; e += 2) {
-    const h2 v = {a[e], a[e + 1]};
-    s = __builtin_amdgcn_fdot2(v, one, s, false);
-    ss = __builtin_amdgcn_fdot2(v, v, ss, false);
-  }
+// sum over the 16 lanes of a DPP row (all 16 end up with the total): rotations by 8, 4, 2, 1
+template <int ROR>
+__device__ __forceinline__ float row_ror_add(float v) {
+  return v + __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x120 + ROR, 0xF, 0xF, false));
 }
-__device__ __forceinline__ void frag_stats(bf16x8 a, float& s, float& ss) {
-  typedef __bf16 b2 __attribute__((ext_vector_type(2)));
-  const b2 one = {(__bf16)1.f, (__bf16)1.f};
-#pragma unroll
-  for (int e = 0; e < 8; e += 2) {
-    const b2 v = {a[e], a[e + 1]};
-    s = __builtin_amdgcn_fdot2_f32_bf16(v, one, s, false);
-    ss = __builtin_amdgcn_fdot2_f32_bf16(v, v, ss, false);
-  }
+__device__ __forceinline__ float row16_sum(float v) {
+  v = row_ror_add<8>(v);
+  v = row_ror_add<4>(v);
+  v = row_ror_add<2>(v);
+  return row_ror_add<1>(v);
 }
 
 // What the main loop needs to know about the operand type: a 128-byte LDS row holds one K-tile (64 x 16-bit or
@@ -120,10 +110,10 @@ struct Mma<fp8> {   // e4m3: v_mfma_scale_f32_32x32x64_f8f6f4 (scales 2^0), 64 k
 };
 
 // FOLD: LayerNorm folded into this GEMM (vidil_gemm_args.ln_fold, include/vidil_hip.h).  A holds the RAW residual
-// stream in the operand type; every wave accumulates sum / sum of squares of its 128 rows from the A fragments of the
-// k-steps it owns (k-step ks belongs to the wave with wc == ks: the four waves that read the same rows split the
-// work), the partials meet in LDS after the main loop, and the epilogue applies
-//   y = rstd * acc - (rstd * mean) * colsum[n] + b'[n].
+// stream in the operand type; the producing GEMM left per-row partial sums / sums of squares (one pair per 64 columns,
+// computed in its memory-bound f32 epilogue — statistics taken from the A fragments inside THIS main loop cost 6-8 % of
+// the kernel: v_dot2c beside MFMAs).  The four waves that own the same rows each add up a quarter of the partials,
+// meet in LDS after the main loop, and the epilogue applies  y = rstd * acc - (rstd * mean) * colsum[n] + b'[n].
 // T: operand type of A and W (f16 / bf16 / fp8); TO: the 16-bit type of 16-bit outputs (== T unless T is fp8).
 template <typename T, typename TO, int EPI, int ACT, bool FOLD>
 __global__ __launch_bounds__(512) void gemm256_kernel(const vidil_gemm_args p) {
@@ -268,12 +258,6 @@ __global__ __launch_bounds__(512) void gemm256_kernel(const vidil_gemm_args p) {
 #pragma unroll
         for (int j = 0; j < 2; ++j)
           acc[RH * 2 + i][j] = Mma<T>::mma(wf[j][ks], a[ks][i], acc[RH * 2 + i][j]);
-      if constexpr (FOLD) {
-        if (wc == ks) {   // wave-uniform
-#pragma unroll
-          for (int i = 0; i < 2; ++i) frag_stats(a[ks][i], st_s[RH * 2 + i], st_ss[RH * 2 + i]);
-        }
-      }
       // this half-period's (up to) three DMA pieces go out behind MFMAs, never right in front of the next barrier
       if constexpr (KS == 4) {
         if (ks < 3) dma_piece(h, ks);
@@ -300,8 +284,23 @@ __global__ __launch_bounds__(512) void gemm256_kernel(const vidil_gemm_args p) {
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[it][j][r] = 0.f;
   if constexpr (FOLD) {
+    // this wave's share of the producer's row partials (parts wc, wc+4, ...; the half-waves alternate): issued here,
+    // consumed after the main loop
+    const int nparts = K >> 6;
+    const f32x2* stats_in = (const f32x2*)p.ln_stats;
 #pragma unroll
-    for (int it = 0; it < 4; ++it) st_s[it] = st_ss[it] = 0.f;
+    for (int it = 0; it < 4; ++it) {
+      int row = m0 + grp * 128 + it * 32 + l31;
+      row = row < M ? row : M - 1;
+      float s = 0.f, ss = 0.f;
+      for (int part = wc + 4 * hi; part < nparts; part += 8) {
+        const f32x2 v = stats_in[(size_t)row * nparts + part];
+        s += v[0];
+        ss += v[1];
+      }
+      st_s[it] = s;
+      st_ss[it] = ss;
+    }
   }
 
   // Both groups run the same straight-line [first half, second half] body per K-tile (so the accumulators
@@ -629,8 +628,17 @@ __global__ __launch_bounds__(512) void gemm256_kernel(const vidil_gemm_args p) {
         f32x4 v = *(const f32x4*)(ep + lr * 256 + ((ch ^ (lr & 7)) << 4));
         const int m = m_w + pass * 32 + lr;
         const int col = n_w + ch * 4;
-        if (m < M && col + 4 <= N) {
-          v += add[iter];
+        const bool ok = m < M && col + 4 <= N;
+        if (ok) v += add[iter];
+        if constexpr (EPI == VIDIL_EPI_F32) {
+          if (p.ln_stats_out != nullptr) {   // wave-uniform: LN-fold producer — (sum, sum of squares) of this row's 64 columns
+            const f32x4 z = ok ? v : f32x4{0.f, 0.f, 0.f, 0.f};
+            const float s = row16_sum((z[0] + z[1]) + (z[2] + z[3]));
+            const float ss = row16_sum((z[0] * z[0] + z[1] * z[1]) + (z[2] * z[2] + z[3] * z[3]));
+            if (ch == 0 && m < M) *(f32x2*)(p.ln_stats_out + ((size_t)m * (N >> 6) + (n_w >> 6)) * 2) = f32x2{s, ss};
+          }
+        }
+        if (ok) {
           if constexpr (EPI == VIDIL_EPI_F32) {
             *(f32x4*)((float*)p.out + (size_t)m * p.ldo + col) = v;
             if (p.out16 != nullptr) {   // the raw stream in the operand type, for the LN-folded consumer GEMM
@@ -701,7 +709,8 @@ bool vidil_gemm256_eligible(const vidil_gemm_args& a, bool any_size) {
   if ((long)a.M * lda >= (1L << 31) || (long)a.N * a.K >= (1L << 31)) return false;   // 32-bit staging offsets
   auto al16 = [](const void* p) { return ((uintptr_t)p & 15) == 0; };
   if (a.bias && !al16(a.bias)) return false;
-  if (a.ln_fold && !(a.ln_colsum && al16(a.ln_colsum) && a.N % 4 == 0)) return false;
+  if (a.ln_fold && !(a.ln_colsum && al16(a.ln_colsum) && a.N % 4 == 0 && a.ln_stats && ((uintptr_t)a.ln_stats & 7) == 0)) return false;
+  if (a.ln_stats_out && !(a.N % 64 == 0 && ((uintptr_t)a.ln_stats_out & 7) == 0)) return false;
   if (a.w_scale && !al16(a.w_scale)) return false;
   switch (a.epi) {
     case VIDIL_EPI_F8:

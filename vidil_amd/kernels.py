@@ -83,8 +83,9 @@ def gemm(a, w, bias=None, **kw):
       * arena=dict(q=,k=,v=,T=,H=,part0=,t_off=,arena_rows=,slot_stride=,Tcap=,q_scale=): Q rows + K/V rows
         appended to a beam-search KV arena [position][slot][H*64] (see vidil_beam_attention).
       * LayerNorm folded into a pre-LN block's GEMM pair (vidil_gemm_args.ln_fold): the residual GEMM passes
-        ``out16=`` (T16 copy of the f32 stream it writes), the next GEMM passes that copy as ``a`` with
-        ``ln=(colsum, eps)`` and weights / bias folded by ``packing.fold_layernorm``.
+        ``out16=`` (T16 copy of the f32 stream it writes) and ``ln_stats_out=`` (per-row partial sums), the next
+        GEMM passes that copy as ``a`` with ``ln=(colsum, eps, stats)`` and weights / bias folded by
+        ``packing.fold_layernorm``.
     """
     g, ret = _gemm_build(a, w, bias, **kw)
     check(_lib.load().vidil_gemm(C.byref(g), _stream()), "gemm")
@@ -100,7 +101,8 @@ def gemm_kernel_name(a, w, bias=None, **kw):
 
 
 def _gemm_build(a, w, bias=None, *, out=None, out_dtype=None, act=ACT_NONE, resid=None,
-                heads=None, patch=None, arena=None, M=None, lda=None, out16=None, ln=None, w_scale=None, dtype16=None):
+                heads=None, patch=None, arena=None, M=None, lda=None, out16=None, ln_stats_out=None, ln=None, w_scale=None,
+                dtype16=None):
     K_ = w.shape[1]
     if lda is None:
         M, Ka = a.shape
@@ -178,10 +180,17 @@ def _gemm_build(a, w, bias=None, *, out=None, out_dtype=None, act=ACT_NONE, resi
     if out16 is not None:      # LN-fold producer: the raw stream in the operand type beside the f32 one
         g.out16 = _ptr(out16, t16, "gemm.out16")
         g.ldo16 = out16.shape[-1]
-    if ln is not None:         # LN-fold consumer: (colsum f32 [N], eps); w / bias are the folded W', b'
-        colsum, eps = ln
+        if ln_stats_out is not None:     # + per-row (sum, sum of squares) partials, one pair per 64 output columns
+            if tuple(ln_stats_out.shape) != (M, N // 64, 2):
+                raise VidilHipError(f"gemm: ln_stats_out must be f32 [{M}, {N // 64}, 2], got {tuple(ln_stats_out.shape)}")
+            g.ln_stats_out = _ptr(ln_stats_out, torch.float32, "gemm.ln_stats_out")
+    if ln is not None:         # LN-fold consumer: (colsum f32 [N], eps, row partials f32 [M,K/64,2]); w / bias are the folded W', b'
+        colsum, eps, stats = ln
+        if tuple(stats.shape) != (M, K // 64, 2):
+            raise VidilHipError(f"gemm: ln stats must be f32 [{M}, {K // 64}, 2], got {tuple(stats.shape)}")
         g.ln_fold = 1
         g.ln_colsum = _ptr(colsum, torch.float32, "gemm.ln_colsum")
+        g.ln_stats = _ptr(stats, torch.float32, "gemm.ln_stats")
         g.ln_eps = float(eps)
     return g, ret
 

@@ -175,19 +175,21 @@ class VisionTransformer(PackedCache, nn.Module):
         # type (``xn`` then holds RAW x, not LN(x)) and the next GEMM applies the LayerNorm to its accumulators.
         fused = p.get("fused", False)
         nblk = len(p["blocks"])
+        stats = torch.empty((M, D // 64, 2), dtype=torch.float32, device=dev) if fused else None
         for i, b in enumerate(p["blocks"]):
             if fused and i > 0:
                 w_, b_, cs = b["qkv_f"]
-                K.gemm(xn, w_, b_, heads=heads, ln=(cs, self.ln_eps))
+                K.gemm(xn, w_, b_, heads=heads, ln=(cs, self.ln_eps, stats))
             else:
                 K.layernorm(x, b["n1g"], b["n1b"], self.ln_eps, out16=xn)
                 K.gemm(xn, b["qkv_w"], b["qkv_b"], heads=heads)
             K.attention(q, k, vt, o, Bq=B, H=H, Nq=T, Nk=T, Tq_cap=T, Tk_cap=T, NP=NP)
             if fused:
-                K.gemm(o, b["proj_w"], b["proj_b"], out=x, resid=x, out16=xn)
+                K.gemm(o, b["proj_w"], b["proj_b"], out=x, resid=x, out16=xn, ln_stats_out=stats)
                 w_, b_, cs = b["fc1_f"]
-                K.gemm(xn, w_, b_, out=hid, act=K.ACT_GELU_ERF, ln=(cs, self.ln_eps))
-                K.gemm(hid, b["fc2_w"], b["fc2_b"], out=x, resid=x, out16=xn if i + 1 < nblk else None)
+                K.gemm(xn, w_, b_, out=hid, act=K.ACT_GELU_ERF, ln=(cs, self.ln_eps, stats))
+                K.gemm(hid, b["fc2_w"], b["fc2_b"], out=x, resid=x, out16=xn if i + 1 < nblk else None,
+                       ln_stats_out=stats if i + 1 < nblk else None)
             else:
                 K.gemm(o, b["proj_w"], b["proj_b"], out=x, resid=x)
                 K.layernorm(x, b["n2g"], b["n2b"], self.ln_eps, out16=xn)
