@@ -131,6 +131,14 @@ typedef struct vidil_gemm_args {
    * (EPI_HEADS q / k / vt); EPI_F8 writes fp8; EPI_F32 / EPI_PATCH as for the 16-bit types.  The 256x256 kernel only. */
   const float* w_scale;   /* f32 [N] or NULL (= 1) */
   int32_t dtype16;        /* VIDIL_DT_F16 / VIDIL_DT_BF16 */
+  /* ---- optional second copy of W in FRAGMENT TILES, for the 128x256 two-workgroups-per-CU kernel (large M): rows
+   * padded to a multiple of 64; per (64-column block cb, K-tile t of 128 bytes of k) one 8-KiB tile at byte
+   * ((cb * K/KT + t) * 8192), holding for every lane l (row l % 32 of column tile j, k half l / 32) the 16-byte
+   * operand slots the MFMA k-steps read, each k-step's slots as contiguous 1-KiB wave loads:
+   *   16-bit: slot (j, ks) at (j*4 + ks)*1024 + l*16 = W[cb*64 + j*32 + l%32][t*64 + ks*16 + (l/32)*8 .. +8]
+   *   fp8   : slot (j, ks, h) at ((j*2 + ks)*2 + h)*1024 + l*16 = W[..][t*128 + ks*64 + (l/32)*32 + h*16 .. +16]
+   * (vidil_amd.packing.tile_weight builds it).  NULL: the kernels that stage W through LDS are used. */
+  const void* W_tiled;
 } vidil_gemm_args;
 
 /* replaces: nn.Linear calls of models/vit.py:35-41,72,84; models/med.py:153-171,

@@ -323,7 +323,15 @@ TileChoice choose_tile(const vidil_gemm_args& a) {
     const char* e = getenv("VIDIL_GEMM256");
     return !(e && e[0] == '0');
   }();
-  if (a.ln_fold || a.out16 || a.ln_stats_out || a.dtype == VIDIL_DT_FP8) return {1, 256, 256, 2};   // always the 256x256 kernel (check_args)
+  // big == 2: the 128x256 two-workgroups-per-CU kernel (needs the fragment-tiled copy of W); VIDIL_GEMM_W4=0 keeps
+  // every large problem on the 256x256 kernel
+  static const bool allow_w4 = []() {
+    const char* e = getenv("VIDIL_GEMM_W4");
+    return !(e && e[0] == '0');
+  }();
+  const bool forced_big = a.ln_fold || a.out16 || a.ln_stats_out || a.dtype == VIDIL_DT_FP8;   // (check_args)
+  if (allow_w4 && a.epi != VIDIL_EPI_ARENA && vidil_gemm128x256_eligible(a, forced_big)) return {2, 128, 256, 4};
+  if (forced_big) return {1, 256, 256, 2};
   if (allow256 && a.epi != VIDIL_EPI_ARENA && vidil_gemm256_eligible(a)) return {1, 256, 256, 2};
 #ifdef VIDIL_GEMM_TUNE
   // developer builds only: VIDIL_GEMM_TILE=<BM>x<BN>x<ST> forces one configuration
@@ -351,6 +359,7 @@ TileChoice choose_tile(const vidil_gemm_args& a) {
 template <typename T, int EPI, int ACT>
 int pick_tile(const vidil_gemm_args& a, hipStream_t s) {
   const TileChoice c = choose_tile(a);
+  if (c.big == 2) return vidil_gemm128x256_launch(a, s);
   if (c.big) return vidil_gemm256_launch(a, s);
 #define VIDIL_TRY(BM_, BN_, ST_) \
   if (c.bm == BM_ && c.bn == BN_ && c.st == ST_) return launch<T, BM_, BN_, ST_, EPI, ACT>(a, s);
@@ -369,6 +378,7 @@ int check_args(const vidil_gemm_args& a) {
   VIDIL_REQUIRE(a.dtype == VIDIL_DT_F16 || a.dtype == VIDIL_DT_BF16 || a.dtype == VIDIL_DT_FP8, "gemm: unknown dtype %d", a.dtype);
   if (a.dtype == VIDIL_DT_FP8) {
     VIDIL_REQUIRE(a.K % 128 == 0, "gemm/fp8: K=%d must be a multiple of 128", a.K);
+    VIDIL_REQUIRE(a.w_scale != nullptr, "gemm/fp8: w_scale (the per-output-column weight scale) is required");
     VIDIL_REQUIRE(a.dtype16 == VIDIL_DT_F16 || a.dtype16 == VIDIL_DT_BF16, "gemm/fp8: dtype16=%d must name the 16-bit output type", a.dtype16);
     VIDIL_REQUIRE(!a.ln_fold && !a.out16, "gemm/fp8: the LayerNorm fold is a 16-bit feature");
     VIDIL_REQUIRE(a.epi != VIDIL_EPI_F16 && a.epi != VIDIL_EPI_ARENA, "gemm/fp8: epilogue %d is not built for fp8 operands", a.epi);
@@ -383,12 +393,15 @@ int check_args(const vidil_gemm_args& a) {
     VIDIL_REQUIRE(a.epi == VIDIL_EPI_F16 || a.epi == VIDIL_EPI_HEADS, "gemm/ln_fold: only EPI_F16 / EPI_HEADS consume a folded LayerNorm");
     VIDIL_REQUIRE(a.ln_colsum != nullptr && a.ln_stats != nullptr && a.ln_eps >= 0.f, "gemm/ln_fold: null ln_colsum / ln_stats");
     VIDIL_REQUIRE(a.lda == 0 || a.lda == a.K, "gemm/ln_fold: A rows must be dense (K = the LayerNorm width)");
+    VIDIL_REQUIRE(a.K <= 1024, "gemm/ln_fold: LayerNorm widths up to 1024 (K=%d)", a.K);
   }
   if (a.out16) {
     VIDIL_REQUIRE(a.epi == VIDIL_EPI_F32, "gemm/out16: only the f32 residual epilogue writes the 16-bit copy");
     VIDIL_REQUIRE(a.ldo16 >= a.N, "gemm/out16: ldo16=%d < N=%d", a.ldo16, a.N);
   }
-  if (a.ln_stats_out) VIDIL_REQUIRE(a.epi == VIDIL_EPI_F32 && a.N % 64 == 0, "gemm/ln_stats_out: f32 residual epilogue, N %% 64 == 0");
+  if (a.ln_stats_out)
+    VIDIL_REQUIRE(a.epi == VIDIL_EPI_F32 && a.act == VIDIL_ACT_NONE && a.N % 64 == 0 && a.dtype != VIDIL_DT_FP8,
+                  "gemm/ln_stats_out: 16-bit operands, f32 residual epilogue without activation, N %% 64 == 0");
   if (a.ln_fold || a.out16 || a.ln_stats_out || a.dtype == VIDIL_DT_FP8)
     VIDIL_REQUIRE(vidil_gemm256_eligible(a, true), "gemm: this LN-folded problem does not meet the 256x256 kernel's alignment / size rules (N %% 4, 16-B aligned vectors, K >= 128)");
   switch (a.epi) {
@@ -470,7 +483,9 @@ extern "C" int vidil_gemm(const vidil_gemm_args* args, void* stream) {
   VIDIL_REQUIRE(args != nullptr, "gemm: null args");
   const int rc = check_args(*args);
   if (rc != VIDIL_OK) return rc;
-  if (args->dtype == VIDIL_DT_FP8) return vidil_gemm256_launch(*args, (hipStream_t)stream);
+  if (args->dtype == VIDIL_DT_FP8)
+    return choose_tile(*args).big == 2 ? vidil_gemm128x256_launch(*args, (hipStream_t)stream)
+                                       : vidil_gemm256_launch(*args, (hipStream_t)stream);
   if (args->dtype == VIDIL_DT_BF16) return dispatch<bf16>(*args, (hipStream_t)stream);
   return dispatch<f16>(*args, (hipStream_t)stream);
 }
@@ -483,7 +498,8 @@ extern "C" int vidil_gemm_kernel_name(const vidil_gemm_args* args, char* buf_hos
   const char* t16 = (args->dtype == VIDIL_DT_FP8 ? args->dtype16 : args->dtype) == VIDIL_DT_BF16 ? "__bf16" : "_Float16";
   const char* t = args->dtype == VIDIL_DT_FP8 ? "fp8" : t16;                 // the spelling rocprofv3 demangles to
   const int act = (args->epi == VIDIL_EPI_F16 || args->epi == VIDIL_EPI_F32 || args->epi == VIDIL_EPI_F8) ? args->act : 0;
-  if (c.big) snprintf(buf_host, n, "gemm256_kernel<%s, %s, %d, %d, %s>", t, t16, args->epi, act, args->ln_fold ? "true" : "false");
+  if (c.big) snprintf(buf_host, n, "%s<%s, %s, %d, %d, %s>", c.big == 2 ? "gemm128x256_kernel" : "gemm256_kernel", t, t16, args->epi, act,
+                      args->ln_fold ? "true" : "false");
   else snprintf(buf_host, n, "gemm_kernel<%s, %d, %d, %d, %d, %d>", t, c.bm, c.bn, c.st, args->epi, act);
   return VIDIL_OK;
 }

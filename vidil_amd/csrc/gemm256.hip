@@ -31,6 +31,7 @@
 #include <type_traits>
 
 #include "common.h"
+#include "gemm_epilogue.h"
 
 namespace {
 
@@ -65,57 +66,13 @@ struct Probe {
 };
 #endif
 
-// sum over the 16 lanes of a DPP row (all 16 end up with the total): rotations by 8, 4, 2, 1
-template <int ROR>
-__device__ __forceinline__ float row_ror_add(float v) {
-  return v + __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x120 + ROR, 0xF, 0xF, false));
-}
-__device__ __forceinline__ float row16_sum(float v) {
-  v = row_ror_add<8>(v);
-  v = row_ror_add<4>(v);
-  v = row_ror_add<2>(v);
-  return row_ror_add<1>(v);
-}
-
-// What the main loop needs to know about the operand type: a 128-byte LDS row holds one K-tile (64 x 16-bit or
-// 128 x fp8), consumed in KS MFMA k-steps; a fragment is the lane's share of one k-step of one 32-row tile.
-template <typename T>
-struct Mma {   // f16 / bf16: v_mfma_f32_32x32x16, 16 k per step, one 16-byte slot per lane
-  static constexpr int KS = 4;
-  typedef typename Elt<T>::x8 Frag;
-  static __device__ __forceinline__ Frag load(const char* row, int ks, int hi, int sw) {
-    return *(const Frag*)(row + (((ks * 2 + hi) ^ sw) << 4));
-  }
-  static __device__ __forceinline__ f32x16 mma(Frag w, Frag a, f32x16 c) { return Elt<T>::mfma32(w, a, c); }
-};
-template <>
-struct Mma<fp8> {   // e4m3: v_mfma_scale_f32_32x32x64_f8f6f4 (scales 2^0), 64 k per step, two 16-byte slots per lane
-  static constexpr int KS = 2;
-  typedef i32x8 Frag;
-  static __device__ __forceinline__ Frag load(const char* row, int ks, int hi, int sw) {
-    // operand layout of the 32x32x64 instruction (tools/micro/mx_fp8_layout.hip, measured): lane l holds row l % 32 and
-    // the 32 consecutive k of half l / 32 — two adjacent 16-byte slots of the 128-byte row
-#ifdef VIDIL_FP8_LAYOUT_INTERLEAVED   // alternative layout (16-byte halves interleaved), kept for the probe
-    const i32x4 lo = *(const i32x4*)(row + (((ks * 4 + hi) ^ sw) << 4));
-    const i32x4 hi4 = *(const i32x4*)(row + (((ks * 4 + 2 + hi) ^ sw) << 4));
-#else
-    const i32x4 lo = *(const i32x4*)(row + (((ks * 4 + hi * 2) ^ sw) << 4));
-    const i32x4 hi4 = *(const i32x4*)(row + (((ks * 4 + hi * 2 + 1) ^ sw) << 4));
-#endif
-    return Frag{lo[0], lo[1], lo[2], lo[3], hi4[0], hi4[1], hi4[2], hi4[3]};
-  }
-  static __device__ __forceinline__ f32x16 mma(Frag w, Frag a, f32x16 c) {
-    return __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(w, a, c, 0, 0, 0, 0x7f7f7f7f, 0, 0x7f7f7f7f);
-  }
-};
-
 // FOLD: LayerNorm folded into this GEMM (vidil_gemm_args.ln_fold, include/vidil_hip.h).  A holds the RAW residual
 // stream in the operand type; the producing GEMM left per-row partial sums / sums of squares (one pair per 64 columns,
 // computed in its memory-bound f32 epilogue — statistics taken from the A fragments inside THIS main loop cost 6-8 % of
 // the kernel: v_dot2c beside MFMAs).  The four waves that own the same rows each add up a quarter of the partials,
 // meet in LDS after the main loop, and the epilogue applies  y = rstd * acc - (rstd * mean) * colsum[n] + b'[n].
 // T: operand type of A and W (f16 / bf16 / fp8); TO: the 16-bit type of 16-bit outputs (== T unless T is fp8).
-template <typename T, typename TO, int EPI, int ACT, bool FOLD>
+template <typename T, typename TO, int EPI, int ACT, bool FOLD, bool STATS>
 __global__ __launch_bounds__(512) void gemm256_kernel(const vidil_gemm_args p) {
   using f16 = TO;                       // (the epilogue is written in terms of "the 16-bit output type")
   using f16x4 = typename Elt<TO>::x4;
@@ -196,7 +153,8 @@ __global__ __launch_bounds__(512) void gemm256_kernel(const vidil_gemm_args p) {
   };
 
   f32x16 acc[4][2];
-  float st_s[4], st_ss[4];   // FOLD: per row tile `it` — partial sum / sum of squares, later rstd / mean*rstd
+  float st_s[4], st_ss[4];   // FOLD: per row tile `it` — rstd / mean*rstd of the lane's row
+  f32x2 st_raw[4][2];        // FOLD: this lane's share of the producer's (sum, sum of squares) row partials
 
   const int sw = (l31 >> 1) & 7;
   const int a_off = grp * SLOT + l31 * 128;
@@ -238,7 +196,10 @@ __global__ __launch_bounds__(512) void gemm256_kernel(const vidil_gemm_args p) {
   auto half_period = [&](auto rh_tag, const char* buf, int h) {
     constexpr int RH = decltype(rh_tag)::value;
     const char* ab = buf + a_off + RH * 8192;
-    Frag a[KS][2];
+    // 16-bit operands: A fragments one k-step ahead.  fp8 fragments are 8-register tuples: one k-step's worth at a
+    // time (the look-ahead made the allocator spill >2000 registers; the other wave of the SIMD covers the LDS latency)
+    constexpr int NA = ESZ == 2 ? KS : 1;
+    Frag a[NA][2];
 #pragma unroll
     for (int i = 0; i < 2; ++i) a[0][i] = Mma<T>::load(ab + i * 4096, 0, hi, sw);
     if constexpr (RH == 0) {
@@ -249,15 +210,20 @@ __global__ __launch_bounds__(512) void gemm256_kernel(const vidil_gemm_args p) {
     }
 #pragma unroll
     for (int ks = 0; ks < KS; ++ks) {
-      if (ks < KS - 1) {
+      if constexpr (NA > 1) {
+        if (ks < KS - 1) {
 #pragma unroll
-        for (int i = 0; i < 2; ++i) a[ks + 1][i] = Mma<T>::load(ab + i * 4096, ks + 1, hi, sw);
+          for (int i = 0; i < 2; ++i) a[ks + 1][i] = Mma<T>::load(ab + i * 4096, ks + 1, hi, sw);
+        }
+      } else if (ks > 0) {
+#pragma unroll
+        for (int i = 0; i < 2; ++i) a[0][i] = Mma<T>::load(ab + i * 4096, ks, hi, sw);
       }
 #pragma unroll
       for (int i = 0; i < 2; ++i)
 #pragma unroll
         for (int j = 0; j < 2; ++j)
-          acc[RH * 2 + i][j] = Mma<T>::mma(wf[j][ks], a[ks][i], acc[RH * 2 + i][j]);
+          acc[RH * 2 + i][j] = Mma<T>::mma(wf[j][ks], a[NA > 1 ? ks : 0][i], acc[RH * 2 + i][j]);
       // this half-period's (up to) three DMA pieces go out behind MFMAs, never right in front of the next barrier
       if constexpr (KS == 4) {
         if (ks < 3) dma_piece(h, ks);
@@ -286,20 +252,16 @@ __global__ __launch_bounds__(512) void gemm256_kernel(const vidil_gemm_args p) {
   if constexpr (FOLD) {
     // this wave's share of the producer's row partials (parts wc, wc+4, ...; the half-waves alternate): issued here,
     // consumed after the main loop
-    const int nparts = K >> 6;
+    // (loaded here, summed after the main loop: used right away they would expose a full memory latency per tile)
+    const int nparts = K >> 6;            // <= 16 (check_args: K <= 1024 for folded consumers)
     const f32x2* stats_in = (const f32x2*)p.ln_stats;
+    const int part0 = wc + 4 * hi;
 #pragma unroll
     for (int it = 0; it < 4; ++it) {
       int row = m0 + grp * 128 + it * 32 + l31;
       row = row < M ? row : M - 1;
-      float s = 0.f, ss = 0.f;
-      for (int part = wc + 4 * hi; part < nparts; part += 8) {
-        const f32x2 v = stats_in[(size_t)row * nparts + part];
-        s += v[0];
-        ss += v[1];
-      }
-      st_s[it] = s;
-      st_ss[it] = ss;
+      st_raw[it][0] = part0 < nparts ? stats_in[(size_t)row * nparts + part0] : f32x2{0.f, 0.f};
+      st_raw[it][1] = part0 + 8 < nparts ? stats_in[(size_t)row * nparts + part0 + 8] : f32x2{0.f, 0.f};
     }
   }
 
@@ -331,8 +293,9 @@ __global__ __launch_bounds__(512) void gemm256_kernel(const vidil_gemm_args p) {
     f32x2* stats = (f32x2*)(smem + LDS_BYTES);
 #pragma unroll
     for (int it = 0; it < 4; ++it) {
-      const float s = st_s[it] + __shfl_xor(st_s[it], 32, 64);
-      const float ss = st_ss[it] + __shfl_xor(st_ss[it], 32, 64);
+      const float s0 = st_raw[it][0][0] + st_raw[it][1][0], ss0 = st_raw[it][0][1] + st_raw[it][1][1];
+      const float s = s0 + __shfl_xor(s0, 32, 64);
+      const float ss = ss0 + __shfl_xor(ss0, 32, 64);
       if (hi == 0) stats[(grp * 4 + wc) * 128 + it * 32 + l31] = f32x2{s, ss};
     }
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
@@ -363,296 +326,17 @@ __global__ __launch_bounds__(512) void gemm256_kernel(const vidil_gemm_args p) {
   // The next tile's first K-tile goes out NOW, into K-tile buffer 0 (every wave is past the barrier above, so
   // the ring is idle); the epilogue below transposes through buffer 1 only.  Its latency — an HBM miss on a new
   // A panel — is then covered by the epilogue instead of idling the CU at the top of the next tile.
-  const bool more = kPersistent<EPI> && remaining > tile_step;   // uniform
+  // (fp8 operands: one tile per workgroup too — the next tile's state across the epilogue costs a few spilled registers)
+  const bool more = kPersistent<EPI> && ESZ == 2 && remaining > tile_step;   // uniform
   if (more) {
     logical += tile_step;
     remaining -= tile_step;
     setup_tile(logical);
     prologue();
   }
-  // (the tile loop continues at `next_tile:`; all early exits of the epilogue go there)
   do {
-  if (n_w >= N) break;
-  char* ep = smem + BUF + wave * 8192;  // private 8 KiB transposition buffer of this wave, inside K-tile buffer 1
-
-  if constexpr (FOLD) {
-    // y = rstd * acc + (b' - (mean * rstd) * colsum): LayerNorm applied to the accumulators (see the kernel comment)
-#pragma unroll
-    for (int j = 0; j < 2; ++j)
-#pragma unroll
-      for (int rq = 0; rq < 4; ++rq) {
-        const int col = n_w + j * 32 + rq * 8 + hi * 4;
-        if (col + 4 <= N) {
-          const f32x4 c4 = *(const f32x4*)(p.ln_colsum + col);
-          f32x4 b4 = {0.f, 0.f, 0.f, 0.f};
-          if (p.bias != nullptr) b4 = *(const f32x4*)(p.bias + col);
-#pragma unroll
-          for (int it = 0; it < 4; ++it)
-#pragma unroll
-            for (int e = 0; e < 4; ++e)
-              acc[it][j][rq * 4 + e] = __builtin_fmaf(acc[it][j][rq * 4 + e], st_s[it], __builtin_fmaf(-st_ss[it], c4[e], b4[e]));
-        }
-      }
-  } else if (ESZ == 1 && p.w_scale != nullptr) {
-    // fp8 weights are stored as W / w_scale[n]: scale the accumulators back, then the bias
-#pragma unroll
-    for (int j = 0; j < 2; ++j)
-#pragma unroll
-      for (int rq = 0; rq < 4; ++rq) {
-        const int col = n_w + j * 32 + rq * 8 + hi * 4;
-        if (col + 4 <= N) {
-          const f32x4 w4 = *(const f32x4*)(p.w_scale + col);
-          f32x4 b4 = {0.f, 0.f, 0.f, 0.f};
-          if (p.bias != nullptr) b4 = *(const f32x4*)(p.bias + col);
-#pragma unroll
-          for (int it = 0; it < 4; ++it)
-#pragma unroll
-            for (int e = 0; e < 4; ++e) acc[it][j][rq * 4 + e] = __builtin_fmaf(acc[it][j][rq * 4 + e], w4[e], b4[e]);
-        }
-      }
-  } else
-  // bias folded into the accumulators once (4 consecutive columns per register quad)
-  if (p.bias != nullptr) {
-#pragma unroll
-    for (int j = 0; j < 2; ++j)
-#pragma unroll
-      for (int rq = 0; rq < 4; ++rq) {
-        const int col = n_w + j * 32 + rq * 8 + hi * 4;
-        if (col + 4 <= N) {
-          const f32x4 b4 = *(const f32x4*)(p.bias + col);
-#pragma unroll
-          for (int it = 0; it < 4; ++it)
-#pragma unroll
-            for (int e = 0; e < 4; ++e) acc[it][j][rq * 4 + e] += b4[e];
-        }
-      }
-  }
-  // activation in place, two accumulators per packed-f32 instruction
-  if constexpr (ACT != VIDIL_ACT_NONE) {
-#pragma unroll
-    for (int it = 0; it < 4; ++it)
-#pragma unroll
-      for (int j = 0; j < 2; ++j)
-#pragma unroll
-        for (int r = 0; r < 16; r += 2) {
-          f32x2 v = {acc[it][j][r], acc[it][j][r + 1]};
-          v = ACT == VIDIL_ACT_GELU_ERF ? gelu_erf2(v) : quick_gelu2(v);
-          acc[it][j][r] = v[0];
-          acc[it][j][r + 1] = v[1];
-        }
-  }
-  auto value = [&](int it, int j, int rq, int e) { return acc[it][j][rq * 4 + e]; };
-
-  int part = 0, head = 0;
-  if constexpr (EPI == VIDIL_EPI_HEADS) {
-    const int hd = p.H * 64;
-    part = p.part0 + n_w / hd;
-    head = (n_w % hd) >> 6;
-  }
-
-  if constexpr (EPI == VIDIL_EPI_HEADS) {
-    if (part == 2 && p.kv_tiled) {
-      // V in fragment tiles (common.h vtile_off).  A lane's accumulator row is one KEY, but the layout keeps the 4
-      // keys {4q .. 4q+3} of a dimension d side by side (8 B): each block of 32 keys goes through the wave's LDS
-      // scratch as [key][d] (rows padded to 136 B), then lane d collects runs of 4 tile-aligned keys of one image
-      // and stores them as 8 B; keys cut off by the block or the image boundary are stored one by one.
-      constexpr int ROWB = 136;
-      const size_t img_stride = (size_t)p.H * p.Tk_cap * 64;
-      f16* const vbase = (f16*)p.vt + (size_t)head * p.Tk_cap * 64;
-#pragma unroll
-      for (int it = 0; it < 4; ++it) {
-        const int mb = m_w + it * 32;
-        const int rows = M - mb < 32 ? M - mb : 32;   // wave-uniform
-        if (rows <= 0) break;
-#pragma unroll
-        for (int j = 0; j < 2; ++j)
-#pragma unroll
-          for (int rq = 0; rq < 4; ++rq) {
-            const f16x4 v = {Elt<TO>::from_f32(value(it, j, rq, 0)), Elt<TO>::from_f32(value(it, j, rq, 1)), Elt<TO>::from_f32(value(it, j, rq, 2)),
-                             Elt<TO>::from_f32(value(it, j, rq, 3))};
-            *(f16x4*)(ep + l31 * ROWB + (j * 32 + rq * 8 + hi * 4) * 2) = v;
-          }
-        int b = mb / p.T, t = mb - b * p.T;
-        for (int r = 0; r < rows;) {
-          const int tt = p.t_off + t;
-          f16* dst = vbase + (size_t)b * img_stride + vtile_off(tt, lane);
-          const char* src = ep + r * ROWB + lane * 2;
-          if ((tt & 3) == 0 && r + 4 <= rows && t + 4 <= p.T) {
-            const f16x4 v = {*(const f16*)src, *(const f16*)(src + ROWB), *(const f16*)(src + 2 * ROWB),
-                             *(const f16*)(src + 3 * ROWB)};
-            *(f16x4*)dst = v;
-            r += 4;
-            t += 4;
-          } else {
-            *dst = *(const f16*)src;
-            r += 1;
-            t += 1;
-          }
-          if (t >= p.T) { t -= p.T; ++b; }
-        }
-      }
-      break;
-    }
-    if (part == 2 && p.NP != 0) {   // (NP == 0: V stays row-major and takes the 16-B store path of K below)
-      // V^T: element (row m, column d) goes to VT[b][h][d][t_off+t]; consecutive lanes = consecutive t
-#pragma unroll
-      for (int it = 0; it < 4; ++it) {
-        const int m = m_w + it * 32 + l31;
-        if (m < M) {
-          const int b = m / p.T, t = m - b * p.T;
-          f16* dst = (f16*)p.vt + (((size_t)b * p.H + head) * 64) * (size_t)p.NP + vt_pos(p.t_off + t);
-#pragma unroll
-          for (int j = 0; j < 2; ++j)
-#pragma unroll
-            for (int rq = 0; rq < 4; ++rq)
-#pragma unroll
-              for (int e = 0; e < 4; ++e) dst[(size_t)(j * 32 + rq * 8 + hi * 4 + e) * p.NP] = Elt<TO>::from_f32(value(it, j, rq, e));
-        }
-      }
-      break;
-    }
-  }
-
-  if constexpr (EPI == VIDIL_EPI_F8) {
-    // ---- fp8 rows of 64 columns (64 B), two passes of 64 rows: [64][64] bytes, 16-B chunk index XOR ((row>>2)&3) ----
-#pragma unroll
-    for (int pass = 0; pass < 2; ++pass) {
-#pragma unroll
-      for (int i = 0; i < 2; ++i) {
-        const int it = pass * 2 + i;
-        const int row = i * 32 + l31;
-#pragma unroll
-        for (int j = 0; j < 2; ++j)
-#pragma unroll
-          for (int rq = 0; rq < 4; ++rq) {
-            const int cb = j * 32 + rq * 8 + hi * 4;      // first of 4 consecutive columns = byte offset in the row
-            *(uint32_t*)(ep + row * 64 + ((((cb >> 4) ^ ((row >> 2) & 3)) << 4) | (cb & 15))) =
-                pack4_fp8(value(it, j, rq, 0), value(it, j, rq, 1), value(it, j, rq, 2), value(it, j, rq, 3));
-          }
-      }
-      const int ch = lane & 3;
-#pragma unroll
-      for (int iter = 0; iter < 4; ++iter) {
-        const int row = iter * 16 + (lane >> 2);
-        const i32x4 v = *(const i32x4*)(ep + row * 64 + ((ch ^ ((row >> 2) & 3)) << 4));
-        const int m = m_w + pass * 64 + row;
-        const int col = n_w + ch * 16;
-        if (m < M && col + 16 <= N) *(i32x4*)((char*)p.out + (size_t)m * p.ldo + col) = v;
-      }
-    }
-  } else if constexpr (EPI == VIDIL_EPI_F16 || EPI == VIDIL_EPI_HEADS) {
-    // ---- f16 rows of 64 columns, two passes of 64 rows: [64][64] halfs, 16-B chunk index XOR (row&7) ------
-    const float scale = (EPI == VIDIL_EPI_HEADS && part == 0) ? p.q_scale : 1.0f;
-#pragma unroll
-    for (int pass = 0; pass < 2; ++pass) {
-#pragma unroll
-      for (int i = 0; i < 2; ++i) {
-        const int it = pass * 2 + i;
-        const int row = i * 32 + l31;
-#pragma unroll
-        for (int j = 0; j < 2; ++j)
-#pragma unroll
-          for (int rq = 0; rq < 4; ++rq) {
-            const f16x4 v = {Elt<TO>::from_f32(value(it, j, rq, 0) * scale), Elt<TO>::from_f32(value(it, j, rq, 1) * scale),
-                             Elt<TO>::from_f32(value(it, j, rq, 2) * scale), Elt<TO>::from_f32(value(it, j, rq, 3) * scale)};
-            *(f16x4*)(ep + row * 128 + (((j * 4 + rq) ^ (row & 7)) << 4) + hi * 8) = v;
-          }
-      }
-      const int ch = lane & 7;
-#pragma unroll 4
-      for (int iter = 0; iter < 8; ++iter) {
-        const int row = iter * 8 + (lane >> 3);
-        const f16x8 v = *(const f16x8*)(ep + row * 128 + ((ch ^ (row & 7)) << 4));
-        const int m = m_w + pass * 64 + row;
-        const int col = n_w + ch * 8;
-        if (m < M && col + 8 <= N) {
-          if constexpr (EPI == VIDIL_EPI_F16) {
-            *(f16x8*)((f16*)p.out + (size_t)m * p.ldo + col) = v;
-          } else {
-            const int b = m / p.T, t = m - b * p.T;
-            const size_t bh = (size_t)b * p.H + head;
-            if (part == 0) {
-              *(f16x8*)((f16*)p.q + (bh * p.Tq_cap + t) * 64 + ch * 8) = v;
-            } else {
-              f16* kv = (f16*)(part == 1 ? p.k : p.vt);
-              if (p.kv_tiled) {   // K in fragment tiles: the lane's 8 columns are one 16-B slot of its key's row
-                *(f16x8*)(kv + bh * p.Tk_cap * 64 + ktile_off(p.t_off + t, ch * 8)) = v;
-              } else {
-                *(f16x8*)(kv + (bh * p.Tk_cap + p.t_off + t) * 64 + ch * 8) = v;
-              }
-            }
-          }
-        }
-      }
-    }
-  } else {
-    // ---- f32 rows of 64 columns, four passes of 32 rows: [32][64] floats, chunk XOR (row&7) ------------
-#pragma unroll
-    for (int pass = 0; pass < 4; ++pass) {
-      // residual / position rows of this pass: all 8 loads of a lane go out before the LDS round trip, so
-      // their latency is paid once per pass (the dependent load -> add -> store chain paid it per group)
-      f32x4 add[8];
-      {
-        const int ch = lane & 15;
-        const int col = n_w + ch * 4;
-#pragma unroll
-        for (int iter = 0; iter < 8; ++iter) {
-          const int lr = iter * 4 + (lane >> 4);
-          const int m = m_w + pass * 32 + lr;
-          add[iter] = f32x4{0.f, 0.f, 0.f, 0.f};
-          if (m < M && col + 4 <= N) {
-            if constexpr (EPI == VIDIL_EPI_F32) {
-              if (p.resid != nullptr) add[iter] = *(const f32x4*)(p.resid + (size_t)m * p.ldo + col);
-            } else {  // EPI_PATCH
-              const int t = m % p.tpi;
-              add[iter] = *(const f32x4*)(p.pos + (size_t)(t + 1) * N + col);
-            }
-          }
-        }
-      }
-      {
-        const int it = pass;
-        const int lr = l31;
-#pragma unroll
-        for (int j = 0; j < 2; ++j)
-#pragma unroll
-          for (int rq = 0; rq < 4; ++rq) {
-            const f32x4 v = {value(it, j, rq, 0), value(it, j, rq, 1), value(it, j, rq, 2), value(it, j, rq, 3)};
-            *(f32x4*)(ep + lr * 256 + (((j * 8 + rq * 2 + hi) ^ (lr & 7)) << 4)) = v;
-          }
-      }
-      const int ch = lane & 15;
-#pragma unroll
-      for (int iter = 0; iter < 8; ++iter) {
-        const int lr = iter * 4 + (lane >> 4);
-        f32x4 v = *(const f32x4*)(ep + lr * 256 + ((ch ^ (lr & 7)) << 4));
-        const int m = m_w + pass * 32 + lr;
-        const int col = n_w + ch * 4;
-        const bool ok = m < M && col + 4 <= N;
-        if (ok) v += add[iter];
-        if constexpr (EPI == VIDIL_EPI_F32) {
-          if (p.ln_stats_out != nullptr) {   // wave-uniform: LN-fold producer — (sum, sum of squares) of this row's 64 columns
-            const f32x4 z = ok ? v : f32x4{0.f, 0.f, 0.f, 0.f};
-            const float s = row16_sum((z[0] + z[1]) + (z[2] + z[3]));
-            const float ss = row16_sum((z[0] * z[0] + z[1] * z[1]) + (z[2] * z[2] + z[3] * z[3]));
-            if (ch == 0 && m < M) *(f32x2*)(p.ln_stats_out + ((size_t)m * (N >> 6) + (n_w >> 6)) * 2) = f32x2{s, ss};
-          }
-        }
-        if (ok) {
-          if constexpr (EPI == VIDIL_EPI_F32) {
-            *(f32x4*)((float*)p.out + (size_t)m * p.ldo + col) = v;
-            if (p.out16 != nullptr) {   // the raw stream in the operand type, for the LN-folded consumer GEMM
-              const f16x4 h4 = {Elt<TO>::from_f32(v[0]), Elt<TO>::from_f32(v[1]), Elt<TO>::from_f32(v[2]), Elt<TO>::from_f32(v[3])};
-              *(f16x4*)((f16*)p.out16 + (size_t)m * p.ldo16 + col) = h4;
-            }
-          } else {  // EPI_PATCH
-            const int b = m / p.tpi;
-            *(f32x4*)((float*)p.out + ((size_t)m + b + 1) * p.ldo + col) = v;
-          }
-        }
-      }
-    }
-  }
+    char* const ep = smem + BUF + wave * 8192;   // private 8-KiB transposition buffer of this wave, inside K-tile buffer 1
+#include "gemm_epilogue.inc"
   } while (0);
   if (!more) break;
   // Before the next tile's counted waits: drain this tile's epilogue traffic (and, with it, the prologue issued
@@ -662,10 +346,10 @@ __global__ __launch_bounds__(512) void gemm256_kernel(const vidil_gemm_args p) {
   }  // tile loop
 }
 
-template <typename T, int EPI, int ACT, bool FOLD = false, typename TO = T>
+template <typename T, int EPI, int ACT, bool FOLD = false, typename TO = T, bool STATS = false>
 int launch256(const vidil_gemm_args& a, hipStream_t s) {
   static bool attr_set = false;
-  auto kern = gemm256_kernel<T, TO, EPI, ACT, FOLD>;
+  auto kern = gemm256_kernel<T, TO, EPI, ACT, FOLD, STATS>;
   constexpr int lds = LDS_BYTES + (FOLD ? STATS_BYTES : 0);
   if (!attr_set) {
     hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
@@ -684,7 +368,7 @@ int launch256(const vidil_gemm_args& a, hipStream_t s) {
   }
   // persistent grid: one workgroup per CU (a multiple of 8 so every XCD gets the same number), never more than tiles
   const int ntiles = ((a.M + 255) / 256) * ((a.N + 255) / 256);
-  const int tiles = !kPersistent<EPI> ? ntiles : ntiles >= num_cu ? num_cu : (ntiles >= 8 ? (ntiles & ~7) : ntiles);
+  const int tiles = !(kPersistent<EPI> && sizeof(T) == 2) ? ntiles : ntiles >= num_cu ? num_cu : (ntiles >= 8 ? (ntiles & ~7) : ntiles);
   hipLaunchKernelGGL(kern, dim3(tiles), dim3(512), lds, s, a);
   VIDIL_CHECK_LAUNCH("gemm256");
   return VIDIL_OK;
@@ -743,6 +427,7 @@ static int launch256_dispatch(const vidil_gemm_args& a, hipStream_t s) {
       if (a.act == VIDIL_ACT_GELU_ERF) return launch256<T, VIDIL_EPI_F16, VIDIL_ACT_GELU_ERF>(a, s);
       return launch256<T, VIDIL_EPI_F16, VIDIL_ACT_QUICK_GELU>(a, s);
     case VIDIL_EPI_F32:
+      if (a.ln_stats_out) return launch256<T, VIDIL_EPI_F32, VIDIL_ACT_NONE, false, T, true>(a, s);   // (check_args: no activation)
       if (a.act == VIDIL_ACT_NONE) return launch256<T, VIDIL_EPI_F32, VIDIL_ACT_NONE>(a, s);
       if (a.act == VIDIL_ACT_GELU_ERF) return launch256<T, VIDIL_EPI_F32, VIDIL_ACT_GELU_ERF>(a, s);
       return launch256<T, VIDIL_EPI_F32, VIDIL_ACT_QUICK_GELU>(a, s);

@@ -116,6 +116,9 @@ def _gemm_build(a, w, bias=None, *, out=None, out_dtype=None, act=ACT_NONE, resi
     g.dtype = _dt(a, "gemm.A", fp8_ok=True)
     g.A = _ptr(a, a.dtype, "gemm.A")
     g.W = _ptr(w, a.dtype, "gemm.W")
+    wt = getattr(w, "_vidil_tiled", None)        # fragment-tiled copy (packing.with_tiles): the 2-workgroups-per-CU kernel
+    if wt is not None and wt.device == w.device:
+        g.W_tiled = wt.data_ptr()
     fp8 = g.dtype == DT_FP8
     # fp8 operands (tower mode): 16-bit outputs are written in the companion type (taken from the output buffers)
     t16 = a.dtype

@@ -38,7 +38,8 @@ def w8(*weights):
     of every output row at half of e4m3's range (224 of 448): the GEMM epilogue multiplies the accumulator by scale[n]."""
     w = (weights[0] if len(weights) == 1 else torch.cat(list(weights), dim=0)).detach().float()
     scale = (w.abs().amax(dim=1) / 224.0).clamp_min(1e-12)
-    return (w / scale[:, None]).to(FP8).contiguous(), scale.contiguous()
+    q = (w / scale[:, None]).to(FP8).contiguous()
+    return (with_tiles(q) if q.is_cuda else q), scale.contiguous()
 
 
 _default = [as_compute_dtype(os.environ.get("VIDIL_DTYPE", "f16"))]
@@ -63,6 +64,33 @@ def compute_dtype(module=None):
     return d if d is not None else _default[0]
 
 
+def tile_weight(w):
+    """The fragment-tiled copy of a GEMM weight [N,K] (16-bit or e4m3) that the 128x256 two-workgroups-per-CU kernel
+    reads straight from L2 into MFMA operand registers (include/vidil_hip.h: vidil_gemm_args.W_tiled).  Rows are zero
+    padded to a multiple of 64.  Layout: [64-column block][K-tile of 128 bytes][8 KiB in operand order]."""
+    N, K = w.shape
+    esz = w.element_size()
+    kt = 128 // esz                                  # elements per K-tile
+    if K % kt:
+        raise ValueError(f"tile_weight: K={K} must be a multiple of {kt}")
+    Np = (N + 63) // 64 * 64
+    raw = w.contiguous().view(torch.uint8).view(N, K * esz)
+    if Np != N:
+        raw = torch.cat([raw, torch.zeros((Np - N, K * esz), dtype=torch.uint8, device=w.device)], dim=0)
+    if esz == 2:    # [cb, j, l31, t, ks, hi, 16 B] -> [cb, t, j, ks, hi, l31, 16 B]  (lane = hi*32 + l31)
+        v = raw.view(Np // 64, 2, 32, K // 64, 4, 2, 16).permute(0, 3, 1, 4, 5, 2, 6)
+    else:           # [cb, j, l31, t, ks, hi, half, 16 B] -> [cb, t, j, ks, half, hi, l31, 16 B]
+        v = raw.view(Np // 64, 2, 32, K // 128, 2, 2, 2, 16).permute(0, 3, 1, 4, 6, 5, 2, 7)
+    return v.contiguous().view(-1)
+
+
+def with_tiles(w):
+    """Attach the fragment-tiled copy to a packed weight (kernels.gemm passes it along when present; slices of the
+    weight simply do not carry it and take the LDS-staged kernels)."""
+    w._vidil_tiled = tile_weight(w)
+    return w
+
+
 def fingerprint(module) -> tuple:
     return tuple((p.data_ptr(), p._version, p.device.index) for p in module.parameters()) + (compute_dtype(module),)
 
@@ -70,7 +98,8 @@ def fingerprint(module) -> tuple:
 def w16(*weights, dtype=None):
     """Concatenate nn.Linear weights along N and cast to the contiguous 16-bit GEMM operand [N,K]."""
     w = weights[0] if len(weights) == 1 else torch.cat(list(weights), dim=0)
-    return w.detach().to(dtype or _default[0]).contiguous()
+    w = w.detach().to(dtype or _default[0]).contiguous()
+    return with_tiles(w) if w.is_cuda and w.shape[1] % 64 == 0 and w.shape[0] >= 256 else w
 
 
 def w16_patch(conv_weight, dtype=None):
@@ -95,6 +124,8 @@ def fold_layernorm(weight, bias, gamma, beta, dtype=None):
     if bias is not None:
         b = b + bias.detach().float()
     colsum = wf.double().sum(dim=1).float()
+    if wf.is_cuda:
+        with_tiles(wf)
     return wf, b.contiguous(), colsum.contiguous()
 
 
