@@ -86,12 +86,8 @@ def test_argument_validation_without_a_gpu():
     assert lib.vidil_gemm_kernel_name(ctypes.byref(g), buf, 128) == -1 and b"w_scale" in lib.vidil_last_error()
     g.w_scale = 16
     assert lib.vidil_gemm_kernel_name(ctypes.byref(g), buf, 128) == 0 and buf.value == b"gemm256_kernel<fp8, _Float16, 1, 0, false>"
-    g.W_tiled = 16                                  # fragment-tiled copy supplied: the two-workgroups-per-CU kernel
-    assert lib.vidil_gemm_kernel_name(ctypes.byref(g), buf, 128) == 0 and buf.value == b"gemm128x256_kernel<fp8, _Float16, 1, 0, false>"
-    g.dtype, g.M, g.w_scale = 0, 201728, None
-    assert lib.vidil_gemm_kernel_name(ctypes.byref(g), buf, 128) == 0 and buf.value == b"gemm128x256_kernel<_Float16, _Float16, 1, 0, false>"
-    g.M = 3072                                      # too few tiles: the small-tile kernel, tiled copy or not
-    assert lib.vidil_gemm_kernel_name(ctypes.byref(g), buf, 128) == 0 and buf.value.startswith(b"gemm_kernel<_Float16, ")
+    g.W_tiled = 16                                  # a fragment-tiled copy alone changes nothing: the 128x256 kernel is opt-in
+    assert lib.vidil_gemm_kernel_name(ctypes.byref(g), buf, 128) == 0 and buf.value == b"gemm256_kernel<fp8, _Float16, 1, 0, false>"
     # out_dtype of the attention: fp8 only from the staged kernel
     assert lib.vidil_attention(16, 16, 16, 16, None, None, None, 0, 0, 1, 12, 4, 64, 4, 64, 64, 1, 0, 0, 768, 0, 0, 2, None) == -1
     assert b"out_dtype" in lib.vidil_last_error()
