@@ -195,10 +195,13 @@ def main():
     ap.add_argument("--cpu-sample-videos", type=int, default=1)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
+    ap.add_argument("--sequential", action="store_true",
+                    help="CapFilt, then visual tokens (the reference's order) instead of vidil_amd.pipeline's interleaving")
     args = ap.parse_args()
 
     from vidil_amd import dist as vdist
     from vidil_amd.capfilt import CapFiltEngine
+    from vidil_amd.pipeline import FramePipeline
     from vidil_amd.visual_tokenization import VisualTokenizer
 
     if not torch.cuda.is_available():
@@ -229,11 +232,15 @@ def main():
     frames = torch.from_numpy(synthetic_frames(Nv, F, args.size, first)).to(dev)
     video_ids = [f"video{first + i}" for i in range(Nv)]
 
+    pipe = FramePipeline(engine, vtok)
+
     def step():
         items = [dict(video_id=v, text=[]) for v in video_ids]
-        engine.process(items, frames)
-        toks = vtok.process(video_ids, frames, [it["unfiltered_text"] for it in items])
-        return items, toks
+        if args.sequential:                      # the two scripts one after the other, as the reference runs them
+            engine.process(items, frames)
+            toks = vtok.process(video_ids, frames, [it["unfiltered_text"] for it in items])
+            return items, toks
+        return pipe.process(items, frames)
 
     def log(msg):
         if rank == 0:

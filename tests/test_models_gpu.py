@@ -763,6 +763,36 @@ def test_results_do_not_depend_on_batch_composition(full_models):
         assert t[f"video{v}"] == all_t[f"video{v}"]
 
 
+def test_interleaved_pipeline_gives_the_results_of_the_two_engines_called_in_turn(full_models):
+    """vidil_amd.pipeline.FramePipeline only re-orders the queueing (towers back to back, host string work behind
+    events): items and visual tokens must equal CapFiltEngine.process followed by VisualTokenizer.process, also with
+    original captions kept and with sentence splitting of the originals switched off."""
+    from vidil_amd.capfilt import CapFiltEngine
+    from vidil_amd.pipeline import FramePipeline
+    from vidil_amd.visual_tokenization import VisualTokenizer
+
+    fm = full_models
+    Nv, F = 3, 8
+    u8 = torch.from_numpy(synthetic_frames(Nv, F, first_video=23)).to(DEV)
+    emb, texts = _ontology()
+    for keep, gen_only in ((False, True), (True, False)):
+        cfg = dict(caption=True, filter=True, filter_generated_only=gen_only, keep_original_caption=keep, threshold=0.4,
+                   filter_mode="max_filter", generation_mode="beam", image_size=224, vit="base", topk_visualize=5,
+                   do_sentence_tokenization=False)
+        eng = CapFiltEngine(cfg, DEV, captioner=fm["cap"], filterer=fm["itm"])
+        vt = VisualTokenizer(cfg, fm["clip"], texts, emb, DEV)
+
+        def fresh():
+            return [dict(video_id=f"video{v}", text=["a person is cooking"] if keep else []) for v in range(Nv)]
+
+        a = fresh()
+        eng.process(a, u8)
+        ta = vt.process([it["video_id"] for it in a], u8, [it["unfiltered_text"] for it in a])
+        b, tb = FramePipeline(eng, vt).process(fresh(), u8)
+        assert a == b and ta == tb
+        assert all(len(it["unfiltered_text"]) >= 1 for it in b)
+
+
 def test_vit_with_fused_layernorm_matches_the_unfused_path_and_the_oracle():
     """fuse_layernorm moves the rounding point of the GEMM operand from LN(x) to x; both variants must sit within the
     same tolerance of the fp32 oracle, and within ~2x the f16 tolerance of each other."""

@@ -5,15 +5,15 @@
 import collections
 import csv
 import glob
-import re
+import os
 import sys
+
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+from kernel_names import pretty  # noqa: E402
 
 
 def short(name):
-    name = re.sub(r"\(anonymous namespace\)::", "", name)
-    name = re.sub(r"^void ", "", name)
-    name = re.sub(r"\(.*$", "", name)
-    return name[:90]
+    return pretty(name)[:90]
 
 
 def main():

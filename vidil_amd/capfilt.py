@@ -141,16 +141,39 @@ class CapFiltEngine:
         self.filterer = filterer.eval().to(self.device)
         self.last_stats = {}
         self.last_frame_captions = []
+        self._pinned = {}
 
     @torch.no_grad()
     def process(self, items, frames_u8):
         """items: list of dicts {'video_id', 'text': [original captions]}; frames_u8: uint8 [Nv,F,H,W,3]
         device tensor (any H x W: resized to S x S like ``process_frame``, run_video_CapFilt.py:128-134).
-        Fills item['text'] / item['unfiltered_text'] like run_video_CapFilt.py:166-204."""
+        Fills item['text'] / item['unfiltered_text'] like run_video_CapFilt.py:166-204.
+
+        The four phases below are public so a caller can put other GPU work between them (vidil_amd.pipeline does, with
+        the CLIP visual tokens): the host only ever waits on an event recorded right after the results it needs, while
+        the queue behind that event already holds the next tower."""
+        st = self.begin(items, frames_u8)
+        self.encode_filter_frames(st)
+        self.captions_ready(st)
+        return self.finish(st)
+
+    def _to_host(self, key, t):
+        """Enqueue a device->pinned-host copy of ``t`` and an event behind it; returns (host tensor, event)."""
+        buf = self._pinned.get(key)
+        if buf is None or buf.shape != t.shape or buf.dtype != t.dtype:
+            buf = self._pinned[key] = torch.empty(t.shape, dtype=t.dtype, pin_memory=True)
+        buf.copy_(t, non_blocking=True)
+        ev = torch.cuda.Event()
+        ev.record()
+        return buf, ev
+
+    @torch.no_grad()
+    def begin(self, items, frames_u8):
+        """Phase 1 (no host wait): resize, caption ViT, the whole beam / nucleus decode, token ids on their way to the host."""
         cfg = self.config
         Nv, F = frames_u8.shape[0], frames_u8.shape[1]
-        flat = blip_frames(frames_u8.reshape(Nv * F, *frames_u8.shape[2:]), cfg.get("image_size", 224))
-        generated = [[] for _ in range(Nv)]
+        st = dict(items=items, Nv=Nv, F=F, tok=None, fy16=None, itm=None)
+        st["flat"] = flat = blip_frames(frames_u8.reshape(Nv * F, *frames_u8.shape[2:]), cfg.get("image_size", 224))
         if cfg["caption"]:
             _, y16 = self.captioner.visual_encoder.forward_u8(flat, CLIP_MEAN, CLIP_STD)
             if cfg.get("generation_mode", "beam") == "beam":
@@ -158,10 +181,28 @@ class CapFiltEngine:
             else:   # nucleus sampling, run_video_CapFilt.py:103-104
                 out_tok = self.captioner.sample_ids(y16, Nv * F, top_p=0.9, max_length=20, min_length=5,
                                                     seed=cfg.get("sample_seed"))
-            caps = self.captioner.decode_captions(out_tok)
+            st["tok"] = self._to_host("tok", out_tok)
+        return st
+
+    @torch.no_grad()
+    def encode_filter_frames(self, st):
+        """Phase 2 (no host wait): the filter's ViT needs the frames only, so it is queued before the host blocks on the
+        caption ids and runs while the captions are decoded to strings, de-duplicated and tokenised again."""
+        if self.config["filter"]:
+            _, st["fy16"] = self.filterer.visual_encoder.forward_u8(st["flat"], CLIP_MEAN, CLIP_STD)
+
+    @torch.no_grad()
+    def captions_ready(self, st):
+        """Phase 3: wait for the caption ids, build the candidate lists (reference branches at :177-195) and queue the
+        ITM pairs; their probabilities start their way to the host."""
+        cfg, items, Nv, F = self.config, st["items"], st["Nv"], st["F"]
+        generated = [[] for _ in range(Nv)]
+        if st["tok"] is not None:
+            host_tok, ev = st["tok"]
+            ev.synchronize()
+            caps = self.captioner.decode_captions(host_tok)
             self.last_frame_captions = caps
             generated = [dedup(caps[v * F:(v + 1) * F]) for v in range(Nv)]
-        # candidate lists per video, reference branches at :177-195
         to_filter = []
         for v, item in enumerate(items):
             orig = split_sentences(item.get("text", []), cfg.get("do_sentence_tokenization", True))
@@ -182,52 +223,56 @@ class CapFiltEngine:
             else:
                 item["text"] = cand
                 to_filter.append(None)
+        st["generated"], st["to_filter"] = generated, to_filter
+        if cfg["filter"]:
+            st["itm"] = self._filter_enqueue(st["fy16"], Nv, F, to_filter)
+
+    @torch.no_grad()
+    def finish(self, st):
+        """Phase 4: wait for the ITM probabilities, apply the threshold rule, fill the items."""
+        cfg, items, Nv, F = self.config, st["items"], st["Nv"], st["F"]
         n_pairs = 0
         if cfg["filter"]:
-            kept = self._filter_batch(flat, Nv, F, to_filter)
+            kept = self._filter_finish(st["itm"], Nv, F, st["to_filter"])
             for v, item in enumerate(items):
                 if cfg["filter_generated_only"]:
                     item["text"] = list(item.get("text", [])) + kept[v]
                 else:
                     item["text"] = kept[v]
-            n_pairs = sum(len(c) for c in to_filter) * F
-        self.last_stats = dict(videos=Nv, frames=Nv * F, unique_captions=sum(len(g) for g in generated), itm_pairs=n_pairs)
+            n_pairs = sum(len(c) for c in st["to_filter"]) * F
+        self.last_stats = dict(videos=Nv, frames=Nv * F, unique_captions=sum(len(g) for g in st["generated"]),
+                               itm_pairs=n_pairs)
         return items
 
-    def _filter_batch(self, flat_u8, Nv, F, caps_per_video):
-        cfg = self.config
+    def _filter_enqueue(self, y16, Nv, F, caps_per_video):
         flt = self.filterer
-        _, y16 = flt.visual_encoder.forward_u8(flat_u8, CLIP_MEAN, CLIP_STD)
-        all_caps, cap_video = [], []
-        for v, caps in enumerate(caps_per_video):
-            for c in caps:
-                all_caps.append(c)
-                cap_video.append(v)
-        kept = [[] for _ in range(Nv)]
+        all_caps = [c for caps in caps_per_video for c in caps]
         if not all_caps:
-            return kept
+            return None
         ids, lens = flt.tokenize(all_caps)
         # pair order: IMAGE-major (video, frame, caption) so the captions of a frame are consecutive and share
         # one fetch of that frame's cross K/V; the reference's loop is caption-major (:110-112) but every
         # (frame, caption) score is independent of the order.
-        cap_first, n = [], 0
-        for caps in caps_per_video:
-            cap_first.append(n)
-            n += len(caps)
-        pair_cap, counts = [], []
-        for v, caps in enumerate(caps_per_video):
-            block = list(range(cap_first[v], cap_first[v] + len(caps)))
-            for _ in range(F):
-                pair_cap.extend(block)
-                counts.append(len(caps))
-        pair_cap = torch.tensor(pair_cap, dtype=torch.long)
+        n_caps = np.fromiter((len(c) for c in caps_per_video), dtype=np.int64, count=Nv)
+        cap_first = np.concatenate([[0], np.cumsum(n_caps)[:-1]])
+        counts = np.repeat(n_caps, F)
+        pair_cap = np.concatenate([np.tile(np.arange(cap_first[v], cap_first[v] + n_caps[v]), F) for v in range(Nv)])
         group_start = torch.zeros(Nv * F + 1, dtype=torch.int32)
-        group_start[1:] = torch.cumsum(torch.tensor(counts, dtype=torch.int32), 0)
+        group_start[1:] = torch.from_numpy(np.cumsum(counts).astype(np.int32))
         # (ids / lens stay one row per distinct caption; pair_cap maps the Nv*F*C pairs onto them)
-        logits = flt.itm_pairs(y16, Nv * F, ids, lens, group_start=group_start, max_group=max(counts),
-                               pair_text=pair_cap)
-        prob = torch.nn.functional.softmax(logits, dim=1)[:, 1].detach().cpu().numpy()
-        gs = group_start.numpy()
+        logits = flt.itm_pairs(y16, Nv * F, ids, lens, group_start=group_start, max_group=int(counts.max()),
+                               pair_text=torch.from_numpy(pair_cap))
+        prob = torch.nn.functional.softmax(logits, dim=1)[:, 1].contiguous()
+        return self._to_host("itm", prob), group_start.numpy()
+
+    def _filter_finish(self, pending, Nv, F, caps_per_video):
+        cfg = self.config
+        kept = [[] for _ in range(Nv)]
+        if pending is None:
+            return kept
+        (prob, ev), gs = pending
+        ev.synchronize()
+        prob = prob.numpy()
         for v, caps in enumerate(caps_per_video):
             if not caps:
                 continue

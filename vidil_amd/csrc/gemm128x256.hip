@@ -226,6 +226,11 @@ __global__ __launch_bounds__(256, 2) void gemm128x256_kernel(const vidil_gemm_ar
       }
     }
     asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+    // The last K-tile's refills are never read, so hipcc considers wraw dead from the moment the asm loads were
+    // issued and may hand those registers to other values while the loads are still in flight (seen as ONE wrong tile
+    // in 5,544): keep them live until the drain above has completed.
+#pragma unroll
+    for (int r = 0; r < 8; ++r) asm volatile("" ::"v"(wraw[r]));
     __builtin_amdgcn_s_barrier();
 
     if constexpr (FOLD) {

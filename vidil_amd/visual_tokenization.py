@@ -159,6 +159,7 @@ class VisualTokenizer:
         self.texts = visual_token_texts
         self.index = OntologyIndex(text_embeds_by_cat, self.device)
         self.topk = config.get("topk_visualize", 5)
+        self._pinned = None
 
     @torch.no_grad()
     def frame_topk(self, frames_u8):
@@ -179,10 +180,27 @@ class VisualTokenizer:
         idx, _ = self.frame_topk(frames_u8.reshape(Nv * F, *frames_u8.shape[2:]))
         return self.assemble(video_ids, idx, captions, F)
 
+    @torch.no_grad()
+    def begin(self, frames_u8):
+        """GPU half of ``process`` without any host wait: queues the tower + ontology scan and a copy of the top-k
+        indices into pinned host memory; returns (host tensor, event behind the copy) for ``assemble``."""
+        Nv, F = frames_u8.shape[0], frames_u8.shape[1]
+        idx, _ = self.frame_topk(frames_u8.reshape(Nv * F, *frames_u8.shape[2:]))
+        if self._pinned is None or self._pinned.shape != idx.shape:
+            self._pinned = torch.empty(idx.shape, dtype=idx.dtype, pin_memory=True)
+        self._pinned.copy_(idx, non_blocking=True)
+        ev = torch.cuda.Event()
+        ev.record()
+        return self._pinned, ev
+
     def assemble(self, video_ids, idx_dev, captions, F):
-        """Host half of ``process``: device top-k indices i32 [Nv*F, 4, topk] -> the per-video token dicts.  Split out
-        so a caller can run ``frame_topk`` on a side stream next to CapFilt (they are independent until here)."""
+        """Host half of ``process``: top-k indices i32 [Nv*F, 4, topk] (a device tensor, or ``begin``'s (host tensor,
+        event) pair) -> the per-video token dicts.  Split out so a caller can keep the GPU busy with CapFilt while the
+        strings are put together (they are independent until here)."""
         Nv = len(video_ids)
+        if isinstance(idx_dev, tuple):
+            idx_dev[1].synchronize()
+            idx_dev = idx_dev[0]
         idx = idx_dev.cpu().numpy().reshape(Nv, F, len(CATEGORIES), self.topk)
         out = {}
         for v, vid in enumerate(video_ids):
@@ -217,6 +235,7 @@ class BlipVisualTokenizer(VisualTokenizer):
         self.k_test = config.get("k_test", 128)
         self.image_size = config.get("image_size", 384)
         self.pairs_per_pass = pairs_per_pass
+        self._pinned = None
         if prompt_functions is None:
             prompt_functions = get_prefix_prompt_functions(config.get("prompt_version_visual_tokenization", "v1"))
         self.prompt_functions = prompt_functions
