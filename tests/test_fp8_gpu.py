@@ -49,7 +49,9 @@ def test_gemm_fp8_transpose_detecting_and_k_order():
     a[torch.arange(M), (torch.arange(M) * 7 + 3) % K] = 1.0          # row m selects column (7m+3) % K of W^T
     w = ((torch.arange(N)[:, None] * 3 + torch.arange(K)[None, :]) % 13).float() - 6.0     # small integers: exact in e4m3
     out = torch.zeros(M, N, dtype=torch.float32, device=DEV)
-    k.gemm(a.to(F8).to(DEV), w.to(F8).to(DEV), None, out=out)
+    k.gemm(a.to(F8).to(DEV), w.to(F8).to(DEV), None, out=out, w_scale=torch.ones(N, device=DEV))
+    with pytest.raises(Exception, match="w_scale"):                  # the per-column scale is part of the fp8 contract
+        k.gemm(a.to(F8).to(DEV), w.to(F8).to(DEV), None, out=out)
     ref = w.t()[(torch.arange(M) * 7 + 3) % K]
     assert torch.equal(out.cpu(), ref)
 

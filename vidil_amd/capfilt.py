@@ -278,8 +278,12 @@ class CapFiltEngine:
                 continue
             # rows of this video: F consecutive blocks of len(caps) pairs -> [F, C] -> per caption over frames
             pv = prob[gs[v * F]: gs[v * F] + F * len(caps)].reshape(F, len(caps))
+            if cfg.get("filter_mode", "max_filter") != "avg_filter":
+                # keep_caption's max rule for all captions of the video at once (a maximum has no rounding to differ in)
+                kept[v] = [c for c, k in zip(caps, pv.max(axis=0) > cfg["threshold"]) if k]
+                continue
             for ci, c in enumerate(caps):
-                if keep_caption(pv[:, ci], cfg["threshold"], cfg.get("filter_mode", "max_filter")):
+                if keep_caption(pv[:, ci], cfg["threshold"], cfg["filter_mode"]):
                     kept[v].append(c)
         return kept
 
