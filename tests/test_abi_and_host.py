@@ -329,3 +329,101 @@ def test_bench_gflop_model_reproduces_baseline_md_section_4():
     assert abs(b.gflop_per_frame("large", 224, "b32")["vit_caption"] - 123.11) < 0.1       # config 4
     assert abs(b.gflop_per_frame("base", 384, "l14")["vit_caption"] - 110.97) < 0.1
     assert abs(b.gflop_per_frame("base", 384, "l14")["clip"] - 162.03) < 0.2
+
+
+def test_itm_short_circuit_host_logic_equals_the_exhaustive_schedule_on_stand_in_models(monkeypatch):
+    """Host logic of CapFiltEngine's two filter schedules with stand-in models (no GPU): a deterministic pseudo-random
+    probability per (frame, caption text), so the kept lists must be identical for every threshold while the short
+    circuit scores fewer pairs; covers captions shared by several frames, original captions (no home frame) and
+    videos whose captions all fail on their own frame."""
+    import zlib
+
+    import numpy as np
+    import torch
+
+    from vidil_amd import capfilt
+    from vidil_amd.capfilt import CapFiltEngine as _Engine
+
+    class _Done:
+        def synchronize(self):
+            pass
+
+    class CapFiltEngine(_Engine):                # the two places the engine touches the device itself
+        def _to_host(self, key, t):
+            return t.clone(), _Done()
+
+    monkeypatch.setattr(capfilt, "blip_frames", lambda frames, size: frames)
+    Nv, F = 5, 4
+    frame_caps = [f"cap {(v * 7 + f * 3) % 5} of {v}" for v in range(Nv) for f in range(F)]      # repeats inside a video
+
+    class _Vis:
+        def forward_u8(self, flat, mean, std):
+            return None, torch.arange(flat.shape[0], dtype=torch.float32).view(-1, 1)             # "features" = frame id
+
+    class _Cap(torch.nn.Module):
+        visual_encoder = _Vis()
+
+        def generate_ids(self, y16, n, **kw):
+            return torch.arange(n).view(-1, 1), None
+
+        def decode_captions(self, tok):
+            return [frame_caps[int(i)] for i in tok.view(-1).tolist()]
+
+    class _Flt(torch.nn.Module):
+        visual_encoder = _Vis()
+        calls = []
+
+        def tokenize(self, caps):
+            self.texts = list(caps)
+            return torch.zeros(len(caps), 35, dtype=torch.int32), torch.full((len(caps),), 9, dtype=torch.int32)
+
+        def project_image_kv(self, y16, n, min_rows):
+            return "cross"
+
+        def itm_pairs(self, y16, n_images, ids, lens, image_index=None, group_start=None, max_group=0, pair_text=None, cross=None):
+            if group_start is not None:
+                gs = group_start.numpy()
+                image_index = np.repeat(np.arange(n_images), np.diff(gs))
+                assert np.diff(gs).max() == max_group
+            img = np.asarray(image_index).astype(np.int64)
+            txt = pair_text.numpy()
+            assert len(img) == len(txt)
+            self.calls.append(len(txt))
+            u = np.array([zlib.crc32(f"{i}|{self.texts[t]}".encode()) / 2 ** 32 for i, t in zip(img, txt)], dtype=np.float64)
+            u = np.clip(u, 1e-6, 1 - 1e-6)
+            logit = np.log(u / (1 - u))
+            return torch.from_numpy(np.stack([np.zeros_like(logit), logit], axis=1).astype(np.float32))
+
+    frames = torch.zeros(Nv, F, 8, 8, 3, dtype=torch.uint8)
+    some_split = False
+    for thr in (0.0, 0.2, 0.5, 0.8, 0.97, 1.0):
+        for keep in (False, True):
+            out = {}
+            for short in (False, True):
+                cfg = dict(caption=True, filter=True, filter_generated_only=not keep, keep_original_caption=keep, threshold=thr,
+                           filter_mode="max_filter", generation_mode="beam", image_size=8, vit="base",
+                           do_sentence_tokenization=False, itm_short_circuit=short)
+                flt = _Flt()
+                flt.calls = []
+                eng = CapFiltEngine(cfg, "cpu", captioner=_Cap(), filterer=flt)
+                items = [dict(video_id=f"v{v}", text=["an original caption", f"another {v}"] if keep else []) for v in range(Nv)]
+                eng.process(items, frames)
+                out[short] = (items, eng.last_stats["itm_pairs"], list(flt.calls))
+            assert out[True][0] == out[False][0], (thr, keep)
+            assert out[True][1] == sum(out[True][2]) and out[False][1] == sum(out[False][2])
+            assert out[True][1] <= out[False][1]
+            kept = sum(len(i["text"]) for i in out[True][0])
+            some_split |= 0 < kept < sum(len(i["unfiltered_text"]) for i in out[True][0])
+            if thr == 0.0 and not keep:       # everything passes on its own frame: one pair per distinct caption
+                assert out[True][1] == sum(len(i["unfiltered_text"]) for i in out[True][0])
+    assert some_split
+    # avg_filter has no short circuit: the flag is ignored
+    cfg = dict(caption=True, filter=True, filter_generated_only=True, keep_original_caption=False, threshold=0.5,
+               filter_mode="avg_filter", generation_mode="beam", image_size=8, vit="base", do_sentence_tokenization=False,
+               itm_short_circuit=True)
+    flt = _Flt()
+    flt.calls = []
+    eng = CapFiltEngine(cfg, "cpu", captioner=_Cap(), filterer=flt)
+    items = [dict(video_id=f"v{v}", text=[]) for v in range(Nv)]
+    eng.process(items, frames)
+    assert eng.last_stats["itm_pairs"] == sum(len(i["unfiltered_text"]) for i in items) * F

@@ -793,6 +793,35 @@ def test_interleaved_pipeline_gives_the_results_of_the_two_engines_called_in_tur
         assert all(len(it["unfiltered_text"]) >= 1 for it in b)
 
 
+def test_itm_short_circuit_keeps_exactly_the_captions_the_exhaustive_schedule_keeps(full_models):
+    """max_filter is an any() over the frames: scoring a caption on its own frame first and on the other frames only
+    if it failed there must give the same kept lists for every threshold, with fewer pairs scored whenever some
+    caption passes early; original captions (no home frame) go through all frames."""
+    from vidil_amd.capfilt import CapFiltEngine
+
+    fm = full_models
+    Nv, F = 3, 8
+    u8 = torch.from_numpy(synthetic_frames(Nv, F, first_video=31)).to(DEV)
+    seen_partial = False
+    for thr in (0.05, 0.35, 0.45, 0.5, 0.55, 0.65, 0.95):
+        for keep in (False, True):
+            res = {}
+            for short in (False, True):
+                cfg = dict(caption=True, filter=True, filter_generated_only=not keep, keep_original_caption=keep,
+                           threshold=thr, filter_mode="max_filter", generation_mode="beam", image_size=224, vit="base",
+                           do_sentence_tokenization=False, itm_short_circuit=short)
+                eng = CapFiltEngine(cfg, DEV, captioner=fm["cap"], filterer=fm["itm"])
+                items = [dict(video_id=f"video{v}", text=["a person is cooking", "two dogs"] if keep else []) for v in range(Nv)]
+                eng.process(items, u8)
+                res[short] = (items, eng.last_stats["itm_pairs"])
+            assert res[True][0] == res[False][0], (thr, keep)
+            assert res[True][1] <= res[False][1]
+            n_kept = sum(len(it["text"]) for it in res[True][0])
+            n_all = sum(len(it["unfiltered_text"]) for it in res[True][0])
+            seen_partial |= 0 < n_kept < n_all
+    assert seen_partial                      # at least one threshold splits the candidates, so both phases decided something
+
+
 def test_vit_with_fused_layernorm_matches_the_unfused_path_and_the_oracle():
     """fuse_layernorm moves the rounding point of the GEMM operand from LN(x) to x; both variants must sit within the
     same tolerance of the fp32 oracle, and within ~2x the f16 tolerance of each other."""

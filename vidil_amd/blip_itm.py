@@ -53,12 +53,23 @@ class BLIP_ITM(PackedCache, nn.Module):
 
     # ------------------------------------------------------------------ de-duplicated schedule
     @torch.no_grad()
-    def itm_pairs(self, enc16, n_images, ids, lens, image_index=None, group_start=None, max_group=0, pair_text=None):
+    def project_image_kv(self, enc16, n_images, min_rows_per_image):
+        """The cross-attention K/V of every layer for a batch of images, for one or more ``itm_pairs`` calls on the same
+        frames (``cross=``).  ``min_rows_per_image``: the smallest number of query rows a launch will present per
+        image — row-major V (cheaper stores) is only readable by the staged kernel, i.e. above 32 rows."""
+        Te = enc16.shape[0] // n_images
+        return self.text_encoder.project_cross_kv(enc16, n_images, Te, v_rowmajor=min_rows_per_image > 32,
+                                                  last_layer_vt=True)
+
+    @torch.no_grad()
+    def itm_pairs(self, enc16, n_images, ids, lens, image_index=None, group_start=None, max_group=0, pair_text=None,
+                  cross=None):
         """enc16 f16 [n_images*Te, width]; ids i32 [P,35]; lens i32 [P].  Either image_index i32 [P] (pair ->
         image, any order) or, for IMAGE-MAJOR pair order, group_start i32 [n_images+1] (pairs of image j are
         group_start[j] .. group_start[j+1]-1, at most max_group of them), which lets one fetch of an image's
         cross K/V serve all its captions.  pair_text (int [P]): ids / lens then hold the U DISTINCT texts and pair p
         scores text pair_text[p] — the text-only front of the encoder runs once per text (BertModel.encode_cls).
+        cross: ``project_image_kv``'s result for these images when several calls score pairs of the same frames.
         Returns f32 [P,2] raw ITM logits."""
         require_cuda(enc16, "BLIP_ITM")
         te = self.text_encoder
@@ -71,7 +82,11 @@ class BLIP_ITM(PackedCache, nn.Module):
         # image-major groups with more than 32 query rows go through the staged attention kernel, which takes V
         # row-major (plain 16-B stores from the K|V GEMM instead of the V^T scatter)
         rows_per_image = (max_group if group_start is not None else 1) * t_eff
-        cross = te.project_cross_kv(enc16, n_images, Te, v_rowmajor=rows_per_image > 32, last_layer_vt=True)
+        if cross is None:
+            cross = te.project_cross_kv(enc16, n_images, Te, v_rowmajor=rows_per_image > 32, last_layer_vt=True)
+        elif cross.NP == 0 and rows_per_image <= 32:
+            raise K.VidilHipError("itm_pairs: cross= holds row-major values but this call has at most 32 query rows "
+                                  "per image (project_image_kv(min_rows_per_image=...))")
         ids = ids[:, :t_eff].to(dev).contiguous()
         lens = lens.to(dev).contiguous()
         if group_start is not None:

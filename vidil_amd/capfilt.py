@@ -126,6 +126,8 @@ class CapFiltEngine:
     config keys (configs/pipeline_config/*.yaml of the reference): caption, filter,
     filter_generated_only, keep_original_caption, threshold, filter_mode, generation_mode,
     do_sentence_tokenization, image_size, vit, caption_model_ckpt, filterer_model_ckpt.
+    Own key: itm_short_circuit (default False = score every (frame, caption) pair like the reference; True = the
+    any()-short-circuit of ``_filter_enqueue``, same kept lists with a fraction of the ITM work).
     """
 
     def __init__(self, config, device, captioner=None, filterer=None):
@@ -203,6 +205,8 @@ class CapFiltEngine:
             caps = self.captioner.decode_captions(host_tok)
             self.last_frame_captions = caps
             generated = [dedup(caps[v * F:(v + 1) * F]) for v in range(Nv)]
+            # the first frame each distinct caption came from (itm_short_circuit scores a caption there first)
+            st["home"] = [{c: f for f, c in reversed(list(enumerate(caps[v * F:(v + 1) * F])))} for v in range(Nv)]
         to_filter = []
         for v, item in enumerate(items):
             orig = split_sentences(item.get("text", []), cfg.get("do_sentence_tokenization", True))
@@ -225,7 +229,7 @@ class CapFiltEngine:
                 to_filter.append(None)
         st["generated"], st["to_filter"] = generated, to_filter
         if cfg["filter"]:
-            st["itm"] = self._filter_enqueue(st["fy16"], Nv, F, to_filter)
+            st["itm"] = self._filter_enqueue(st["fy16"], Nv, F, to_filter, st.get("home"))
 
     @torch.no_grad()
     def finish(self, st):
@@ -239,52 +243,132 @@ class CapFiltEngine:
                     item["text"] = list(item.get("text", [])) + kept[v]
                 else:
                     item["text"] = kept[v]
-            n_pairs = sum(len(c) for c in st["to_filter"]) * F
+            n_pairs = st["itm"]["n_pairs"] if st["itm"] is not None else 0
         self.last_stats = dict(videos=Nv, frames=Nv * F, unique_captions=sum(len(g) for g in st["generated"]),
                                itm_pairs=n_pairs)
         return items
 
-    def _filter_enqueue(self, y16, Nv, F, caps_per_video):
-        flt = self.filterer
+    def _pairs_image_major(self, flt, y16, cross, Nv, F, caps_per_video, ids, lens, cap_first, skip=None):
+        """Queue the ITM of every (frame, caption) pair of the batch except ``skip[v][ci]`` = the one frame already
+        scored for that caption (or -1).  Pair order is IMAGE-major (video, frame, caption) so the captions of a frame
+        are consecutive and share one fetch of that frame's cross K/V; the reference's loop is caption-major
+        (run_video_CapFilt.py:110-112) but every (frame, caption) score is independent of the order.
+        caps_per_video[v]: indices (into that video's candidate list) of the captions to score.
+        Returns ((pinned probabilities, event), pair_first [Nv*F+1])."""
+        pair_cap, counts = [], np.zeros(Nv * F, dtype=np.int64)
+        for v, sel in enumerate(caps_per_video):
+            if not len(sel):
+                continue
+            sel = np.asarray(sel, dtype=np.int64)
+            if skip is None:
+                counts[v * F:(v + 1) * F] = len(sel)
+                pair_cap.append(np.tile(cap_first[v] + sel, F))
+            else:
+                home = np.asarray([skip[v][ci] for ci in sel], dtype=np.int64)
+                for f in range(F):
+                    here = sel[home != f]
+                    counts[v * F + f] = len(here)
+                    pair_cap.append(cap_first[v] + here)
+        if not pair_cap or counts.sum() == 0:
+            return None
+        pair_cap = np.concatenate(pair_cap)
+        group_start = torch.zeros(Nv * F + 1, dtype=torch.int32)
+        group_start[1:] = torch.from_numpy(np.cumsum(counts).astype(np.int32))
+        # (ids / lens stay one row per distinct caption; pair_cap maps the pairs onto them)
+        logits = flt.itm_pairs(y16, Nv * F, ids, lens, group_start=group_start, max_group=int(counts.max()),
+                               pair_text=torch.from_numpy(pair_cap), cross=cross)
+        prob = torch.nn.functional.softmax(logits, dim=1)[:, 1].contiguous()
+        return self._to_host("itm", prob), group_start.numpy()
+
+    def _filter_enqueue(self, y16, Nv, F, caps_per_video, home=None):
+        """Queue the filter's text side.  Default: every (frame, caption) pair, as the reference evaluates them.
+        ``itm_short_circuit`` (config, max_filter only): the rule ``max over frames > threshold`` is an any(); a
+        generated caption is first scored against the frame it was generated from (``home``), and only the captions
+        that did not pass there are scored against the other frames.  Each probability is the one the exhaustive
+        schedule computes (a pair's score does not depend on the batch around it), so the kept lists are identical;
+        on real captions — which nearly always match their own frame — this is ~1/F of the ITM work."""
+        cfg, flt = self.config, self.filterer
         all_caps = [c for caps in caps_per_video for c in caps]
         if not all_caps:
             return None
         ids, lens = flt.tokenize(all_caps)
-        # pair order: IMAGE-major (video, frame, caption) so the captions of a frame are consecutive and share
-        # one fetch of that frame's cross K/V; the reference's loop is caption-major (:110-112) but every
-        # (frame, caption) score is independent of the order.
         n_caps = np.fromiter((len(c) for c in caps_per_video), dtype=np.int64, count=Nv)
         cap_first = np.concatenate([[0], np.cumsum(n_caps)[:-1]])
-        counts = np.repeat(n_caps, F)
-        pair_cap = np.concatenate([np.tile(np.arange(cap_first[v], cap_first[v] + n_caps[v]), F) for v in range(Nv)])
-        group_start = torch.zeros(Nv * F + 1, dtype=torch.int32)
-        group_start[1:] = torch.from_numpy(np.cumsum(counts).astype(np.int32))
-        # (ids / lens stay one row per distinct caption; pair_cap maps the Nv*F*C pairs onto them)
-        logits = flt.itm_pairs(y16, Nv * F, ids, lens, group_start=group_start, max_group=int(counts.max()),
-                               pair_text=torch.from_numpy(pair_cap))
-        prob = torch.nn.functional.softmax(logits, dim=1)[:, 1].contiguous()
-        return self._to_host("itm", prob), group_start.numpy()
+        pend = dict(ids=ids, lens=lens, cap_first=cap_first, y16=y16, n_pairs=0, phase1=None, cross=None)
+        short = (cfg.get("itm_short_circuit", False) and cfg.get("filter_mode", "max_filter") != "avg_filter"
+                 and home is not None and F > 1)
+        if not short:
+            pend["all"] = self._pairs_image_major(flt, y16, None, Nv, F, [range(n) for n in n_caps], ids, lens, cap_first)
+            pend["n_pairs"] = int(n_caps.sum()) * F
+            return pend
+        # phase 1: one pair per caption that has a home frame (pair -> image map; a frame is home to at most one caption)
+        homes = [[home[v].get(c, -1) for c in caps] for v, caps in enumerate(caps_per_video)]
+        p_text = np.asarray([cap_first[v] + ci for v, hs in enumerate(homes) for ci, h in enumerate(hs) if h >= 0], dtype=np.int64)
+        p_image = np.asarray([v * F + h for v, hs in enumerate(homes) for h in hs if h >= 0], dtype=np.int32)
+        # both phases are cut to the longest caption (itm_pairs); phase 1 presents one caption per image
+        pend["cross"] = cross = flt.project_image_kv(y16, Nv * F, min(int(ids.shape[1]), int(lens.max().item())))
+        pend["homes"] = homes
+        if len(p_text):
+            logits = flt.itm_pairs(y16, Nv * F, ids, lens, image_index=torch.from_numpy(p_image),
+                                   pair_text=torch.from_numpy(p_text), cross=cross)
+            prob = torch.nn.functional.softmax(logits, dim=1)[:, 1].contiguous()
+            pend["phase1"] = self._to_host("itm1", prob)
+            pend["n_pairs"] = len(p_text)
+        return pend
 
     def _filter_finish(self, pending, Nv, F, caps_per_video):
         cfg = self.config
         kept = [[] for _ in range(Nv)]
         if pending is None:
             return kept
-        (prob, ev), gs = pending
-        ev.synchronize()
-        prob = prob.numpy()
+        thr = cfg["threshold"]
+        if "all" in pending:
+            (prob, ev), gs = pending["all"]
+            ev.synchronize()
+            prob = prob.numpy()
+            for v, caps in enumerate(caps_per_video):
+                if not caps:
+                    continue
+                # rows of this video: F consecutive blocks of len(caps) pairs -> [F, C] -> per caption over frames
+                pv = prob[gs[v * F]: gs[v * F] + F * len(caps)].reshape(F, len(caps))
+                if cfg.get("filter_mode", "max_filter") != "avg_filter":
+                    # keep_caption's max rule for all captions of the video at once (a maximum has no rounding to differ in)
+                    kept[v] = [c for c, k in zip(caps, pv.max(axis=0) > thr) if k]
+                    continue
+                for ci, c in enumerate(caps):
+                    if keep_caption(pv[:, ci], thr, cfg["filter_mode"]):
+                        kept[v].append(c)
+            return kept
+        # short circuit: captions that passed on their home frame are decided; the rest meet the other frames
+        homes = pending["homes"]
+        passed = [np.zeros(len(c), dtype=bool) for c in caps_per_video]
+        if pending["phase1"] is not None:
+            prob1, ev = pending["phase1"]
+            ev.synchronize()
+            prob1, n = prob1.numpy(), 0
+            for v, hs in enumerate(homes):
+                for ci, h in enumerate(hs):
+                    if h >= 0:
+                        passed[v][ci] = prob1[n] > thr
+                        n += 1
+        rest = [np.flatnonzero(~p) for p in passed]
+        second = self._pairs_image_major(self.filterer, pending["y16"], pending["cross"], Nv, F, rest, pending["ids"],
+                                         pending["lens"], pending["cap_first"], skip=homes)
+        if second is not None:
+            (prob, ev), gs = second
+            pending["n_pairs"] += len(prob)
+            ev.synchronize()
+            prob = prob.numpy()
+            for v, sel in enumerate(rest):
+                if not len(sel):
+                    continue
+                hs = np.asarray([homes[v][ci] for ci in sel])
+                for f in range(F):
+                    here = sel[hs != f]
+                    row = prob[gs[v * F + f]: gs[v * F + f + 1]]
+                    passed[v][here] |= row > thr
         for v, caps in enumerate(caps_per_video):
-            if not caps:
-                continue
-            # rows of this video: F consecutive blocks of len(caps) pairs -> [F, C] -> per caption over frames
-            pv = prob[gs[v * F]: gs[v * F] + F * len(caps)].reshape(F, len(caps))
-            if cfg.get("filter_mode", "max_filter") != "avg_filter":
-                # keep_caption's max rule for all captions of the video at once (a maximum has no rounding to differ in)
-                kept[v] = [c for c, k in zip(caps, pv.max(axis=0) > cfg["threshold"]) if k]
-                continue
-            for ci, c in enumerate(caps):
-                if keep_caption(pv[:, ci], cfg["threshold"], cfg["filter_mode"]):
-                    kept[v].append(c)
+            kept[v] = [c for c, k in zip(caps, passed[v]) if k]
         return kept
 
 
