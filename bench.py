@@ -200,6 +200,8 @@ def main():
     ap.add_argument("--itm-short-circuit", action="store_true",
                     help="secondary number: score a caption on the frame it came from first and on the other frames only if "
                          "it failed there (identical kept lists; the headline scores every pair like the reference)")
+    ap.add_argument("--decode-streams", type=int, default=2,
+                    help="parts of the batch whose beam searches run side by side on their own HIP streams (1 = one search over all images)")
     ap.add_argument("--sequential", action="store_true",
                     help="CapFilt, then visual tokens (the reference's order) instead of vidil_amd.pipeline's interleaving")
     args = ap.parse_args()
@@ -228,7 +230,8 @@ def main():
     onto_embeds, onto_texts = synthetic_ontology(dim=clip.config.projection_dim)
     config = dict(caption=True, filter=True, filter_generated_only=True, keep_original_caption=False,
                   threshold=0.4, filter_mode="max_filter", generation_mode="beam", do_sentence_tokenization=False,
-                  image_size=args.size, vit=args.vit, topk_visualize=5, itm_short_circuit=args.itm_short_circuit)
+                  image_size=args.size, vit=args.vit, topk_visualize=5, itm_short_circuit=args.itm_short_circuit,
+                  decode_streams=args.decode_streams)
     engine = CapFiltEngine(config, dev, captioner=cap, filterer=flt)
     vtok = VisualTokenizer(config, clip, onto_texts, onto_embeds, dev)
 

@@ -420,6 +420,28 @@ def test_captured_decode_graphs_replay_the_eager_result(full_models):
         cap.__dict__.pop("_decode_state", None)
 
 
+def test_beam_search_split_over_streams_gives_the_unsplit_tokens(full_models):
+    """generate_ids(streams=n): the images' searches run in n parts side by side on n HIP streams (eager, then captured
+    graphs per part); a search is per image, so tokens and lengths equal the single-stream run bit for bit — also for
+    parts of unequal size."""
+    from oracle import clip_ref
+
+    cap = full_models["cap"]
+    B = 7
+    u8 = synthetic_frames(1, B, first_video=60)[0]
+    _, y16 = cap.visual_encoder.forward_u8(torch.from_numpy(u8).to(DEV), clip_ref.CLIP_MEAN, clip_ref.CLIP_STD)
+    cap.__dict__.pop("_decode_state", None)
+    try:
+        want_tok, want_len = (t.cpu() for t in cap.generate_ids(y16, B, num_beams=3, max_length=20, min_length=5))
+        for n in (2, 3):
+            for rep in range(4):                   # eager, capture, replay, replay
+                tok, ln = cap.generate_ids(y16, B, num_beams=3, max_length=20, min_length=5, streams=n)
+                torch.cuda.synchronize()
+                assert torch.equal(tok.cpu(), want_tok) and torch.equal(ln.cpu(), want_len), (n, rep)
+    finally:
+        cap.__dict__.pop("_decode_state", None)
+
+
 def test_blip_at_384_vit_decoder_and_itm_vs_oracle():
     """image_size 384 (what every pipeline_config_*.yaml of the reference sets): 577 image tokens, i.e. chunked
     LDS attention in the ViT / ITM cross-attention and the multi-round direct kernel in the decode cross-attention."""

@@ -167,10 +167,59 @@ class BLIP_Decoder(nn.Module):
     # ------------------------------------------------------------------ beam decode
     @torch.no_grad()
     def generate_ids(self, enc16, B, *, num_beams=3, max_length=30, min_length=10, trace: DecodeTrace = None,
-                     check_done_every=4):
+                     check_done_every=2, streams=1):
         """enc16: f16 [B*Te, width] image tokens of B images.  Returns (tokens i32 [B,max_length], lens i32 [B]):
-        best hypothesis incl. the prompt, then [SEP] if it fits, then [PAD]."""
+        best hypothesis incl. the prompt, then [SEP] if it fits, then [PAD].
+
+        ``streams`` > 1: the images are cut into that many contiguous parts whose searches run side by side on their
+        own HIP streams (``_beam_search`` is a generator that yields after queueing each step; the parts are stepped
+        round robin).  A decode step is ~160 launches that are either latency-bound (4.6-9k-row GEMMs, one-query
+        attention over the arena) or HBM-bound (the cross-attention re-reading every image's K/V): two independent
+        parts fill each other's bubbles.  A search is per image, so the tokens do not depend on the split."""
         require_cuda(enc16, "BLIP_Decoder.generate")
+        kw = dict(num_beams=num_beams, max_length=max_length, min_length=min_length, check_done_every=check_done_every)
+        if streams <= 1 or trace is not None or B < 2 * streams:
+            g = self._beam_search(enc16, B, trace=trace, slot=0, **kw)
+            while True:
+                try:
+                    next(g)
+                except StopIteration as done:
+                    return done.value
+        main = torch.cuda.current_stream()
+        side = self.__dict__.setdefault("_decode_streams", {})
+        Te = enc16.shape[0] // B
+        bounds = [(B * i // streams, B * (i + 1) // streams) for i in range(streams)]
+        fork = torch.cuda.Event()
+        fork.record(main)
+        gens = []
+        for i, (lo, hi) in enumerate(bounds):
+            st = side.get((i, enc16.device))
+            if st is None:
+                st = side[(i, enc16.device)] = torch.cuda.Stream(device=enc16.device)
+            st.wait_event(fork)
+            gens.append((st, self._beam_search(enc16[lo * Te:hi * Te], hi - lo, slot=i, **kw)))
+        results = [None] * streams
+        live = list(range(streams))
+        while live:
+            for i in list(live):
+                st, g = gens[i]
+                with torch.cuda.stream(st):
+                    try:
+                        next(g)
+                    except StopIteration as done:
+                        results[i] = done.value
+                        live.remove(i)
+        for i, (st, _) in enumerate(gens):
+            join = torch.cuda.Event()
+            join.record(st)
+            main.wait_event(join)
+            for t in results[i]:
+                t.record_stream(main)
+        return torch.cat([r[0] for r in results]), torch.cat([r[1] for r in results])
+
+    def _beam_search(self, enc16, B, *, num_beams, max_length, min_length, trace=None, check_done_every=2, slot=0):
+        """Generator: queues the prompt pass and one decode step per ``next()`` on the current stream, returns
+        (tokens, lens) through StopIteration."""
         dec, bert = self.text_decoder, self.text_decoder.bert
         cfg = dec.config
         tok = self.tokenizer
@@ -178,25 +227,26 @@ class BLIP_Decoder(nn.Module):
         dev = enc16.device
         nb = num_beams
         V = cfg.vocab_size
-        # Session state (KV arena, cross K/V, beam buffers) is kept per shape and reused by the next batch: besides
-        # saving the allocations it keeps every device address stable, which is what lets the decode steps — ~160
-        # launches of 8-30 us kernels each, issued faster by the GPU than Python can enqueue them — be captured once
-        # into HIP graphs (one per step index: the position is baked into the launches) and replayed.
+        # Session state (KV arena, cross K/V, beam buffers) is kept per shape (and per stream slot) and reused by the
+        # next batch: besides saving the allocations it keeps every device address stable, which is what lets the
+        # decode steps — ~160 launches of 8-30 us kernels each, issued faster by the GPU than Python can enqueue them
+        # — be captured once into HIP graphs (one per step index: the position is baked into the launches) and replayed.
         prompt = self.prompt_ids(B, dev)
         P = prompt.shape[1]
-        key = (B, nb, max_length, min_length, str(dev), enc16.shape[0] // B, P)
+        key = (B, nb, max_length, min_length, str(dev), enc16.shape[0] // B, P, slot)
         cache = self.__dict__.setdefault("_decode_state", {})
         st = cache.get(key)
         packs = (dec.packed(), bert.packed())     # captured graphs hold the addresses of these packed weights
         if st is not None and not (st["packs"][0] is packs[0] and st["packs"][1] is packs[1]):
             st = None                              # parameters changed since the capture (e.g. a checkpoint was loaded)
         if st is None:
-            if len(cache) >= 4:
+            if len(cache) >= 8:
                 cache.clear()
             # (the shared prompt pass has P query rows per image, a decode step nb)
             st = cache[key] = dict(sess=DecoderSession(dec, enc16, B, nb, max_length, tiled_cross=P <= 32 and nb <= 32),
                                    bufs=K.BeamBuffers(B, nb, max_length, dev), graphs={}, pool=None, calls=0, packs=packs,
-                                   graphs_ok=os.environ.get("VIDIL_DECODE_GRAPHS", "1") != "0")
+                                   graphs_ok=os.environ.get("VIDIL_DECODE_GRAPHS", "1") != "0",
+                                   n_done_host=torch.zeros((1,), dtype=torch.int32, pin_memory=True))
         else:
             st["sess"].rebind(enc16)
         st["calls"] += 1
@@ -219,11 +269,26 @@ class BLIP_Decoder(nn.Module):
 
         # ---- prompt pass, once per image: the beams of an image are identical until the first update
         first_unit(sess.prefill(prompt.contiguous().view(-1), P, shared=True))
+        yield
         cur_len = P + 1
         use_graphs = st["graphs_ok"] and trace is None and st["calls"] >= 2    # the first batch warms every kernel up
+        probe = None
         while cur_len < max_length:
-            if check_done_every and (cur_len % check_done_every == 0) and int(bufs.n_done.item()) == B:
-                break
+            # "every image has its nb finished hypotheses" (BeamSearchScorer.is_done) is polled WITHOUT a host wait: the
+            # counter travels to pinned memory behind an event and is looked at when it has arrived.  A step queued
+            # after the last image finished changes nothing (finished images are skipped by beam_update, like
+            # process() skips done batches, and beam_finalize takes their stored hypotheses).
+            if check_done_every and trace is None and cur_len % check_done_every == 0:
+                if probe is not None and probe.query():
+                    if int(st["n_done_host"][0]) == B:
+                        break
+                    probe = None
+                if probe is None:
+                    st["n_done_host"].copy_(bufs.n_done, non_blocking=True)
+                    probe = torch.cuda.Event()
+                    probe.record()
+            elif check_done_every and trace is not None and int(bufs.n_done.item()) == B:
+                break                        # parity traces stop exactly where the reference's loop stops
             g = st["graphs"].get(cur_len) if use_graphs else None
             if g is not None:
                 g.replay()
@@ -238,17 +303,19 @@ class BLIP_Decoder(nn.Module):
                     st["pool"] = g.pool()
                     st["graphs"][cur_len] = g
                     g.replay()            # capture records, replay executes (host-side state already advanced)
-                except Exception as e:    # capture unsupported here: redo this batch with plain launches, loudly
+                except Exception as e:    # capture unsupported here: finish this batch with plain launches, loudly
                     import warnings
                     warnings.warn(f"vidil_amd: decode-step graph capture failed ({e!r}); continuing without graphs")
                     torch.cuda.synchronize()
                     st["graphs_ok"] = False
                     st["graphs"].clear()
-                    return self.generate_ids(enc16, B, num_beams=num_beams, max_length=max_length, min_length=min_length,
-                                             trace=trace, check_done_every=check_done_every)
+                    inner = self._beam_search(enc16, B, num_beams=num_beams, max_length=max_length, min_length=min_length,
+                                              trace=trace, check_done_every=check_done_every, slot=slot)
+                    return (yield from inner)
             else:
                 unit(cur_len)
             cur_len += 1
+            yield
         out_tok, out_len, _ = K.beam_finalize(bufs, cur_len, eos, pad)
         return out_tok, out_len
 
