@@ -367,8 +367,13 @@ int launch256(const vidil_gemm_args& a, hipStream_t s) {
     num_cu = n & ~7;
   }
   // persistent grid: one workgroup per CU (a multiple of 8 so every XCD gets the same number), never more than tiles
+  int cus = num_cu;
+  if (const char* e = getenv("VIDIL_GEMM_CUS")) {      // a stream confined to fewer CUs by a CU mask (see vidil_amd/streams.py)
+    const int v = atoi(e) & ~7;
+    if (v >= 8 && v < cus) cus = v;
+  }
   const int ntiles = ((a.M + 255) / 256) * ((a.N + 255) / 256);
-  const int tiles = !(kPersistent<EPI> && sizeof(T) == 2) ? ntiles : ntiles >= num_cu ? num_cu : (ntiles >= 8 ? (ntiles & ~7) : ntiles);
+  const int tiles = !(kPersistent<EPI> && sizeof(T) == 2) ? ntiles : ntiles >= cus ? cus : (ntiles >= 8 ? (ntiles & ~7) : ntiles);
   hipLaunchKernelGGL(kern, dim3(tiles), dim3(512), lds, s, a);
   VIDIL_CHECK_LAUNCH("gemm256");
   return VIDIL_OK;
