@@ -200,7 +200,7 @@ def main():
     ap.add_argument("--itm-short-circuit", action="store_true",
                     help="secondary number: score a caption on the frame it came from first and on the other frames only if "
                          "it failed there (identical kept lists; the headline scores every pair like the reference)")
-    ap.add_argument("--decode-streams", type=int, default=2,
+    ap.add_argument("--decode-streams", type=int, default=1,
                     help="parts of the batch whose beam searches run side by side on their own HIP streams (1 = one search over all images)")
     ap.add_argument("--sequential", action="store_true",
                     help="CapFilt, then visual tokens (the reference's order) instead of vidil_amd.pipeline's interleaving")

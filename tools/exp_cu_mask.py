@@ -33,6 +33,7 @@ def main():
     dev = torch.device("cuda", 0)
     dt = sys.argv[1] if len(sys.argv) > 1 else "bf16"
     cap, flt, clip, tok = build_models(dev, 224, "b32", "base", dt)
+    cap, flt = cap.to(dev), flt.to(dev)
     Nv, F = 384, 8
     frames = torch.from_numpy(synthetic_frames(Nv, F, 224, 0)).to(dev).reshape(Nv * F, 224, 224, 3)
 

@@ -173,9 +173,10 @@ class BLIP_Decoder(nn.Module):
 
         ``streams`` > 1: the images are cut into that many contiguous parts whose searches run side by side on their
         own HIP streams (``_beam_search`` is a generator that yields after queueing each step; the parts are stepped
-        round robin).  A decode step is ~160 launches that are either latency-bound (4.6-9k-row GEMMs, one-query
-        attention over the arena) or HBM-bound (the cross-attention re-reading every image's K/V): two independent
-        parts fill each other's bubbles.  A search is per image, so the tokens do not depend on the split."""
+        round robin).  Measured at 3,072 images: 2 parts +0.2 %, 3 parts -1.4 %, 4 parts -3.8 % of the whole step — the
+        ~160 launches of a decode step are short but each already covers the chip (decode time scales ~1/CUs under a
+        CU mask, tools/exp_cu_mask.py), so the default stays 1; kept for small batches per part of a larger job.
+        A search is per image, so the tokens do not depend on the split."""
         require_cuda(enc16, "BLIP_Decoder.generate")
         kw = dict(num_beams=num_beams, max_length=max_length, min_length=min_length, check_done_every=check_done_every)
         if streams <= 1 or trace is not None or B < 2 * streams:

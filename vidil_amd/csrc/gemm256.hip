@@ -368,7 +368,7 @@ int launch256(const vidil_gemm_args& a, hipStream_t s) {
   }
   // persistent grid: one workgroup per CU (a multiple of 8 so every XCD gets the same number), never more than tiles
   int cus = num_cu;
-  if (const char* e = getenv("VIDIL_GEMM_CUS")) {      // a stream confined to fewer CUs by a CU mask (see vidil_amd/streams.py)
+  if (const char* e = getenv("VIDIL_GEMM_CUS")) {      // developer: a stream confined to fewer CUs by a CU mask (tools/exp_cu_mask.py)
     const int v = atoi(e) & ~7;
     if (v >= 8 && v < cus) cus = v;
   }
