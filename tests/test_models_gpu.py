@@ -693,9 +693,9 @@ def test_device_beam_search_equals_installed_transformers_when_nothing_ends_earl
 
 
 # =============================================================== end to end vs the oracle pipeline
-def _ontology(dim=512, seed=3):
+def _ontology(dim=512, seed=3, sizes=None):
     g = torch.Generator().manual_seed(seed)
-    sizes = dict(objects=700, attributes=333, scenes=65, verbs=96)
+    sizes = sizes or dict(objects=700, attributes=333, scenes=65, verbs=96)
     emb, texts = {}, {}
     for k, n in sizes.items():
         e = torch.randn(n, dim, generator=g)
@@ -706,24 +706,33 @@ def _ontology(dim=512, seed=3):
     return emb, texts
 
 
-def test_end_to_end_two_videos_vs_oracle_pipeline(full_models):
-    from oracle import clip_ref, pipeline_ref
+def test_end_to_end_three_videos_vs_oracle_pipeline_at_the_vg_ontology_size(full_models):
+    """Config 1's shape per video (8 frames 224^2, beam 3, max_filter, CLIP ViT-B/32 against an ontology with the vg
+    category sizes 19,958 / 15,026 / 365 / 7,410) through CapFiltEngine + VisualTokenizer, against the fp32 oracle
+    pipeline.  Captions: equal wherever every beam decision of the oracle had a margin; filter: equal unless a
+    probability sits on the threshold; visual tokens: EQUAL rank by rank wherever the oracle's own scores separate the
+    ranks by more than the towers' 16-bit error (the mask is counted and bounded), never a percentage."""
+    from oracle import clip_ref, pipeline_ref, tokens_ref
     from vidil_amd.capfilt import CapFiltEngine, collect_outputs
     from vidil_amd.visual_tokenization import CATEGORIES, VisualTokenizer
 
     fm = full_models
-    Nv, F = 2, 4
+    Nv, F = 3, 8
     u8 = synthetic_frames(Nv, F, first_video=7)
     cfg = dict(caption=True, filter=True, filter_generated_only=True, keep_original_caption=False, threshold=0.4,
                filter_mode="max_filter", generation_mode="beam", image_size=224, vit="base", topk_visualize=5)
     eng = CapFiltEngine(cfg, DEV, captioner=fm["cap"], filterer=fm["itm"])
     items = [dict(video_id=f"video{v}", text=[]) for v in range(Nv)]
     eng.process(items, torch.from_numpy(u8).to(DEV))
-    emb, texts = _ontology()
+    emb, texts = _ontology(sizes=dict(objects=19958, attributes=15026, scenes=365, verbs=7410))
     vt = VisualTokenizer(cfg, fm["clip"], texts, emb, DEV)
     toks = vt.process([it["video_id"] for it in items], torch.from_numpy(u8).to(DEV), [it["unfiltered_text"] for it in items])
     prompt = fm["cap"].prompt_ids(1, "cpu")[0].long().numpy()
     checked = 0
+    ranks = masked = 0
+    # cosine scores: the 16-bit tower moves an embedding element by < 5e-4 (test_full_clip_vs_oracle), i.e. a score by
+    # ~1e-4 typically and < 5e-4 over 42k classes; ranks closer than 3x that in the oracle's own scores are not decided
+    GAP = 1.5e-3
     for v in range(Nv):
         x = clip_ref.preprocess_u8(u8[v])
         otrace = []
@@ -742,18 +751,35 @@ def test_end_to_end_two_videos_vs_oracle_pipeline(full_models):
         kept, probs = pipeline_ref.filter_video(fm["sd_itm"], x, caps, fm["tok"], 0.4, return_probs=True)
         if all(abs(float(np.max(p)) - 0.4) > 2e-3 for p in probs):
             assert items[v]["text"] == kept
-        ref = pipeline_ref.visual_tokens_video(fm["sd_clip"], x, emb, texts, topk=5)
+        # visual tokens: the reference form (fp32 embeds @ text.T, argsort, run_visual_tokenization.py:276,298-308)
+        with torch.no_grad():
+            ie = clip_ref.image_embeds(fm["sd_clip"], x)
         got = toks[f"video{v}"]
-        same = total = 0
-        for f in range(F):
-            for key in CATEGORIES:
-                total += 5
-                same += sum(a == b for a, b in zip(got["frame_tokens"][f][key], ref["frame_tokens"][f][key]))
-        assert same / total >= 0.97, (same, total)       # rank flips only between near-equal scores
-        assert set(got["aggregated_tokens"].keys()) == set(CATEGORIES)
+        for key in CATEGORIES:
+            sc = (ie @ emb[key].t()).numpy()                                    # [F, n_classes]
+            order = np.argsort(sc, axis=1)[:, ::-1][:, :6]
+            top = np.take_along_axis(sc, order, axis=1)                          # 6 best scores per frame, descending
+            for f in range(F):
+                ref_texts = [texts[key][i] for i in order[f, :5]]
+                for r in range(5):
+                    ranks += 1
+                    # rank r is determined when it is separated from both neighbours in the oracle's own scores
+                    clear = (top[f, r] - top[f, r + 1] > GAP) and (r == 0 or top[f, r - 1] - top[f, r] > GAP)
+                    if clear:
+                        assert got["frame_tokens"][f][key][r] == ref_texts[r], (v, f, key, r)
+                    else:
+                        masked += 1
+                # whatever the order inside a near-tie, the device's five are among the oracle's near-top
+                near = {texts[key][i] for i in np.flatnonzero(sc[f] >= top[f, 4] - GAP)}
+                assert set(got["frame_tokens"][f][key]) <= near, (v, f, key)
+        agg = tokens_ref.aggregate_frame_tokens(got["frame_tokens"])
+        assert got["aggregated_tokens"] == agg and set(agg.keys()) == set(CATEGORIES)
+    print(f"e2e: {checked}/{Nv * F} free-running captions equal the fp32 oracle's; visual-token ranks compared exactly "
+          f"{ranks - masked}/{ranks} (the rest lie within {GAP} of a neighbour in the oracle's own scores)")
     assert checked >= (Nv * F) // 2, checked      # most free-running captions equal the fp32 oracle's
+    assert masked <= 0.6 * ranks, (masked, ranks)
     f_out, u_out = collect_outputs(items)
-    assert list(u_out.keys()) == ["video0", "video1"]
+    assert list(u_out.keys()) == ["video0", "video1", "video2"]
 
 
 def test_results_do_not_depend_on_batch_composition(full_models):
