@@ -375,7 +375,10 @@ def test_itm_short_circuit_host_logic_equals_the_exhaustive_schedule_on_stand_in
 
         def tokenize(self, caps):
             self.texts = list(caps)
-            return torch.zeros(len(caps), 35, dtype=torch.int32), torch.full((len(caps),), 9, dtype=torch.int32)
+            ids = torch.zeros(len(caps), 35, dtype=torch.int32)
+            ids[:, 1] = torch.arange(len(caps), dtype=torch.int32)          # "token" 1 names the caption
+            lens = torch.tensor([5 + zlib.crc32(c.encode()) % 30 for c in caps], dtype=torch.int32)   # 5..34: all buckets
+            return ids, lens
 
         def project_image_kv(self, y16, n, min_rows):
             return "cross"
@@ -386,7 +389,8 @@ def test_itm_short_circuit_host_logic_equals_the_exhaustive_schedule_on_stand_in
                 image_index = np.repeat(np.arange(n_images), np.diff(gs))
                 assert np.diff(gs).max() == max_group
             img = np.asarray(image_index).astype(np.int64)
-            txt = pair_text.numpy()
+            assert int(lens.max()) <= max(e for e in (8, 12, 16, 20, 24, 28, 35) if e >= int(lens.max()))
+            txt = ids[:, 1].numpy()[pair_text.numpy()]                      # rows of ids are a subset of the captions
             assert len(img) == len(txt)
             self.calls.append(len(txt))
             u = np.array([zlib.crc32(f"{i}|{self.texts[t]}".encode()) / 2 ** 32 for i, t in zip(img, txt)], dtype=np.float64)
@@ -396,7 +400,8 @@ def test_itm_short_circuit_host_logic_equals_the_exhaustive_schedule_on_stand_in
 
     frames = torch.zeros(Nv, F, 8, 8, 3, dtype=torch.uint8)
     some_split = False
-    for thr in (0.0, 0.2, 0.5, 0.8, 0.97, 1.0):
+    for thr, min_pairs in [(t, m) for t in (0.0, 0.2, 0.5, 0.8, 0.97, 1.0) for m in (1, 2048)]:
+        CapFiltEngine.MIN_BUCKET_PAIRS = min_pairs          # 1: every length bucket is its own call; 2048: one call
         for keep in (False, True):
             out = {}
             for short in (False, True):
@@ -412,6 +417,7 @@ def test_itm_short_circuit_host_logic_equals_the_exhaustive_schedule_on_stand_in
             assert out[True][0] == out[False][0], (thr, keep)
             assert out[True][1] == sum(out[True][2]) and out[False][1] == sum(out[False][2])
             assert out[True][1] <= out[False][1]
+            assert (len(out[False][2]) > 1) == (min_pairs == 1)          # length buckets really were separate calls
             kept = sum(len(i["text"]) for i in out[True][0])
             some_split |= 0 < kept < sum(len(i["unfiltered_text"]) for i in out[True][0])
             if thr == 0.0 and not keep:       # everything passes on its own frame: one pair per distinct caption

@@ -870,6 +870,31 @@ def test_itm_short_circuit_keeps_exactly_the_captions_the_exhaustive_schedule_ke
     assert seen_partial                      # at least one threshold splits the candidates, so both phases decided something
 
 
+def test_itm_length_buckets_keep_exactly_what_one_padded_call_keeps(full_models, monkeypatch):
+    """The reference pads every caption to 35 tokens; the engine scores captions of similar length together, each call
+    cut to its longest caption.  Padded keys are masked and padded rows feed nothing, so the kept lists (max and avg
+    rule, several thresholds) must not depend on the bucketing — checked with original captions of 2...30 words."""
+    from vidil_amd.capfilt import CapFiltEngine
+
+    fm = full_models
+    Nv, F = 3, 8
+    u8 = torch.from_numpy(synthetic_frames(Nv, F, first_video=41)).to(DEV)
+    originals = [" ".join(f"w{2000 + 37 * i + 11 * j}" for j in range(n)) for i, n in enumerate((2, 6, 11, 17, 30))]
+    for mode in ("max_filter", "avg_filter"):
+        for thr in (0.3, 0.45, 0.5, 0.55, 0.7):
+            res = {}
+            for min_pairs in (1, 10 ** 9):
+                monkeypatch.setattr(CapFiltEngine, "MIN_BUCKET_PAIRS", min_pairs)
+                cfg = dict(caption=True, filter=True, filter_generated_only=False, keep_original_caption=True, threshold=thr,
+                           filter_mode=mode, generation_mode="beam", image_size=224, vit="base",
+                           do_sentence_tokenization=False)
+                eng = CapFiltEngine(cfg, DEV, captioner=fm["cap"], filterer=fm["itm"])
+                items = [dict(video_id=f"video{v}", text=originals[v:v + 3]) for v in range(Nv)]
+                eng.process(items, u8)
+                res[min_pairs] = (items, eng.last_stats["itm_pairs"])
+            assert res[1] == res[10 ** 9], (mode, thr)
+
+
 def test_vit_with_fused_layernorm_matches_the_unfused_path_and_the_oracle():
     """fuse_layernorm moves the rounding point of the GEMM operand from LN(x) to x; both variants must sit within the
     same tolerance of the fp32 oracle, and within ~2x the f16 tolerance of each other."""

@@ -250,72 +250,121 @@ class CapFiltEngine:
                                itm_pairs=n_pairs)
         return items
 
-    def _pairs_image_major(self, flt, y16, cross, Nv, F, caps_per_video, ids, lens, cap_first, skip=None):
-        """Queue the ITM of every (frame, caption) pair of the batch except ``skip[v][ci]`` = the one frame already
-        scored for that caption (or -1).  Pair order is IMAGE-major (video, frame, caption) so the captions of a frame
-        are consecutive and share one fetch of that frame's cross K/V; the reference's loop is caption-major
-        (run_video_CapFilt.py:110-112) but every (frame, caption) score is independent of the order.
-        caps_per_video[v]: indices (into that video's candidate list) of the captions to score.
-        Returns ((pinned probabilities, event), pair_first [Nv*F+1])."""
-        pair_cap, counts = [], np.zeros(Nv * F, dtype=np.int64)
-        for v, sel in enumerate(caps_per_video):
-            if not len(sel):
-                continue
-            sel = np.asarray(sel, dtype=np.int64)
-            if skip is None:
-                counts[v * F:(v + 1) * F] = len(sel)
-                pair_cap.append(np.tile(cap_first[v] + sel, F))
-            else:
-                home = np.asarray([skip[v][ci] for ci in sel], dtype=np.int64)
+    # ------------------------------------------------------------------ the filter's text side
+    # Candidate captions of the batch are numbered globally (video-major); a (caption, frame) pair is scored by at most
+    # one ``itm_pairs`` call and lands in a dense [captions, F] probability matrix (NaN = never scored).  Calls differ
+    # in WHICH pairs they hold — all of them, one length bucket, a short-circuit phase — never in what a pair's score is.
+
+    #: upper token counts of the length buckets (CLS + words + SEP, models/blip_itm.py:46 pads everything to 35)
+    LENGTH_EDGES = (8, 12, 16, 20, 24, 28, 35)
+    #: a bucket with fewer pairs than this is merged into the next longer one (its GEMMs would not fill the chip)
+    MIN_BUCKET_PAIRS = 2048
+
+    def _length_buckets(self, cap_idx, lens_np, pairs_per_cap):
+        """Split caption indices by token count so that a call's rows are cut to ITS longest caption (the reference pads
+        to 35; itm_pairs already cuts a call to the longest caption in it).  Invisible when all captions have the same
+        length; on real captions (10-14 tokens, a few long ones) it removes the padding rows of the short ones."""
+        buckets, cur, cur_pairs = [], [], 0
+        order = cap_idx[np.argsort(lens_np[cap_idx], kind="stable")]
+        edge = 0
+        for c in order:
+            while lens_np[c] > self.LENGTH_EDGES[edge]:
+                edge += 1
+                if cur and cur_pairs >= self.MIN_BUCKET_PAIRS:
+                    buckets.append(np.sort(np.asarray(cur)))
+                    cur, cur_pairs = [], 0
+            cur.append(c)
+            cur_pairs += pairs_per_cap
+        if cur:
+            buckets.append(np.sort(np.asarray(cur)))
+        return buckets
+
+    def _score(self, pend, cap_idx, frame_of=None):
+        """Queue the ITM of captions ``cap_idx`` (global indices, ascending) against the frames of their videos — all
+        F, or only ``frame_of[c]`` when given (int array aligned with cap_idx).  Pair order is IMAGE-major (video, frame,
+        caption) so the captions of a frame are consecutive and share one fetch of that frame's cross K/V; the
+        reference's loop is caption-major (run_video_CapFilt.py:110-112) but a pair's score does not depend on the order."""
+        F, flt = pend["F"], self.filterer
+        vid = pend["cap_video"][cap_idx]
+        sub = torch.from_numpy(cap_idx)
+        ids, lens = pend["ids"].index_select(0, sub), pend["lens"].index_select(0, sub)
+        local = np.arange(len(cap_idx), dtype=np.int64)
+        if frame_of is not None:                      # one pair per caption: pair -> image map
+            image = (vid * F + frame_of).astype(np.int32)
+            logits = flt.itm_pairs(pend["y16"], pend["n_images"], ids, lens, image_index=torch.from_numpy(image),
+                                   pair_text=torch.from_numpy(local), cross=pend["cross"])
+            pair_c, pair_f = cap_idx, np.asarray(frame_of, dtype=np.int64)
+        else:
+            skip = pend.get("skip")
+            pair_c, pair_f, counts = [], [], np.zeros(pend["n_images"], dtype=np.int64)
+            # captions are video-major, so the captions of one video are one run of cap_idx
+            starts = np.flatnonzero(np.r_[True, vid[1:] != vid[:-1]])
+            ends = np.r_[starts[1:], len(vid)]
+            for a, b in zip(starts, ends):
+                v = int(vid[a])
+                run = local[a:b]
                 for f in range(F):
-                    here = sel[home != f]
+                    here = run if skip is None else run[skip[cap_idx[a:b]] != f]
                     counts[v * F + f] = len(here)
-                    pair_cap.append(cap_first[v] + here)
-        if not pair_cap or counts.sum() == 0:
-            return None
-        pair_cap = np.concatenate(pair_cap)
-        group_start = torch.zeros(Nv * F + 1, dtype=torch.int32)
-        group_start[1:] = torch.from_numpy(np.cumsum(counts).astype(np.int32))
-        # (ids / lens stay one row per distinct caption; pair_cap maps the pairs onto them)
-        logits = flt.itm_pairs(y16, Nv * F, ids, lens, group_start=group_start, max_group=int(counts.max()),
-                               pair_text=torch.from_numpy(pair_cap), cross=cross)
+                    pair_c.append(here)
+                    pair_f.append(np.full(len(here), f, dtype=np.int64))
+            pair_l = np.concatenate(pair_c)
+            pair_c, pair_f = cap_idx[pair_l], np.concatenate(pair_f)
+            if not len(pair_l):
+                return
+            group_start = torch.zeros(pend["n_images"] + 1, dtype=torch.int32)
+            group_start[1:] = torch.from_numpy(np.cumsum(counts).astype(np.int32))
+            logits = flt.itm_pairs(pend["y16"], pend["n_images"], ids, lens, group_start=group_start,
+                                   max_group=int(counts.max()), pair_text=torch.from_numpy(pair_l), cross=pend["cross"])
         prob = torch.nn.functional.softmax(logits, dim=1)[:, 1].contiguous()
-        return self._to_host("itm", prob), group_start.numpy()
+        pend["calls"].append((self._to_host(f"itm{len(pend['calls'])}", prob), pair_c, pair_f))
+        pend["n_pairs"] += len(pair_c)
+
+    def _collect(self, pend):
+        """Wait for the queued calls and scatter their probabilities into the [captions, F] matrix."""
+        for (prob, ev), pair_c, pair_f in pend["calls"]:
+            ev.synchronize()
+            pend["prob"][pair_c, pair_f] = prob.numpy()
+        pend["calls"] = []
 
     def _filter_enqueue(self, y16, Nv, F, caps_per_video, home=None):
-        """Queue the filter's text side.  Default: every (frame, caption) pair, as the reference evaluates them.
-        ``itm_short_circuit`` (config, max_filter only): the rule ``max over frames > threshold`` is an any(); a
-        generated caption is first scored against the frame it was generated from (``home``), and only the captions
-        that did not pass there are scored against the other frames.  Each probability is the one the exhaustive
-        schedule computes (a pair's score does not depend on the batch around it), so the kept lists are identical;
-        on real captions — which nearly always match their own frame — this is ~1/F of the ITM work."""
+        """Queue the filter's text side.  Default: every (frame, caption) pair, as the reference evaluates them, in
+        length buckets.  ``itm_short_circuit`` (config, max_filter only): the rule ``max over frames > threshold`` is an
+        any(); a generated caption is first scored against the frame it was generated from (``home``), and only the
+        captions that did not pass there are scored against the other frames.  Each probability is the one the
+        exhaustive schedule computes (a pair's score does not depend on the batch around it), so the kept lists are
+        identical; on real captions — which nearly always match their own frame — this is ~1/F of the ITM work."""
         cfg, flt = self.config, self.filterer
         all_caps = [c for caps in caps_per_video for c in caps]
         if not all_caps:
             return None
         ids, lens = flt.tokenize(all_caps)
+        lens_np = lens.numpy().astype(np.int64)
         n_caps = np.fromiter((len(c) for c in caps_per_video), dtype=np.int64, count=Nv)
-        cap_first = np.concatenate([[0], np.cumsum(n_caps)[:-1]])
-        pend = dict(ids=ids, lens=lens, cap_first=cap_first, y16=y16, n_pairs=0, phase1=None, cross=None)
+        pend = dict(ids=ids, lens=lens, y16=y16, F=F, n_images=Nv * F, n_pairs=0, calls=[],
+                    cap_video=np.repeat(np.arange(Nv, dtype=np.int64), n_caps),
+                    prob=np.full((len(all_caps), F), np.nan, dtype=np.float32), short=False)
+        every = np.arange(len(all_caps), dtype=np.int64)
         short = (cfg.get("itm_short_circuit", False) and cfg.get("filter_mode", "max_filter") != "avg_filter"
                  and home is not None and F > 1)
+        buckets = self._length_buckets(every, lens_np, F)
+        # Row-major cross values (cheaper stores) are only readable by the staged attention kernel, i.e. when every call
+        # has more than 32 query rows on its busiest image; the short circuit's first phase has one caption per image.
+        t_cut = min(int(ids.shape[1]), int(lens_np.max()))
+        min_rows = min(min(int(ids.shape[1]), int(lens_np[b].max())) for b in buckets) if not short else 0
+        if not short and min_rows > 32 and len(buckets) == 1:
+            min_rows = t_cut * int(n_caps.max())        # one call, all captions of a frame together (the round-1 layout)
+        pend["cross"] = flt.project_image_kv(y16, Nv * F, min_rows)
         if not short:
-            pend["all"] = self._pairs_image_major(flt, y16, None, Nv, F, [range(n) for n in n_caps], ids, lens, cap_first)
-            pend["n_pairs"] = int(n_caps.sum()) * F
+            for b in buckets:
+                self._score(pend, b)
             return pend
-        # phase 1: one pair per caption that has a home frame (pair -> image map; a frame is home to at most one caption)
-        homes = [[home[v].get(c, -1) for c in caps] for v, caps in enumerate(caps_per_video)]
-        p_text = np.asarray([cap_first[v] + ci for v, hs in enumerate(homes) for ci, h in enumerate(hs) if h >= 0], dtype=np.int64)
-        p_image = np.asarray([v * F + h for v, hs in enumerate(homes) for h in hs if h >= 0], dtype=np.int32)
-        # both phases are cut to the longest caption (itm_pairs); phase 1 presents one caption per image
-        pend["cross"] = cross = flt.project_image_kv(y16, Nv * F, min(int(ids.shape[1]), int(lens.max().item())))
-        pend["homes"] = homes
-        if len(p_text):
-            logits = flt.itm_pairs(y16, Nv * F, ids, lens, image_index=torch.from_numpy(p_image),
-                                   pair_text=torch.from_numpy(p_text), cross=cross)
-            prob = torch.nn.functional.softmax(logits, dim=1)[:, 1].contiguous()
-            pend["phase1"] = self._to_host("itm1", prob)
-            pend["n_pairs"] = len(p_text)
+        pend["short"] = True
+        home_of = np.asarray([home[v].get(c, -1) for v, caps in enumerate(caps_per_video) for c in caps], dtype=np.int64)
+        pend["skip"] = home_of
+        first = every[home_of >= 0]
+        for b in (self._length_buckets(first, lens_np, 1) if len(first) else []):
+            self._score(pend, b, frame_of=home_of[b])
         return pend
 
     def _filter_finish(self, pending, Nv, F, caps_per_video):
@@ -324,53 +373,27 @@ class CapFiltEngine:
         if pending is None:
             return kept
         thr = cfg["threshold"]
-        if "all" in pending:
-            (prob, ev), gs = pending["all"]
-            ev.synchronize()
-            prob = prob.numpy()
-            for v, caps in enumerate(caps_per_video):
-                if not caps:
-                    continue
-                # rows of this video: F consecutive blocks of len(caps) pairs -> [F, C] -> per caption over frames
-                pv = prob[gs[v * F]: gs[v * F] + F * len(caps)].reshape(F, len(caps))
-                if cfg.get("filter_mode", "max_filter") != "avg_filter":
-                    # keep_caption's max rule for all captions of the video at once (a maximum has no rounding to differ in)
-                    kept[v] = [c for c, k in zip(caps, pv.max(axis=0) > thr) if k]
-                    continue
-                for ci, c in enumerate(caps):
-                    if keep_caption(pv[:, ci], thr, cfg["filter_mode"]):
-                        kept[v].append(c)
-            return kept
-        # short circuit: captions that passed on their home frame are decided; the rest meet the other frames
-        homes = pending["homes"]
-        passed = [np.zeros(len(c), dtype=bool) for c in caps_per_video]
-        if pending["phase1"] is not None:
-            prob1, ev = pending["phase1"]
-            ev.synchronize()
-            prob1, n = prob1.numpy(), 0
-            for v, hs in enumerate(homes):
-                for ci, h in enumerate(hs):
-                    if h >= 0:
-                        passed[v][ci] = prob1[n] > thr
-                        n += 1
-        rest = [np.flatnonzero(~p) for p in passed]
-        second = self._pairs_image_major(self.filterer, pending["y16"], pending["cross"], Nv, F, rest, pending["ids"],
-                                         pending["lens"], pending["cap_first"], skip=homes)
-        if second is not None:
-            (prob, ev), gs = second
-            pending["n_pairs"] += len(prob)
-            ev.synchronize()
-            prob = prob.numpy()
-            for v, sel in enumerate(rest):
-                if not len(sel):
-                    continue
-                hs = np.asarray([homes[v][ci] for ci in sel])
-                for f in range(F):
-                    here = sel[hs != f]
-                    row = prob[gs[v * F + f]: gs[v * F + f + 1]]
-                    passed[v][here] |= row > thr
+        self._collect(pending)
+        prob = pending["prob"]
+        if pending["short"]:
+            # captions that passed on their home frame are decided; the rest meet the other frames
+            with np.errstate(invalid="ignore"):
+                passed = np.nan_to_num(prob, nan=-1.0).max(axis=1) > thr
+            rest = np.flatnonzero(~passed)
+            if len(rest):
+                lens_np = pending["lens"].numpy().astype(np.int64)
+                for b in self._length_buckets(rest, lens_np, F - 1):
+                    self._score(pending, b)
+                self._collect(pending)
+            keep = np.nan_to_num(prob, nan=-1.0).max(axis=1) > thr
+        elif cfg.get("filter_mode", "max_filter") != "avg_filter":
+            keep = prob.max(axis=1) > thr         # keep_caption's max rule for every caption at once (no rounding to differ in)
+        else:
+            keep = np.asarray([keep_caption(prob[c], thr, "avg_filter") for c in range(prob.shape[0])], dtype=bool)
+        n = 0
         for v, caps in enumerate(caps_per_video):
-            kept[v] = [c for c, k in zip(caps, passed[v]) if k]
+            kept[v] = [c for c, k in zip(caps, keep[n:n + len(caps)]) if k]
+            n += len(caps)
         return kept
 
 
