@@ -21,7 +21,82 @@ def synth(seed, n_frames, vocab):
     return {"frame_tokens": frames, "caption": ["c"]}
 
 
+def prompt_string_cases():
+    """construct_prompt (visual_token_generation/prompts.py:120-313) over the template families, tasks and add_* flags,
+    and the fixed-prefix generator's loop (generate_prompts_fixed_prefix.py:16-91; its module imports ruamel.yaml, which
+    this image lacks and the function never uses: an empty stand-in module satisfies the import)."""
+    import copy
+    import itertools
+    import tempfile
+    import types
+
+    rng = random.Random(99)
+    cases = []
+    base = dict(topk=4, visual_token_aggregation_version="v2", prompt_temporal_template="temporal_natural", prompt_task="caption",
+                add_objects=True, add_events=True, add_attributes=True, add_scenes=True, add_ASR=True, add_original_caption=True,
+                add_frame_captions=True, add_answer=True)
+    grid = []
+    for template, task in itertools.product(("temporal_natural", "temporal_index", "static"), ("caption", "qa", "vlep", "multichoice")):
+        for version, topk in (("v2", 4), ("v3", 4), ("v2", 2), ("v2", 8), ("v3", 3)):
+            grid.append(dict(base, prompt_temporal_template=template, prompt_task=task, visual_token_aggregation_version=version, topk=topk))
+    for i in range(40):                                   # random flag subsets
+        c = dict(rng.choice(grid))
+        for k in [k for k in c if k.startswith("add_")]:
+            c[k] = rng.random() < 0.6
+        grid.append(c)
+    for n, cfg in enumerate(grid):
+        seed = 100 + n
+        obj = synth(seed, rng.choice([4, 8, 8, 16]), rng.choice([2, 3, 6, 12]))
+        obj["caption"] = rng.choice([["a man cooks. ", " two dogs run", "x y z"], " a single caption string ", [], ["only one"]])
+        n_caps = rng.choice([1, 2, 3, 4, 5, 8, 9])
+        fc = {"vid": [rng.choice(["a dog runs.", " a man talks . ", "cars on a road", "people dance.."]) + str(j) * (j % 2) for j in range(n_caps)]}
+        task = cfg["prompt_task"]
+        call = dict(question="what is shown?" if task == "qa" else None, answer="a dog" if task == "qa" else None,
+                    asr=rng.choice([None, "hello there", ""]),
+                    vlep_example=dict(events=["he leaves", "she stays"], answer=" A ") if task == "multichoice" else None)
+        conf = dict(cfg, prompt_task="vlep" if task == "multichoice" else task)
+        want_obj = copy.deepcopy(obj)
+        p = Prompt("PREFIX\n", seed=seed)
+        try:
+            out = p.construct_prompt("vid", want_obj, fc, conf, call["question"], call["answer"], call["asr"], call["vlep_example"])
+            err = None
+        except Exception as e:                             # table lookups fail on 0 / > 8 items: the error type is the contract
+            out, err = None, type(e).__name__
+        cases.append(dict(seed=seed, object=obj, frame_captions=fc, config=conf, call=call, prompt=out, error=err,
+                          caption_after=want_obj["caption"]))
+    # the fixed-prefix generator's loop
+    sys.modules.setdefault("ruamel", types.ModuleType("ruamel"))
+    sys.modules.setdefault("ruamel.yaml", types.ModuleType("ruamel.yaml"))
+    sys.modules["ruamel"].yaml = sys.modules["ruamel.yaml"]
+    import generate_prompts_fixed_prefix as gp
+
+    runs = []
+    for task in ("caption", "qa"):
+        for caption_all in (True, False):
+            vt = {f"v{i}": synth(300 + i, 8, 5) for i in range(6)}
+            filt = {f"v{i}": [f"cap {i} {j}." for j in range(1 + i)] for i in (0, 1, 3)}
+            unf = {f"v{i}": [f"raw {i} {j}" for j in range(5)] for i in (0, 1, 2, 3, 4)}
+            qa = {"v0": [dict(question="q0?", answer="a0"), dict(question="q1?", answer="a1")], "v2": [dict(question="q2?", answer="a2")]}
+            asr = {"v0": ["hi", "there"], "v1": [], "v2": [""], "v3": ["x"]}
+            with tempfile.TemporaryDirectory() as d:
+                cfg = dict(base, prompt_task=task, add_events=False, add_scenes=False, add_original_caption=False, add_answer=False,
+                           caption_all_video=caption_all, output_path=os.path.join(d, "out_q.jsonl"),
+                           request_body=dict(engine="text-davinci-002", prompt="", temperature=0.0, max_tokens=64, top_p=1,
+                                             frequency_penalty=0, presence_penalty=0))
+                gp.save_prompt_lines(copy.deepcopy(vt), filt, unf, Prompt("PRE ", seed=7), cfg, qa if task == "qa" else None, asr)
+                lines = open(cfg["output_path"]).read().splitlines()
+                idx = json.load(open(os.path.join(d, "out_q__idx_2_videoid.json")))
+            cfg_out = {k: v for k, v in cfg.items() if k != "output_path"}
+            cfg_out["request_body"] = dict(cfg_out["request_body"], prompt="")
+            runs.append(dict(visual_tokens=vt, filtered=filt, unfiltered=unf, qa=qa if task == "qa" else None, asr=asr, config=cfg_out,
+                             lines=lines, idx=idx))
+    json.dump(dict(cases=cases, fixed_prefix_runs=runs), open(os.path.join(HERE, "prompt_strings_golden.json"), "w"), indent=0)
+    print("wrote", len(cases), "construct_prompt cases,", len(runs), "fixed-prefix runs;",
+          sum(c["error"] is not None for c in cases), "of the cases are errors")
+
+
 def main():
+    prompt_string_cases()
     p = Prompt("{x}")
     cases = []
     for seed, (n_frames, vocab, topk) in enumerate([(8, 3, 4), (8, 6, 4), (8, 2, 8), (16, 5, 4), (4, 3, 2), (8, 12, 3), (5, 4, 4)]):
