@@ -139,6 +139,12 @@ typedef struct vidil_gemm_args {
    *   fp8   : slot (j, ks, h) at ((j*2 + ks)*2 + h)*1024 + l*16 = W[..][t*128 + ks*64 + (l/32)*32 + h*16 .. +16]
    * (vidil_amd.packing.tile_weight builds it).  NULL: the kernels that stage W through LDS are used. */
   const void* W_tiled;
+  /* Order in which the persistent 256x256 kernel walks its output tiles (a tuning knob; results do not depend on it).
+   * 0: library default for the shape.  w > 0: the N dimension is cut into blocks of w column tiles (w * 256 outputs)
+   * and the tiles are enumerated block by block, row panel by row panel inside a block, so the weight rows an XCD's
+   * workgroups read at any one time are those of w column tiles (w * 256 * K * operand size bytes against a 4-MiB L2).
+   * < 0: the plain row-panel-major order. */
+  int32_t col_block;
 } vidil_gemm_args;
 
 /* replaces: nn.Linear calls of models/vit.py:35-41,72,84; models/med.py:153-171,
