@@ -102,7 +102,7 @@ def gemm_kernel_name(a, w, bias=None, **kw):
 
 def _gemm_build(a, w, bias=None, *, out=None, out_dtype=None, act=ACT_NONE, resid=None,
                 heads=None, patch=None, arena=None, M=None, lda=None, out16=None, ln_stats_out=None, ln=None, w_scale=None,
-                dtype16=None):
+                dtype16=None, col_block=0):
     K_ = w.shape[1]
     if lda is None:
         M, Ka = a.shape
@@ -119,6 +119,7 @@ def _gemm_build(a, w, bias=None, *, out=None, out_dtype=None, act=ACT_NONE, resi
     wt = getattr(w, "_vidil_tiled", None)        # fragment-tiled copy (packing.with_tiles): the 2-workgroups-per-CU kernel
     if wt is not None and wt.device == w.device:
         g.W_tiled = wt.data_ptr()
+    g.col_block = int(col_block)                 # tile order of the persistent kernel (tuning knob, results unaffected)
     fp8 = g.dtype == DT_FP8
     # fp8 operands (tower mode): 16-bit outputs are written in the companion type (taken from the output buffers)
     t16 = a.dtype
