@@ -6,7 +6,7 @@ import time
 import numpy as np
 import torch
 
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 
 from oracle import beam_ref, clip_ref, med_ref, vit_ref  # noqa: E402
 from vidil_amd.blip import BLIP_Decoder, DecodeTrace  # noqa: E402
