@@ -189,3 +189,43 @@ def test_youcook2_ontology_mapping_is_the_documented_one():
     assert set(yc["attributes"]) <= set(json.load(open(os.path.join(root, "vg", "vg_original_attributes_synsets_keys_cleaned_remove_similar0.9.json"))))
     with pytest.raises(ValueError):
         load_visual_token_texts(root, "coco")
+
+
+def test_evaluation_of_fp8_cross_kv_for_the_decode_steps():
+    """VERDICT r1 #10 asked to EVALUATE e4m3 image K/V for the decode cross-attention (the kernel re-reads 1.86 GB of
+    16-bit K/V per launch at the HBM ceiling).  Done at the oracle level before writing a kernel: the captioner's
+    cross K/V of every layer rounded to e4m3 (per-head amax scale) against f16 rounding, everything else fp32.
+    Printed; the bounds only pin the order of magnitude that DESIGN.md §7 quotes."""
+    from common import perturb_
+    from oracle import med_ref
+    from vidil_amd.blip import BLIP_Decoder
+    from vidil_amd.tokenizer import SyntheticBertTokenizer
+
+    torch.manual_seed(3)
+    cap = BLIP_Decoder(image_size=224, vit="base", tokenizer=SyntheticBertTokenizer()).eval()
+    perturb_(cap, 17)
+    sd = {k: v.clone() for k, v in cap.state_dict().items()}
+    enc = torch.randn(2, 197, 768)
+    ids = cap.prompt_ids(2, "cpu").long()
+
+    def run(round_fn):
+        cache = {}
+        with torch.no_grad():
+            ref, _ = med_ref.decoder_logits(sd, ids, enc, cross_cache=cache)
+            if round_fn is None:
+                return ref
+            for p, (k, v) in list(cache.items()):
+                cache[p] = (round_fn(k), round_fn(v))
+            out, _ = med_ref.decoder_logits(sd, ids, enc, cross_cache=cache)
+        return out
+
+    def to_e4m3(x):                                   # [B, H, T, 64]: one scale per (image, head), amax -> 448
+        s = x.abs().amax(dim=(-1, -2), keepdim=True).clamp_min(1e-12) / 448.0
+        return (x / s).to(torch.float8_e4m3fn).float() * s
+
+    ref = run(None)
+    e16 = (run(lambda x: x.half().float()) - ref).abs().max().item()
+    e8 = (run(to_e4m3) - ref).abs().max().item()
+    scale = ref.abs().max().item()
+    print(f"cross K/V rounding, caption logits max|d| (scale {scale:.2f}): f16 {e16:.2e}, e4m3 {e8:.2e} ({e8 / max(e16, 1e-12):.0f}x)")
+    assert e16 < 2e-3 and e8 < 0.5 and e8 > 5 * e16
