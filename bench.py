@@ -142,39 +142,82 @@ class GemmTimer:
         return agg
 
 
-def cpu_baseline(cap, flt, clip, tok, onto_embeds, onto_texts, n_videos, frames, size, vit="base"):
-    """The CPU oracle on a bounded sample (rank 0, N=1 only), on ALL host cores the process may use, in both schedules
-    SURVEY.md §8d asks for: the reference's (ViT per caption, cross K/V per decoder call — `value`) and the
-    de-duplicated one the GPU path uses (`dedup_value`).  Same frames, same weights."""
+CPU_WORKER_THREADS = 16       # measured on the GPU box's 2 x EPYC 9575F: one 8-frame video is FASTEST on 16 threads (0.9 s per
+#                               2-frame caption pass; 1.7 s on 32, 4.8 s on 64, 16.6 s on 128, minutes on 256): the oracle's
+#                               per-video tensors are too small for more, so the host is filled with independent workers
+
+
+def cpu_worker(args):
+    """One CPU worker of the baseline (own process, `--cpu-worker i`): video i of the synthetic set through the oracle
+    in both schedules SURVEY.md §8d asks for — the reference's (ViT per caption, cross K/V per decoder call) and the
+    de-duplicated one the GPU path uses — after a file barrier so that all workers compute at the same time."""
+    torch.set_num_threads(args.cpu_threads)
     from oracle import clip_ref, pipeline_ref
 
-    ncpu = len(os.sched_getaffinity(0))
-    nthreads = int(os.environ.get("VIDIL_CPU_THREADS", ncpu))
-    torch.set_num_threads(nthreads)
-    depth, heads = (12, 12) if vit == "base" else (24, 16)
-    sd_cap = {k: v.detach().float().cpu() for k, v in cap.state_dict().items()}
-    sd_itm = {k: v.detach().float().cpu() for k, v in flt.state_dict().items()}
-    sd_clip = {k: v.detach().float().cpu() for k, v in clip.state_dict().items()}
+    cap, flt, clip, tok = build_models("cpu", args.size, args.clip, args.vit, "f16")      # seed 0: the GPU run's weights
+    onto_embeds, onto_texts = synthetic_ontology(dim=clip.config.projection_dim)
+    depth, heads = (12, 12) if args.vit == "base" else (24, 16)
+    sd_cap = {k: v.detach().float() for k, v in cap.state_dict().items()}
+    sd_itm = {k: v.detach().float() for k, v in flt.state_dict().items()}
+    sd_clip = {k: v.detach().float() for k, v in clip.state_dict().items()}
     prompt = cap.prompt_ids(1, "cpu")[0].long().numpy()
-    fr = synthetic_frames(n_videos, frames, size)
+    x = clip_ref.preprocess_u8(synthetic_frames(1, args.frames, args.size, args.cpu_worker)[0])
+    open(os.path.join(args.cpu_sync_dir, f"ready{args.cpu_worker}"), "w").close()
+    while not os.path.exists(os.path.join(args.cpu_sync_dir, "go")):
+        time.sleep(0.01)
     out = {}
     for label, dedup in (("reference", False), ("dedup", True)):
         t0 = time.time()
-        n_caps = 0
-        for v in range(n_videos):
-            x = clip_ref.preprocess_u8(fr[v])
-            kept, caps = pipeline_ref.capfilt_video(sd_cap, sd_itm, x, prompt, tok, cap.prompt, threshold=0.4, dedup=dedup,
-                                                    depth=depth, heads=heads)
-            n_caps += len(caps)
-            pipeline_ref.visual_tokens_video(sd_clip, x, onto_embeds, onto_texts, topk=5)
-        out[label] = (time.time() - t0, n_caps)
-    dt, n_caps = out["reference"]
-    dt2, _ = out["dedup"]
-    return dict(value=round(n_videos * frames / dt, 4), unit="frames/s", cores=ncpu, threads=torch.get_num_threads(),
-                os_cpu_count=os.cpu_count(), kind="port", dedup_value=round(n_videos * frames / dt2, 4),
-                sample=f"{n_videos} video(s) x {frames} frames, oracle (PyTorch fp32, {torch.get_num_threads()} threads on "
-                       f"{ncpu} usable cores of {os.cpu_count()}): reference schedule incl. {n_caps} ITM caption passes "
-                       f"{dt:.1f} s; de-duplicated schedule (filter ViT once per frame, cross K/V once per image) {dt2:.1f} s")
+        kept, caps = pipeline_ref.capfilt_video(sd_cap, sd_itm, x, prompt, tok, cap.prompt, threshold=0.4, dedup=dedup,
+                                                depth=depth, heads=heads)
+        pipeline_ref.visual_tokens_video(sd_clip, x, onto_embeds, onto_texts, topk=5)
+        out[label] = (time.time() - t0, len(caps))
+    print(json.dumps(dict(worker=args.cpu_worker, reference=out["reference"][0], dedup=out["dedup"][0], n_caps=out["reference"][1])),
+          flush=True)
+
+
+def cpu_baseline(args, budget_s=240):
+    """The CPU oracle on a bounded sample (rank 0, N=1 only): W worker processes x 16 threads, one 8-frame video each,
+    W chosen to fill the physical cores this process may use; frames/s = W videos' frames / the slowest worker.  The
+    workers are subprocesses of this script, so a pathological host cannot hang the bench: past ``budget_s`` they are
+    stopped and the line says so."""
+    import subprocess
+    import tempfile
+
+    ncpu = len(os.sched_getaffinity(0))
+    cap_threads = int(os.environ.get("VIDIL_CPU_THREADS", max(1, ncpu // 2)))          # SMT siblings do not help GEMMs
+    t_per = min(CPU_WORKER_THREADS, cap_threads)
+    workers = max(1, min(cap_threads // t_per, 16))
+    with tempfile.TemporaryDirectory() as sync:
+        cmd = [sys.executable, os.path.abspath(__file__), "--cpu-threads", str(t_per), "--cpu-sync-dir", sync, "--frames", str(args.frames),
+               "--size", str(args.size), "--vit", args.vit, "--clip", args.clip]
+        env = dict(os.environ, OMP_NUM_THREADS=str(t_per), HIP_VISIBLE_DEVICES="", CUDA_VISIBLE_DEVICES="")
+        procs = [subprocess.Popen(cmd + ["--cpu-worker", str(i)], stdout=subprocess.PIPE, stderr=subprocess.DEVNULL, env=env, text=True)
+                 for i in range(workers)]
+        t0 = time.time()
+        while len([f for f in os.listdir(sync) if f.startswith("ready")]) < workers and time.time() - t0 < budget_s \
+                and all(p.poll() is None for p in procs):
+            time.sleep(0.05)
+        open(os.path.join(sync, "go"), "w").close()
+        res = []
+        for p in procs:
+            try:
+                o, _ = p.communicate(timeout=max(1.0, budget_s - (time.time() - t0)))
+                res.append(json.loads(o.strip().splitlines()[-1]))
+            except Exception:                      # over budget or died: report what is known, never hang
+                p.kill()
+    base = dict(unit="frames/s", cores=workers * t_per, threads_per_worker=t_per, workers=workers, usable_cpus=ncpu,
+                os_cpu_count=os.cpu_count(), kind="port")
+    if len(res) < workers:
+        return dict(base, value=None, dedup_value=None,
+                    sample=f"{workers - len(res)} of {workers} CPU workers did not finish within {budget_s} s")
+    dt, dt2 = max(r["reference"] for r in res), max(r["dedup"] for r in res)
+    n_caps = sum(r["n_caps"] for r in res)
+    return dict(base, value=round(workers * args.frames / dt, 4), dedup_value=round(workers * args.frames / dt2, 4),
+                sample=f"{workers} videos x {args.frames} frames, one per worker process ({workers} x {t_per} threads = "
+                       f"{workers * t_per} of the host's {ncpu} hardware threads), oracle (PyTorch fp32) at the same time: reference "
+                       f"schedule incl. {n_caps} ITM caption passes {dt:.1f} s (slowest worker); de-duplicated schedule (filter ViT "
+                       f"once per frame, cross K/V once per image) {dt2:.1f} s")
 
 
 def main():
@@ -194,7 +237,9 @@ def main():
     ap.add_argument("--vit", choices=["base", "large"], default="base", help="BLIP vision tower (config 4: large = ViT-L/16)")
     ap.add_argument("--size", type=int, default=224, help="frame / BLIP image size (the headline metric is 224)")
     ap.add_argument("--clip", choices=["b32", "l14"], default="b32", help="CLIP tower (headline metric: ViT-B/32)")
-    ap.add_argument("--cpu-sample-videos", type=int, default=1)
+    ap.add_argument("--cpu-worker", type=int, default=None, help=argparse.SUPPRESS)          # internal: see cpu_worker()
+    ap.add_argument("--cpu-threads", type=int, default=CPU_WORKER_THREADS, help=argparse.SUPPRESS)
+    ap.add_argument("--cpu-sync-dir", default=None, help=argparse.SUPPRESS)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
     ap.add_argument("--itm-short-circuit", action="store_true",
@@ -211,6 +256,8 @@ def main():
     from vidil_amd.pipeline import FramePipeline
     from vidil_amd.visual_tokenization import VisualTokenizer
 
+    if args.cpu_worker is not None:          # a worker process of cpu_baseline(): oracle only, no GPU
+        return cpu_worker(args)
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an AMD GPU (no CPU fallback for the product path)")
     # (developer smoke of the N > 1 launch path on a one-GPU box: VIDIL_BENCH_SMOKE_ONE_DEVICE=1 puts every rank
@@ -344,8 +391,7 @@ def main():
                                                "ms": round(v[2] * 1e3, 3)} for k, v in agg.items()}}
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         log("cpu baseline...")
-        result["cpu_baseline"] = cpu_baseline(cap, flt, clip, tok, onto_embeds, onto_texts, args.cpu_sample_videos, F, args.size,
-                                              args.vit)
+        result["cpu_baseline"] = cpu_baseline(args)
     if rank == 0:
         print(json.dumps(result), flush=True)
 
