@@ -173,7 +173,7 @@ __device__ __forceinline__ void store_rows(const AttnP<T>& p, const RowInfo& ri,
 
 // ------------------------------------------------------------------ LDS-staged kernel
 template <typename T, int NKT, int NW>
-__global__ __launch_bounds__(NW * 64) void attn_lds_kernel(const AttnP<T> p) {
+__global__ __launch_bounds__(NW * 64, NW == 8 ? 4 : 2) void attn_lds_kernel(const AttnP<T> p) {
   using f16 = T;                       // (the body below is written in terms of "the 16-bit operand type")
   using f16x8 = typename Elt<T>::x8;
   constexpr int NKEY = NKT * 32;
@@ -202,7 +202,83 @@ __global__ __launch_bounds__(NW * 64) void attn_lds_kernel(const AttnP<T> p) {
 
   const f16* kg = p.k + ((size_t)bk * p.H + h) * p.Tk_cap * 64;
   const f16* vg = p.vt + ((size_t)bk * p.H + h) * 64 * (size_t)p.NP;
+  // Staging issues EVERY global load of a thread before the first LDS store (compile-time trip counts, predicated):
+  // written as load -> store loops with run-time bounds the compiler kept one load in flight per thread, and a
+  // workgroup spent 4-7 serial HBM round trips here before its first MFMA.
+  constexpr int KIT = (NKEY * 8 + NT - 1) / NT;          // 16-byte chunks of K per thread
+  constexpr int VIT = (64 * NKT * 4 + NT - 1) / NT;       // 16-byte chunks of V^T per thread (same count: NKEY * 8)
   auto stage = [&](int k0) {
+    f16x8 kreg[KIT], vreg[VIT];        // (both batches of loads are issued before the first store below)
+    // ---- K rows k0 .. k0+NKEY-1 (rows >= Nk zero) -------------------------------------------------------
+#pragma unroll
+    for (int i = 0; i < KIT; ++i) {
+      const int q = tid + i * NT;
+      const int row = q >> 3, c = q & 7;
+      kreg[i] = zero8<T>();
+      if (q < NKEY * 8 && k0 + row < nk) kreg[i] = *(const f16x8*)(kg + (size_t)(k0 + row) * 64 + c * 8);
+    }
+    if (p.NP == 0) {
+      // ---- V given ROW-MAJOR ([keys][64], NP == 0: the QKV GEMM then stores V like K, 16 B per lane, instead of
+      //      scattering V^T with 2-byte stores): transpose while staging.  Lanes walk consecutive keys, so for a
+      //      fixed d the 64 lanes of a wave write 128 contiguous bytes of one V^T row (no bank conflicts); the
+      //      16-byte global reads of a wave cover 64 key rows and are re-used from L1 by the next d-chunk.
+      const f16* vrow = p.vt + ((size_t)bk * p.H + h) * p.Tk_cap * 64;
+#pragma unroll
+      for (int i = 0; i < KIT; ++i) {
+        const int q = tid + i * NT;
+        const int c = q / NKEY, r = q - c * NKEY;
+        vreg[i] = zero8<T>();
+        if (q < NKEY * 8 && k0 + r < nk) vreg[i] = *(const f16x8*)(vrow + (size_t)(k0 + r) * 64 + c * 8);
+      }
+    } else {
+      // ---- V^T columns k0 .. (keys >= Nk zero: masked P is 0 but 0*garbage must stay 0) -------------------
+#pragma unroll
+      for (int i = 0; i < VIT; ++i) {
+        const int q = tid + i * NT;
+        const int d = q / (NKT * 4), kc = q - d * (NKT * 4);
+        const int pos0 = k0 + kc * 8;           // storage columns pos0..pos0+7 (key = vt_pos(column))
+        vreg[i] = zero8<T>();
+        if (q < 64 * NKT * 4 && (pos0 & ~15) < nk && pos0 + 8 <= p.NP) vreg[i] = *(const f16x8*)(vg + (size_t)d * p.NP + pos0);
+      }
+    }
+    // ---- LDS stores ------------------------------------------------------------------------------------
+#pragma unroll
+    for (int i = 0; i < KIT; ++i) {
+      const int q = tid + i * NT;
+      if (q < NKEY * 8) *(f16x8*)(Ks + (q >> 3) * KROW + (q & 7) * 8) = kreg[i];
+    }
+    if (p.NP == 0) {
+#pragma unroll
+      for (int i = 0; i < KIT; ++i) {
+        const int q = tid + i * NT;
+        const int c = q / NKEY, r = q - c * NKEY;
+        if (q < NKEY * 8) {
+          const int col = vt_pos(r);
+#pragma unroll
+          for (int e = 0; e < 8; ++e) Vs[(c * 8 + e) * VROW + col] = vreg[i][e];
+        }
+      }
+    } else {
+#pragma unroll
+      for (int i = 0; i < VIT; ++i) {
+        const int q = tid + i * NT;
+        const int d = q / (NKT * 4), kc = q - d * (NKT * 4);
+        const int pos0 = k0 + kc * 8;
+        if (q < 64 * NKT * 4) {
+          f16x8 v = vreg[i];
+          if ((pos0 | 15) + 1 > nk) {            // the 16-key block that straddles Nk: zero the keys past the end
+#pragma unroll
+            for (int e = 0; e < 8; ++e)
+              if (vt_pos(pos0 + e) >= nk) v[e] = (f16)0.f;
+          }
+          *(f16x8*)(Vs + d * VROW + kc * 8) = v;
+        }
+      }
+    }
+  };
+
+  auto stage_next = [&](int k0) {   // chunks after the first (sequences over NKEY keys): the accumulators and Q
+    // fragments are live here, so this one keeps a single load in flight per thread instead of a batch
     // ---- stage K rows k0 .. k0+NKEY-1 (rows >= Nk zero) ------------------------------------------------
     for (int q = tid; q < NKEY * 8; q += NT) {
       const int row = q >> 3, c = q & 7;
@@ -247,6 +323,8 @@ __global__ __launch_bounds__(NW * 64) void attn_lds_kernel(const AttnP<T> p) {
   // 224-key chunks): stage the chunk, run its key tiles through the online softmax, re-stage.  Multi-chunk
   // launches keep one row block per wave (its (m, l, O) lives across the chunks).
   const int nblk = nk <= NKEY ? p.rb : 1;
+  stage(0);                                     // before any per-wave state (Q fragments, accumulators) is live
+  __syncthreads();
 #pragma unroll 1
   for (int rbi = 0; rbi < nblk; ++rbi) {
     const int v0 = base + (rbi * NW + wave) * 32;
@@ -277,9 +355,9 @@ __global__ __launch_bounds__(NW * 64) void attn_lds_kernel(const AttnP<T> p) {
 
 #pragma unroll 1
     for (int k0 = 0; k0 < nk; k0 += NKEY) {
-      if (rbi == 0) {
-        if (k0 > 0) __syncthreads();            // every wave is done reading the previous chunk
-        stage(k0);
+      if (rbi == 0 && k0 > 0) {
+        __syncthreads();                        // every wave is done reading the previous chunk
+        stage_next(k0);
         __syncthreads();
       }
       if (!active) continue;
