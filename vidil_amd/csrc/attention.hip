@@ -323,20 +323,26 @@ __global__ __launch_bounds__(NW * 64, NW == 8 ? 4 : 2) void attn_lds_kernel(cons
   // 224-key chunks): stage the chunk, run its key tiles through the online softmax, re-stage.  Multi-chunk
   // launches keep one row block per wave (its (m, l, O) lives across the chunks).
   const int nblk = nk <= NKEY ? p.rb : 1;
-  stage(0);                                     // before any per-wave state (Q fragments, accumulators) is live
+  // The first row block's Q fragments and the first K/V chunk are requested together, before anything else is live.
+  RowInfo ri;
+  f16x8 qf[4];
+  bool active;
+  auto load_q = [&](int rbi) {
+    const int v0 = base + (rbi * NW + wave) * 32;
+    active = v0 < rows;                        // waves without rows still stage and meet the barriers
+    ri = row_info(p, (active ? v0 : 0) + l31, first, rows);
+    const f16* qg = p.q + (((size_t)ri.qb * p.H + h) * p.Tq_cap + ri.t) * 64 + hi * 8;
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks) qf[ks] = *(const f16x8*)(qg + ks * 16);
+  };
+  load_q(0);
+  stage(0);
   __syncthreads();
 #pragma unroll 1
   for (int rbi = 0; rbi < nblk; ++rbi) {
-    const int v0 = base + (rbi * NW + wave) * 32;
-    const bool active = v0 < rows;            // waves without rows still stage and meet the barriers
-    if (rbi > 0 && !active) break;            // (single chunk: nothing left to stage, no barrier ahead)
-    const RowInfo ri = row_info(p, (active ? v0 : 0) + l31, first, rows);
-
-    f16x8 qf[4];
-    {
-      const f16* qg = p.q + (((size_t)ri.qb * p.H + h) * p.Tq_cap + ri.t) * 64 + hi * 8;
-#pragma unroll
-      for (int ks = 0; ks < 4; ++ks) qf[ks] = *(const f16x8*)(qg + ks * 16);
+    if (rbi > 0) {
+      load_q(rbi);
+      if (!active) break;                      // (single chunk: nothing left to stage, no barrier ahead)
     }
     // smallest klim in the wave decides from which tile on masking is needed
     int kmin = ri.klim;
