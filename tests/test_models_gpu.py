@@ -442,6 +442,45 @@ def test_beam_search_split_over_streams_gives_the_unsplit_tokens(full_models):
         cap.__dict__.pop("_decode_state", None)
 
 
+def test_finished_images_leave_the_decode_batch_without_changing_any_caption(full_models):
+    """Real captions end at different lengths.  With the [SEP] logit biased upwards the searches of a 40-image batch
+    finish step by step; the searching images then move to smaller sessions (30 / 20 / 10 / 5 images here) — eager on
+    the first batch, captured graphs afterwards — and every token and length must equal the run that keeps the whole
+    batch to the end."""
+    from oracle import clip_ref
+
+    cap = full_models["cap"]
+    B = 40
+    u8 = synthetic_frames(5, 8, first_video=70).reshape(B, 224, 224, 3)
+    _, y16 = cap.visual_encoder.forward_u8(torch.from_numpy(u8).to(DEV), clip_ref.CLIP_MEAN, clip_ref.CLIP_STD)
+    bias = cap.text_decoder.cls.predictions.bias
+    sep = cap.tokenizer.sep_token_id
+    kw = dict(num_beams=3, max_length=20, min_length=5)
+    compacted = 0
+    try:
+        for boost in (5.0, 7.0, 9.0):
+            with torch.no_grad():
+                bias[sep] += boost
+            try:
+                cap.__dict__.pop("_decode_state", None)
+                want_tok, want_len = (t.cpu() for t in cap.generate_ids(y16, B, compact_min=0, **kw))
+                cap.__dict__.pop("_decode_state", None)
+                for rep in range(3):                       # eager, capture, replay — in the parent and in every bucket
+                    tok, ln = cap.generate_ids(y16, B, compact_min=5, **kw)
+                    assert torch.equal(tok.cpu(), want_tok) and torch.equal(ln.cpu(), want_len), (boost, rep)
+                used = [k for k in cap._decode_state if isinstance(k[-1], tuple) and k[-1][0] == "compact"]
+                compacted += len(used)
+                lens = want_len.tolist()
+                print(f"[SEP] bias +{boost}: caption lengths {min(lens)}..{max(lens)}, sessions used besides the full batch: "
+                      f"{sorted(k[0] for k in used)} images")
+            finally:
+                with torch.no_grad():
+                    bias[sep] -= boost
+    finally:
+        cap.__dict__.pop("_decode_state", None)
+    assert compacted >= 2                              # the path under test really ran
+
+
 def test_blip_at_384_vit_decoder_and_itm_vs_oracle():
     """image_size 384 (what every pipeline_config_*.yaml of the reference sets): 577 image tokens, i.e. chunked
     LDS attention in the ViT / ITM cross-attention and the multi-round direct kernel in the decode cross-attention."""

@@ -16,7 +16,7 @@ import torch
 import torch.nn as nn
 
 from . import kernels as K
-from .med import BeamArena, BertConfig, BertLMHeadModel
+from .med import BeamArena, BertConfig, BertLMHeadModel, CrossKV
 from .packing import require_cuda
 from .tokenizer import init_tokenizer, refuse_synthetic_with_checkpoint  # noqa: F401  (init_tokenizer re-exported, reference API)
 from .vit import VisionTransformer, interpolate_pos_embed
@@ -105,6 +105,41 @@ class DecoderSession:
         self.ws_prefill, self.ws_step = {}, {}
         self.logits = None
 
+    @classmethod
+    def like(cls, parent, B):
+        """A session for ``B`` images with the parent's geometry and EMPTY buffers (no projection): ``adopt`` fills it
+        with the state of a subset of the parent's images in the middle of a search."""
+        self = cls.__new__(cls)
+        self.dec, self.bert = parent.dec, parent.bert
+        self.B, self.nb, self.R = B, parent.nb, B * parent.nb
+        self.H, self.L = parent.H, parent.L
+        self.tiled_cross, self.Tcap = parent.tiled_cross, parent.Tcap
+        pc = parent.cross
+        self.cross = CrossKV(torch.empty((pc.k.shape[0], B) + tuple(pc.k.shape[2:]), dtype=pc.k.dtype, device=pc.k.device),
+                             torch.empty((pc.vt.shape[0], B) + tuple(pc.vt.shape[2:]), dtype=pc.vt.dtype, device=pc.vt.device),
+                             B, pc.Te, pc.NP, tiled=pc.tiled, Tk_cap=pc.Tk_cap)
+        pa = parent.arena
+        self.arena = BeamArena(pa.L, pa.Tcap, self.R, pa.k.shape[-1], pa.k.device, dtype=pa.k.dtype)
+        self.ws_prefill, self.ws_step = {}, {}
+        self.logits = None
+        return self
+
+    def adopt(self, parent, images, n_pos):
+        """Take over the search state of the parent's images ``images`` (int64 [B] on the device; entries may repeat:
+        padding) after ``n_pos`` cached positions: their cross K/V, their rows of the K/V arena and their ancestry
+        rows, with the slot numbers (= beam rows, always rows of the same image) renumbered."""
+        nb = self.nb
+        j = torch.arange(nb, device=images.device)
+        rows = (images[:, None] * nb + j).view(-1)                                        # parent row of each new row
+        shift = ((torch.arange(self.B, device=images.device) - images) * nb).repeat_interleave(nb).to(torch.int32)
+        self.cross.k.copy_(parent.cross.k.index_select(1, images))
+        self.cross.vt.copy_(parent.cross.vt.index_select(1, images))
+        self.arena.k[:, :n_pos].copy_(parent.arena.k[:, :n_pos].index_select(2, rows))
+        self.arena.v[:, :n_pos].copy_(parent.arena.v[:, :n_pos].index_select(2, rows))
+        self.arena._cur = parent.arena._cur                                                # the orientation step graphs expect
+        self.arena.anc[:, :n_pos] = parent.arena.anc.index_select(0, rows)[:, :n_pos] + shift[:, None]
+        return rows, shift
+
     def rebind(self, enc16):
         """Start a new search on another batch of the same shape IN THE SAME BUFFERS (cross K/V re-projected in place,
         arena orientation reset): device addresses stay what the captured decode-step graphs recorded."""
@@ -167,7 +202,7 @@ class BLIP_Decoder(nn.Module):
     # ------------------------------------------------------------------ beam decode
     @torch.no_grad()
     def generate_ids(self, enc16, B, *, num_beams=3, max_length=30, min_length=10, trace: DecodeTrace = None,
-                     check_done_every=2, streams=1):
+                     check_done_every=2, streams=1, compact_min=256):
         """enc16: f16 [B*Te, width] image tokens of B images.  Returns (tokens i32 [B,max_length], lens i32 [B]):
         best hypothesis incl. the prompt, then [SEP] if it fits, then [PAD].
 
@@ -178,7 +213,8 @@ class BLIP_Decoder(nn.Module):
         CU mask, tools/exp_cu_mask.py), so the default stays 1; kept for small batches per part of a larger job.
         A search is per image, so the tokens do not depend on the split."""
         require_cuda(enc16, "BLIP_Decoder.generate")
-        kw = dict(num_beams=num_beams, max_length=max_length, min_length=min_length, check_done_every=check_done_every)
+        kw = dict(num_beams=num_beams, max_length=max_length, min_length=min_length, check_done_every=check_done_every,
+                  compact_min=compact_min)
         if streams <= 1 or trace is not None or B < 2 * streams:
             g = self._beam_search(enc16, B, trace=trace, slot=0, **kw)
             while True:
@@ -218,7 +254,8 @@ class BLIP_Decoder(nn.Module):
                 t.record_stream(main)
         return torch.cat([r[0] for r in results]), torch.cat([r[1] for r in results])
 
-    def _beam_search(self, enc16, B, *, num_beams, max_length, min_length, trace=None, check_done_every=2, slot=0):
+    def _beam_search(self, enc16, B, *, num_beams, max_length, min_length, trace=None, check_done_every=2, slot=0,
+                     compact_min=256):
         """Generator: queues the prompt pass and one decode step per ``next()`` on the current stream, returns
         (tokens, lens) through StopIteration."""
         dec, bert = self.text_decoder, self.text_decoder.bert
@@ -251,10 +288,14 @@ class BLIP_Decoder(nn.Module):
         else:
             st["sess"].rebind(enc16)
         st["calls"] += 1
-        sess, bufs = st["sess"], st["bufs"]
-        bufs.reset(prompt)
+        st["bufs"].reset(prompt)
+        # `cur`: the session the loop is driving — the full batch, or (after compaction, below) a smaller session that
+        # adopted the images that are still searching
+        cur = dict(st=st, sess=st["sess"], bufs=st["bufs"], B=B,
+                   use_graphs=st["graphs_ok"] and trace is None and st["calls"] >= 2)    # the first batch warms every kernel up
 
         def first_unit(logits):
+            bufs = cur["bufs"]
             cs, ci = K.logsoftmax_topk(logits, bufs.beam_scores, B, nb, eos if P < min_length else -1, beams_in_logits=1)
             if trace is not None:
                 trace.logits.append(logits.clone()); trace.cand_scores.append(cs.clone()); trace.cand_index.append(ci.clone())
@@ -262,17 +303,78 @@ class BLIP_Decoder(nn.Module):
 
         def unit(c):
             """Decode step at length c: forward of the token appended last, candidate selection, beam update."""
+            sess, bufs = cur["sess"], cur["bufs"]
             logits = sess.step(bufs.next_tok, bufs.beam_idx, c - 1)
-            cs, ci = K.logsoftmax_topk(logits, bufs.beam_scores, B, nb, eos if c < min_length else -1)
+            cs, ci = K.logsoftmax_topk(logits, bufs.beam_scores, cur["B"], nb, eos if c < min_length else -1)
             if trace is not None:
                 trace.logits.append(logits.clone()); trace.cand_scores.append(cs.clone()); trace.cand_index.append(ci.clone())
             K.beam_update(bufs, cs, ci, V, c, eos, pad)
 
+        # ---- finished images leave the batch (VIDIL_DECODE_COMPACT=0 switches it off) --------------------------------
+        # Real captions end at different lengths; an image whose nb hypotheses are complete only burns rows.  When the
+        # polled counter says the searching images fit the next smaller bucket (3/4, 1/2, 1/4, 1/8 of B, at least
+        # `compact_min` images), they move to a session of that size: cross K/V, arena rows, ancestry rows and beam
+        # state are gathered (a few ms at 1,500 images), the finished ones are finalised where they are.  A search is
+        # per image and every kernel's arithmetic is independent of the batch around a row, so the tokens do not change.
+        # The random-weight benchmark never triggers this (nothing finishes before the length limit).
+        compact = compact_min > 0 and trace is None and os.environ.get("VIDIL_DECODE_COMPACT", "1") != "0"
+        gran = 64 if compact_min >= 64 else 1                                   # bucket sizes in whole 64-image steps
+        buckets = sorted({max(compact_min, -(-(B * f) // (8 * gran)) * gran) for f in (6, 4, 2, 1)}, reverse=True) if compact else []
+        buckets = [b for b in buckets if b < B]
+        final_tok = final_len = None
+        orig = None                                # device int64: original image of each image of the current session
+
+        def retire_and_compact(cur_len):
+            """Blocking: read the exact done mask, finalise everything into the result buffers, move the searching images
+            into the largest bucket they fit.  Returns False when they do not fit a smaller bucket after all."""
+            nonlocal final_tok, final_len, orig
+            bufs, sess = cur["bufs"], cur["sess"]
+            active = (bufs.done == 0).nonzero().view(-1)                      # (host wait: exact state)
+            A = int(active.numel())
+            fit = [b for b in buckets if A <= b < cur["B"]]
+            if not fit or A == 0:
+                return False
+            Bp = fit[-1]
+            out_tok, out_len, _ = K.beam_finalize(bufs, cur_len, eos, pad)
+            if final_tok is None:
+                final_tok, final_len = out_tok, out_len
+                orig = torch.arange(B, device=dev)
+            else:
+                final_tok[orig] = out_tok[:orig.numel()]
+                final_len[orig] = out_len[:orig.numel()]
+            images = torch.cat([active, active[-1:].expand(Bp - A)])           # padding: copies of the last one, marked done
+            key2 = (Bp, nb, max_length, min_length, str(dev), enc16.shape[0] // B, P, ("compact", slot))
+            st2 = cache.get(key2)
+            if st2 is not None and not (st2["packs"][0] is packs[0] and st2["packs"][1] is packs[1]):
+                st2 = None
+            if st2 is None:
+                st2 = cache[key2] = dict(sess=DecoderSession.like(st["sess"], Bp), bufs=K.BeamBuffers(Bp, nb, max_length, dev),
+                                         graphs={}, pool=None, calls=0, packs=packs, graphs_ok=st["graphs_ok"],
+                                         n_done_host=torch.zeros((1,), dtype=torch.int32, pin_memory=True), last_call=-1)
+            if st2.get("last_call") != st["calls"]:                             # one use per search of the parent
+                st2["calls"] += 1
+                st2["last_call"] = st["calls"]
+            rows, shift = st2["sess"].adopt(sess, images, cur_len)
+            nb2 = st2["bufs"]
+            if getattr(nb2, "swapped", False) != getattr(bufs, "swapped", False):
+                nb2.swap()                                                      # same buffer roles as the step graphs saw
+            nb2.seqs.copy_(bufs.seqs.index_select(0, rows))
+            nb2.beam_scores.copy_(bufs.beam_scores.index_select(0, rows))
+            nb2.next_tok.copy_(bufs.next_tok.index_select(0, rows))
+            nb2.beam_idx.copy_(bufs.beam_idx.index_select(0, rows) + shift)
+            for name in ("done", "n_hyp", "hyp_score", "hyp_len", "hyp_tok", "worst"):
+                getattr(nb2, name).copy_(getattr(bufs, name).index_select(0, images))
+            nb2.done[A:] = 1
+            nb2.n_done.fill_(Bp - A)
+            orig = orig.index_select(0, active)
+            cur.update(st=st2, sess=st2["sess"], bufs=nb2, B=Bp,
+                       use_graphs=st2["graphs_ok"] and st2["calls"] >= 2)
+            return True
+
         # ---- prompt pass, once per image: the beams of an image are identical until the first update
-        first_unit(sess.prefill(prompt.contiguous().view(-1), P, shared=True))
+        first_unit(cur["sess"].prefill(prompt.contiguous().view(-1), P, shared=True))
         yield
         cur_len = P + 1
-        use_graphs = st["graphs_ok"] and trace is None and st["calls"] >= 2    # the first batch warms every kernel up
         probe = None
         while cur_len < max_length:
             # "every image has its nb finished hypotheses" (BeamSearchScorer.is_done) is polled WITHOUT a host wait: the
@@ -281,44 +383,52 @@ class BLIP_Decoder(nn.Module):
             # process() skips done batches, and beam_finalize takes their stored hypotheses).
             if check_done_every and trace is None and cur_len % check_done_every == 0:
                 if probe is not None and probe.query():
-                    if int(st["n_done_host"][0]) == B:
-                        break
+                    n_done = int(cur["st"]["n_done_host"][0])
                     probe = None
+                    if n_done == cur["B"]:
+                        break
+                    if buckets and max_length - cur_len >= 3 and any(cur["B"] - n_done <= b < cur["B"] for b in buckets):
+                        retire_and_compact(cur_len)
                 if probe is None:
-                    st["n_done_host"].copy_(bufs.n_done, non_blocking=True)
+                    cur["st"]["n_done_host"].copy_(cur["bufs"].n_done, non_blocking=True)
                     probe = torch.cuda.Event()
                     probe.record()
-            elif check_done_every and trace is not None and int(bufs.n_done.item()) == B:
+            elif check_done_every and trace is not None and int(cur["bufs"].n_done.item()) == B:
                 break                        # parity traces stop exactly where the reference's loop stops
-            g = st["graphs"].get(cur_len) if use_graphs else None
+            g = cur["st"]["graphs"].get(cur_len) if cur["use_graphs"] else None
             if g is not None:
                 g.replay()
-                sess.arena._cur ^= 1      # the host-side halves of arena.reorder() and beam_update()
-                bufs.swap()
-            elif use_graphs:
+                cur["sess"].arena._cur ^= 1      # the host-side halves of arena.reorder() and beam_update()
+                cur["bufs"].swap()
+            elif cur["use_graphs"]:
                 try:
                     g = torch.cuda.CUDAGraph()
                     # thread_local: other threads (the RCCL watchdog of a multi-GPU run) may touch the runtime meanwhile
-                    with torch.cuda.graph(g, pool=st["pool"], capture_error_mode="thread_local"):
+                    with torch.cuda.graph(g, pool=cur["st"]["pool"], capture_error_mode="thread_local"):
                         unit(cur_len)
-                    st["pool"] = g.pool()
-                    st["graphs"][cur_len] = g
+                    cur["st"]["pool"] = g.pool()
+                    cur["st"]["graphs"][cur_len] = g
                     g.replay()            # capture records, replay executes (host-side state already advanced)
                 except Exception as e:    # capture unsupported here: finish this batch with plain launches, loudly
                     import warnings
                     warnings.warn(f"vidil_amd: decode-step graph capture failed ({e!r}); continuing without graphs")
                     torch.cuda.synchronize()
-                    st["graphs_ok"] = False
-                    st["graphs"].clear()
+                    for s_ in cache.values():
+                        s_["graphs_ok"] = False
+                        s_["graphs"].clear()
                     inner = self._beam_search(enc16, B, num_beams=num_beams, max_length=max_length, min_length=min_length,
-                                              trace=trace, check_done_every=check_done_every, slot=slot)
+                                              trace=trace, check_done_every=check_done_every, slot=slot, compact_min=compact_min)
                     return (yield from inner)
             else:
                 unit(cur_len)
             cur_len += 1
             yield
-        out_tok, out_len, _ = K.beam_finalize(bufs, cur_len, eos, pad)
-        return out_tok, out_len
+        out_tok, out_len, _ = K.beam_finalize(cur["bufs"], cur_len, eos, pad)
+        if final_tok is None:
+            return out_tok, out_len
+        final_tok[orig] = out_tok[:orig.numel()]
+        final_len[orig] = out_len[:orig.numel()]
+        return final_tok, final_len
 
     # ------------------------------------------------------------------ nucleus sampling
     @torch.no_grad()
