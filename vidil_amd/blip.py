@@ -335,13 +335,6 @@ class BLIP_Decoder(nn.Module):
             if not fit or A == 0:
                 return False
             Bp = fit[-1]
-            out_tok, out_len, _ = K.beam_finalize(bufs, cur_len, eos, pad)
-            if final_tok is None:
-                final_tok, final_len = out_tok, out_len
-                orig = torch.arange(B, device=dev)
-            else:
-                final_tok[orig] = out_tok[:orig.numel()]
-                final_len[orig] = out_len[:orig.numel()]
             images = torch.cat([active, active[-1:].expand(Bp - A)])           # padding: copies of the last one, marked done
             key2 = (Bp, nb, max_length, min_length, str(dev), enc16.shape[0] // B, P, ("compact", slot))
             st2 = cache.get(key2)
@@ -366,6 +359,16 @@ class BLIP_Decoder(nn.Module):
                 getattr(nb2, name).copy_(getattr(bufs, name).index_select(0, images))
             nb2.done[A:] = 1
             nb2.n_done.fill_(Bp - A)
+            # only now: beam_finalize ADDS the running beams of unfinished images to their hypothesis lists in place
+            # (BeamSearchScorer.finalize does), which must not reach the copies made above; the state left behind in
+            # the old session is dead — its next search starts with reset()
+            out_tok, out_len, _ = K.beam_finalize(bufs, cur_len, eos, pad)
+            if final_tok is None:
+                final_tok, final_len = out_tok, out_len
+                orig = torch.arange(B, device=dev)
+            else:
+                final_tok[orig] = out_tok[:orig.numel()]
+                final_len[orig] = out_len[:orig.numel()]
             orig = orig.index_select(0, active)
             cur.update(st=st2, sess=st2["sess"], bufs=nb2, B=Bp,
                        use_graphs=st2["graphs_ok"] and st2["calls"] >= 2)
