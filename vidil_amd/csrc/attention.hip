@@ -571,12 +571,26 @@ __global__ __launch_bounds__(64) void attn_wave_kernel(const AttnP<T> p) {
   const f16* qg = p.q + (((size_t)ri.qb * p.H + h) * p.Tq_cap + ri.t) * 64 + hi * 8;
   int krow = l31 < nk ? l31 : nk - 1;
   const f16* kr = kg + (size_t)krow * 64 + hi * 8;
+  // every operand of the unit is requested before the first MFMA: K and Q fragments, and the four V^T fragments
+  f16x8 kf[4], qf[4], vf[2][2];
+#pragma unroll
+  for (int ks = 0; ks < 4; ++ks) {
+    kf[ks] = *(const f16x8*)(kr + ks * 16);
+    qf[ks] = *(const f16x8*)(qg + ks * 16);
+  }
+#pragma unroll
+  for (int dt = 0; dt < 2; ++dt)
+#pragma unroll
+    for (int hb = 0; hb < 2; ++hb) {
+      const int blk0 = hb * 16;
+      vf[dt][hb] = zero8<T>();
+      if (blk0 < nk) vf[dt][hb] = *(const f16x8*)(vg + (size_t)(dt * 32 + l31) * p.NP + blk0 + 8 * hi);
+    }
   f32x16 S;
 #pragma unroll
   for (int r = 0; r < 16; ++r) S[r] = 0.f;
 #pragma unroll
-  for (int ks = 0; ks < 4; ++ks)
-    S = Elt<T>::mfma32(*(const f16x8*)(kr + ks * 16), *(const f16x8*)(qg + ks * 16), S);
+  for (int ks = 0; ks < 4; ++ks) S = Elt<T>::mfma32(kf[ks], qf[ks], S);
   float m = -INFINITY, l = 0.f;
   f32x16 O[2];
 #pragma unroll
@@ -585,13 +599,10 @@ __global__ __launch_bounds__(64) void attn_wave_kernel(const AttnP<T> p) {
     for (int r = 0; r < 16; ++r) O[dt][r] = 0.f;
   softmax_pv_tile<T>(S, 0, ri.klim, true, m, l, O, [&](int dt, int hb) {
     const int blk0 = hb * 16;
-    f16x8 v = zero8<T>();
-    if (blk0 < nk) {
-      v = *(const f16x8*)(vg + (size_t)(dt * 32 + l31) * p.NP + blk0 + 8 * hi);
+    f16x8 v = vf[dt][hb];
 #pragma unroll
-      for (int e = 0; e < 8; ++e)
-        if (blk0 + 4 * hi + (e & 3) + 8 * (e >> 2) >= nk) v[e] = (f16)0.f;
-    }
+    for (int e = 0; e < 8; ++e)
+      if (blk0 + 4 * hi + (e & 3) + 8 * (e >> 2) >= nk) v[e] = (f16)0.f;      // keys past Nk: 0 * garbage must stay 0
     return v;
   });
   l += __shfl_xor(l, 32, 64);
