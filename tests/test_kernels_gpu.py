@@ -149,6 +149,27 @@ def test_gemm256_f16_and_f32(M, N, K):
     assert torch.equal(o_small, o32[sub])
 
 
+@pytest.mark.parametrize("col_block", [-1, 1, 2, 3, 5, 12, 40])
+def test_gemm256_tile_order_knob_changes_nothing(col_block):
+    """vidil_gemm_args.col_block only re-orders the persistent kernel's walk over the output tiles (blocks of w column
+    tiles, a narrower last block when w does not divide the count, w >= the count = plain order): every tile must still be
+    computed exactly once — bit-identical output, including the ragged last row panel, for two epilogues."""
+    k = _k()
+    M, N, K = 256 * 40 + 19, 256 * 11 + 64, 256          # 41 x 12 tiles, ragged in both directions
+    a = _rand(M, K, seed=90).half().to(DEV)
+    w = _rand(N, K, scale=0.05, seed=91).half().to(DEV)
+    bias = _rand(N, seed=92).to(DEV)
+    assert k.gemm_kernel_name(a, w, bias, out_dtype=torch.float16).startswith("gemm256_kernel")
+    base16 = k.gemm(a, w, bias, out_dtype=torch.float16)
+    got16 = k.gemm(a, w, bias, out_dtype=torch.float16, col_block=col_block)
+    assert torch.equal(base16, got16)
+    x0 = _rand(M, N, seed=93).to(DEV)
+    xa, xb = x0.clone(), x0.clone()
+    k.gemm(a, w, bias, out=xa, resid=xa)
+    k.gemm(a, w, bias, out=xb, resid=xb, col_block=col_block)
+    assert torch.equal(xa, xb)
+
+
 def test_gemm256_transpose_detecting_and_tails():
     k = _k()
     M, N, K = 256 * 170 + 3, 320, 256        # 171 x 2 tiles; last row tile has 3 rows, last column tile 64 columns
