@@ -145,6 +145,13 @@ typedef struct vidil_gemm_args {
    * workgroups read at any one time are those of w column tiles (w * 256 * K * operand size bytes against a 4-MiB L2).
    * < 0: the plain row-panel-major order. */
   int32_t col_block;
+  /* LayerNorm of the RESIDUAL (post-LN stacks, models/med.py:236-239,306-317: h = LN(x + dense(...)) feeds the next
+   * dense AND is the next residual).  Non-NULL (both, f32 [N]) with epi F32, resid, ln_stats and ln_stats_out: `resid`
+   * holds the previous block's RAW sum u; the epilogue adds ((u - mean) * rstd) * rln_gamma[n] + rln_beta[n] instead of u,
+   * mean / rstd of row m from the partials `ln_stats` ([M][N/64][2], written by the GEMM that produced u; ln_eps).
+   * ln_fold stays 0 (A is not normalised here).  N % 64 == 0, N <= 1024. */
+  const float* rln_gamma;
+  const float* rln_beta;
 } vidil_gemm_args;
 
 /* replaces: nn.Linear calls of models/vit.py:35-41,72,84; models/med.py:153-171,

@@ -30,7 +30,7 @@ def test_library_exports_every_declared_symbol():
         assert hasattr(lib, n), f"{n} declared in include/vidil_hip.h but not exported"
     assert set(names) == set(_lib.SIGNATURES), set(names) ^ set(_lib.SIGNATURES)
     assert lib.vidil_num_entry_points() == len(names)
-    assert lib.vidil_abi_version() == 6
+    assert lib.vidil_abi_version() == 7
 
 
 def test_gemm_args_struct_matches_header_field_order():
@@ -74,7 +74,7 @@ def test_argument_validation_without_a_gpu():
     g = _lib.GemmArgs()
     g.A, g.W, g.out, g.M, g.N, g.K, g.ldo, g.epi, g.dtype = 16, 16, 16, 201728, 768, 768, 768, 1, 1
     buf = ctypes.create_string_buffer(128)
-    assert lib.vidil_gemm_kernel_name(ctypes.byref(g), buf, 128) == 0 and buf.value == b"gemm256_kernel<__bf16, __bf16, 1, 0, false, false>"
+    assert lib.vidil_gemm_kernel_name(ctypes.byref(g), buf, 128) == 0 and buf.value == b"gemm256_kernel<__bf16, __bf16, 1, 0, false, false, false>"
     g.M, g.dtype = 3072, 0
     assert lib.vidil_gemm_kernel_name(ctypes.byref(g), buf, 128) == 0 and buf.value.startswith(b"gemm_kernel<_Float16, ")
     g.dtype = 5
@@ -85,9 +85,9 @@ def test_argument_validation_without_a_gpu():
     g.K, g.M = 768, 100
     assert lib.vidil_gemm_kernel_name(ctypes.byref(g), buf, 128) == -1 and b"w_scale" in lib.vidil_last_error()
     g.w_scale = 16
-    assert lib.vidil_gemm_kernel_name(ctypes.byref(g), buf, 128) == 0 and buf.value == b"gemm256_kernel<fp8, _Float16, 1, 0, false, false>"
+    assert lib.vidil_gemm_kernel_name(ctypes.byref(g), buf, 128) == 0 and buf.value == b"gemm256_kernel<fp8, _Float16, 1, 0, false, false, false>"
     g.W_tiled = 16                                  # a fragment-tiled copy alone changes nothing: the 128x256 kernel is opt-in
-    assert lib.vidil_gemm_kernel_name(ctypes.byref(g), buf, 128) == 0 and buf.value == b"gemm256_kernel<fp8, _Float16, 1, 0, false, false>"
+    assert lib.vidil_gemm_kernel_name(ctypes.byref(g), buf, 128) == 0 and buf.value == b"gemm256_kernel<fp8, _Float16, 1, 0, false, false, false>"
     # out_dtype of the attention: fp8 only from the staged kernel
     assert lib.vidil_attention(16, 16, 16, 16, None, None, None, 0, 0, 1, 12, 4, 64, 4, 64, 64, 1, 0, 0, 768, 0, 0, 2, None) == -1
     assert b"out_dtype" in lib.vidil_last_error()

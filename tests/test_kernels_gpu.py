@@ -750,6 +750,37 @@ def test_gemm_layernorm_fold_consumer_vs_torch(dtype, M, D, N, act):
 
 
 @pytest.mark.parametrize("dtype", [torch.float16, torch.bfloat16])
+@pytest.mark.parametrize("M,N,K", [(35 * 9, 768, 768), (18 * 1400 + 7, 768, 3072), (200, 1024, 256)])
+def test_gemm_residual_layernorm_epilogue_vs_torch(dtype, M, N, K):
+    """Post-LN stacks: out = LayerNorm(u; gamma, beta) + a W^T + b where u is the previous block's RAW sum (f32, in the
+    residual buffer) and its per-row partials come with it (vidil_gemm_args.rln_gamma); the result is left raw again,
+    with its 16-bit copy and its own partials.  In place (out == resid), rows with a large mean included."""
+    k = _k()
+    u = _rand(M, N, seed=100) * 1.3
+    u[:, 11] += 7.0
+    u[::5] += 2.5
+    g, bt = _rand(N, seed=101) * 0.2 + 1.0, _rand(N, seed=102) * 0.2
+    a = _rand(M, K, seed=103).to(dtype)
+    w, b = _rand(N, K, scale=0.03, seed=104).to(dtype), _rand(N, seed=105) * 0.1
+    st_in = _row_partials(u).to(DEV)
+    x = u.to(DEV).clone()
+    x16 = torch.zeros(M, N, dtype=dtype, device=DEV)
+    st_out = torch.zeros(M, N // 64, 2, device=DEV)
+    kw = dict(out=x, resid=x, out16=x16, ln_stats_out=st_out, rln=(g.to(DEV), bt.to(DEV), 1e-12, st_in))
+    assert k.gemm_kernel_name(a.to(DEV), w.to(DEV), b.to(DEV), **kw).endswith("false, true, true>")
+    k.gemm(a.to(DEV), w.to(DEV), b.to(DEV), **kw)
+    ref = torch.nn.functional.layer_norm(u, (N,), g, bt, 1e-12) + a.float() @ w.float().t() + b
+    n = min(M, 1500)
+    got = x[:n].cpu()
+    assert torch.allclose(got, ref[:n], rtol=1e-4, atol=3e-3), (got - ref[:n]).abs().max()
+    assert torch.equal(x16[:n].cpu(), got.to(dtype))                                   # the 16-bit copy of what was written
+    assert torch.allclose(st_out[:n].cpu(), _row_partials(got), rtol=1e-4, atol=2e-2)   # partials of the NEW raw stream
+    # argument errors: the residual LayerNorm without the statistics of the residual, or together with ln_fold
+    with pytest.raises(Exception, match="rln"):
+        k.gemm(a.to(DEV), w.to(DEV), b.to(DEV), out=x, resid=x, out16=x16, rln=(g.to(DEV), bt.to(DEV), 1e-12, st_in))
+
+
+@pytest.mark.parametrize("dtype", [torch.float16, torch.bfloat16])
 def test_gemm_layernorm_fold_heads_consumer_and_out16_producer(dtype):
     from vidil_amd.packing import fold_layernorm
 

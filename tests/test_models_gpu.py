@@ -374,6 +374,45 @@ def test_full_itm_vs_oracle(full_models):
     assert (p_got - p_ref).abs().max().item() < 1e-3
 
 
+def test_itm_with_layernorms_folded_into_the_text_stack_vs_oracle_and_vs_the_unfused_path(full_models, monkeypatch):
+    """Big ITM batches run the post-LN text stack without LayerNorm launches (BertModel._run_layers_fused: raw sums +
+    row partials, ln_fold consumers, rln residuals).  Forced here at test size: logits against the fp32 oracle within
+    the ITM tolerance, and against the unfused path within the rounding-point difference — for the reference call shape
+    (one caption per image) and for the de-duplicated CapFilt shape (image-major groups, shared text front)."""
+    from oracle import clip_ref, med_ref, vit_ref
+
+    fm = full_models
+    itm, sd = fm["itm"], fm["sd_itm"]
+    F = 4
+    u8 = synthetic_frames(1, F, first_video=3)[0]
+    x = clip_ref.preprocess_u8(u8)
+    caps = ["w2000 w2001 w2002", "w5 w6 w7 w8 w9 w10 w11 w12 w13", "a picture of w77", "w1234"]
+    ids, lens = itm.tokenize(caps)
+    am = (torch.arange(35)[None] < lens[:, None]).long()
+    with torch.no_grad():
+        enc_ref = vit_ref.vit_forward(sd, x)
+        ref = med_ref.itm_logits(sd, enc_ref, ids.long(), am)
+        # every caption against every frame (image-major): the CapFilt shape
+        ref_all = torch.stack([med_ref.itm_logits(sd, enc_ref[f:f + 1].expand(len(caps), -1, -1), ids.long(), am) for f in range(F)])
+    _, y16 = itm.visual_encoder.forward_both(x.to(DEV))
+    group_start = torch.arange(F + 1, dtype=torch.int32) * len(caps)
+    pair_text = torch.arange(len(caps)).repeat(F)
+    out = {}
+    for mode, env in (("fused", {"VIDIL_FUSE_LN_MIN_ROWS": "0"}), ("unfused", {"VIDIL_FUSE_LN": "0"})):
+        for k_ in ("VIDIL_FUSE_LN_MIN_ROWS", "VIDIL_FUSE_LN"):
+            monkeypatch.delenv(k_, raising=False)
+        for k_, v_ in env.items():
+            monkeypatch.setenv(k_, v_)
+        a = itm.itm_pairs(y16, F, ids, lens, torch.arange(F, dtype=torch.int32)).cpu()
+        b = itm.itm_pairs(y16, F, ids, lens, group_start=group_start, max_group=len(caps), pair_text=pair_text).cpu()
+        out[mode] = (a, b.view(F, len(caps), 2))
+        assert (a - ref).abs().max().item() < 2e-3, mode
+        assert (out[mode][1] - ref_all).abs().max().item() < 2e-3, mode
+    d = max((out["fused"][0] - out["unfused"][0]).abs().max().item(), (out["fused"][1] - out["unfused"][1]).abs().max().item())
+    print(f"ITM logits, LayerNorm-folded text stack vs separate LayerNorm launches: max|d| = {d:.2e}")
+    assert 0 < d < 2e-3                      # different rounding point, same function (0 would mean the path did not switch)
+
+
 def test_captured_decode_graphs_replay_the_eager_result(full_models):
     """generate_ids reuses its session per shape: call 1 runs eagerly, call 2 captures one HIP graph per decode step,
     call 3+ replays them.  All must produce the tokens of a fresh eager search — also on a DIFFERENT batch, which

@@ -37,7 +37,7 @@ class GemmArgs(C.Structure):
         ("arena_rows", C.c_int32), ("slot_stride", C.c_int32),
         ("pos", C.c_void_p), ("tpi", C.c_int32), ("kv_tiled", C.c_int32), ("dtype", C.c_int32),
         ("out16", C.c_void_p), ("ldo16", C.c_int32), ("ln_fold", C.c_int32), ("ln_colsum", C.c_void_p), ("ln_eps", C.c_float), ("ln_stats_out", C.c_void_p), ("ln_stats", C.c_void_p),
-        ("w_scale", C.c_void_p), ("dtype16", C.c_int32), ("W_tiled", C.c_void_p), ("col_block", C.c_int32),
+        ("w_scale", C.c_void_p), ("dtype16", C.c_int32), ("W_tiled", C.c_void_p), ("col_block", C.c_int32), ("rln_gamma", C.c_void_p), ("rln_beta", C.c_void_p),
     ]
 
 

@@ -403,6 +403,13 @@ int check_args(const vidil_gemm_args& a) {
   if (a.ln_stats_out)
     VIDIL_REQUIRE(a.epi == VIDIL_EPI_F32 && a.act == VIDIL_ACT_NONE && a.N % 64 == 0 && a.dtype != VIDIL_DT_FP8,
                   "gemm/ln_stats_out: 16-bit operands, f32 residual epilogue without activation, N %% 64 == 0");
+  if (a.rln_gamma || a.rln_beta) {
+    VIDIL_REQUIRE(a.rln_gamma && a.rln_beta && a.epi == VIDIL_EPI_F32 && a.resid && a.ln_stats && a.ln_stats_out && !a.ln_fold,
+                  "gemm/rln: the residual LayerNorm needs rln_gamma, rln_beta, the f32 residual epilogue, resid, ln_stats (of resid) and ln_stats_out, and no ln_fold");
+    VIDIL_REQUIRE(a.N % 64 == 0 && a.N <= 1024 && a.ldo == a.N, "gemm/rln: dense residual rows of width N %% 64 == 0, N <= 1024 (N=%d ldo=%d)", a.N, a.ldo);
+    VIDIL_REQUIRE(((uintptr_t)a.rln_gamma & 15) == 0 && ((uintptr_t)a.rln_beta & 15) == 0 && ((uintptr_t)a.ln_stats & 7) == 0,
+                  "gemm/rln: rln_gamma / rln_beta 16-byte aligned, ln_stats 8-byte aligned");
+  }
   if (a.ln_fold || a.out16 || a.ln_stats_out || a.dtype == VIDIL_DT_FP8)
     VIDIL_REQUIRE(vidil_gemm256_eligible(a, true), "gemm: this LN-folded problem does not meet the 256x256 kernel's alignment / size rules (N %% 4, 16-B aligned vectors, K >= 128)");
   switch (a.epi) {
@@ -499,8 +506,10 @@ extern "C" int vidil_gemm_kernel_name(const vidil_gemm_args* args, char* buf_hos
   const char* t16 = (args->dtype == VIDIL_DT_FP8 ? args->dtype16 : args->dtype) == VIDIL_DT_BF16 ? "__bf16" : "_Float16";
   const char* t = args->dtype == VIDIL_DT_FP8 ? "fp8" : t16;                 // the spelling rocprofv3 demangles to
   const int act = (args->epi == VIDIL_EPI_F16 || args->epi == VIDIL_EPI_F32 || args->epi == VIDIL_EPI_F8) ? args->act : 0;
-  if (c.big) snprintf(buf_host, n, "%s<%s, %s, %d, %d, %s, %s>", c.big == 2 ? "gemm128x256_kernel" : "gemm256_kernel", t, t16, args->epi, act,
-                      args->ln_fold ? "true" : "false", (args->ln_stats_out && args->epi == VIDIL_EPI_F32) ? "true" : "false");
+  const char* stats = (args->ln_stats_out && args->epi == VIDIL_EPI_F32) ? "true" : "false";
+  if (c.big == 2) snprintf(buf_host, n, "gemm128x256_kernel<%s, %s, %d, %d, %s, %s>", t, t16, args->epi, act, args->ln_fold ? "true" : "false", stats);
+  else if (c.big) snprintf(buf_host, n, "gemm256_kernel<%s, %s, %d, %d, %s, %s, %s>", t, t16, args->epi, act, args->ln_fold ? "true" : "false",
+                           stats, args->rln_gamma ? "true" : "false");
   else snprintf(buf_host, n, "gemm_kernel<%s, %d, %d, %d, %d, %d>", t, c.bm, c.bn, c.st, args->epi, act);
   return VIDIL_OK;
 }

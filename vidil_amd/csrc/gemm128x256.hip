@@ -277,6 +277,7 @@ __global__ __launch_bounds__(256, 2) void gemm128x256_kernel(const vidil_gemm_ar
     }
     do {
       char* const ep = smem + 2 * ASLOT + wave * 8192;   // this wave's 8-KiB transposition scratch (ring slots 2, 3)
+constexpr bool RLN = false;   // (residual LayerNorm: 256x256 kernel only)
 #include "gemm_epilogue.inc"
     } while (0);
     if (!more) break;
@@ -355,6 +356,7 @@ int dispatch_w4_fp8(const vidil_gemm_args& a, hipStream_t s) {
 // epilogue rules of the 256x256 kernel (whose epilogue it shares).
 bool vidil_gemm128x256_eligible(const vidil_gemm_args& a, bool any_size) {
   if (a.W_tiled == nullptr || ((uintptr_t)a.W_tiled & 15) != 0) return false;
+  if (a.rln_gamma != nullptr) return false;           // the residual LayerNorm lives in the 256x256 kernel only
   const long tiles = (long)((a.M + 127) / 128) * ((a.N + 255) / 256);
   if (tiles < 320 && !any_size) return false;
   return vidil_gemm256_eligible(a, true);

@@ -72,8 +72,13 @@ struct Probe {
 // the kernel: v_dot2c beside MFMAs).  The four waves that own the same rows each add up a quarter of the partials,
 // meet in LDS after the main loop, and the epilogue applies  y = rstd * acc - (rstd * mean) * colsum[n] + b'[n].
 // T: operand type of A and W (f16 / bf16 / fp8); TO: the 16-bit type of 16-bit outputs (== T unless T is fp8).
-template <typename T, typename TO, int EPI, int ACT, bool FOLD, bool STATS>
+// RLN: the f32 residual is the RAW sum of a post-LN block and is normalised on the way in (vidil_gemm_args.rln_gamma):
+// the same row statistics machinery as FOLD, applied to the residual rows instead of the accumulators.
+template <typename T, typename TO, int EPI, int ACT, bool FOLD, bool STATS, bool RLN>
 __global__ __launch_bounds__(512) void gemm256_kernel(const vidil_gemm_args p) {
+  constexpr bool ROWSTAT = FOLD || RLN;          // per-row mean / rstd from a producer's partials
+  static_assert(!(FOLD && RLN), "a GEMM normalises either its A rows or its residual rows");
+  static_assert(!RLN || EPI == VIDIL_EPI_F32, "the residual exists in the f32 epilogue only");
   using f16 = TO;                       // (the epilogue is written in terms of "the 16-bit output type")
   using f16x4 = typename Elt<TO>::x4;
   using f16x8 = typename Elt<TO>::x8;
@@ -263,11 +268,11 @@ __global__ __launch_bounds__(512) void gemm256_kernel(const vidil_gemm_args p) {
     for (int j = 0; j < 2; ++j)
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[it][j][r] = 0.f;
-  if constexpr (FOLD) {
+  if constexpr (ROWSTAT) {
     // this wave's share of the producer's row partials (parts wc, wc+4, ...; the half-waves alternate): issued here,
     // consumed after the main loop
     // (loaded here, summed after the main loop: used right away they would expose a full memory latency per tile)
-    const int nparts = K >> 6;            // <= 16 (check_args: K <= 1024 for folded consumers)
+    const int nparts = (FOLD ? K : N) >> 6;   // <= 16 (check_args: the normalised rows are at most 1024 wide)
     const f32x2* stats_in = (const f32x2*)p.ln_stats;
     const int part0 = wc + 4 * hi;
 #pragma unroll
@@ -300,7 +305,7 @@ __global__ __launch_bounds__(512) void gemm256_kernel(const vidil_gemm_args p) {
   asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
   __builtin_amdgcn_s_barrier();
 
-  if constexpr (FOLD) {
+  if constexpr (ROWSTAT) {
     // LayerNorm statistics of this tile's rows: every wave holds, per row, the sums over the k-steps it owns (and a
     // half-wave over its 8 of the step's 16 k) -> combine the half-waves, meet the other three waves of the group in
     // LDS (a region past the ring: nothing else touches it), then rstd and mean*rstd per row in fixed wave order.
@@ -314,7 +319,7 @@ __global__ __launch_bounds__(512) void gemm256_kernel(const vidil_gemm_args p) {
     }
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();
-    const float inv_k = 1.0f / (float)K;
+    const float inv_k = 1.0f / (float)(FOLD ? K : N);
 #pragma unroll
     for (int it = 0; it < 4; ++it) {
       float s = 0.f, ss = 0.f;
@@ -341,7 +346,8 @@ __global__ __launch_bounds__(512) void gemm256_kernel(const vidil_gemm_args p) {
   // the ring is idle); the epilogue below transposes through buffer 1 only.  Its latency — an HBM miss on a new
   // A panel — is then covered by the epilogue instead of idling the CU at the top of the next tile.
   // (fp8 operands: one tile per workgroup too — the next tile's state across the epilogue costs a few spilled registers)
-  const bool more = kPersistent<EPI> && ESZ == 2 && remaining > tile_step;   // uniform
+  const bool more = kPersistent<EPI> && ESZ == 2 && !RLN && remaining > tile_step;   // uniform (RLN: one tile per
+  //                                                                                  workgroup — 18 spilled registers otherwise)
   if (more) {
     logical += tile_step;
     remaining -= tile_step;
@@ -370,11 +376,11 @@ static int default_col_block(const vidil_gemm_args& a) {
   return -1;
 }
 
-template <typename T, int EPI, int ACT, bool FOLD = false, typename TO = T, bool STATS = false>
+template <typename T, int EPI, int ACT, bool FOLD = false, typename TO = T, bool STATS = false, bool RLN = false>
 int launch256(const vidil_gemm_args& a, hipStream_t s) {
   static bool attr_set = false;
-  auto kern = gemm256_kernel<T, TO, EPI, ACT, FOLD, STATS>;
-  constexpr int lds = LDS_BYTES + (FOLD ? STATS_BYTES : 0);
+  auto kern = gemm256_kernel<T, TO, EPI, ACT, FOLD, STATS, RLN>;
+  constexpr int lds = LDS_BYTES + ((FOLD || RLN) ? STATS_BYTES : 0);
   if (!attr_set) {
     hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
     if (e != hipSuccess) {
@@ -397,7 +403,7 @@ int launch256(const vidil_gemm_args& a, hipStream_t s) {
     if (v >= 8 && v < cus) cus = v;
   }
   const int ntiles = ((a.M + 255) / 256) * ((a.N + 255) / 256);
-  const int tiles = !(kPersistent<EPI> && sizeof(T) == 2) ? ntiles : ntiles >= cus ? cus : (ntiles >= 8 ? (ntiles & ~7) : ntiles);
+  const int tiles = !(kPersistent<EPI> && sizeof(T) == 2 && !RLN) ? ntiles : ntiles >= cus ? cus : (ntiles >= 8 ? (ntiles & ~7) : ntiles);
   vidil_gemm_args b = a;
   if (b.col_block == 0) b.col_block = default_col_block(a);
   hipLaunchKernelGGL(kern, dim3(tiles), dim3(512), lds, s, b);
@@ -458,6 +464,7 @@ static int launch256_dispatch(const vidil_gemm_args& a, hipStream_t s) {
       if (a.act == VIDIL_ACT_GELU_ERF) return launch256<T, VIDIL_EPI_F16, VIDIL_ACT_GELU_ERF>(a, s);
       return launch256<T, VIDIL_EPI_F16, VIDIL_ACT_QUICK_GELU>(a, s);
     case VIDIL_EPI_F32:
+      if (a.rln_gamma) return launch256<T, VIDIL_EPI_F32, VIDIL_ACT_NONE, false, T, true, true>(a, s);   // (check_args: with ln_stats_out)
       if (a.ln_stats_out) return launch256<T, VIDIL_EPI_F32, VIDIL_ACT_NONE, false, T, true>(a, s);   // (check_args: no activation)
       if (a.act == VIDIL_ACT_NONE) return launch256<T, VIDIL_EPI_F32, VIDIL_ACT_NONE>(a, s);
       if (a.act == VIDIL_ACT_GELU_ERF) return launch256<T, VIDIL_EPI_F32, VIDIL_ACT_GELU_ERF>(a, s);

@@ -102,7 +102,7 @@ def gemm_kernel_name(a, w, bias=None, **kw):
 
 def _gemm_build(a, w, bias=None, *, out=None, out_dtype=None, act=ACT_NONE, resid=None,
                 heads=None, patch=None, arena=None, M=None, lda=None, out16=None, ln_stats_out=None, ln=None, w_scale=None,
-                dtype16=None, col_block=0):
+                dtype16=None, col_block=0, rln=None):
     K_ = w.shape[1]
     if lda is None:
         M, Ka = a.shape
@@ -120,6 +120,10 @@ def _gemm_build(a, w, bias=None, *, out=None, out_dtype=None, act=ACT_NONE, resi
     if wt is not None and wt.device == w.device:
         g.W_tiled = wt.data_ptr()
     g.col_block = int(col_block)                 # tile order of the persistent kernel (tuning knob, results unaffected)
+    if rln is not None:                          # (gamma, beta, eps, stats of the residual): `resid` is a post-LN block's raw sum
+        rg, rb, reps, rstats = rln
+        g.rln_gamma, g.rln_beta = _ptr(rg, torch.float32, "gemm.rln_gamma"), _ptr(rb, torch.float32, "gemm.rln_beta")
+        g.ln_stats, g.ln_eps = _ptr(rstats, torch.float32, "gemm.ln_stats"), float(reps)
     fp8 = g.dtype == DT_FP8
     # fp8 operands (tower mode): 16-bit outputs are written in the companion type (taken from the output buffers)
     t16 = a.dtype

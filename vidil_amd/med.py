@@ -16,12 +16,13 @@ Schedule differences from the reference (results are the same function):
 from __future__ import annotations
 
 import json
+import os
 
 import torch
 import torch.nn as nn
 
 from . import kernels as K
-from .packing import PackedCache, require_cuda, v32, w16
+from .packing import PackedCache, fold_layernorm, require_cuda, v32, w16
 
 LN_EPS_DEFAULT = 1e-12
 
@@ -201,6 +202,30 @@ class BertModel(PackedCache, nn.Module):
             p["layers"].append(d)
         return p
 
+    def _folded(self, p):
+        """Weights of the LN-folded text stack (built on first use, kept with the pack): per layer the cross query and
+        fc1 against the LayerNorms of the SAME layer's self / cross blocks, and (from layer 1 on) Q|K|V against the
+        previous layer's output LayerNorm — W' = T16(gamma (.) W), b' = b + W·beta, colsum (packing.fold_layernorm)."""
+        if "folded" in p:
+            return p["folded"]
+        c = self.cdt
+        out = []
+        layers = list(self.encoder.layer)
+        for i, l in enumerate(layers):
+            d = {}
+            if hasattr(l, "crossattention"):
+                ln1, ln2 = l.attention.output.LayerNorm, l.crossattention.output.LayerNorm
+                ca = l.crossattention.self
+                d["cq"] = fold_layernorm(ca.query.weight, ca.query.bias, ln1.weight, ln1.bias, c)
+                d["fc1"] = fold_layernorm(l.intermediate.dense.weight, l.intermediate.dense.bias, ln2.weight, ln2.bias, c)
+            if i > 0:
+                a, ln3 = l.attention.self, layers[i - 1].output.LayerNorm
+                d["qkv"] = fold_layernorm(torch.cat([a.query.weight, a.key.weight, a.value.weight]),
+                                          torch.cat([a.query.bias, a.key.bias, a.value.bias]), ln3.weight, ln3.bias, c)
+            out.append(d)
+        p["folded"] = out
+        return out
+
     # --------------------------------------------------------- cross K/V (once per image)
     def project_cross_kv(self, enc16, B, Te, out: "CrossKV" = None, v_rowmajor=False, last_layer_vt=False, tiled=False):
         """enc16: f16 [B*Te, encoder_width] image tokens.  One fused K|V GEMM per layer.  ``out``: buffers of a
@@ -252,7 +277,7 @@ class BertModel(PackedCache, nn.Module):
     def run_layers(self, h32, h16, *, rows, T, self_k, self_vt, t_off, Tk_cap, NPs, causal, kv_len,
                    cross: CrossKV, cross_index=None, cross_group=1, cross_groups=None, cross_max_group=0, ws=None,
                    arena: "BeamArena" = None, arena_slot_stride=1, n_layers=None, self_done_first=False,
-                   stop_after_self=False):
+                   stop_after_self=False, fused=None):
         """Run every layer on the f32/f16 hidden pair (both [rows*T, C], updated in place).
 
         self_k / self_vt: [L][rows,H,Tk_cap,64] / [L][rows,H,64,NPs] — this call's keys are appended at
@@ -270,6 +295,15 @@ class BertModel(PackedCache, nn.Module):
         M = rows * T
         dev = h32.device
         cdt = h16.dtype
+        if fused is None:          # big encoder batches (the ITM pairs): LayerNorms folded into the neighbouring GEMMs
+            fused = (os.environ.get("VIDIL_FUSE_LN", "1") != "0" and cross is not None and arena is None and not stop_after_self
+                     and M >= int(os.environ.get("VIDIL_FUSE_LN_MIN_ROWS", 40960)) and C % 64 == 0 and C <= 1024
+                     and cdt in (torch.float16, torch.bfloat16))
+        if fused:
+            return self._run_layers_fused(h32, h16, rows=rows, T=T, self_k=self_k, self_vt=self_vt, t_off=t_off, Tk_cap=Tk_cap,
+                                          NPs=NPs, causal=causal, kv_len=kv_len, cross=cross, cross_index=cross_index,
+                                          cross_group=cross_group, cross_groups=cross_groups, cross_max_group=cross_max_group,
+                                          n_layers=n_layers, self_done_first=self_done_first)
         if ws is None:
             ws = {}
         q = ws.get("q")
@@ -320,6 +354,68 @@ class BertModel(PackedCache, nn.Module):
             K.gemm(h16, d["i_w"], d["i_b"], out=inter, act=K.ACT_GELU_ERF)
             K.gemm(inter, d["o_w"], d["o_b"], out=tmp, resid=h32)
             K.layernorm(tmp, d["o_g"], d["o_bt"], eps, out16=h16, out32=h32)
+        return h32, h16
+
+    def _run_layers_fused(self, h32, h16, *, rows, T, self_k, self_vt, t_off, Tk_cap, NPs, causal, kv_len, cross, cross_index,
+                          cross_group, cross_groups, cross_max_group, n_layers, self_done_first):
+        """run_layers for encoder batches with cross-attention, WITHOUT LayerNorm launches between the GEMMs
+        (models/med.py:236-239,306-317 are post-LN: h = LN(x + dense(.)) is the next dense's input AND the next residual).
+        The stream is kept as the RAW sums u (f32 in h32's storage, a 16-bit copy in h16's) plus per-row (sum, sum of
+        squares) partials written by the producing GEMM's epilogue; a consumer GEMM normalises its A rows algebraically
+        (ln_fold: gamma-scaled weights, mean / rstd applied to the accumulators) and a residual GEMM normalises the
+        residual rows on the way in (rln_gamma / rln_beta).  One LayerNorm launch at the end restores the (h32, h16)
+        contract for the caller.  Same arithmetic as run_layers up to the rounding point of the GEMM operands (raw u
+        instead of LN(u) is rounded to 16 bits)."""
+        p = self.packed()
+        fw = self._folded(p)
+        cfg = self.config
+        H, C = cfg.num_attention_heads, cfg.hidden_size
+        eps = cfg.layer_norm_eps
+        M = rows * T
+        dev, cdt = h32.device, h16.dtype
+        q = torch.empty((rows, H, T, 64), dtype=cdt, device=dev)
+        o = torch.empty((M, C), dtype=cdt, device=dev)
+        inter = torch.empty((M, cfg.intermediate_size), dtype=cdt, device=dev)
+        stats = [torch.empty((M, C // 64, 2), dtype=torch.float32, device=dev) for _ in range(2)]
+        cur = 0                      # stats[cur] describes the raw stream when `pend` is set
+        pend = None                  # (gamma, beta) of the LayerNorm still owed to the stream; None: h32 / h16 are normalised
+        Nk = t_off + T
+
+        def residual_gemm(a, w, b, ln_g, ln_b):
+            """stream <- LN_pending(stream) + a·w^T + b, left RAW with fresh partials; (ln_g, ln_b) become pending."""
+            nonlocal cur, pend
+            kw = dict(out=h32, resid=h32, out16=h16, ln_stats_out=stats[cur ^ 1])
+            if pend is not None:
+                kw["rln"] = (pend[0], pend[1], eps, stats[cur])
+            K.gemm(a, w, b, **kw)
+            cur ^= 1
+            pend = (ln_g, ln_b)
+
+        def consumer(name, i, w, b, **kw):
+            """a GEMM whose A operand is the stream: plain when it is normalised, LN-folded when a LayerNorm is pending."""
+            if pend is None:
+                return K.gemm(h16, w, b, **kw)
+            wf, bf, cs = fw[i][name]
+            return K.gemm(h16, wf, bf, ln=(cs, eps, stats[cur]), **kw)
+
+        layers = p["layers"][:n_layers]
+        for i, d in enumerate(layers):
+            if not (self_done_first and i == 0):
+                consumer("qkv", i, d["qkv_w"], d["qkv_b"],
+                         heads=dict(q=q, k=self_k[i], vt=self_vt[i], T=T, H=H, part0=0, t_off=t_off, Tq_cap=T, Tk_cap=Tk_cap,
+                                    NP=NPs, q_scale=0.125))
+                K.attention(q, self_k[i], self_vt[i], o, Bq=rows, H=H, Nq=T, Nk=Nk, Tq_cap=T, Tk_cap=Tk_cap, NP=NPs,
+                            causal=causal, causal_off=t_off, kv_len=kv_len)
+                residual_gemm(o, d["ao_w"], d["ao_b"], d["ao_g"], d["ao_bt"])
+            consumer("cq", i, d["cq_w"], d["cq_b"], heads=dict(q=q, T=T, H=H, part0=0, Tq_cap=T, q_scale=0.125))
+            K.attention(q, cross.k[i], cross.vt[i], o, Bq=rows, H=H, Nq=T, Nk=cross.Te, Tq_cap=T, Tk_cap=cross.Tk_cap,
+                        NP=cross.NP, kv_group=cross_group, kv_index=cross_index, group_start=cross_groups,
+                        max_group=cross_max_group, kv_tiled=cross.tiled)
+            residual_gemm(o, d["co_w"], d["co_b"], d["co_g"], d["co_bt"])
+            consumer("fc1", i, d["i_w"], d["i_b"], out=inter, act=K.ACT_GELU_ERF)
+            residual_gemm(inter, d["o_w"], d["o_b"], d["o_g"], d["o_bt"])
+        if pend is not None:         # hand the caller normalised (h32, h16) again
+            K.layernorm(h32, pend[0], pend[1], eps, out16=h16, out32=h32)
         return h32, h16
 
     def embed(self, ids_i32, T, pos_off):
