@@ -170,6 +170,24 @@ def test_gemm256_tile_order_knob_changes_nothing(col_block):
     assert torch.equal(xa, xb)
 
 
+def test_gemm256_rows_times_k_beyond_2_to_the_31():
+    """A batch of 3,584+ frames makes M * K of the fc2 GEMM (706,048 x 3,072) exceed 2^31 elements: the staging offsets
+    are 32-bit but relative to the tile's row panel, so the rows past the 2^31st element must come out right (they did
+    not exist for the kernel before: such problems were refused)."""
+    k = _k()
+    M, N, K = 197 * 3600, 256, 3072                    # 709,200 rows: M * K = 2.18e9
+    g = torch.Generator(device=DEV).manual_seed(5)
+    a = (torch.randn(M, K, generator=g, device=DEV) * 0.5).half()
+    w = (torch.randn(N, K, generator=g, device=DEV) * 0.05).half()
+    bias = torch.randn(N, generator=g, device=DEV)
+    assert k.gemm_kernel_name(a, w, bias, out_dtype=torch.float32).startswith("gemm256_kernel")
+    out = k.gemm(a, w, bias, out_dtype=torch.float32)
+    for lo in (0, 349_000, 699_040, M - 300):           # 699,051 is the first row past 2^31 elements
+        rows = slice(lo, lo + 300)
+        ref = a[rows].float() @ w.float().t() + bias
+        assert torch.allclose(out[rows], ref, rtol=1e-4, atol=3e-3), (lo, (out[rows] - ref).abs().max().item())
+
+
 def test_gemm256_transpose_detecting_and_tails():
     k = _k()
     M, N, K = 256 * 170 + 3, 320, 256        # 171 x 2 tiles; last row tile has 3 rows, last column tile 64 columns

@@ -357,6 +357,7 @@ int dispatch_w4_fp8(const vidil_gemm_args& a, hipStream_t s) {
 bool vidil_gemm128x256_eligible(const vidil_gemm_args& a, bool any_size) {
   if (a.W_tiled == nullptr || ((uintptr_t)a.W_tiled & 15) != 0) return false;
   if (a.rln_gamma != nullptr) return false;           // the residual LayerNorm lives in the 256x256 kernel only
+  if ((long)a.M * (a.lda > 0 ? a.lda : a.K) >= (1L << 31)) return false;   // this kernel's A offsets are 32-bit from p.A
   const long tiles = (long)((a.M + 127) / 128) * ((a.N + 255) / 256);
   if (tiles < 320 && !any_size) return false;
   return vidil_gemm256_eligible(a, true);

@@ -128,6 +128,7 @@ __global__ __launch_bounds__(512) void gemm256_kernel(const vidil_gemm_args p) {
   // tiles); col_block == w -> blocks of w column tiles, row panels inside a block (the XCD's live W is w column tiles)
   const int cbw = p.col_block > 0 && p.col_block < tiles_n ? p.col_block : 0;
   const int cb_tiles = tiles_m * cbw;                              // logical tiles per full column block
+  const T* baseA = (const T*)p.A;        // first row of the current tile (setup_tile)
   auto setup_tile = [&](int lt) {
     int tile_m, tile_n;
     if (cbw == 0) {
@@ -154,12 +155,12 @@ __global__ __launch_bounds__(512) void gemm256_kernel(const vidil_gemm_args p) {
         ra = ra < M ? ra : M - 1;
         int rw = n0 + hf * 128 + r;
         rw = rw < N ? rw : N - 1;
-        gA[hf][i] = ra * lda + c * (16 / ESZ);
+        gA[hf][i] = (ra - m0) * lda + c * (16 / ESZ);     // relative to the tile's first row (baseA below): < 256 * lda
         gW[hf][i] = rw * K + c * (16 / ESZ);
       }
+    baseA = (const T*)p.A + (size_t)m0 * lda;             // uniform: 64-bit once per tile, so M * lda may exceed 2^31
   };
   setup_tile(logical);
-  const T* const baseA = (const T*)p.A;
   const T* const baseW = (const T*)p.W;
   // slot ids inside a K-tile buffer: 0 = A0, 1 = A1, 2 = W0, 3 = W1.  Tiles past the end re-fetch the
   // last tile into the slot the schedule says is free, so the counted waits stay uniform.
@@ -427,7 +428,7 @@ bool vidil_gemm256_eligible(const vidil_gemm_args& a, bool any_size) {
   if (a.K < 128) return false;
   if (a.dtype == VIDIL_DT_FP8 && (a.K % 128 != 0 || (a.lda != 0 && a.lda % 16 != 0))) return false;
   const long lda = a.lda > 0 ? a.lda : a.K;
-  if ((long)a.M * lda >= (1L << 31) || (long)a.N * a.K >= (1L << 31)) return false;   // 32-bit staging offsets
+  if (256L * lda >= (1L << 31) || (long)a.N * a.K >= (1L << 31)) return false;   // 32-bit staging offsets (A: per row panel)
   auto al16 = [](const void* p) { return ((uintptr_t)p & 15) == 0; };
   if (a.bias && !al16(a.bias)) return false;
   if (a.ln_fold && !(a.ln_colsum && al16(a.ln_colsum) && a.N % 4 == 0 && a.ln_stats && ((uintptr_t)a.ln_stats & 7) == 0)) return false;
