@@ -228,7 +228,7 @@ def main():
     # 384 videos = 3072 frames per step: 605,184 ViT rows = 2364 row tiles of 256, i.e. 27.7 rounds of 256-tile
     # workgroups on the N = 768 GEMMs (98.9 % of the last round filled; 128 videos give 9.23 rounds = 92 %), and
     # 9216 beam rows per decode step (measured: 128 -> 3.7k, 192 -> 3.8-3.95k, 384 -> 4.1k, 576 -> 3.9k frames/s)
-    ap.add_argument("--videos-per-step", type=int, default=384)
+    ap.add_argument("--videos-per-step", type=int, default=448)
     ap.add_argument("--frames", type=int, default=8, help="frames per video (config 4: 16)")
     ap.add_argument("--dtype", choices=["f16", "bf16", "fp8"], default="bf16",
                     help="MFMA operand type. Default bf16: the type BASELINE.json's configs[1] ('1xMI355X bf16') and north_star "
