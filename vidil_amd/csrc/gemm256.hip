@@ -370,8 +370,8 @@ __global__ __launch_bounds__(512) void gemm256_kernel(const vidil_gemm_args p) {
 // Tile order when the caller leaves col_block at 0 (see include/vidil_hip.h).  Measured at M = 605,184 (round 2):
 // blocks of 1 / 2 / 3 / 4 / 6 column tiles against row-panel-major — QKV (9 column tiles) 700 / 750 / 766 / 766 / 772
 // vs 806 TFLOP/s, fc1 (12) 749 / 771 / 790 / 767 / 792 vs 783, fc2 and proj (3) equal from 3 up: the re-reads of A and W
-// that the L2 misses (PMC: 7.5 GB fetched per fc1 launch for 0.93 GB of A) come from the Infinity Cache at a cost
-// below the noise, so the order stays row-panel-major.
+// that the L2 misses (PMC: 7.5 GB fetched per fc1 launch for 0.93 GB of A) cost less than the noise, so the order stays
+// row-panel-major.
 static int default_col_block(const vidil_gemm_args& a) {
   if (const char* e = getenv("VIDIL_GEMM_COLBLOCK")) return atoi(e) == 0 ? -1 : atoi(e);     // developer override
   return -1;
