@@ -241,8 +241,13 @@ def test_full_blip_caption_logits_and_beam_bf16_vs_fp32_oracle(bf16_models):
         assert np.array_equal(toks[b][: len(seqs[b])], seqs[b])
 
 
-def test_itm_and_clip_bf16_vs_fp32_oracle(bf16_models):
+@pytest.mark.parametrize("text_stack", ["layernorm launches", "layernorm folded"])
+def test_itm_and_clip_bf16_vs_fp32_oracle(bf16_models, text_stack, monkeypatch):
+    """(the benchmark's ITM batches run the LN-folded text stack: forced here at test size for the second case)"""
     from oracle import clip_ref, med_ref, vit_ref
+
+    if text_stack == "layernorm folded":
+        monkeypatch.setenv("VIDIL_FUSE_LN_MIN_ROWS", "0")
 
     fm = bf16_models
     u8 = synthetic_frames(1, 3, first_video=3)[0]
