@@ -1,0 +1,59 @@
+"""BASELINE's full batch size (448 videos x 8 frames per step, the bench configuration: bf16 operands, 42,759-class
+ontology, folded LayerNorms, interleaved pipeline, captured decode graphs) through size-independent properties — the
+oracle cannot run this size, so what is checked is that a video's results do not depend on the 447 others:
+
+* the captions, kept captions and visual tokens of videos processed inside the full batch equal those of the same
+  videos processed alone or in a small batch (different kernels / tile counts / bucket sizes get selected);
+* two passes over the same batch (eager first, graphs afterwards) give identical results;
+* every video gets 1..8 distinct captions, 4 x 5 tokens per frame, and the kept lists are sub-lists of the candidates."""
+import os
+import sys
+
+import pytest
+import torch
+
+from common import ROOT
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda"
+
+
+def test_full_batch_results_equal_small_batch_results():
+    sys.path.insert(0, ROOT)
+    import bench
+    from vidil_amd.capfilt import CapFiltEngine
+    from vidil_amd.pipeline import FramePipeline
+    from vidil_amd.visual_tokenization import CATEGORIES, VisualTokenizer
+
+    Nv, F = 448, 8
+    cap, flt, clip, tok = bench.build_models(DEV, 224, "b32", "base", "bf16")
+    onto_embeds, onto_texts = bench.synthetic_ontology(dim=clip.config.projection_dim)
+    cfg = dict(caption=True, filter=True, filter_generated_only=True, keep_original_caption=False, threshold=0.4,
+               filter_mode="max_filter", generation_mode="beam", do_sentence_tokenization=False, image_size=224, vit="base",
+               topk_visualize=5)
+    eng = CapFiltEngine(cfg, DEV, captioner=cap, filterer=flt)
+    vt = VisualTokenizer(cfg, clip, onto_texts, onto_embeds, DEV)
+    pipe = FramePipeline(eng, vt)
+    frames = torch.from_numpy(bench.synthetic_frames(Nv, F, 224, 0)).to(DEV)
+
+    def run(lo, hi):
+        items = [dict(video_id=f"video{i}", text=[]) for i in range(lo, hi)]
+        items, toks = pipe.process(items, frames[lo:hi])
+        return items, toks
+
+    full1 = run(0, Nv)
+    full2 = run(0, Nv)                                   # second pass: captured decode-step graphs
+    full3 = run(0, Nv)                                   # third: replay
+    assert full1 == full2 == full3
+    items, toks = full1
+    for it in items:
+        n = len(it["unfiltered_text"])
+        assert 1 <= n <= F and len(set(it["unfiltered_text"])) == n
+        assert [c for c in it["unfiltered_text"] if c in it["text"]] == it["text"]
+        ft = toks[it["video_id"]]["frame_tokens"]
+        assert len(ft) == F and all(len(f[k]) == 5 for f in ft for k in CATEGORIES)
+    for lo, hi in ((0, 1), (200, 203), (445, 448), (96, 128)):
+        small_items, small_toks = run(lo, hi)
+        assert small_items == items[lo:hi], (lo, hi)
+        for it in small_items:
+            assert small_toks[it["video_id"]] == toks[it["video_id"]], it["video_id"]
