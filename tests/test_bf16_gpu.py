@@ -243,11 +243,12 @@ def test_full_blip_caption_logits_and_beam_bf16_vs_fp32_oracle(bf16_models):
 
 @pytest.mark.parametrize("text_stack", ["layernorm launches", "layernorm folded"])
 def test_itm_and_clip_bf16_vs_fp32_oracle(bf16_models, text_stack, monkeypatch):
-    """(the benchmark's ITM batches run the LN-folded text stack: forced here at test size for the second case)"""
+    """(encoder batches run the LN-folded text stack; $VIDIL_FUSE_LN=0 keeps the LayerNorm launches — read per call by the
+    text stack, at construction by the towers, so only the text stack changes here)"""
     from oracle import clip_ref, med_ref, vit_ref
 
-    if text_stack == "layernorm folded":
-        monkeypatch.setenv("VIDIL_FUSE_LN_MIN_ROWS", "0")
+    if text_stack == "layernorm launches":
+        monkeypatch.setenv("VIDIL_FUSE_LN", "0")
 
     fm = bf16_models
     u8 = synthetic_frames(1, 3, first_video=3)[0]

@@ -295,9 +295,12 @@ class BertModel(PackedCache, nn.Module):
         M = rows * T
         dev = h32.device
         cdt = h16.dtype
-        if fused is None:          # big encoder batches (the ITM pairs): LayerNorms folded into the neighbouring GEMMs
+        if fused is None:
+            # encoder batches with cross-attention (the ITM pairs) run without LayerNorm launches, WHATEVER their size: a
+            # pair's logits must not depend on how many other pairs share its batch (ranks / tail batches of different
+            # sizes write the same JSON), so the choice cannot depend on M ($VIDIL_FUSE_LN_MIN_ROWS is for experiments)
             fused = (os.environ.get("VIDIL_FUSE_LN", "1") != "0" and cross is not None and arena is None and not stop_after_self
-                     and M >= int(os.environ.get("VIDIL_FUSE_LN_MIN_ROWS", 40960)) and C % 64 == 0 and C <= 1024
+                     and M >= int(os.environ.get("VIDIL_FUSE_LN_MIN_ROWS", 0)) and C % 64 == 0 and C <= 1024
                      and cdt in (torch.float16, torch.bfloat16))
         if fused:
             return self._run_layers_fused(h32, h16, rows=rows, T=T, self_k=self_k, self_vt=self_vt, t_off=t_off, Tk_cap=Tk_cap,
