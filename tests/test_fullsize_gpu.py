@@ -57,3 +57,26 @@ def test_full_batch_results_equal_small_batch_results():
         assert small_items == items[lo:hi], (lo, hi)
         for it in small_items:
             assert small_toks[it["video_id"]] == toks[it["video_id"]], it["video_id"]
+
+
+def test_itm_logits_of_a_pair_do_not_depend_on_the_batch_around_it():
+    """Bit-exact: the same (frame, caption) pairs scored inside a 4,096-pair call (256x256 GEMM tiles, LayerNorm-folded
+    text stack, staged attention) and in calls of 8 pairs and of 1 pair (the same stack — the fold is not a matter
+    of size) — what makes the filter's decisions independent of how videos are batched or sharded."""
+    sys.path.insert(0, ROOT)
+    import bench
+    from vidil_amd.blip import CLIP_MEAN, CLIP_STD
+
+    cap, flt, clip, tok = bench.build_models(DEV, 224, "b32", "base", "bf16")
+    flt = flt.to(DEV)
+    frames = torch.from_numpy(bench.synthetic_frames(32, 8, 224, 0)).to(DEV).reshape(256, 224, 224, 3)
+    _, y16 = flt.visual_encoder.forward_u8(frames, CLIP_MEAN, CLIP_STD)
+    caps = [" ".join(f"w{3000 + 13 * i + j}" for j in range(3 + i % 9)) for i in range(64)]
+    ids, lens = flt.tokenize(caps)
+    P = 4096
+    image = (torch.arange(P) * 7) % 256
+    text = (torch.arange(P) * 5) % 64
+    big = flt.itm_pairs(y16, 256, ids, lens, image_index=image.to(torch.int32), pair_text=text)
+    for n in (8, 1):
+        small = flt.itm_pairs(y16, 256, ids, lens, image_index=image[:n].to(torch.int32), pair_text=text[:n])
+        assert torch.equal(big[:n], small), n
