@@ -299,9 +299,8 @@ class BertModel(PackedCache, nn.Module):
             # encoder batches with cross-attention (the ITM pairs) run without LayerNorm launches, WHATEVER their size: a
             # pair's logits must not depend on how many other pairs share its batch (ranks / tail batches of different
             # sizes write the same JSON), so the choice cannot depend on M ($VIDIL_FUSE_LN_MIN_ROWS is for experiments)
-            fused = (os.environ.get("VIDIL_FUSE_LN", "1") != "0" and cross is not None and arena is None and not stop_after_self
-                     and M >= int(os.environ.get("VIDIL_FUSE_LN_MIN_ROWS", 0)) and C % 64 == 0 and C <= 1024
-                     and cdt in (torch.float16, torch.bfloat16))
+            fused = (self._text_fold_ok(cdt) and cross is not None and arena is None and not stop_after_self
+                     and M >= int(os.environ.get("VIDIL_FUSE_LN_MIN_ROWS", 0)))
         if fused:
             return self._run_layers_fused(h32, h16, rows=rows, T=T, self_k=self_k, self_vt=self_vt, t_off=t_off, Tk_cap=Tk_cap,
                                           NPs=NPs, causal=causal, kv_len=kv_len, cross=cross, cross_index=cross_index,
@@ -359,8 +358,14 @@ class BertModel(PackedCache, nn.Module):
             K.layernorm(tmp, d["o_g"], d["o_bt"], eps, out16=h16, out32=h32)
         return h32, h16
 
-    def _run_layers_fused(self, h32, h16, *, rows, T, self_k, self_vt, t_off, Tk_cap, NPs, causal, kv_len, cross, cross_index,
-                          cross_group, cross_groups, cross_max_group, n_layers, self_done_first):
+    def _text_fold_ok(self, cdt):
+        C = self.config.hidden_size
+        return (os.environ.get("VIDIL_FUSE_LN", "1") != "0" and C % 64 == 0 and C <= 1024
+                and cdt in (torch.float16, torch.bfloat16))
+
+    def _run_layers_fused(self, h32, h16, *, rows, T, self_k, self_vt, t_off, Tk_cap, NPs, causal, kv_len, cross, cross_index=None,
+                          cross_group=1, cross_groups=None, cross_max_group=0, n_layers=None, self_done_first=False,
+                          stop_after_self=False, state_in=None):
         """run_layers for encoder batches with cross-attention, WITHOUT LayerNorm launches between the GEMMs
         (models/med.py:236-239,306-317 are post-LN: h = LN(x + dense(.)) is the next dense's input AND the next residual).
         The stream is kept as the RAW sums u (f32 in h32's storage, a 16-bit copy in h16's) plus per-row (sum, sum of
@@ -368,7 +373,11 @@ class BertModel(PackedCache, nn.Module):
         (ln_fold: gamma-scaled weights, mean / rstd applied to the accumulators) and a residual GEMM normalises the
         residual rows on the way in (rln_gamma / rln_beta).  One LayerNorm launch at the end restores the (h32, h16)
         contract for the caller.  Same arithmetic as run_layers up to the rounding point of the GEMM operands (raw u
-        instead of LN(u) is rounded to 16 bits)."""
+        instead of LN(u) is rounded to 16 bits).
+        stop_after_self: run layer 0's self-attention block only and return the RAW state (h32, h16, partials, (gamma,
+        beta)) — what encode_cls computes once per distinct text; state_in = (partials, (gamma, beta)): start from such
+        a state (h32 / h16 hold raw sums), so the per-text front and the per-pair rest are the same arithmetic as one
+        pass over the expanded batch."""
         p = self.packed()
         fw = self._folded(p)
         cfg = self.config
@@ -382,6 +391,8 @@ class BertModel(PackedCache, nn.Module):
         stats = [torch.empty((M, C // 64, 2), dtype=torch.float32, device=dev) for _ in range(2)]
         cur = 0                      # stats[cur] describes the raw stream when `pend` is set
         pend = None                  # (gamma, beta) of the LayerNorm still owed to the stream; None: h32 / h16 are normalised
+        if state_in is not None:
+            stats[0], pend = state_in
         Nk = t_off + T
 
         def residual_gemm(a, w, b, ln_g, ln_b):
@@ -410,6 +421,8 @@ class BertModel(PackedCache, nn.Module):
                 K.attention(q, self_k[i], self_vt[i], o, Bq=rows, H=H, Nq=T, Nk=Nk, Tq_cap=T, Tk_cap=Tk_cap, NP=NPs,
                             causal=causal, causal_off=t_off, kv_len=kv_len)
                 residual_gemm(o, d["ao_w"], d["ao_b"], d["ao_g"], d["ao_bt"])
+            if stop_after_self:
+                return h32, h16, stats[cur], pend
             consumer("cq", i, d["cq_w"], d["cq_b"], heads=dict(q=q, T=T, H=H, part0=0, Tq_cap=T, q_scale=0.125))
             K.attention(q, cross.k[i], cross.vt[i], o, Bq=rows, H=H, Nq=T, Nk=cross.Te, Tq_cap=T, Tk_cap=cross.Tk_cap,
                         NP=cross.NP, kv_group=cross_group, kv_index=cross_index, group_start=cross_groups,
@@ -489,11 +502,18 @@ class BertModel(PackedCache, nn.Module):
 
         h32, h16 = self.embed(ids_i32.reshape(-1), T, 0)
         shared = pair_text is not None and cross is not None and L > 1
+        fold = self._text_fold_ok(cdt) and cross is not None and L > 1
+        state = None
         if shared:
             U = ids_i32.shape[0]
             _, _, uk, uv = scratch(U)
-            self.run_layers(h32, h16, rows=U, T=T, self_k=uk, self_vt=uv, t_off=0, Tk_cap=T, NPs=NPs, causal=False,
-                            kv_len=kv_len_i32, cross=None, n_layers=1, stop_after_self=True)
+            kw = dict(rows=U, T=T, self_k=uk, self_vt=uv, t_off=0, Tk_cap=T, NPs=NPs, causal=False, kv_len=kv_len_i32, cross=None,
+                      n_layers=1, stop_after_self=True)
+            if fold:     # the text-only front leaves the raw sum + partials, exactly as the expanded batch's layer 0 would
+                h32, h16, st0, pend0 = self._run_layers_fused(h32, h16, **kw)
+                state = (st0.view(U, T, -1).index_select(0, pair_text).view(-1, st0.shape[1], 2).contiguous(), pend0)
+            else:
+                self.run_layers(h32, h16, **kw)
             h32 = h32.view(U, T, C).index_select(0, pair_text).view(-1, C)
             h16 = h16.view(U, T, C).index_select(0, pair_text).view(-1, C)
             kv_len_i32 = kv_len_i32.index_select(0, pair_text).contiguous()
@@ -503,9 +523,13 @@ class BertModel(PackedCache, nn.Module):
             kv_len_i32 = kv_len_i32.index_select(0, pair_text).contiguous()
         P = h32.shape[0] // T
         sk, sv, sk_l, sv_l = scratch(P)
-        self.run_layers(h32, h16, rows=P, T=T, self_k=sk_l, self_vt=sv_l, t_off=0, Tk_cap=T, NPs=NPs, causal=False,
-                        kv_len=kv_len_i32, cross=cross, cross_index=cross_index, cross_groups=cross_groups,
-                        cross_max_group=cross_max_group, n_layers=L - 1, self_done_first=shared)
+        kw = dict(rows=P, T=T, self_k=sk_l, self_vt=sv_l, t_off=0, Tk_cap=T, NPs=NPs, causal=False, kv_len=kv_len_i32, cross=cross,
+                  cross_index=cross_index, cross_groups=cross_groups, cross_max_group=cross_max_group, n_layers=L - 1,
+                  self_done_first=shared)
+        if state is not None:
+            self._run_layers_fused(h32, h16, state_in=state, **kw)
+        else:
+            self.run_layers(h32, h16, **kw)
         d = p["layers"][L - 1]
         q1 = torch.empty((P, H, 1, 64), dtype=cdt, device=dev)
         o1 = torch.empty((P, C), dtype=cdt, device=dev)
