@@ -22,7 +22,7 @@ import torch
 import torch.nn as nn
 
 from . import kernels as K
-from .packing import PackedCache, fold_layernorm, require_cuda, v32, w16
+from .packing import FP8, PackedCache, fold_layernorm, require_cuda, v32, w8, w16
 
 LN_EPS_DEFAULT = 1e-12
 
@@ -199,6 +199,8 @@ class BertModel(PackedCache, nn.Module):
                          ckv_w=w16(ca.key.weight, ca.value.weight, dtype=c), ckv_b=v32(ca.key.bias, ca.value.bias),
                          co_w=w16(co.dense.weight, dtype=c), co_b=v32(co.dense.bias),
                          co_g=v32(co.LayerNorm.weight), co_bt=v32(co.LayerNorm.bias))
+                if self.fp8:     # fp8 tower mode: the image-side K|V projection (its A rows are a tower's output) on e4m3 too
+                    d["ckv_w8"], d["ckv_s"] = w8(ca.key.weight, ca.value.weight)
             p["layers"].append(d)
         return p
 
@@ -239,6 +241,15 @@ class BertModel(PackedCache, nn.Module):
         p = self.packed()
         H = self.config.num_attention_heads
         cdt = enc16.dtype
+        if self.fp8 and "ckv_w8" in p["layers"][0] and enc16.shape[1] % 128 == 0:
+            # fp8 tower mode (BASELINE config 5): e4m3 image tokens x e4m3 K|V weights, K / V written in the 16-bit type
+            enc8 = enc16.to(FP8)
+
+            def kv_gemm(d, **heads):
+                K.gemm(enc8, d["ckv_w8"], d["ckv_b"], w_scale=d["ckv_s"], dtype16=cdt, heads=heads)
+        else:
+            def kv_gemm(d, **heads):
+                K.gemm(enc16, d["ckv_w"], d["ckv_b"], heads=heads)
         if tiled:
             Tc = (Te + 31) // 32 * 32
             L = len(p["layers"])
@@ -249,8 +260,7 @@ class BertModel(PackedCache, nn.Module):
                 k = torch.empty((L, B, H, Tc, 64), dtype=cdt, device=dev)
                 v = torch.empty((L, B, H, Tc, 64), dtype=cdt, device=dev)
             for i, d in enumerate(p["layers"]):
-                K.gemm(enc16, d["ckv_w"], d["ckv_b"],
-                       heads=dict(k=k[i], vt=v[i], T=Te, H=H, part0=1, t_off=0, Tk_cap=Tc, tiled=True))
+                kv_gemm(d, k=k[i], vt=v[i], T=Te, H=H, part0=1, t_off=0, Tk_cap=Tc, tiled=True)
             return CrossKV(k, v, B, Te, Tc, tiled=True, Tk_cap=Tc)
         NPt = (Te + 15) // 16 * 16
         NP = 0 if v_rowmajor else NPt
@@ -266,11 +276,9 @@ class BertModel(PackedCache, nn.Module):
             last_vt = torch.empty((B, H, 64, NPt), dtype=cdt, device=dev)
         for i, d in enumerate(p["layers"]):
             if last_vt is not None and i == L - 1:
-                K.gemm(enc16, d["ckv_w"], d["ckv_b"],
-                       heads=dict(k=k[i], vt=last_vt, T=Te, H=H, part0=1, t_off=0, Tk_cap=Te, NP=NPt))
+                kv_gemm(d, k=k[i], vt=last_vt, T=Te, H=H, part0=1, t_off=0, Tk_cap=Te, NP=NPt)
             else:
-                K.gemm(enc16, d["ckv_w"], d["ckv_b"],
-                       heads=dict(k=k[i], vt=vt[i], T=Te, H=H, part0=1, t_off=0, Tk_cap=Te, NP=NP))
+                kv_gemm(d, k=k[i], vt=vt[i], T=Te, H=H, part0=1, t_off=0, Tk_cap=Te, NP=NP)
         return CrossKV(k, vt, B, Te, NP, last_vt, NPt if last_vt is not None else 0)
 
     # ------------------------------------------------------------------ layers
