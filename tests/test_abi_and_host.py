@@ -30,7 +30,7 @@ def test_library_exports_every_declared_symbol():
         assert hasattr(lib, n), f"{n} declared in include/vidil_hip.h but not exported"
     assert set(names) == set(_lib.SIGNATURES), set(names) ^ set(_lib.SIGNATURES)
     assert lib.vidil_num_entry_points() == len(names)
-    assert lib.vidil_abi_version() == 7
+    assert lib.vidil_abi_version() == 7 == _lib.ABI_VERSION
 
 
 def test_gemm_args_struct_matches_header_field_order():
@@ -433,3 +433,11 @@ def test_itm_short_circuit_host_logic_equals_the_exhaustive_schedule_on_stand_in
     items = [dict(video_id=f"v{v}", text=[]) for v in range(Nv)]
     eng.process(items, frames)
     assert eng.last_stats["itm_pairs"] == sum(len(i["unfiltered_text"]) for i in items) * F
+
+
+def test_the_drivers_build_hook_passes():
+    """__graft_entry__.build() is what the driver runs every round: make (a no-op on an up-to-date tree), the oracle's C
+    part, and its own checks of the loaded library — an ABI bump that forgets the hook must fail here, not there."""
+    import __graft_entry__ as g
+
+    g.build()

@@ -88,8 +88,11 @@ class VidilHipError(RuntimeError):
     pass
 
 
+ABI_VERSION = 7      # include/vidil_hip.h as this binding mirrors it (struct layouts, argument lists)
+
+
 def load():
-    """Load (once) and return the ctypes library with typed entry points."""
+    """Load (once) and return the ctypes library with typed entry points; a library of another ABI version is refused."""
     global _lib
     if _lib is not None:
         return _lib
@@ -103,6 +106,9 @@ def load():
         fn = getattr(lib, name)  # AttributeError if the symbol is not exported
         fn.restype = res
         fn.argtypes = args
+    if lib.vidil_abi_version() != ABI_VERSION:
+        raise VidilHipError(f"{LIB_PATH} implements ABI {lib.vidil_abi_version()}, this binding ABI {ABI_VERSION}: rebuild it "
+                            "(`make -C vidil_amd/csrc`)")
     _lib = lib
     return lib
 
