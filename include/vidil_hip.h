@@ -35,6 +35,12 @@ extern "C" {
 #define VIDIL_DT_F16 0
 #define VIDIL_DT_BF16 1
 #define VIDIL_DT_FP8 2      /* OCP e4m3fn: GEMM A / W operands (and the tensors feeding them) of the fp8 tower mode */
+/* Flag OR-ed onto the 16-bit type of an OUTPUT (vidil_layernorm dtype16, vidil_patchify_* dtype, vidil_attention /
+ * vidil_beam_attention out_dtype): the rows are written as error-compensated GEMM operands [hi | lo | hi] — three planes
+ * of the logical row width, hi = T16(x), lo = T16(x - hi) — exactly what vidil_split3_f32 makes of an f32 row.  Against
+ * a weight [W_hi | W_hi | W_lo] one K-tripled GEMM then yields x·W to ~2^-21 relative instead of ~2^-11 (the "parity"
+ * precision mode of vidil_amd: caption logits within 1e-3 of the fp32 reference). */
+#define VIDIL_DT_SPLIT3 0x100
 
 #define VIDIL_OK 0
 #define VIDIL_EINVAL (-1)   /* bad argument (shape, alignment, null pointer)  */
@@ -131,20 +137,6 @@ typedef struct vidil_gemm_args {
    * (EPI_HEADS q / k / vt); EPI_F8 writes fp8; EPI_F32 / EPI_PATCH as for the 16-bit types.  The 256x256 kernel only. */
   const float* w_scale;   /* f32 [N] or NULL (= 1) */
   int32_t dtype16;        /* VIDIL_DT_F16 / VIDIL_DT_BF16 */
-  /* ---- optional second copy of W in FRAGMENT TILES, for the 128x256 two-workgroups-per-CU kernel (large M): rows
-   * padded to a multiple of 64; per (64-column block cb, K-tile t of 128 bytes of k) one 8-KiB tile at byte
-   * ((cb * K/KT + t) * 8192), holding for every lane l (row l % 32 of column tile j, k half l / 32) the 16-byte
-   * operand slots the MFMA k-steps read, each k-step's slots as contiguous 1-KiB wave loads:
-   *   16-bit: slot (j, ks) at (j*4 + ks)*1024 + l*16 = W[cb*64 + j*32 + l%32][t*64 + ks*16 + (l/32)*8 .. +8]
-   *   fp8   : slot (j, ks, h) at ((j*2 + ks)*2 + h)*1024 + l*16 = W[..][t*128 + ks*64 + (l/32)*32 + h*16 .. +16]
-   * (vidil_amd.packing.tile_weight builds it).  NULL: the kernels that stage W through LDS are used. */
-  const void* W_tiled;
-  /* Order in which the persistent 256x256 kernel walks its output tiles (a tuning knob; results do not depend on it).
-   * 0: library default for the shape.  w > 0: the N dimension is cut into blocks of w column tiles (w * 256 outputs)
-   * and the tiles are enumerated block by block, row panel by row panel inside a block, so the weight rows an XCD's
-   * workgroups read at any one time are those of w column tiles (w * 256 * K * operand size bytes against a 4-MiB L2).
-   * < 0: the plain row-panel-major order. */
-  int32_t col_block;
   /* LayerNorm of the RESIDUAL (post-LN stacks, models/med.py:236-239,306-317: h = LN(x + dense(...)) feeds the next
    * dense AND is the next residual).  Non-NULL (both, f32 [N]) with epi F32, resid, ln_stats and ln_stats_out: `resid`
    * holds the previous block's RAW sum u; the epilogue adds ((u - mean) * rstd) * rln_gamma[n] + rln_beta[n] instead of u,
@@ -164,8 +156,9 @@ int vidil_gemm_kernel_name(const vidil_gemm_args* args, char* buf_host, int32_t 
 
 /* ------------------------------------------------------------------------ */
 /* LayerNorm over the last dim.  x f32 rows of length D at stride x_stride    */
-/* (elements); writes T16 (dtype16; VIDIL_DT_FP8 too: the fp8 mode's GEMM operand)   */
-/* and/or f32 outputs (either may be NULL), dense.                                */
+/* (elements); writes T16 (dtype16; VIDIL_DT_FP8 too: the fp8 mode's GEMM operand;  */
+/* T16 | VIDIL_DT_SPLIT3: rows [hi | lo | hi], 3D wide) and/or f32 outputs (either   */
+/* may be NULL), dense.                                                            */
 /* D must be a multiple of 64 and <= 1024... (768, 512, 1024 on this path)    */
 /* replaces: nn.LayerNorm at models/vit.py:108-109,192 (eps 1e-6),            */
 /* models/med.py:92,238,316,514 (eps 1e-12), HF CLIP layer norms (eps 1e-5).  */
@@ -201,7 +194,9 @@ int vidil_layernorm(const float* x, int64_t x_stride, const float* gamma,
 /* additionally excludes key > q + causal_off.                                */
 /* out row (b*Nq + q), column h*64+d, row stride ldo (multiple of 8), in      */
 /* out_dtype: the operand type `dtype`, or VIDIL_DT_FP8 (staged kernel only:  */
-/* the fp8 tower mode feeds the attention output straight to the proj GEMM).  */
+/* the fp8 tower mode feeds the attention output straight to the proj GEMM),  */
+/* or dtype | VIDIL_DT_SPLIT3: row = three planes [hi | lo | hi] of ldo/3     */
+/* columns each (ldo a multiple of 24, ldo/3 >= H*64).                        */
 /* replaces: models/vit.py:75-83; models/med.py:178-220 (self, cross, cached);*/
 /* HF CLIPAttention.                                                          */
 /* ------------------------------------------------------------------------ */
@@ -239,7 +234,9 @@ int vidil_resample_u8(const uint8_t* src, uint8_t* dst, int32_t B, int32_t in_h,
 /* ------------------------------------------------------------------------ */
 /* Frame -> patch rows (im2col for stride==kernel conv), fused with dtype     */
 /* conversion.  out T16 [B*(S/ps)^2, 3*ps*ps], column = c*ps*ps + py*ps + px  */
-/* (the flattening of a conv weight [N,3,ps,ps]).                             */
+/* (the flattening of a conv weight [N,3,ps,ps]); rows are zero padded to a   */
+/* multiple of 64 columns.  dtype | VIDIL_DT_SPLIT3: rows [hi | lo | hi] of   */
+/* the f32 pixel values, three times that width.                              */
 /* replaces: timm PatchEmbed / HF CLIPVisionEmbeddings conv input read.       */
 /* ------------------------------------------------------------------------ */
 int vidil_patchify_f32(const float* img /*[B,3,S,S]*/, void* out, int32_t B,
@@ -318,10 +315,6 @@ int vidil_beam_finalize(const vidil_beam_state* st, int32_t B, int32_t nb,
                         int32_t cur_len, int32_t max_len, int32_t eos_id,
                         int32_t pad_id, int32_t* out_tokens, int32_t* out_len,
                         float* out_score, void* stream);
-/* KV-cache reorder (models/med.py:951-955): for every layer l, row s:        */
-/* dst[l][s] = src[l][beam_idx[s]]; a row is row_halfs 16-bit values.         */
-int vidil_kv_reorder(const void* src, void* dst, const int32_t* beam_idx,
-                     int32_t L, int32_t rows, int64_t row_halfs, void* stream);
 
 /* ------------------------------------------------------------------------ */
 /* Beam-search KV arena: the same _reorder_cache semantics (models/med.py:    */
@@ -335,7 +328,8 @@ int vidil_kv_reorder(const void* src, void* dst, const int32_t* beam_idx,
 /*   vidil_beam_attention: one query token per beam row r (q T16 [rows][H*64],*/
 /*     pre-scaled) over positions 0..n_keys-1 of its ancestry:                */
 /*     out[r][h*64+d] = softmax_t(q_rh . K[t][anc[r][t]][h]) V[t][anc[r][t]][h]*/
-/*     f32 scores / softmax / accumulation, T16 output (row stride ldo).      */
+/*     f32 scores / softmax / accumulation, T16 output (row stride ldo;       */
+/*     out_dtype = dtype, or dtype | VIDIL_DT_SPLIT3: planes ldo/3 apart).    */
 /*     n_keys <= 64.  Replaces the cached self-attention of models/med.py:    */
 /*     178-220 on decode steps (past_key_values + _reorder_cache).            */
 /* ------------------------------------------------------------------------ */
@@ -345,7 +339,8 @@ int vidil_beam_ancestry(const int32_t* anc_src, int32_t* anc_dst,
 int vidil_beam_attention(const void* q, const void* k_arena, const void* v_arena,
                          const int32_t* anc, void* out, int32_t rows, int32_t H,
                          int32_t n_keys, int32_t arena_rows, int32_t Tcap,
-                         int32_t ldo, int32_t dtype, void* stream);
+                         int32_t ldo, int32_t dtype, int32_t out_dtype,
+                         void* stream);
 
 /* ------------------------------------------------------------------------ */
 /* One nucleus-sampling step (HF transformers 4.15 sample() as configured by  */

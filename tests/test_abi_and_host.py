@@ -30,7 +30,7 @@ def test_library_exports_every_declared_symbol():
         assert hasattr(lib, n), f"{n} declared in include/vidil_hip.h but not exported"
     assert set(names) == set(_lib.SIGNATURES), set(names) ^ set(_lib.SIGNATURES)
     assert lib.vidil_num_entry_points() == len(names)
-    assert lib.vidil_abi_version() == 7 == _lib.ABI_VERSION
+    assert lib.vidil_abi_version() == 8 == _lib.ABI_VERSION
 
 
 def test_gemm_args_struct_matches_header_field_order():
@@ -86,10 +86,15 @@ def test_argument_validation_without_a_gpu():
     assert lib.vidil_gemm_kernel_name(ctypes.byref(g), buf, 128) == -1 and b"w_scale" in lib.vidil_last_error()
     g.w_scale = 16
     assert lib.vidil_gemm_kernel_name(ctypes.byref(g), buf, 128) == 0 and buf.value == b"gemm256_kernel<fp8, _Float16, 1, 0, false, false, false>"
-    g.W_tiled = 16                                  # a fragment-tiled copy alone changes nothing: the 128x256 kernel is opt-in
-    assert lib.vidil_gemm_kernel_name(ctypes.byref(g), buf, 128) == 0 and buf.value == b"gemm256_kernel<fp8, _Float16, 1, 0, false, false, false>"
     # out_dtype of the attention: fp8 only from the staged kernel
     assert lib.vidil_attention(16, 16, 16, 16, None, None, None, 0, 0, 1, 12, 4, 64, 4, 64, 64, 1, 0, 0, 768, 0, 0, 2, None) == -1
+    assert b"out_dtype" in lib.vidil_last_error()
+    # VIDIL_DT_SPLIT3 outputs ([hi | lo | hi] planes): ldo must hold three planes of >= H*64 columns
+    assert lib.vidil_attention(16, 16, 16, 16, None, None, None, 0, 0, 1, 12, 4, 64, 4, 64, 64, 1, 0, 0, 768, 0, 0, 0x100, None) == -1
+    assert b"split3" in lib.vidil_last_error()
+    assert lib.vidil_beam_attention(16, 16, 16, 16, 16, 4, 12, 3, 4, 8, 768, 0, 0x100, None) == -1
+    assert b"split3" in lib.vidil_last_error()
+    assert lib.vidil_beam_attention(16, 16, 16, 16, 16, 4, 12, 3, 4, 8, 768, 0, 1, None) == -1
     assert b"out_dtype" in lib.vidil_last_error()
 
 

@@ -149,27 +149,6 @@ def test_gemm256_f16_and_f32(M, N, K):
     assert torch.equal(o_small, o32[sub])
 
 
-@pytest.mark.parametrize("col_block", [-1, 1, 2, 3, 5, 12, 40])
-def test_gemm256_tile_order_knob_changes_nothing(col_block):
-    """vidil_gemm_args.col_block only re-orders the persistent kernel's walk over the output tiles (blocks of w column
-    tiles, a narrower last block when w does not divide the count, w >= the count = plain order): every tile must still be
-    computed exactly once — bit-identical output, including the ragged last row panel, for two epilogues."""
-    k = _k()
-    M, N, K = 256 * 40 + 19, 256 * 11 + 64, 256          # 41 x 12 tiles, ragged in both directions
-    a = _rand(M, K, seed=90).half().to(DEV)
-    w = _rand(N, K, scale=0.05, seed=91).half().to(DEV)
-    bias = _rand(N, seed=92).to(DEV)
-    assert k.gemm_kernel_name(a, w, bias, out_dtype=torch.float16).startswith("gemm256_kernel")
-    base16 = k.gemm(a, w, bias, out_dtype=torch.float16)
-    got16 = k.gemm(a, w, bias, out_dtype=torch.float16, col_block=col_block)
-    assert torch.equal(base16, got16)
-    x0 = _rand(M, N, seed=93).to(DEV)
-    xa, xb = x0.clone(), x0.clone()
-    k.gemm(a, w, bias, out=xa, resid=xa)
-    k.gemm(a, w, bias, out=xb, resid=xb, col_block=col_block)
-    assert torch.equal(xa, xb)
-
-
 def test_gemm256_rows_times_k_beyond_2_to_the_31():
     """A batch of 3,584+ frames makes M * K of the fc2 GEMM (706,048 x 3,072) exceed 2^31 elements: the staging offsets
     are 32-bit but relative to the tile's row panel, so the rows past the 2^31st element must come out right (they did
@@ -531,16 +510,6 @@ def test_logsoftmax_topk(nb, V, ban):
     s, i = k.logsoftmax_topk(logits.to(DEV), bs.to(DEV), B, nb, ban)
     assert torch.equal(i.cpu().long(), ri)
     assert torch.allclose(s.cpu(), rs, rtol=1e-5, atol=1e-5)
-
-
-def test_kv_reorder():
-    k = _k()
-    L, rows, rh = 3, 10, 64 * 12
-    src = _rand(L, rows, rh, seed=52).half().to(DEV)
-    dst = torch.zeros_like(src)
-    idx = torch.tensor([3, 3, 0, 9, 1, 1, 1, 8, 2, 0], dtype=torch.int32)
-    k.kv_reorder(src, dst, idx.to(DEV), L, rows)
-    assert torch.equal(dst.cpu(), src.cpu()[:, idx.long()])
 
 
 def test_gemm_arena_epilogue():

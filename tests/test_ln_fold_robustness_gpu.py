@@ -1,0 +1,135 @@
+"""LayerNorm folded into the GEMMs (vidil_gemm_args.ln_fold / ln_stats_out / rln_gamma) on rows that are NOT zero-mean.
+
+The fold rounds the RAW stream x to 16 bits and normalises the accumulators; the unfused path rounds LayerNorm(x).  With
+a row mean mu and standard deviation sigma the raw value carries sqrt(mu^2 + sigma^2) / sigma times the magnitude of the
+normalised one, so the operand-rounding error of the folded GEMM is amplified by
+
+        A(mu / sigma) = sqrt(1 + (mu / sigma)^2)           (1.4x at 1, 3.2x at 3, 10x at 10)
+
+relative to the unfused path (an outlier CHANNEL is not amplified: LayerNorm keeps it an outlier, both paths round it
+with the same relative error).  These tests measure that factor — FOLD consumer, STATS producer and RLN residual
+LayerNorm, f16 and bf16, mean / sigma in {0, 1, 3, 10}, one channel at 100 sigma — against fp32 F.layer_norm + F.linear of
+the f32 stream (reference: models/vit.py:107-110 pre-LN blocks; models/med.py:228-239,306-317 post-LN blocks) and assert
+it stays inside the model above.  DESIGN.md §4 records the numbers and what they mean for trained weights."""
+import json
+import math
+import os
+
+import pytest
+import torch
+
+from common import ROOT
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda"
+RESULTS = []
+
+
+def _k():
+    from vidil_amd import kernels
+    return kernels
+
+
+def _rand(*shape, scale=1.0, seed=0):
+    g = torch.Generator(device="cpu").manual_seed(seed)
+    return torch.randn(*shape, generator=g) * scale
+
+
+def _row_partials(x32):
+    M, D = x32.shape
+    xs = x32.view(M, D // 64, 64)
+    return torch.stack([xs.sum(-1), (xs * xs).sum(-1)], dim=-1).contiguous()
+
+
+def _stream(M, D, ratio, seed, outlier=True):
+    """f32 rows with standard deviation ~1.5, row mean = ratio * sigma, and (optionally) one channel at 100 sigma."""
+    x = _rand(M, D, seed=seed) * 1.5
+    if outlier:
+        x[:, 5] = 150.0 * torch.sign(_rand(M, seed=seed + 1))
+    sigma = x.std(dim=1, keepdim=True)
+    return x - x.mean(dim=1, keepdim=True) + ratio * sigma
+
+
+@pytest.fixture(scope="module", autouse=True)
+def _dump():
+    yield
+    if RESULTS:
+        os.makedirs(os.path.join(ROOT, "gpurun_out"), exist_ok=True)
+        with open(os.path.join(ROOT, "gpurun_out", "ln_fold_robustness.json"), "w") as f:
+            json.dump(RESULTS, f, indent=1)
+
+
+@pytest.mark.parametrize("dtype", [torch.float16, torch.bfloat16])
+@pytest.mark.parametrize("ratio", [0.0, 1.0, 3.0, 10.0])
+@pytest.mark.parametrize("outlier", [False, True])
+def test_fold_consumer_error_amplification_on_rows_with_a_mean(dtype, ratio, outlier):
+    """FOLD: y = LN(x) W^T + b through the folded GEMM on T16(x) vs the unfused path (LayerNorm kernel -> T16 -> plain GEMM),
+    both against fp32 F.layer_norm + F.linear of the f32 stream."""
+    from vidil_amd.packing import fold_layernorm
+
+    k = _k()
+    M, D, N = 1024, 768, 3072
+    x = _stream(M, D, ratio, seed=200, outlier=outlier)
+    g, bt = _rand(D, seed=71) * 0.2 + 1.0, _rand(D, seed=72) * 0.2
+    w, b = _rand(N, D, scale=0.03, seed=73), _rand(N, seed=74) * 0.1
+    ref = (torch.nn.functional.layer_norm(x.double(), (D,), g.double(), bt.double(), 1e-6) @ w.double().t() + b.double())
+    # folded: raw 16-bit copy + partials of the f32 stream (what the STATS producer leaves)
+    wf, bf, cs = fold_layernorm(w, b, g, bt, dtype)
+    st = _row_partials(x).to(DEV)
+    # (the folded consumers write 16-bit outputs: the common output rounding is taken out below)
+    y_fold = k.gemm(x.to(dtype).to(DEV), wf.to(DEV), bf.to(DEV), ln=(cs.to(DEV), 1e-6, st)).float().cpu().double()
+    # unfused: LayerNorm kernel -> T16 -> plain GEMM
+    xn = torch.empty(M, D, dtype=dtype, device=DEV)
+    k.layernorm(x.to(DEV), g.to(DEV), bt.to(DEV), 1e-6, out16=xn)
+    y_plain = k.gemm(xn, w.to(dtype).to(DEV), b.to(DEV)).float().cpu().double()
+    # the 16-bit OUTPUT rounding is common to both: take it out by comparing with the rounded reference too
+    out_round = (ref.float().to(dtype).double() - ref).abs().pow(2).mean().sqrt().item()
+    e_fold = (y_fold - ref).pow(2).mean().sqrt().item()
+    e_plain = (y_plain - ref).pow(2).mean().sqrt().item()
+    op_fold = math.sqrt(max(e_fold ** 2 - out_round ** 2, 0.0))
+    op_plain = math.sqrt(max(e_plain ** 2 - out_round ** 2, 1e-30))
+    amp, model = op_fold / op_plain, math.sqrt(1.0 + ratio * ratio)
+    RESULTS.append(dict(kernel="FOLD", dtype=str(dtype), mean_over_sigma=ratio, outlier_channel=outlier, rms_err_fold=e_fold,
+                        rms_err_unfused=e_plain, rms_output_rounding=out_round, operand_error_amplification=amp, model=model,
+                        ref_rms=ref.pow(2).mean().sqrt().item()))
+    print(f"FOLD {dtype} mean/sigma={ratio} outlier={outlier}: rms err folded {e_fold:.2e} unfused {e_plain:.2e} "
+          f"(output rounding {out_round:.2e}) -> operand-error amplification {amp:.2f}x (model {model:.2f}x)")
+    assert amp < 1.6 * model + 0.3, (amp, model)
+    # absolute sanity at the magnitudes a trained tower shows (mean / sigma <= 1): inside the unfused path's tolerance x2
+    if ratio <= 1.0:
+        assert e_fold < 2.0 * e_plain + 1e-6
+
+
+@pytest.mark.parametrize("dtype", [torch.float16, torch.bfloat16])
+@pytest.mark.parametrize("ratio", [1.0, 3.0, 10.0])
+def test_stats_producer_partials_and_residual_layernorm_on_rows_with_a_mean(dtype, ratio):
+    """STATS + RLN: u' = LN(u) + a W^T + b where u has mean / sigma = ratio and a 100-sigma channel; the statistics come from
+    E[x^2] - mean^2 in f32 (cancellation grows with ratio^2).  The residual LayerNorm is f32 arithmetic on f32 u — only the
+    variance cancellation can hurt it — and the partials written for the NEXT consumer are those of the new f32 stream."""
+    k = _k()
+    M, N, K = 777, 768, 768
+    u = _stream(M, N, ratio, seed=300)
+    g, bt = _rand(N, seed=101) * 0.2 + 1.0, _rand(N, seed=102) * 0.2
+    a = _rand(M, K, seed=103).to(dtype)
+    w, b = _rand(N, K, scale=0.03, seed=104).to(dtype), _rand(N, seed=105) * 0.1
+    st_in = _row_partials(u).to(DEV)
+    x = u.to(DEV).clone()
+    x16 = torch.zeros(M, N, dtype=dtype, device=DEV)
+    st_out = torch.zeros(M, N // 64, 2, device=DEV)
+    k.gemm(a.to(DEV), w.to(DEV), b.to(DEV), out=x, resid=x, out16=x16, ln_stats_out=st_out, rln=(g.to(DEV), bt.to(DEV), 1e-12, st_in))
+    ref = (torch.nn.functional.layer_norm(u.double(), (N,), g.double(), bt.double(), 1e-12) + a.double() @ w.double().t() + b.double())
+    got = x.cpu()
+    err = (got.double() - ref).abs().max().item()
+    RESULTS.append(dict(kernel="RLN+STATS", dtype=str(dtype), mean_over_sigma=ratio, max_abs_err=err, ref_absmax=ref.abs().max().item()))
+    print(f"RLN {dtype} mean/sigma={ratio}: max|d| {err:.2e} at scale {ref.abs().max().item():.1f}")
+    # f32 statistics: relative variance error ~ 2^-23 * (1 + ratio^2) * a few -> tiny against the 100-sigma channel's magnitude
+    assert err < 1e-5 * ref.abs().max().item() * (1.0 + ratio * ratio) + 2e-5
+    assert torch.equal(x16.cpu(), got.to(dtype))
+    want = _row_partials(got)
+    assert torch.allclose(st_out.cpu(), want, rtol=1e-5, atol=1e-3 * (1 + ratio)), (st_out.cpu() - want).abs().max()
+    # and the statistics a consumer derives from those partials reproduce mean / var of the new stream
+    s = st_out.cpu().double().sum(dim=1)
+    mean = s[:, 0] / N
+    var = s[:, 1] / N - mean * mean
+    assert torch.allclose(mean, got.double().mean(dim=1), rtol=1e-6, atol=1e-6)
+    assert torch.allclose(var, got.double().var(dim=1, unbiased=False), rtol=1e-4 * (1 + ratio * ratio))

@@ -101,8 +101,9 @@ def test_decoder_small_vs_golden_prefill_reorder_and_steps():
     kref = torch.from_numpy(g["k_cache_l1"])                          # [6,4,4,64]
     assert (kc[0][1][:, :, :4].float().cpu() - kref).abs().max().item() < 5e-3
     beam_idx = torch.from_numpy(g["beam_idx"]).to(torch.int32).to(DEV)
-    K.kv_reorder(kc[0], kc[1], beam_idx, L, R)
-    K.kv_reorder(vc[0], vc[1], beam_idx, L, R)
+    # models/med.py:951-955 _reorder_cache in its literal form (test plumbing; the product reorders an ancestry table)
+    kc[1].copy_(kc[0].index_select(1, beam_idx.long()))
+    vc[1].copy_(vc[0].index_select(1, beam_idx.long()))
     for step, (key_ids, key_ref) in enumerate([("ids1", "logits1"), ("ids2", "logits2")]):
         tok = torch.from_numpy(g[key_ids][:, -1].copy()).to(torch.int32).to(DEV)
         h32, h16 = bert.embed(tok, 1, 4 + step)

@@ -1,4 +1,8 @@
-"""Developer microbenchmark: the GEMM shapes of the hot path, per epilogue (TFLOP/s, random data)."""
+"""Developer microbenchmark: the GEMM shapes of the hot path, per epilogue (TFLOP/s, random data).
+
+`--calibrate` additionally times the LIBRARY GEMM (hipBLASLt / rocBLAS behind torch.matmul — tools only, never on the
+product path) on the same box, same shapes, same random operands, bare (no bias, no activation, no residual): what the
+silicon and its power cap give a tuned library kernel, to price "what 1.4 kW buys" against a measurement."""
 import os
 import sys
 
@@ -21,9 +25,30 @@ def timeit(fn, iters=20):
     return e0.elapsed_time(e1) / iters * 1e-3
 
 
+def calibrate(dev, M, dtypes=(torch.float16, torch.bfloat16)):
+    """torch.matmul (hipBLASLt) on the path's three tower shapes + ours, bare 16-bit output, side by side."""
+    for dt in dtypes:
+        for name, m, n, k in (("qkv", M, 2304, 768), ("fc1", M, 3072, 768), ("fc2", M, 768, 3072), ("proj", M, 768, 768)):
+            a = (torch.randn(m, k, device=dev) * 0.5).to(dt)
+            w = (torch.randn(n, k, device=dev) * 0.05).to(dt)
+            wt = w.t()                                   # [K, N] view: A @ W^T, the NT form nn.Linear uses
+            o = torch.empty(m, n, dtype=dt, device=dev)
+            t_lib = timeit(lambda: torch.matmul(a, wt, out=o))
+            t_own = timeit(lambda: K.gemm(a, w, None, out=o))
+            f = 2.0 * m * n * k / 1e12
+            print(f"calibrate {str(dt)[6:]:8s} {name:5s} M={m:6d} N={n:5d} K={k:4d}  hipBLASLt {t_lib * 1e6:8.1f} us {f / t_lib:7.1f} TFLOP/s"
+                  f"   gemm256 {t_own * 1e6:8.1f} us {f / t_own:7.1f} TFLOP/s   ratio {t_lib / t_own:5.2f}")
+
+
 def main():
     dev = "cuda"
-    B = int(sys.argv[1]) if len(sys.argv) > 1 else 512
+    args = [a for a in sys.argv[1:] if not a.startswith("--")]
+    B = int(args[0]) if args else 512
+    if "--calibrate" in sys.argv:
+        torch.manual_seed(0)
+        calibrate(dev, B * 197)
+        if "--only-calibrate" in sys.argv:
+            return
     T, H = 197, 12
     M = B * T
     torch.manual_seed(0)

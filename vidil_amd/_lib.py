@@ -18,6 +18,7 @@ LIB_PATH = os.environ.get("VIDIL_HIP_LIB") or os.path.join(_HERE, "csrc", "libvi
 
 EPI_F16, EPI_F32, EPI_HEADS, EPI_PATCH, EPI_ARENA, EPI_F8 = 0, 1, 2, 3, 4, 5
 DT_F16, DT_BF16, DT_FP8 = 0, 1, 2
+DT_SPLIT3 = 0x100     # output flag: rows written as error-compensated operands [hi | lo | hi] (include/vidil_hip.h)
 ACT_NONE, ACT_GELU_ERF, ACT_QUICK_GELU = 0, 1, 2
 
 
@@ -37,7 +38,7 @@ class GemmArgs(C.Structure):
         ("arena_rows", C.c_int32), ("slot_stride", C.c_int32),
         ("pos", C.c_void_p), ("tpi", C.c_int32), ("kv_tiled", C.c_int32), ("dtype", C.c_int32),
         ("out16", C.c_void_p), ("ldo16", C.c_int32), ("ln_fold", C.c_int32), ("ln_colsum", C.c_void_p), ("ln_eps", C.c_float), ("ln_stats_out", C.c_void_p), ("ln_stats", C.c_void_p),
-        ("w_scale", C.c_void_p), ("dtype16", C.c_int32), ("W_tiled", C.c_void_p), ("col_block", C.c_int32), ("rln_gamma", C.c_void_p), ("rln_beta", C.c_void_p),
+        ("w_scale", C.c_void_p), ("dtype16", C.c_int32), ("rln_gamma", C.c_void_p), ("rln_beta", C.c_void_p),
     ]
 
 
@@ -71,9 +72,8 @@ SIGNATURES = {
     "vidil_logsoftmax_topk": (_i32, [_p, _p, _i32, _i32, _i32, _i32, _i32, _p, _p, _p]),
     "vidil_beam_update": (_i32, [C.POINTER(BeamState), _p, _p] + [_i32] * 7 + [_p]),
     "vidil_beam_finalize": (_i32, [C.POINTER(BeamState)] + [_i32] * 6 + [_p, _p, _p, _p]),
-    "vidil_kv_reorder": (_i32, [_p, _p, _p, _i32, _i32, _i64, _p]),
     "vidil_beam_ancestry": (_i32, [_p, _p, _p, _i32, _i32, _i32, _p]),
-    "vidil_beam_attention": (_i32, [_p, _p, _p, _p, _p] + [_i32] * 7 + [_p]),
+    "vidil_beam_attention": (_i32, [_p, _p, _p, _p, _p] + [_i32] * 8 + [_p]),
     "vidil_sample_top_k_top_p": (_i32, [_p, _p, _p, _p, _p] + [_i32] * 8 + [_f32, _f32, C.c_uint64, _i32, _i32, _p]),
     "vidil_scan_scores": (_i32, [_p, _p, _i32, _i32, _i32, _p, _p]),
     "vidil_topk_rows": (_i32, [_p, _i64, _i32, _i32, _i32, _p, _p, _p]),
@@ -88,7 +88,7 @@ class VidilHipError(RuntimeError):
     pass
 
 
-ABI_VERSION = 7      # include/vidil_hip.h as this binding mirrors it (struct layouts, argument lists)
+ABI_VERSION = 8      # include/vidil_hip.h as this binding mirrors it (struct layouts, argument lists)
 
 
 def load():

@@ -43,7 +43,8 @@ struct AttnP {
   const int32_t* kv_index;     // per query batch -> kv batch (only with kv_group == 1 semantics), or null
   const int32_t* group_start;  // [n_kv+1] prefix of query batches per kv batch, or null
   int Bq, H, Nq, Nk, Tq_cap, Tk_cap, NP, kv_group, causal, causal_off, ldo, n_kv;
-  int out_fp8;                 // `out` holds e4m3 bytes (the fp8 tower mode's proj-GEMM operand); store_rows kernels only
+  int out_mode;                // 0: T rows; 1: e4m3 bytes (the fp8 tower mode's proj-GEMM operand; store_rows kernels only);
+                               // 2: error-compensated rows [hi | lo | hi] in three planes ldo/3 apart (VIDIL_DT_SPLIT3)
   int tiled;                   // K and V in 32-key fragment tiles (common.h: ktile_off / vtile_off); direct kernel only
   int rb;                      // staged kernel, single key chunk: rounds of NW row blocks per workgroup (launch_lds)
 };
@@ -150,7 +151,27 @@ __device__ __forceinline__ void store_rows(const AttnP<T>& p, const RowInfo& ri,
   using f16 = T;
   if (!ri.valid) return;
   const int hi = (threadIdx.x & 63) >> 5;
-  if (p.out_fp8) {   // wave-uniform
+  if (p.out_mode == 2) {   // wave-uniform: hi = T(o), lo = T(o - hi), planes [hi | lo | hi]
+    const int pl = p.ldo / 3;
+    f16* og = p.out + ((size_t)ri.qb * p.Nq + ri.t) * p.ldo + h * 64 + 4 * hi;
+#pragma unroll
+    for (int dt = 0; dt < 2; ++dt)
+#pragma unroll
+      for (int rq = 0; rq < 4; ++rq) {
+        f16x4 vh, vl;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          const float v = O[dt][rq * 4 + e] * inv;
+          vh[e] = Elt<T>::from_f32(v);
+          vl[e] = Elt<T>::from_f32(v - (float)vh[e]);
+        }
+        *(f16x4*)(og + dt * 32 + rq * 8) = vh;
+        *(f16x4*)(og + pl + dt * 32 + rq * 8) = vl;
+        *(f16x4*)(og + 2 * pl + dt * 32 + rq * 8) = vh;
+      }
+    return;
+  }
+  if (p.out_mode == 1) {   // wave-uniform
     uint8_t* o8 = (uint8_t*)p.out + ((size_t)ri.qb * p.Nq + ri.t) * p.ldo + h * 64 + 4 * hi;
 #pragma unroll
     for (int dt = 0; dt < 2; ++dt)
@@ -536,7 +557,7 @@ __global__ __launch_bounds__(256) void attn_direct_kernel(const AttnP<T> p) {
       const float inv = lt > 0.f ? 1.0f / lt : 0.f;
       const int g = row / p.Nq;
       const int qb = first + g, t = row - g * p.Nq;
-      f16x8 o8;
+      f16x8 o8, l8;
 #pragma unroll
       for (int e = 0; e < 8; ++e) {
         const int d = db * 8 + e;
@@ -544,8 +565,15 @@ __global__ __launch_bounds__(256) void attn_direct_kernel(const AttnP<T> p) {
 #pragma unroll
         for (int w = 0; w < 4; ++w) acc += part_o[w][d][row] * sc[w];
         o8[e] = (f16)(acc * inv);
+        l8[e] = Elt<T>::from_f32(acc * inv - (float)o8[e]);
       }
-      *(f16x8*)(p.out + ((size_t)qb * p.Nq + t) * p.ldo + h * 64 + db * 8) = o8;
+      f16* const og = p.out + ((size_t)qb * p.Nq + t) * p.ldo + h * 64 + db * 8;
+      *(f16x8*)og = o8;
+      if (p.out_mode == 2) {       // [hi | lo | hi] planes (VIDIL_DT_SPLIT3)
+        const int pl = p.ldo / 3;
+        *(f16x8*)(og + pl) = l8;
+        *(f16x8*)(og + 2 * pl) = o8;
+      }
     }
   }
 }
@@ -716,12 +744,15 @@ extern "C" int vidil_attention(const void* q, const void* k, const void* vt, voi
   // NP == 0: `vt` holds V row-major [Bk][H][Tk_cap][64]; only the LDS-staged kernel transposes on the way in
   VIDIL_REQUIRE(NP != 0 || max_rows > 32, "attention: row-major V (NP == 0) needs more than 32 query rows per unit (got %d)",
                 max_rows);
-  VIDIL_REQUIRE(out_dtype == dtype || (out_dtype == VIDIL_DT_FP8 && max_rows > 32 && ldo % 16 == 0),
-                "attention: out_dtype=%d must equal dtype=%d, or be fp8 with more than 32 query rows per unit (staged kernel)",
-                out_dtype, dtype);
+  const bool split3 = out_dtype == (dtype | VIDIL_DT_SPLIT3);
+  VIDIL_REQUIRE(out_dtype == dtype || split3 || (out_dtype == VIDIL_DT_FP8 && max_rows > 32 && ldo % 16 == 0),
+                "attention: out_dtype=%d must equal dtype=%d (optionally | VIDIL_DT_SPLIT3), or be fp8 with more than 32 query "
+                "rows per unit (staged kernel)", out_dtype, dtype);
+  VIDIL_REQUIRE(!split3 || (ldo % 24 == 0 && ldo / 3 >= H * 64), "attention: split3 output needs ldo=%d = 3 planes of >= H*64, "
+                "each a multiple of 8", ldo);
   VIDIL_DISPATCH_DTYPE(dtype, "attention", {
     const AttnP<T> p{(const T*)q, (const T*)k, (const T*)vt, (T*)out, kv_len, kv_index, group_start, Bq, H, Nq, Nk,
-                     Tq_cap, Tk_cap, NP, kv_group, causal, causal_off, ldo, units, out_dtype == VIDIL_DT_FP8 ? 1 : 0,
+                     Tq_cap, Tk_cap, NP, kv_group, causal, causal_off, ldo, units, out_dtype == VIDIL_DT_FP8 ? 1 : (split3 ? 2 : 0),
                      kv_tiled ? 1 : 0, 1};
     return attention_dispatch<T>(p, nkt, max_rows, Nk, (hipStream_t)stream);
   });

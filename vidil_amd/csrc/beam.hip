@@ -10,7 +10,6 @@
 //   beam_update     : one thread per image; BeamSearchScorer.process + the
 //                     input_ids gather/append.
 //   beam_finalize   : one thread per image; BeamSearchScorer.finalize.
-//   kv_reorder      : BertLMHeadModel._reorder_cache (models/med.py:951-955).
 #include <math.h>
 #include "common.h"
 
@@ -246,16 +245,6 @@ __global__ void beam_finalize_kernel(const vidil_beam_state st, int B, int nb, i
   out_score[b] = (float)hs[best];
 }
 
-__global__ __launch_bounds__(256) void kv_reorder_kernel(const uint4* __restrict__ src, uint4* __restrict__ dst,
-                                                         const int32_t* __restrict__ beam_idx, int rows,
-                                                         int64_t row_vec) {
-  const int s = blockIdx.x, l = blockIdx.y;
-  const int from = beam_idx[s];
-  const uint4* a = src + ((size_t)l * rows + from) * row_vec;
-  uint4* d = dst + ((size_t)l * rows + s) * row_vec;
-  for (int64_t i = threadIdx.x; i < row_vec; i += 256) d[i] = a[i];
-}
-
 }  // namespace
 
 extern "C" int vidil_logsoftmax_topk(const float* logits, const float* beam_scores, int32_t B, int32_t nb,
@@ -318,16 +307,5 @@ extern "C" int vidil_beam_finalize(const vidil_beam_state* st, int32_t B, int32_
   hipLaunchKernelGGL(beam_finalize_kernel, dim3((B + 63) / 64), dim3(64), 0, (hipStream_t)stream, *st, B, nb, cur_len,
                      max_len, eos_id, pad_id, out_tokens, out_len, out_score);
   VIDIL_CHECK_LAUNCH("beam_finalize");
-  return VIDIL_OK;
-}
-
-extern "C" int vidil_kv_reorder(const void* src, void* dst, const int32_t* beam_idx, int32_t L, int32_t rows,
-                                int64_t row_halfs, void* stream) {
-  VIDIL_REQUIRE(src && dst && beam_idx && src != dst, "kv_reorder: bad pointers (src must differ from dst)");
-  VIDIL_REQUIRE(L > 0 && rows > 0 && row_halfs > 0 && row_halfs % 8 == 0, "kv_reorder: row_halfs must be a multiple of 8");
-  VIDIL_REQUIRE(L <= 65535, "kv_reorder: too many layers");
-  hipLaunchKernelGGL(kv_reorder_kernel, dim3(rows, L), dim3(256), 0, (hipStream_t)stream, (const uint4*)src, (uint4*)dst,
-                     beam_idx, rows, row_halfs / 8);
-  VIDIL_CHECK_LAUNCH("kv_reorder");
   return VIDIL_OK;
 }

@@ -26,6 +26,7 @@ struct BeamAttnP {
   const int32_t* anc;
   T* out;
   int rows, H, n_keys, arena_rows, Tcap, ldo;
+  int split3;   // out rows are [hi | lo | hi] planes ldo/3 apart (VIDIL_DT_SPLIT3)
 };
 
 template <typename T, int MAXJ>
@@ -116,7 +117,15 @@ __global__ __launch_bounds__(256) void beam_attn_kernel(const BeamAttnP<T> p) {
   const float send = b0 ? o2[0] : o2[1];
   const float od = keep + __shfl_xor(send, 8, 64);
   const int d = 8 * c + (b2 ? 4 : 0) + (b1 ? 2 : 0) + (b0 ? 1 : 0);
-  p.out[(size_t)r * p.ldo + h * 64 + d] = Elt<T>::from_f32(od * (1.0f / l));
+  const float ov = od * (1.0f / l);
+  const T oh = Elt<T>::from_f32(ov);
+  T* const og = p.out + (size_t)r * p.ldo + h * 64 + d;
+  og[0] = oh;
+  if (p.split3) {
+    const int pl = p.ldo / 3;
+    og[pl] = Elt<T>::from_f32(ov - (float)oh);
+    og[2 * pl] = oh;
+  }
 }
 
 __global__ __launch_bounds__(256) void beam_ancestry_kernel(const int32_t* __restrict__ src, int32_t* __restrict__ dst,
@@ -152,12 +161,15 @@ extern "C" int vidil_beam_ancestry(const int32_t* anc_src, int32_t* anc_dst, con
 
 extern "C" int vidil_beam_attention(const void* q, const void* k_arena, const void* v_arena, const int32_t* anc, void* out,
                                     int32_t rows, int32_t H, int32_t n_keys, int32_t arena_rows, int32_t Tcap, int32_t ldo,
-                                    int32_t dtype, void* stream) {
+                                    int32_t dtype, int32_t out_dtype, void* stream) {
   VIDIL_REQUIRE(q && k_arena && v_arena && anc && out, "beam_attention: null pointer");
   VIDIL_REQUIRE(rows > 0 && H > 0 && n_keys > 0, "beam_attention: bad shape rows=%d H=%d n_keys=%d", rows, H, n_keys);
   VIDIL_REQUIRE(n_keys <= Tcap, "beam_attention: n_keys=%d exceeds the ancestry capacity Tcap=%d", n_keys, Tcap);
   VIDIL_REQUIRE(arena_rows >= rows, "beam_attention: arena_rows=%d < rows=%d", arena_rows, rows);
   VIDIL_REQUIRE(ldo >= H * 64, "beam_attention: ldo=%d must be >= H*64", ldo);
+  const bool split3 = out_dtype == (dtype | VIDIL_DT_SPLIT3);
+  VIDIL_REQUIRE(out_dtype == dtype || split3, "beam_attention: out_dtype=%d must be dtype=%d, optionally | VIDIL_DT_SPLIT3", out_dtype, dtype);
+  VIDIL_REQUIRE(!split3 || (ldo % 3 == 0 && ldo / 3 >= H * 64), "beam_attention: split3 output needs ldo=%d = 3 planes of >= H*64", ldo);
   VIDIL_REQUIRE(((uintptr_t)q & 15) == 0 && ((uintptr_t)k_arena & 15) == 0 && ((uintptr_t)v_arena & 15) == 0,
                 "beam_attention: q / arenas must be 16-B aligned");
   VIDIL_REQUIRE(n_keys <= 64, "beam_attention: n_keys=%d > 64 not supported by this kernel", n_keys);
@@ -165,7 +177,7 @@ extern "C" int vidil_beam_attention(const void* q, const void* k_arena, const vo
   const dim3 grid((unsigned)((units + 3) / 4));
   hipStream_t s = (hipStream_t)stream;
   VIDIL_DISPATCH_DTYPE(dtype, "beam_attention", {
-    const BeamAttnP<T> p{(const T*)q, (const T*)k_arena, (const T*)v_arena, anc, (T*)out, rows, H, n_keys, arena_rows, Tcap, ldo};
+    const BeamAttnP<T> p{(const T*)q, (const T*)k_arena, (const T*)v_arena, anc, (T*)out, rows, H, n_keys, arena_rows, Tcap, ldo, split3 ? 1 : 0};
     if (n_keys <= 32) {
       hipLaunchKernelGGL((beam_attn_kernel<T, 4>), grid, dim3(256), 0, s, p);
     } else {

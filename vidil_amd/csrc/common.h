@@ -23,9 +23,6 @@ void vidil_set_error(const char* fmt, ...);
 // gemm256.hip: the 256x256 8-wave kernel for large problems (dispatched from vidil_gemm_f16)
 bool vidil_gemm256_eligible(const vidil_gemm_args& a, bool any_size = false);
 int vidil_gemm256_launch(const vidil_gemm_args& a, hipStream_t s);
-// gemm128x256.hip: 128x256 tile, two 4-wave workgroups per CU, W from fragment tiles (vidil_gemm_args.W_tiled)
-bool vidil_gemm128x256_eligible(const vidil_gemm_args& a, bool any_size = false);
-int vidil_gemm128x256_launch(const vidil_gemm_args& a, hipStream_t s);
 
 #define VIDIL_REQUIRE(cond, ...)                \
   do {                                          \

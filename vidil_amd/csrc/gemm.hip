@@ -323,15 +323,7 @@ TileChoice choose_tile(const vidil_gemm_args& a) {
     const char* e = getenv("VIDIL_GEMM256");
     return !(e && e[0] == '0');
   }();
-  // big == 2: the 128x256 two-workgroups-per-CU kernel (needs the fragment-tiled copy of W).  Opt-in with
-  // VIDIL_GEMM_W4=1: measured 3-7 % SLOWER than the 256x256 kernel on every shape of the path, kept as
-  // the recorded experiment it is.
-  static const bool allow_w4 = []() {
-    const char* e = getenv("VIDIL_GEMM_W4");
-    return e && e[0] == '1';
-  }();
   const bool forced_big = a.ln_fold || a.out16 || a.ln_stats_out || a.dtype == VIDIL_DT_FP8;   // (check_args)
-  if (allow_w4 && a.epi != VIDIL_EPI_ARENA && vidil_gemm128x256_eligible(a, forced_big)) return {2, 128, 256, 4};
   if (forced_big) return {1, 256, 256, 2};
   if (allow256 && a.epi != VIDIL_EPI_ARENA && vidil_gemm256_eligible(a)) return {1, 256, 256, 2};
 #ifdef VIDIL_GEMM_TUNE
@@ -360,7 +352,6 @@ TileChoice choose_tile(const vidil_gemm_args& a) {
 template <typename T, int EPI, int ACT>
 int pick_tile(const vidil_gemm_args& a, hipStream_t s) {
   const TileChoice c = choose_tile(a);
-  if (c.big == 2) return vidil_gemm128x256_launch(a, s);
   if (c.big) return vidil_gemm256_launch(a, s);
 #define VIDIL_TRY(BM_, BN_, ST_) \
   if (c.bm == BM_ && c.bn == BN_ && c.st == ST_) return launch<T, BM_, BN_, ST_, EPI, ACT>(a, s);
@@ -492,8 +483,7 @@ extern "C" int vidil_gemm(const vidil_gemm_args* args, void* stream) {
   const int rc = check_args(*args);
   if (rc != VIDIL_OK) return rc;
   if (args->dtype == VIDIL_DT_FP8)
-    return choose_tile(*args).big == 2 ? vidil_gemm128x256_launch(*args, (hipStream_t)stream)
-                                       : vidil_gemm256_launch(*args, (hipStream_t)stream);
+    return vidil_gemm256_launch(*args, (hipStream_t)stream);
   if (args->dtype == VIDIL_DT_BF16) return dispatch<bf16>(*args, (hipStream_t)stream);
   return dispatch<f16>(*args, (hipStream_t)stream);
 }
@@ -507,8 +497,7 @@ extern "C" int vidil_gemm_kernel_name(const vidil_gemm_args* args, char* buf_hos
   const char* t = args->dtype == VIDIL_DT_FP8 ? "fp8" : t16;                 // the spelling rocprofv3 demangles to
   const int act = (args->epi == VIDIL_EPI_F16 || args->epi == VIDIL_EPI_F32 || args->epi == VIDIL_EPI_F8) ? args->act : 0;
   const char* stats = (args->ln_stats_out && args->epi == VIDIL_EPI_F32) ? "true" : "false";
-  if (c.big == 2) snprintf(buf_host, n, "gemm128x256_kernel<%s, %s, %d, %d, %s, %s>", t, t16, args->epi, act, args->ln_fold ? "true" : "false", stats);
-  else if (c.big) snprintf(buf_host, n, "gemm256_kernel<%s, %s, %d, %d, %s, %s, %s>", t, t16, args->epi, act, args->ln_fold ? "true" : "false",
+  if (c.big) snprintf(buf_host, n, "gemm256_kernel<%s, %s, %d, %d, %s, %s, %s>", t, t16, args->epi, act, args->ln_fold ? "true" : "false",
                            stats, args->rln_gamma ? "true" : "false");
   else snprintf(buf_host, n, "gemm_kernel<%s, %d, %d, %d, %d, %d>", t, c.bm, c.bn, c.st, args->epi, act);
   return VIDIL_OK;

@@ -124,24 +124,12 @@ __global__ __launch_bounds__(512) void gemm256_kernel(const vidil_gemm_args p) {
   int gA[2][2];
   int gW[2][2];
   int m0, n0;
-  // tile order: col_block == 0 -> row-panel-major (consecutive logical tiles share an A row panel and sweep all W column
-  // tiles); col_block == w -> blocks of w column tiles, row panels inside a block (the XCD's live W is w column tiles)
-  const int cbw = p.col_block > 0 && p.col_block < tiles_n ? p.col_block : 0;
-  const int cb_tiles = tiles_m * cbw;                              // logical tiles per full column block
+  // tile order: row-panel-major (consecutive logical tiles share an A row panel and sweep all W column tiles; orders
+  // that keep fewer column tiles of W live per XCD measured -13 ... +1 %)
   const T* baseA = (const T*)p.A;        // first row of the current tile (setup_tile)
   auto setup_tile = [&](int lt) {
-    int tile_m, tile_n;
-    if (cbw == 0) {
-      tile_m = lt / tiles_n;
-      tile_n = lt - tile_m * tiles_n;
-    } else {
-      const int cb = lt / cb_tiles;
-      const int r = lt - cb * cb_tiles;
-      const int rest = tiles_n - cb * cbw;
-      const int w = rest < cbw ? rest : cbw;                       // (the last block may be narrower)
-      tile_m = r / w;
-      tile_n = cb * cbw + (r - tile_m * w);
-    }
+    const int tile_m = lt / tiles_n;
+    const int tile_n = lt - tile_m * tiles_n;
     m0 = tile_m << 8;
     n0 = tile_n << 8;
 #pragma unroll
@@ -367,16 +355,6 @@ __global__ __launch_bounds__(512) void gemm256_kernel(const vidil_gemm_args p) {
   }  // tile loop
 }
 
-// Tile order when the caller leaves col_block at 0 (see include/vidil_hip.h).  Measured at M = 605,184 (round 2):
-// blocks of 1 / 2 / 3 / 4 / 6 column tiles against row-panel-major — QKV (9 column tiles) 700 / 750 / 766 / 766 / 772
-// vs 806 TFLOP/s, fc1 (12) 749 / 771 / 790 / 767 / 792 vs 783, fc2 and proj (3) equal from 3 up: the re-reads of A and W
-// that the L2 misses (PMC: 7.5 GB fetched per fc1 launch for 0.93 GB of A) cost less than the noise, so the order stays
-// row-panel-major.
-static int default_col_block(const vidil_gemm_args& a) {
-  if (const char* e = getenv("VIDIL_GEMM_COLBLOCK")) return atoi(e) == 0 ? -1 : atoi(e);     // developer override
-  return -1;
-}
-
 template <typename T, int EPI, int ACT, bool FOLD = false, typename TO = T, bool STATS = false, bool RLN = false>
 int launch256(const vidil_gemm_args& a, hipStream_t s) {
   static bool attr_set = false;
@@ -405,9 +383,7 @@ int launch256(const vidil_gemm_args& a, hipStream_t s) {
   }
   const int ntiles = ((a.M + 255) / 256) * ((a.N + 255) / 256);
   const int tiles = !(kPersistent<EPI> && sizeof(T) == 2 && !RLN) ? ntiles : ntiles >= cus ? cus : (ntiles >= 8 ? (ntiles & ~7) : ntiles);
-  vidil_gemm_args b = a;
-  if (b.col_block == 0) b.col_block = default_col_block(a);
-  hipLaunchKernelGGL(kern, dim3(tiles), dim3(512), lds, s, b);
+  hipLaunchKernelGGL(kern, dim3(tiles), dim3(512), lds, s, a);
   VIDIL_CHECK_LAUNCH("gemm256");
   return VIDIL_OK;
 }

@@ -14,7 +14,7 @@ template <typename T, int VPL>  // float4 vectors per lane: D = 256*VPL
 __global__ __launch_bounds__(256) void layernorm_kernel(const float* __restrict__ x, int64_t x_stride,
                                                         const float* __restrict__ gamma,
                                                         const float* __restrict__ beta, float eps, int M,
-                                                        T* __restrict__ out16, float* __restrict__ out32) {
+                                                        T* __restrict__ out16, float* __restrict__ out32, int split3) {
   using x4 = typename std::conditional<sizeof(T) == 1, uint32_t, typename Elt<typename std::conditional<sizeof(T) == 1, f16, T>::type>::x4>::type;
   constexpr int D = 256 * VPL;
   const int lane = threadIdx.x & 63;
@@ -52,6 +52,17 @@ __global__ __launch_bounds__(256) void layernorm_kernel(const float* __restrict_
     if (out16 != nullptr) {
       if constexpr (sizeof(T) == 1) {
         __builtin_nontemporal_store(pack4_fp8(y[0], y[1], y[2], y[3]), (uint32_t*)((uint8_t*)out16 + (size_t)row * D + c));
+      } else if (split3) {      // error-compensated operand rows [hi | lo | hi], row stride 3D (VIDIL_DT_SPLIT3)
+        x4 h4, l4;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          h4[e] = Elt<T>::from_f32(y[e]);
+          l4[e] = Elt<T>::from_f32(y[e] - (float)h4[e]);
+        }
+        T* o = out16 + (size_t)row * 3 * D + c;
+        *(x4*)o = h4;
+        *(x4*)(o + D) = l4;
+        *(x4*)(o + 2 * D) = h4;
       } else {
         __builtin_nontemporal_store(x4{(T)y[0], (T)y[1], (T)y[2], (T)y[3]}, (x4*)(out16 + (size_t)row * D + c));
       }
@@ -145,7 +156,7 @@ __global__ __launch_bounds__(256) void patchify_u8_kernel(const uint8_t* __restr
 // (the weight is zero padded the same way by the host packing: exact).
 template <typename T, bool U8>
 __global__ __launch_bounds__(256) void patchify_any_kernel(const void* __restrict__ img, T* __restrict__ out, int B, int S,
-                                                           int ps, int ldk, Norm3 nm) {
+                                                           int ps, int ldk, Norm3 nm, int split3 = 0) {
   const int G = S / ps;
   const int pp = ps * ps;
   const size_t total = (size_t)B * G * G * ldk;
@@ -166,7 +177,15 @@ __global__ __launch_bounds__(256) void patchify_any_kernel(const void* __restric
         v = ((const float*)img)[(((size_t)b * 3 + c) * S + row) * S + cx];
       }
     }
-    out[i] = (T)v;
+    if (split3) {       // error-compensated operand rows [hi | lo | hi], 3*ldk wide (VIDIL_DT_SPLIT3)
+      const T h = Elt<T>::from_f32(v);
+      T* o = out + (i / ldk) * (size_t)(3 * ldk) + col;
+      o[0] = h;
+      o[ldk] = Elt<T>::from_f32(v - (float)h);
+      o[2 * ldk] = h;
+    } else {
+      out[i] = (T)v;
+    }
   }
 }
 
@@ -230,14 +249,14 @@ inline int grid_for(size_t total, int block) {
 
 template <typename T>
 static int layernorm_launch(const float* x, int64_t x_stride, const float* gamma, const float* beta, float eps, int M, int D,
-                            T* out16, float* out32, hipStream_t s) {
+                            T* out16, float* out32, hipStream_t s, int split3 = 0) {
   dim3 grid((M + 3) / 4), block(256);
   switch (D) {
-    case 256: hipLaunchKernelGGL((layernorm_kernel<T, 1>), grid, block, 0, s, x, x_stride, gamma, beta, eps, M, out16, out32); break;
-    case 512: hipLaunchKernelGGL((layernorm_kernel<T, 2>), grid, block, 0, s, x, x_stride, gamma, beta, eps, M, out16, out32); break;
-    case 768: hipLaunchKernelGGL((layernorm_kernel<T, 3>), grid, block, 0, s, x, x_stride, gamma, beta, eps, M, out16, out32); break;
-    case 1024: hipLaunchKernelGGL((layernorm_kernel<T, 4>), grid, block, 0, s, x, x_stride, gamma, beta, eps, M, out16, out32); break;
-    case 1280: hipLaunchKernelGGL((layernorm_kernel<T, 5>), grid, block, 0, s, x, x_stride, gamma, beta, eps, M, out16, out32); break;
+    case 256: hipLaunchKernelGGL((layernorm_kernel<T, 1>), grid, block, 0, s, x, x_stride, gamma, beta, eps, M, out16, out32, split3); break;
+    case 512: hipLaunchKernelGGL((layernorm_kernel<T, 2>), grid, block, 0, s, x, x_stride, gamma, beta, eps, M, out16, out32, split3); break;
+    case 768: hipLaunchKernelGGL((layernorm_kernel<T, 3>), grid, block, 0, s, x, x_stride, gamma, beta, eps, M, out16, out32, split3); break;
+    case 1024: hipLaunchKernelGGL((layernorm_kernel<T, 4>), grid, block, 0, s, x, x_stride, gamma, beta, eps, M, out16, out32, split3); break;
+    case 1280: hipLaunchKernelGGL((layernorm_kernel<T, 5>), grid, block, 0, s, x, x_stride, gamma, beta, eps, M, out16, out32, split3); break;
     default:
       vidil_set_error("layernorm: D=%d not supported (256/512/768/1024/1280)", D);
       return VIDIL_EUNSUP;
@@ -253,8 +272,9 @@ extern "C" int vidil_layernorm(const float* x, int64_t x_stride, const float* ga
   VIDIL_REQUIRE(x_stride % 4 == 0, "layernorm: x_stride must be a multiple of 4");
   if (out16 && dtype16 == VIDIL_DT_FP8)
     return layernorm_launch<fp8>(x, x_stride, gamma, beta, eps, M, D, (fp8*)out16, out_f32, (hipStream_t)stream);
-  VIDIL_DISPATCH_DTYPE(out16 ? dtype16 : VIDIL_DT_F16, "layernorm",
-                       return layernorm_launch<T>(x, x_stride, gamma, beta, eps, M, D, (T*)out16, out_f32, (hipStream_t)stream));
+  const int split3 = out16 && (dtype16 & VIDIL_DT_SPLIT3) ? 1 : 0;      // out16 rows are [hi | lo | hi], 3D wide
+  VIDIL_DISPATCH_DTYPE(out16 ? (dtype16 & ~VIDIL_DT_SPLIT3) : VIDIL_DT_F16, "layernorm",
+                       return layernorm_launch<T>(x, x_stride, gamma, beta, eps, M, D, (T*)out16, out_f32, (hipStream_t)stream, split3));
 }
 
 extern "C" int vidil_split3_f32(const float* x, void* out16, int32_t M, int32_t D, int32_t dtype, void* stream) {
@@ -270,12 +290,14 @@ extern "C" int vidil_split3_f32(const float* x, void* out16, int32_t M, int32_t 
 extern "C" int vidil_patchify_f32(const float* img, void* out, int32_t B, int32_t S, int32_t ps, int32_t dtype, void* stream) {
   VIDIL_REQUIRE(img && out && B > 0, "patchify_f32: bad args");
   VIDIL_REQUIRE(ps > 0 && S % ps == 0, "patchify_f32: S=%d ps=%d (S%%ps==0 required)", S, ps);
-  if (ps % 8 != 0) {
+  const int split3 = (dtype & VIDIL_DT_SPLIT3) ? 1 : 0;    // out rows [hi | lo | hi], 3 * round_up(3*ps*ps, 64) wide
+  dtype &= ~VIDIL_DT_SPLIT3;
+  if (ps % 8 != 0 || split3) {
     const int ldk = (3 * ps * ps + 63) / 64 * 64;
     const size_t n = (size_t)B * (S / ps) * (S / ps) * ldk;
     VIDIL_DISPATCH_DTYPE(dtype, "patchify_f32",
                          hipLaunchKernelGGL((patchify_any_kernel<T, false>), dim3(grid_for(n, 256)), dim3(256), 0,
-                                            (hipStream_t)stream, (const void*)img, (T*)out, B, S, ps, ldk, Norm3{}));
+                                            (hipStream_t)stream, (const void*)img, (T*)out, B, S, ps, ldk, Norm3{}, split3));
     VIDIL_CHECK_LAUNCH("patchify_f32");
     return VIDIL_OK;
   }
@@ -297,12 +319,14 @@ extern "C" int vidil_patchify_u8(const uint8_t* img, void* out, int32_t B, int32
     nm.scale[c] = 1.0f / (255.0f * std3_host[c]);
     nm.shift[c] = -mean3_host[c] / std3_host[c];
   }
-  if (ps % 8 != 0) {
+  const int split3 = (dtype & VIDIL_DT_SPLIT3) ? 1 : 0;    // out rows [hi | lo | hi], 3 * round_up(3*ps*ps, 64) wide
+  dtype &= ~VIDIL_DT_SPLIT3;
+  if (ps % 8 != 0 || split3) {
     const int ldk = (3 * ps * ps + 63) / 64 * 64;
     const size_t n = (size_t)B * (S / ps) * (S / ps) * ldk;
     VIDIL_DISPATCH_DTYPE(dtype, "patchify_u8",
                          hipLaunchKernelGGL((patchify_any_kernel<T, true>), dim3(grid_for(n, 256)), dim3(256), 0,
-                                            (hipStream_t)stream, (const void*)img, (T*)out, B, S, ps, ldk, nm));
+                                            (hipStream_t)stream, (const void*)img, (T*)out, B, S, ps, ldk, nm, split3));
     VIDIL_CHECK_LAUNCH("patchify_u8");
     return VIDIL_OK;
   }

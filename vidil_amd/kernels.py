@@ -11,13 +11,13 @@ import ctypes as C
 import torch
 
 from . import _lib
-from ._lib import (ACT_GELU_ERF, ACT_NONE, ACT_QUICK_GELU, DT_BF16, DT_F16, DT_FP8, EPI_ARENA, EPI_F8, EPI_F16, EPI_F32,
+from ._lib import (ACT_GELU_ERF, ACT_NONE, ACT_QUICK_GELU, DT_BF16, DT_F16, DT_FP8, DT_SPLIT3, EPI_ARENA, EPI_F8, EPI_F16, EPI_F32,
                    EPI_HEADS, EPI_PATCH, BeamState, GemmArgs, VidilHipError, check)
 
 __all__ = [
     "gemm", "layernorm", "attention", "patchify_f32", "patchify_u8", "set_cls_row",
     "embed_tokens", "gather_rows", "l2_normalize_rows", "logsoftmax_topk", "BeamBuffers",
-    "beam_update", "beam_finalize", "kv_reorder", "scan_topk", "scan_topk_ws_bytes",
+    "beam_update", "beam_finalize", "scan_topk", "scan_topk_ws_bytes",
     "ACT_NONE", "ACT_GELU_ERF", "ACT_QUICK_GELU", "VidilHipError",
 ]
 
@@ -102,7 +102,7 @@ def gemm_kernel_name(a, w, bias=None, **kw):
 
 def _gemm_build(a, w, bias=None, *, out=None, out_dtype=None, act=ACT_NONE, resid=None,
                 heads=None, patch=None, arena=None, M=None, lda=None, out16=None, ln_stats_out=None, ln=None, w_scale=None,
-                dtype16=None, col_block=0, rln=None):
+                dtype16=None, rln=None):
     K_ = w.shape[1]
     if lda is None:
         M, Ka = a.shape
@@ -116,10 +116,6 @@ def _gemm_build(a, w, bias=None, *, out=None, out_dtype=None, act=ACT_NONE, resi
     g.dtype = _dt(a, "gemm.A", fp8_ok=True)
     g.A = _ptr(a, a.dtype, "gemm.A")
     g.W = _ptr(w, a.dtype, "gemm.W")
-    wt = getattr(w, "_vidil_tiled", None)        # fragment-tiled copy (packing.with_tiles): the 2-workgroups-per-CU kernel
-    if wt is not None and wt.device == w.device:
-        g.W_tiled = wt.data_ptr()
-    g.col_block = int(col_block)                 # tile order of the persistent kernel (tuning knob, results unaffected)
     if rln is not None:                          # (gamma, beta, eps, stats of the residual): `resid` is a post-LN block's raw sum
         rg, rb, reps, rstats = rln
         g.rln_gamma, g.rln_beta = _ptr(rg, torch.float32, "gemm.rln_gamma"), _ptr(rb, torch.float32, "gemm.rln_beta")
@@ -204,15 +200,21 @@ def _gemm_build(a, w, bias=None, *, out=None, out_dtype=None, act=ACT_NONE, resi
 
 
 # ---------------------------------------------------------------------- row kernels
-def layernorm(x, gamma, beta, eps, *, M=None, D=None, x_stride=None, out16=None, out32=None):
-    """LayerNorm rows of f32 ``x``.  Rows are ``x_stride`` elements apart (default dense)."""
+def layernorm(x, gamma, beta, eps, *, M=None, D=None, x_stride=None, out16=None, out32=None, split3=False):
+    """LayerNorm rows of f32 ``x``.  Rows are ``x_stride`` elements apart (default dense).
+    split3: ``out16`` is [M, 3D] and receives the error-compensated operand rows [hi | lo | hi] (VIDIL_DT_SPLIT3)."""
     lib = _lib.load()
     D = D if D is not None else x.shape[-1]
     M = M if M is not None else x.numel() // D
     x_stride = x_stride if x_stride is not None else D
+    dt16 = DT_F16
+    if out16 is not None:
+        dt16 = _dt(out16, "ln.out16", fp8_ok=not split3) | (DT_SPLIT3 if split3 else 0)
+        if split3 and out16.shape[-1] != 3 * D:
+            raise VidilHipError(f"layernorm: split3 out16 must be [M, {3 * D}], got {tuple(out16.shape)}")
     check(lib.vidil_layernorm(_ptr(x, torch.float32, "ln.x"), x_stride, _ptr(gamma, torch.float32, "ln.gamma"),
                               _ptr(beta, torch.float32, "ln.beta"), float(eps), M, D,
-                              _ptr(out16, None, "ln.out16"), _dt(out16, "ln.out16", fp8_ok=True) if out16 is not None else DT_F16,
+                              _ptr(out16, None, "ln.out16"), dt16,
                               _ptr(out32, torch.float32, "ln.out32"), _stream()), "layernorm")
 
 
@@ -225,11 +227,13 @@ def split3(x32, out16):
 
 
 def attention(q, k, vt, out, *, Bq, H, Nq, Nk, Tq_cap, Tk_cap, NP, kv_group=1, causal=False,
-              causal_off=0, kv_len=None, kv_index=None, group_start=None, max_group=0, ldo=None, kv_tiled=False):
+              causal_off=0, kv_len=None, kv_index=None, group_start=None, max_group=0, ldo=None, kv_tiled=False,
+              split3=False):
     """group_start: int32 [n_kv+1] device prefix table (query batches per kv batch), with max_group.
-    kv_tiled: k / vt are fragment-tiled (gemm heads=dict(tiled=True)); at most 32 query rows per unit."""
+    kv_tiled: k / vt are fragment-tiled (gemm heads=dict(tiled=True)); at most 32 query rows per unit.
+    split3: ``out`` is [rows, 3*H*64] and receives the error-compensated operand rows [hi | lo | hi] (VIDIL_DT_SPLIT3)."""
     lib = _lib.load()
-    ldo = ldo if ldo is not None else H * 64
+    ldo = ldo if ldo is not None else (3 if split3 else 1) * H * 64
     n_kv = 0 if group_start is None else group_start.numel() - 1
     t16 = q.dtype
     check(lib.vidil_attention(_ptr(q, t16, "attn.q"), _ptr(k, t16, "attn.k"),
@@ -238,7 +242,7 @@ def attention(q, k, vt, out, *, Bq, H, Nq, Nk, Tq_cap, Tk_cap, NP, kv_group=1, c
                               _ptr(group_start, torch.int32, "attn.group_start"), n_kv, max_group,
                               Bq, H, Nq, Nk, Tq_cap, Tk_cap, NP,
                               kv_group, int(bool(causal)), causal_off, ldo, int(bool(kv_tiled)), _dt(q, "attn.q"),
-                              _dt(out, "attn.out", fp8_ok=True), _stream()), "attention")
+                              _dt(out, "attn.out", fp8_ok=True) | (DT_SPLIT3 if split3 else 0), _stream()), "attention")
     return out
 
 
@@ -259,31 +263,32 @@ def patch_row_halfs(ps: int) -> int:
     return (3 * ps * ps + 63) // 64 * 64
 
 
-def patchify_f32(img, ps, out=None, dtype=torch.float16):
+def patchify_f32(img, ps, out=None, dtype=torch.float16, split3=False):
+    """split3: rows are [hi | lo | hi] of the f32 pixel values, 3 * patch_row_halfs(ps) wide (VIDIL_DT_SPLIT3)."""
     lib = _lib.load()
     B, Cc, S, S2 = img.shape
     if Cc != 3 or S != S2:
         raise VidilHipError(f"patchify_f32: expected [B,3,S,S], got {tuple(img.shape)}")
     G = S // ps
     if out is None:
-        out = torch.empty((B * G * G, patch_row_halfs(ps)), dtype=dtype, device=img.device)
+        out = torch.empty((B * G * G, (3 if split3 else 1) * patch_row_halfs(ps)), dtype=dtype, device=img.device)
     check(lib.vidil_patchify_f32(_ptr(img, torch.float32, "patchify.img"), _ptr(out, None, "patchify.out"),
-                                 B, S, ps, _dt(out, "patchify.out"), _stream()), "patchify_f32")
+                                 B, S, ps, _dt(out, "patchify.out") | (DT_SPLIT3 if split3 else 0), _stream()), "patchify_f32")
     return out
 
 
-def patchify_u8(img, ps, mean, std, out=None, dtype=torch.float16):
+def patchify_u8(img, ps, mean, std, out=None, dtype=torch.float16, split3=False):
     lib = _lib.load()
     B, S, S2, Cc = img.shape
     if Cc != 3 or S != S2:
         raise VidilHipError(f"patchify_u8: expected [B,S,S,3], got {tuple(img.shape)}")
     G = S // ps
     if out is None:
-        out = torch.empty((B * G * G, patch_row_halfs(ps)), dtype=dtype, device=img.device)
+        out = torch.empty((B * G * G, (3 if split3 else 1) * patch_row_halfs(ps)), dtype=dtype, device=img.device)
     m3 = (C.c_float * 3)(*[float(v) for v in mean])
     s3 = (C.c_float * 3)(*[float(v) for v in std])
     check(lib.vidil_patchify_u8(_ptr(img, torch.uint8, "patchify.img"), _ptr(out, None, "patchify.out"),
-                                B, S, ps, m3, s3, _dt(out, "patchify.out"), _stream()), "patchify_u8")
+                                B, S, ps, m3, s3, _dt(out, "patchify.out") | (DT_SPLIT3 if split3 else 0), _stream()), "patchify_u8")
     return out
 
 
@@ -394,12 +399,6 @@ def beam_finalize(bufs: BeamBuffers, cur_len, eos_id, pad_id):
     return out_tok, out_len, out_score
 
 
-def kv_reorder(src, dst, beam_idx, L, rows):
-    row_halfs = src.numel() // (L * rows)
-    check(_lib.load().vidil_kv_reorder(_ptr(src, None), _ptr(dst, src.dtype),
-                                       _ptr(beam_idx, torch.int32), L, rows, row_halfs, _stream()), "kv_reorder")
-
-
 def sample_top_k_top_p(logits, seqs, done, n_done, next_tok, *, cur_len, min_length, eos_id, pad_id, top_k=50,
                        top_p=0.9, rep_penalty=1.1, seed=0, step=0, row_offset=0):
     """One nucleus-sampling step on logits f32 [B,V] (see vidil_sample_top_k_top_p); appends to seqs i32 [B,max_len]."""
@@ -418,14 +417,15 @@ def beam_ancestry(anc_src, anc_dst, beam_idx, cur_pos):
                                           _ptr(beam_idx, torch.int32), rows, Tcap, cur_pos, _stream()), "beam_ancestry")
 
 
-def beam_attention(q, k_arena, v_arena, anc, out, *, rows, H, n_keys, ldo=None):
+def beam_attention(q, k_arena, v_arena, anc, out, *, rows, H, n_keys, ldo=None, split3=False):
     """Decode-step self-attention over the KV arena: q f16 [rows,H*64]; arenas f16 [Tcap,arena_rows,H*64];
-    anc i32 [rows,Tcap]; out f16 [rows,ldo]."""
+    anc i32 [rows,Tcap]; out f16 [rows,ldo] (split3: [rows, 3*H*64] = [hi | lo | hi], VIDIL_DT_SPLIT3)."""
     Tcap, arena_rows = k_arena.shape[0], k_arena.shape[1]
     t16 = q.dtype
     check(_lib.load().vidil_beam_attention(_ptr(q, t16), _ptr(k_arena, t16), _ptr(v_arena, t16), _ptr(anc, torch.int32),
                                            _ptr(out, t16), rows, H, n_keys, arena_rows, anc.shape[1],
-                                           ldo if ldo is not None else out.shape[-1], _dt(q, "beam_attention.q"), _stream()),
+                                           ldo if ldo is not None else out.shape[-1], _dt(q, "beam_attention.q"),
+                                           _dt(q, "beam_attention.q") | (DT_SPLIT3 if split3 else 0), _stream()),
           "beam_attention")
 
 

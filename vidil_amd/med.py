@@ -22,7 +22,7 @@ import torch
 import torch.nn as nn
 
 from . import kernels as K
-from .packing import FP8, PackedCache, fold_layernorm, require_cuda, v32, w8, w16
+from .packing import FP8, PackedCache, fold_layernorm, require_cuda, v32, w3, w8, w16
 
 LN_EPS_DEFAULT = 1e-12
 
@@ -201,8 +201,18 @@ class BertModel(PackedCache, nn.Module):
                          co_g=v32(co.LayerNorm.weight), co_bt=v32(co.LayerNorm.bias))
                 if self.fp8:     # fp8 tower mode: the image-side K|V projection (its A rows are a tower's output) on e4m3 too
                     d["ckv_w8"], d["ckv_s"] = w8(ca.key.weight, ca.value.weight)
+            if self.parity:      # parity precision mode: [W_hi | W_hi | W_lo] for every GEMM of the stack
+                d.update(qkv_w3=w3(a.query.weight, a.key.weight, a.value.weight, dtype=c), ao_w3=w3(o.dense.weight, dtype=c),
+                         i_w3=w3(l.intermediate.dense.weight, dtype=c), o_w3=w3(l.output.dense.weight, dtype=c))
+                if hasattr(l, "crossattention"):
+                    d.update(cq_w3=w3(ca.query.weight, dtype=c), ckv_w3=w3(ca.key.weight, ca.value.weight, dtype=c),
+                             co_w3=w3(co.dense.weight, dtype=c))
             p["layers"].append(d)
+        p["parity"] = self.parity
         return p
+
+    def pack_flags(self):
+        return (self.parity,)
 
     def _folded(self, p):
         """Weights of the LN-folded text stack (built on first use, kept with the pack): per layer the cross query and
@@ -241,9 +251,18 @@ class BertModel(PackedCache, nn.Module):
         p = self.packed()
         H = self.config.num_attention_heads
         cdt = enc16.dtype
-        if self.fp8 and "ckv_w8" in p["layers"][0] and enc16.shape[1] % 128 == 0:
+        if p["parity"]:
+            # parity precision mode: enc16 holds [hi | lo | hi] rows of the image tokens (the ViT's parity output)
+            if enc16.shape[1] != 3 * self.config.encoder_width:
+                raise K.VidilHipError(f"project_cross_kv (parity mode): image tokens must be [hi | lo | hi] rows of width "
+                                      f"{3 * self.config.encoder_width}, got {tuple(enc16.shape)}")
+
+            def kv_gemm(d, **heads):
+                K.gemm(enc16, d["ckv_w3"], d["ckv_b"], heads=heads)
+        elif self.fp8 and "ckv_w8" in p["layers"][0] and enc16.shape[1] % 128 == 0:
             # fp8 tower mode (BASELINE config 5): e4m3 image tokens x e4m3 K|V weights, K / V written in the 16-bit type
-            enc8 = enc16.to(FP8)
+            # (clamped first: torch's e4m3 cast does not saturate — 470 becomes NaN — while every device-side conversion does)
+            enc8 = enc16.clamp(-448.0, 448.0).to(FP8)
 
             def kv_gemm(d, **heads):
                 K.gemm(enc8, d["ckv_w8"], d["ckv_b"], w_scale=d["ckv_s"], dtype16=cdt, heads=heads)
@@ -303,6 +322,14 @@ class BertModel(PackedCache, nn.Module):
         M = rows * T
         dev = h32.device
         cdt = h16.dtype
+        if p["parity"]:
+            if self_done_first or stop_after_self or n_layers is not None:
+                raise K.VidilHipError("run_layers: the parity precision mode covers the caption decoder (and plain encode); "
+                                      "encode_cls' split schedules are not built for it")
+            return self._run_layers_parity(p, h32, h16, rows=rows, T=T, self_k=self_k, self_vt=self_vt, t_off=t_off,
+                                           Tk_cap=Tk_cap, NPs=NPs, causal=causal, kv_len=kv_len, cross=cross,
+                                           cross_index=cross_index, cross_group=cross_group, cross_groups=cross_groups,
+                                           cross_max_group=cross_max_group, ws=ws, arena=arena, arena_slot_stride=arena_slot_stride)
         if fused is None:
             # encoder batches with cross-attention (the ITM pairs) run without LayerNorm launches, WHATEVER their size: a
             # pair's logits must not depend on how many other pairs share its batch (ranks / tail batches of different
@@ -365,6 +392,60 @@ class BertModel(PackedCache, nn.Module):
             K.gemm(inter, d["o_w"], d["o_b"], out=tmp, resid=h32)
             K.layernorm(tmp, d["o_g"], d["o_bt"], eps, out16=h16, out32=h32)
         return h32, h16
+
+    def _run_layers_parity(self, p, h32, h3, *, rows, T, self_k, self_vt, t_off, Tk_cap, NPs, causal, kv_len, cross, cross_index,
+                           cross_group, cross_groups, cross_max_group, ws, arena, arena_slot_stride):
+        """run_layers in the parity precision mode: ``h3`` [rows*T, 3C] carries the hidden states as [hi | lo | hi]
+        operand rows, every GEMM runs against [W_hi | W_hi | W_lo] with K tripled, LayerNorm / attention write split rows
+        directly and the GELU output goes through f32 + vidil_split3_f32.  Same launch sequence otherwise."""
+        cfg = self.config
+        H, C = cfg.num_attention_heads, cfg.hidden_size
+        eps = cfg.layer_norm_eps
+        M = rows * T
+        dev, cdt = h32.device, h3.dtype
+        if ws is None:
+            ws = {}
+        q = ws.get("q")
+        if q is None or q.shape[0] < rows or q.shape[2] != T:
+            q = torch.empty((rows, H, T, 64), dtype=cdt, device=dev)
+            ws["q"] = q
+        o3 = torch.empty((M, 3 * C), dtype=cdt, device=dev)
+        tmp = torch.empty((M, C), dtype=torch.float32, device=dev)
+        inter32 = torch.empty((M, cfg.intermediate_size), dtype=torch.float32, device=dev)
+        inter3 = torch.empty((M, 3 * cfg.intermediate_size), dtype=cdt, device=dev)
+        Nk = t_off + T
+        if arena is not None and T > 1 and t_off != 0:
+            raise K.VidilHipError("run_layers: a multi-token block can only be appended to a beam arena at position 0")
+        for i, d in enumerate(p["layers"]):
+            if arena is not None and T == 1:
+                K.gemm(h3, d["qkv_w3"], d["qkv_b"],
+                       arena=dict(q=q, k=arena.k[i], v=arena.v[i], T=1, H=H, part0=0, t_off=t_off, Tcap=arena.Tcap,
+                                  arena_rows=arena.rows, slot_stride=1, q_scale=0.125))
+                K.beam_attention(q, arena.k[i], arena.v[i], arena.anc, o3, rows=rows, H=H, n_keys=Nk, split3=True)
+            else:
+                K.gemm(h3, d["qkv_w3"], d["qkv_b"],
+                       heads=dict(q=q, k=self_k[i], vt=self_vt[i], T=T, H=H, part0=0, t_off=t_off, Tq_cap=T,
+                                  Tk_cap=Tk_cap, NP=NPs, q_scale=0.125))
+                K.attention(q, self_k[i], self_vt[i], o3, Bq=rows, H=H, Nq=T, Nk=Nk, Tq_cap=T, Tk_cap=Tk_cap, NP=NPs,
+                            causal=causal, causal_off=t_off, kv_len=kv_len, split3=True)
+                if arena is not None:
+                    K.gemm(h3, d["qkv_w3"][C:], d["qkv_b"][C:],
+                           arena=dict(k=arena.k[i], v=arena.v[i], T=T, H=H, part0=1, t_off=0, Tcap=arena.Tcap,
+                                      arena_rows=arena.rows, slot_stride=arena_slot_stride))
+            K.gemm(o3, d["ao_w3"], d["ao_b"], out=tmp, resid=h32)
+            K.layernorm(tmp, d["ao_g"], d["ao_bt"], eps, out16=h3, out32=h32, split3=True)
+            if cross is not None:
+                K.gemm(h3, d["cq_w3"], d["cq_b"], heads=dict(q=q, T=T, H=H, part0=0, Tq_cap=T, q_scale=0.125))
+                K.attention(q, cross.k[i], cross.vt[i], o3, Bq=rows, H=H, Nq=T, Nk=cross.Te, Tq_cap=T,
+                            Tk_cap=cross.Tk_cap, NP=cross.NP, kv_group=cross_group, kv_index=cross_index,
+                            group_start=cross_groups, max_group=cross_max_group, kv_tiled=cross.tiled, split3=True)
+                K.gemm(o3, d["co_w3"], d["co_b"], out=tmp, resid=h32)
+                K.layernorm(tmp, d["co_g"], d["co_bt"], eps, out16=h3, out32=h32, split3=True)
+            K.gemm(h3, d["i_w3"], d["i_b"], out=inter32, act=K.ACT_GELU_ERF)
+            K.split3(inter32, inter3)
+            K.gemm(inter3, d["o_w3"], d["o_b"], out=tmp, resid=h32)
+            K.layernorm(tmp, d["o_g"], d["o_bt"], eps, out16=h3, out32=h32, split3=True)
+        return h32, h3
 
     def _text_fold_ok(self, cdt):
         C = self.config.hidden_size
@@ -452,8 +533,9 @@ class BertModel(PackedCache, nn.Module):
         raw = torch.empty((M, C), dtype=torch.float32, device=dev)
         K.embed_tokens(ids_i32, p["word"], p["pos"], raw, T=T, pos_off=pos_off)
         h32 = torch.empty((M, C), dtype=torch.float32, device=dev)
-        h16 = torch.empty((M, C), dtype=cdt, device=dev)
-        K.layernorm(raw, p["emb_g"], p["emb_b"], self.config.layer_norm_eps, out16=h16, out32=h32)
+        par = p["parity"]                 # parity precision mode: the 16-bit companion is [hi | lo | hi] rows
+        h16 = torch.empty((M, 3 * C if par else C), dtype=cdt, device=dev)
+        K.layernorm(raw, p["emb_g"], p["emb_b"], self.config.layer_norm_eps, out16=h16, out32=h32, split3=par)
         return h32, h16
 
     def encode(self, ids_i32, kv_len_i32, cross: CrossKV, cross_index=None, cross_groups=None, cross_max_group=0):
@@ -590,15 +672,6 @@ class _LMHead(nn.Module):
         self.predictions = _LMPredictions(cfg)
 
 
-def _w3(weight, dtype):
-    """[N,K] f32 -> 16-bit [N,3K] = [W_hi | W_hi | W_lo] (hi = T16(W), lo = T16(W - hi)): the weight side of an
-    error-compensated GEMM whose activation rows are [x_hi | x_lo | x_hi] (vidil_split3_f32)."""
-    w = weight.detach().float()
-    hi = w.to(dtype)
-    lo = (w - hi.float()).to(dtype)
-    return torch.cat([hi, hi, lo], dim=1).contiguous()
-
-
 class BertLMHeadModel(PackedCache, nn.Module):
     """Caption decoder: ``bert`` trunk + ``cls`` LM head (models/med.py:811-955).
 
@@ -624,13 +697,13 @@ class BertLMHeadModel(PackedCache, nn.Module):
         c = self.cdt
         p = dict(t_w=w16(pr.transform.dense.weight, dtype=c), t_b=v32(pr.transform.dense.bias),
                  t_g=v32(pr.transform.LayerNorm.weight), t_bt=v32(pr.transform.LayerNorm.bias),
-                 dec_w=w16(pr.decoder.weight, dtype=c), dec_b=v32(pr.bias), precise=self.precise_head)
-        if self.precise_head:
-            p.update(t_w3=_w3(pr.transform.dense.weight, c), dec_w3=_w3(pr.decoder.weight, c))
+                 dec_w=w16(pr.decoder.weight, dtype=c), dec_b=v32(pr.bias), precise=self.precise_head or self.parity)
+        if p["precise"]:
+            p.update(t_w3=w3(pr.transform.dense.weight, dtype=c), dec_w3=w3(pr.decoder.weight, dtype=c))
         return p
 
     def pack_flags(self):
-        return (self.precise_head,)
+        return (self.precise_head, self.parity)
 
     def lm_logits(self, h16, rows, T, out=None, h32=None):
         """LM head (models/med.py:501-545) on the LAST token of each of ``rows`` sequences of length T:
@@ -642,7 +715,9 @@ class BertLMHeadModel(PackedCache, nn.Module):
         C = cfg.hidden_size
         dev = h16.device
         cdt = h16.dtype
-        if self.precise_head and h32 is not None:
+        if p["precise"]:
+            if h32 is None:
+                raise K.VidilHipError("lm_logits: the error-compensated head (precise_head / parity mode) needs the f32 hidden states")
             last32 = h32.view(rows, T, C)[:, T - 1].contiguous()
             a3 = K.split3(last32, torch.empty((rows, 3 * C), dtype=cdt, device=dev))
             t32 = torch.empty((rows, C), dtype=torch.float32, device=dev)

@@ -27,7 +27,7 @@ import torch
 import torch.nn as nn
 
 from . import kernels as K
-from .packing import FP8, PackedCache, fold_layernorm, require_cuda, v32, w8, w16, w16_patch
+from .packing import FP8, PackedCache, fold_layernorm, require_cuda, v32, w3, w3_patch, w8, w16, w16_patch
 
 
 class PatchEmbed(nn.Module):
@@ -106,7 +106,7 @@ class VisionTransformer(PackedCache, nn.Module):
 
     # ------------------------------------------------------------------ packing
     def pack_flags(self):
-        return (self.fuse_layernorm, self.fp8)
+        return (self.fuse_layernorm, self.fp8, self.parity)
 
     def _pack(self):
         D = self.embed_dim
@@ -124,7 +124,11 @@ class VisionTransformer(PackedCache, nn.Module):
                 n2g=v32(b.norm2.weight), n2b=v32(b.norm2.bias),
                 fc1_w=w16(b.mlp.fc1.weight, dtype=c), fc1_b=v32(b.mlp.fc1.bias),
                 fc2_w=w16(b.mlp.fc2.weight, dtype=c), fc2_b=v32(b.mlp.fc2.bias))
-            if self.fp8:
+            if self.parity:
+                # parity precision mode (packing.set_parity_mode): [W_hi | W_hi | W_lo] against [x_hi | x_lo | x_hi] rows
+                for name, lin in (("qkv", b.attn.qkv), ("proj", b.attn.proj), ("fc1", b.mlp.fc1), ("fc2", b.mlp.fc2)):
+                    d[name + "_w3"] = w3(lin.weight, dtype=c)
+            elif self.fp8:
                 # fp8 tower mode: the four big GEMMs on e4m3 operands (weights per-output-row scaled), LayerNorm as
                 # a stand-alone kernel writing fp8 (its output is well scaled; the raw stream is not)
                 for name, lin in (("qkv", b.attn.qkv), ("proj", b.attn.proj), ("fc1", b.mlp.fc1), ("fc2", b.mlp.fc2)):
@@ -136,8 +140,11 @@ class VisionTransformer(PackedCache, nn.Module):
                 if i > 0:
                     d["qkv_f"] = fold_layernorm(b.attn.qkv.weight, b.attn.qkv.bias, b.norm1.weight, b.norm1.bias, c)
             p["blocks"].append(d)
-        p["fused"] = self.fuse_layernorm and not self.fp8
+        p["fused"] = self.fuse_layernorm and not self.fp8 and not self.parity
         p["fp8"] = self.fp8
+        p["parity"] = self.parity
+        if self.parity:
+            p["pe_w3"] = w3_patch(pe.weight, c)
         return p
 
     # ------------------------------------------------------------------ forward
@@ -147,7 +154,8 @@ class VisionTransformer(PackedCache, nn.Module):
         D, P = self.embed_dim, self.patch_embed.num_patches
         T = P + 1
         x = torch.empty((B * T, D), dtype=torch.float32, device=patches16.device)
-        K.gemm(patches16, p["pe_w"], p["pe_b"], patch=dict(out=x, pos=p["pos"], tpi=P))
+        # (parity mode: patches16 holds [hi | lo | hi] rows, see forward_u8)
+        K.gemm(patches16, p["pe_w3"] if p["parity"] else p["pe_w"], p["pe_b"], patch=dict(out=x, pos=p["pos"], tpi=P))
         K.set_cls_row(x, p["cls"], p["pos"], B, T, D)
         return x
 
@@ -169,6 +177,8 @@ class VisionTransformer(PackedCache, nn.Module):
         o = torch.empty((M, D), dtype=cdt, device=dev)
         hid = torch.empty((M, p["blocks"][0]["fc1_w"].shape[0]), dtype=cdt, device=dev)
         heads = dict(q=q, k=k, vt=vt, T=T, H=H, part0=0, t_off=0, Tq_cap=T, Tk_cap=T, NP=NP, q_scale=0.125)
+        if p.get("parity"):
+            return self._run_blocks_parity(p, x, B, T, q, k, vt, heads, NP, want16)
         if p.get("fp8"):
             return self._run_blocks_fp8(p, x, B, T, q, k, vt, heads, NP, want16)
         # Fused LayerNorm (models/vit.py:107-110): the residual GEMMs (proj, fc2) also store the stream in the operand
@@ -200,6 +210,33 @@ class VisionTransformer(PackedCache, nn.Module):
         K.layernorm(x, p["norm_g"], p["norm_b"], self.ln_eps, out16=y16, out32=y32)
         return y32, y16
 
+    def _run_blocks_parity(self, p, x, B, T, q, k, vt, heads, NP, want16):
+        """Parity precision mode: the same block sequence with every GEMM on error-compensated operands (K tripled):
+        LayerNorm and attention write [hi | lo | hi] rows directly (VIDIL_DT_SPLIT3), the GELU output goes through f32
+        and vidil_split3_f32.  Returns (y32, y3) with y3 = [M, 3D] split rows of the final LayerNorm (the cross K|V
+        projection's operand).  ~3x the MFMA work of the plain path; Q / K / V and the softmax probabilities are still
+        rounded to 16 bits inside the attention kernels."""
+        D, H = self.embed_dim, self.num_heads
+        dev, cdt = x.device, q.dtype
+        M = B * T
+        Dh = p["blocks"][0]["fc1_w"].shape[0]
+        a3 = torch.empty((M, 3 * D), dtype=cdt, device=dev)
+        o3 = torch.empty((M, 3 * D), dtype=cdt, device=dev)
+        hid32 = torch.empty((M, Dh), dtype=torch.float32, device=dev)
+        hid3 = torch.empty((M, 3 * Dh), dtype=cdt, device=dev)
+        for b in p["blocks"]:
+            K.layernorm(x, b["n1g"], b["n1b"], self.ln_eps, out16=a3, split3=True)
+            K.gemm(a3, b["qkv_w3"], b["qkv_b"], heads=heads)
+            K.attention(q, k, vt, o3, Bq=B, H=H, Nq=T, Nk=T, Tq_cap=T, Tk_cap=T, NP=NP, split3=True)
+            K.gemm(o3, b["proj_w3"], b["proj_b"], out=x, resid=x)
+            K.layernorm(x, b["n2g"], b["n2b"], self.ln_eps, out16=a3, split3=True)
+            K.gemm(a3, b["fc1_w3"], b["fc1_b"], out=hid32, act=K.ACT_GELU_ERF)
+            K.split3(hid32, hid3)
+            K.gemm(hid3, b["fc2_w3"], b["fc2_b"], out=x, resid=x)
+        y32 = torch.empty((M, D), dtype=torch.float32, device=dev)
+        K.layernorm(x, p["norm_g"], p["norm_b"], self.ln_eps, out16=a3 if want16 else None, out32=y32, split3=True)
+        return y32, (a3 if want16 else None)
+
     def _run_blocks_fp8(self, p, x, B, T, q, k, vt, heads, NP, want16):
         """fp8 tower mode (BASELINE config 5): LN -> fp8, QKV / proj / fc1 / fc2 on e4m3 operands at twice the 16-bit
         MFMA rate, attention on the 16-bit companion type writing fp8, f32 residual stream.  NOT a parity mode: e4m3
@@ -228,7 +265,7 @@ class VisionTransformer(PackedCache, nn.Module):
         require_cuda(x, "VisionTransformer.forward")
         B = x.shape[0]
         ps = self.patch_embed.patch_size[0]
-        patches = K.patchify_f32(x.contiguous().float(), ps, dtype=self.cdt)
+        patches = K.patchify_f32(x.contiguous().float(), ps, dtype=self.cdt, split3=self.parity)
         xr = self.embed_patches(patches, B)
         y32, y16 = self.run_blocks(xr, B)
         return y32.view(B, -1, self.embed_dim), y16
@@ -238,7 +275,7 @@ class VisionTransformer(PackedCache, nn.Module):
         require_cuda(frames_u8, "VisionTransformer.forward_u8")
         B = frames_u8.shape[0]
         ps = self.patch_embed.patch_size[0]
-        patches = K.patchify_u8(frames_u8.contiguous(), ps, mean, std, dtype=self.cdt)
+        patches = K.patchify_u8(frames_u8.contiguous(), ps, mean, std, dtype=self.cdt, split3=self.parity)
         xr = self.embed_patches(patches, B)
         y32, y16 = self.run_blocks(xr, B)
         return y32.view(B, -1, self.embed_dim), y16
