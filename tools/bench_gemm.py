@@ -44,6 +44,19 @@ def main():
     dev = "cuda"
     args = [a for a in sys.argv[1:] if not a.startswith("--")]
     B = int(args[0]) if args else 512
+    if "--shape" in sys.argv:            # --shape M N K: plain 16-bit-out GEMM of that shape, ours vs the library
+        i = sys.argv.index("--shape")
+        m, n, k = (int(v) for v in sys.argv[i + 1:i + 4])
+        torch.manual_seed(0)
+        for dt in (torch.float16, torch.bfloat16):
+            a = (torch.randn(m, k, device=dev) * 0.5).to(dt)
+            w = (torch.randn(n, k, device=dev) * 0.05).to(dt)
+            o = torch.empty(m, n, dtype=dt, device=dev)
+            t_lib = timeit(lambda: torch.matmul(a, w.t(), out=o))
+            t_own = timeit(lambda: K.gemm(a, w, None, out=o))
+            f = 2.0 * m * n * k / 1e12
+            print(f"shape {m}x{n}x{k} {str(dt)[6:]:8s} hipBLASLt {f / t_lib:7.1f} TFLOP/s   {K.gemm_kernel_name(a, w, None, out=o).split('<')[0]} {f / t_own:7.1f} TFLOP/s")
+        return
     if "--calibrate" in sys.argv:
         torch.manual_seed(0)
         calibrate(dev, B * 197)

@@ -498,7 +498,7 @@ extern "C" int vidil_gemm_kernel_name(const vidil_gemm_args* args, char* buf_hos
   const int act = (args->epi == VIDIL_EPI_F16 || args->epi == VIDIL_EPI_F32 || args->epi == VIDIL_EPI_F8) ? args->act : 0;
   const char* stats = (args->ln_stats_out && args->epi == VIDIL_EPI_F32) ? "true" : "false";
   if (c.big) snprintf(buf_host, n, "gemm256_kernel<%s, %s, %d, %d, %s, %s, %s>", t, t16, args->epi, act, args->ln_fold ? "true" : "false",
-                           stats, args->rln_gamma ? "true" : "false");
+                      stats, args->rln_gamma ? "true" : "false");
   else snprintf(buf_host, n, "gemm_kernel<%s, %d, %d, %d, %d, %d>", t, c.bm, c.bn, c.st, args->epi, act);
   return VIDIL_OK;
 }
