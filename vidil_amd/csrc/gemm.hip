@@ -190,7 +190,7 @@ __global__ __launch_bounds__(2 * waves_n(BM, BN) * 64) void gemm_kernel(const vi
 #pragma unroll
       for (int r = 0; r < 16; r += 2) {
         f32x2 v = {acc[i][j][r] + bias, acc[i][j][r + 1] + bias};
-        if constexpr (ACT == VIDIL_ACT_GELU_ERF) v = gelu_erf2(v);
+        if constexpr (ACT == VIDIL_ACT_GELU_ERF) v = EPI == VIDIL_EPI_F32 ? gelu_erf2(v) : gelu_fast2(v);   // (as gemm_epilogue.inc)
         if constexpr (ACT == VIDIL_ACT_QUICK_GELU) v = quick_gelu2(v);
         acc[i][j][r] = v[0];
         acc[i][j][r + 1] = v[1];
