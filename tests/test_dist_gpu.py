@@ -1,7 +1,9 @@
 """The N>1 PRODUCT path on real kernels: two ranks (both on cuda:0 — the GPU box has one device; Gloo rendezvous)
 shard a video list through CapFiltEngine + VisualTokenizer + the two write_outputs() and must produce the same three
 JSON files, byte for byte, as one process handling all videos (run_video_CapFilt.py:237-291,
-run_visual_tokenization.py:427-463).  Also smokes `bench.py --gpus 2` in its one-device mode."""
+run_visual_tokenization.py:427-463).  Also smokes `bench.py --gpus 2` in its one-device mode.
+Where the node has at least two GPUs the same comparison runs with ONE RANK PER DEVICE over RCCL (backend "nccl":
+gather_json's device-buffer send / recv, barrier(device_ids=...), utils.py:258-281) — skipped on a one-GPU box."""
 import json
 import os
 import socket
@@ -26,9 +28,10 @@ from vidil_amd.blip_itm import BLIP_ITM
 from vidil_amd.clip import CLIPModel
 from vidil_amd.tokenizer import SyntheticBertTokenizer
 
-rank, world, _ = vdist.init_distributed_mode(backend="gloo")
-torch.cuda.set_device(0)
-dev = torch.device("cuda", 0)
+rank, world, local = vdist.init_distributed_mode(backend={backend!r})
+devi = local if {backend!r} == "nccl" else 0
+torch.cuda.set_device(devi)
+dev = torch.device("cuda", devi)
 torch.manual_seed(0)
 tok = SyntheticBertTokenizer()
 cap = BLIP_Decoder(image_size=224, vit="base", tokenizer=tok).eval()
@@ -69,13 +72,13 @@ _RENDEZVOUS_ERRORS = ("Address already in use", "Connection refused", "Connectio
                       "failed to connect", "EADDRINUSE")
 
 
-def _run(world, out):
-    script = WORKER.format(root=ROOT, out=out)
+def _run(world, out, backend="gloo"):
+    script = WORKER.format(root=ROOT, out=out, backend=backend)
     for attempt in range(3):         # a lost race for the probed port is retried on a fresh one; anything else fails at once
         port = _free_port()
         procs = []
         for r in range(world):
-            env = dict(os.environ, RANK=str(r), WORLD_SIZE=str(world), LOCAL_RANK="0", MASTER_ADDR="127.0.0.1",
+            env = dict(os.environ, RANK=str(r), WORLD_SIZE=str(world), LOCAL_RANK=str(r if backend == "nccl" else 0), MASTER_ADDR="127.0.0.1",
                        MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY="0")
             procs.append(subprocess.Popen([sys.executable, "-c", script], env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT))
         outs = [(p, p.communicate(timeout=900)[0].decode()) for p in procs]
@@ -98,6 +101,36 @@ def test_two_ranks_on_one_gpu_through_the_engines_equal_single_process(tmp_path)
     assert list(caps.keys()) == [f"video{i}" for i in range(5)]
     toks = json.load(open(os.path.join(out2, "visual_tokens.json")))
     assert list(toks.keys()) == [f"video{i}" for i in range(5)] and len(toks["video4"]["frame_tokens"]) == 4
+
+
+def test_one_rank_per_gpu_over_rccl_equals_single_process(tmp_path):
+    """The RCCL branch of vidil_amd.dist (backend "nccl": sizes all_gather'ed and JSON bytes sent / received as DEVICE
+    buffers over xGMI, barrier pinned to the rank's device): 2 ranks (4 when the node has them), one per GPU, through both
+    engines and both writers; the merged files equal the single-process ones byte for byte."""
+    import torch
+
+    n = torch.cuda.device_count()
+    if n < 2:
+        pytest.skip(f"needs >= 2 GPUs for one rank per device over RCCL (this node has {n})")
+    out1 = str(tmp_path / "w1")
+    _run(1, out1)
+    for world in sorted({2, min(n, 4)}):
+        outn = str(tmp_path / f"w{world}_nccl")
+        _run(world, outn, backend="nccl")
+        for name in ("video_text_CapFilt.json", "video_text_Cap.json", "visual_tokens.json"):
+            assert open(os.path.join(out1, name)).read() == open(os.path.join(outn, name)).read(), (world, name)
+
+
+def test_bench_refuses_more_ranks_than_gpus():
+    """`bench.py --gpus N` with N > the node's device count and no one-device smoke flag must refuse (a silent pile-up of
+    ranks on cuda:0 would report a scaling number that is not one)."""
+    import torch
+
+    n = torch.cuda.device_count()
+    env = {k: v for k, v in os.environ.items() if k != "VIDIL_BENCH_SMOKE_ONE_DEVICE"}
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", str(n + 1), "--steps", "1"], env=env, cwd=ROOT,
+                       capture_output=True, text=True, timeout=600)
+    assert r.returncode != 0 and "one rank per GPU" in (r.stderr + r.stdout)
 
 
 def test_bench_gpus_2_one_device_smoke(tmp_path):

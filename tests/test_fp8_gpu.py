@@ -135,12 +135,27 @@ def test_vit_fp8_tower_vs_fp32_oracle_measured_deviation():
     assert rel8 < 0.15 and cos > 0.99            # 3-bit mantissas through 48 GEMMs: a throughput mode, not a parity mode
 
 
-def test_fp8_tower_end_to_end_runs_and_mostly_agrees_with_f16():
+def test_fp8_tower_accuracy_contract_over_32_videos():
+    """BASELINE config 5 ("fp8 MFMA ViT path ... throughput run"): what the fp8 tower mode costs in RESULTS, measured over
+    32 videos x 8 frames against the f16 path on the same weights and frames, printed and bounded:
+      * ITM match probability of every (frame, its own f16 caption) pair: |delta p| (max, mean) and flipped keep / drop
+        decisions at the reference's threshold 0.4 (run_video_CapFilt.py:186-203);
+      * free-running beam captions identical to the f16 path's (random-init weights: near-flat token distributions, the
+        hardest case for agreement);
+      * top-5 visual tokens in common per (frame, category) (run_visual_tokenization.py:298-308).
+    e4m3 carries 3 mantissa bits: each operand is off by 2.7 % rms, each GEMM output by 3.7 %, WHATEVER the block scale
+    (tests/test_oracle_cpu.py::test_evaluation_of_e8m0_block_scales_for_the_fp8_tower) — the mode trades that for +16 %
+    throughput; the bounds below are its contract."""
+    import json
+    import os
+
+    from common import ROOT
     from vidil_amd.blip import BLIP_Decoder
-    from vidil_amd.capfilt import CapFiltEngine
     from vidil_amd.blip_itm import BLIP_ITM
+    from vidil_amd.capfilt import CapFiltEngine
     from vidil_amd.clip import CLIPModel
     from vidil_amd.packing import set_compute_dtype
+    from oracle import clip_ref
     from vidil_amd.tokenizer import SyntheticBertTokenizer
     from vidil_amd.visual_tokenization import CATEGORIES, VisualTokenizer
 
@@ -149,29 +164,63 @@ def test_fp8_tower_end_to_end_runs_and_mostly_agrees_with_f16():
     cap = BLIP_Decoder(image_size=224, vit="base", tokenizer=tok).eval()
     itm = BLIP_ITM(image_size=224, vit="base", tokenizer=tok).eval()
     clip = CLIPModel().eval()
+    for i, m in enumerate((cap, itm, clip)):
+        perturb_(m, 500 + i)
     cfg = dict(caption=True, filter=True, filter_generated_only=True, keep_original_caption=False, threshold=0.4,
                filter_mode="max_filter", generation_mode="beam", image_size=224, vit="base", topk_visualize=5)
-    u8 = torch.from_numpy(synthetic_frames(2, 8, first_video=50)).to(DEV)
+    NV, F = 32, 8
+    u8 = torch.from_numpy(synthetic_frames(NV, F, first_video=50)).to(DEV)
     g = torch.Generator().manual_seed(3)
     sizes = dict(objects=700, attributes=333, scenes=65, verbs=96)
     emb = {k: torch.nn.functional.normalize(torch.randn(n, 512, generator=g), dim=-1) for k, n in sizes.items()}
     texts = {k: [f"{k}{i}" for i in range(n)] for k, n in sizes.items()}
+    vids = [f"video{v}" for v in range(NV)]
     outs = {}
     for mode in ("f16", "fp8"):
         set_compute_dtype(mode, cap, itm, clip)
         eng = CapFiltEngine(cfg, DEV, captioner=cap, filterer=itm)
-        items = [dict(video_id=f"video{v}", text=[]) for v in range(2)]
+        items = [dict(video_id=v, text=[]) for v in vids]
         eng.process(items, u8)
-        toks = VisualTokenizer(cfg, clip, texts, emb, DEV).process(["video0", "video1"], u8, [[], []])
-        outs[mode] = (list(eng.last_frame_captions), toks)
-    assert cap.visual_encoder.fp8 and not cap.text_decoder.fp8 is False or True
-    assert len(outs["fp8"][0]) == 16 and all(len(c) > 0 for c in outs["fp8"][0])
+        toks = VisualTokenizer(cfg, clip, texts, emb, DEV).process(vids, u8, [[] for _ in vids])
+        outs[mode] = dict(caps=list(eng.last_frame_captions), toks=toks, kept=[it["text"] for it in items])
+        if mode == "fp8":           # the mode really is on: e4m3 weights packed, the tower's GEMMs take them
+            p = cap.visual_encoder.packed()
+            assert cap.visual_encoder.fp8 and p["fp8"] and p["blocks"][0]["qkv_w8"].dtype == F8
+    assert len(outs["fp8"]["caps"]) == NV * F and all(len(c) > 0 for c in outs["fp8"]["caps"])
+    # ITM probability of (frame, the f16 path's caption of that frame), both modes, through the reference API
+    frames32 = clip_ref.preprocess_u8(u8.reshape(NV * F, 224, 224, 3).cpu().numpy()).to(DEV)     # /255, CLIP mean / std, CHW
+    probs = {}
+    for mode in ("f16", "fp8"):
+        set_compute_dtype(mode, itm)
+        pr = []
+        for s0 in range(0, NV * F, 64):
+            lg = itm(frames32[s0:s0 + 64], outs["f16"]["caps"][s0:s0 + 64], match_head="itm")
+            pr.append(torch.softmax(lg.float(), dim=1)[:, 1].cpu())
+        probs[mode] = torch.cat(pr)
+    dp = (probs["fp8"] - probs["f16"]).abs()
+    flips = int(((probs["fp8"] > 0.4) != (probs["f16"] > 0.4)).sum())
+    same_caps = sum(a == b for a, b in zip(outs["f16"]["caps"], outs["fp8"]["caps"]))
     same_tok = tot = 0
-    for vid in ("video0", "video1"):
-        for f in range(8):
+    for vid in vids:
+        for f in range(F):
             for key in CATEGORIES:
-                a, b = outs["f16"][1][vid]["frame_tokens"][f][key], outs["fp8"][1][vid]["frame_tokens"][f][key]
+                a, b = outs["f16"]["toks"][vid]["frame_tokens"][f][key], outs["fp8"]["toks"][vid]["frame_tokens"][f][key]
                 same_tok += len(set(a) & set(b)); tot += 5
-    print(f"fp8 tower vs f16: {same_tok}/{tot} top-5 visual tokens in common, "
-          f"{sum(a == b for a, b in zip(*[outs[m][0] for m in ('f16', 'fp8')]))}/16 identical captions (random-init weights)")
-    assert same_tok / tot > 0.5
+    same_kept = sum(a == b for a, b in zip(outs["f16"]["kept"], outs["fp8"]["kept"]))
+    rec = dict(videos=NV, frames=NV * F, itm_dp_max=dp.max().item(), itm_dp_mean=dp.mean().item(), itm_decision_flips=flips,
+               identical_captions=same_caps, top5_overlap=same_tok / tot, identical_kept_lists=same_kept)
+    os.makedirs(os.path.join(ROOT, "gpurun_out"), exist_ok=True)
+    with open(os.path.join(ROOT, "gpurun_out", "fp8_contract.json"), "w") as fh:
+        json.dump(rec, fh, indent=1)
+    print(f"fp8 tower vs f16 over {NV} videos: ITM |dp| max {rec['itm_dp_max']:.3f} mean {rec['itm_dp_mean']:.4f}, {flips}/{NV * F} keep/drop "
+          f"decisions flipped at 0.4; {same_caps}/{NV * F} identical free-running captions; top-5 overlap {rec['top5_overlap']:.3f}; "
+          f"{same_kept}/{NV} identical kept lists")
+    assert rec["itm_dp_mean"] < FP8_ITM_DP_MEAN and rec["itm_dp_max"] < FP8_ITM_DP_MAX
+    assert rec["top5_overlap"] > FP8_TOP5_OVERLAP
+    assert same_caps >= FP8_MIN_SAME_CAPTIONS * NV * F
+
+
+# the contract of the fp8 tower mode (measured on MI355X, random-init ViT-B/16 / MED / CLIP ViT-B/32; see the test above)
+FP8_ITM_DP_MEAN, FP8_ITM_DP_MAX = 0.05, 0.35
+FP8_TOP5_OVERLAP = 0.6
+FP8_MIN_SAME_CAPTIONS = 0.05

@@ -785,6 +785,32 @@ def _ontology(dim=512, seed=3, sizes=None):
     return emb, texts
 
 
+def _compare_visual_tokens_rank_by_rank(got, ie, emb, texts, F, gap):
+    """The device's per-frame top-5 against the reference FORM (fp32 embeds @ text.T + argsort,
+    run_visual_tokenization.py:276,298-308): rank r must carry the identical class text wherever the oracle's own scores
+    separate it from both neighbours by more than `gap`; whatever the order inside a near-tie, the device's five lie in
+    the oracle's near-top set.  Returns (ranks compared, ranks masked as undecided)."""
+    from vidil_amd.visual_tokenization import CATEGORIES
+
+    ranks = masked = 0
+    for key in CATEGORIES:
+        sc = (ie @ emb[key].t()).numpy()                                    # [F, n_classes]
+        order = np.argsort(sc, axis=1)[:, ::-1][:, :6]
+        top = np.take_along_axis(sc, order, axis=1)                          # 6 best scores per frame, descending
+        for f in range(F):
+            ref_texts = [texts[key][i] for i in order[f, :5]]
+            for r in range(5):
+                ranks += 1
+                clear = (top[f, r] - top[f, r + 1] > gap) and (r == 0 or top[f, r - 1] - top[f, r] > gap)
+                if clear:
+                    assert got["frame_tokens"][f][key][r] == ref_texts[r], (f, key, r)
+                else:
+                    masked += 1
+            near = {texts[key][i] for i in np.flatnonzero(sc[f] >= top[f, 4] - gap)}
+            assert set(got["frame_tokens"][f][key]) <= near, (f, key)
+    return ranks, masked
+
+
 def test_end_to_end_three_videos_vs_oracle_pipeline_at_the_vg_ontology_size(full_models):
     """Config 1's shape per video (8 frames 224^2, beam 3, max_filter, CLIP ViT-B/32 against an ontology with the vg
     category sizes 19,958 / 15,026 / 365 / 7,410) through CapFiltEngine + VisualTokenizer, against the fp32 oracle
@@ -1029,7 +1055,10 @@ def test_config4_vit_large_16_frames_end_to_end_vs_oracle_pipeline():
     eng = CapFiltEngine(cfg, DEV, captioner=cap, filterer=itm)
     items = [dict(video_id="yc0", text=[])]
     eng.process(items, torch.from_numpy(u8).to(DEV))
-    emb, texts = _ontology()
+    # the youcook2 category sizes (visual_tokenization._ONTOLOGY_FILES["youcook2"] on the reference's files after its
+    # filter: 1,207 cooking nouns / 16,124 attributes / 365 scenes / 1,970 cooking verbs + relation triples;
+    # tests/test_oracle_cpu.py pins the mapping) through the DEVICE scan
+    emb, texts = _ontology(sizes=dict(objects=1207, attributes=16124, scenes=365, verbs=1970))
     vt = VisualTokenizer(cfg, clip, texts, emb, DEV)
     toks = vt.process(["yc0"], torch.from_numpy(u8).to(DEV), [items[0]["unfiltered_text"]])
     x = clip_ref.preprocess_u8(u8[0])
@@ -1049,9 +1078,15 @@ def test_config4_vit_large_16_frames_end_to_end_vs_oracle_pipeline():
     kept, probs = pipeline_ref.filter_video(sd_itm, x, caps, tok, 0.5, depth=24, heads=16, return_probs=True, dedup=True)
     if all(abs(float(np.max(p)) - 0.5) > 4e-3 for p in probs):
         assert items[0]["text"] == kept
-    ref = pipeline_ref.visual_tokens_video(sd_clip, x, emb, texts, topk=5)
+    # visual tokens, rank by rank against the reference form (no percentage: every rank the oracle's own scores decide
+    # must be identical; the undecided ones are counted and bounded)
+    from oracle import tokens_ref
+    with torch.no_grad():
+        ie = clip_ref.image_embeds(sd_clip, x)
     got = toks["yc0"]
-    tot = sum(5 for _ in range(F) for _ in CATEGORIES)
-    eq = sum(a == b for f in range(F) for key in CATEGORIES for a, b in zip(got["frame_tokens"][f][key], ref["frame_tokens"][f][key]))
-    assert eq / tot >= 0.97, (eq, tot)
     assert len(got["frame_tokens"]) == F
+    ranks, masked = _compare_visual_tokens_rank_by_rank(got, ie, emb, texts, F, gap=1.5e-3)
+    print(f"config 4: {same}/{F} free-running captions equal the fp32 oracle's; visual-token ranks compared exactly "
+          f"{ranks - masked}/{ranks} at the youcook2 category sizes")
+    assert masked <= 0.6 * ranks, (masked, ranks)
+    assert got["aggregated_tokens"] == tokens_ref.aggregate_frame_tokens(got["frame_tokens"])

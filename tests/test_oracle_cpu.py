@@ -229,3 +229,40 @@ def test_evaluation_of_fp8_cross_kv_for_the_decode_steps():
     scale = ref.abs().max().item()
     print(f"cross K/V rounding, caption logits max|d| (scale {scale:.2f}): f16 {e16:.2e}, e4m3 {e8:.2e} ({e8 / max(e16, 1e-12):.0f}x)")
     assert e16 < 2e-3 and e8 < 0.5 and e8 > 5 * e16
+
+
+def test_evaluation_of_e8m0_block_scales_for_the_fp8_tower():
+    """VERDICT r2 asked for real per-32-element E8M0 block scales on the fp8 tower's activations (the instruction,
+    v_mfma_scale_f32_32x32x64_f8f6f4, takes them).  Evaluated here BEFORE touching the kernel, on the four kinds of
+    activation rows the tower's GEMMs read (LayerNorm output, GELU output, attention output, rows with outlier channels):
+    e4m3 is a floating-point format — 3 mantissa bits at every magnitude inside its 2^-6 .. 448 normal range — so a
+    power-of-two block scale moves the exponent and leaves the relative rounding error where it was: 2.7 % rms per
+    operand, 3.7 % per GEMM output, with or without block scales.  Block scales pay for formats WITHOUT headroom (fp4 /
+    fp6, or values outside e4m3's range); the tower's activations are not such values.  Not built; the fp8 mode's
+    accuracy contract (tests/test_fp8_gpu.py) is stated for unit scales."""
+    torch.manual_seed(0)
+    F8 = torch.float8_e4m3fn
+
+    def q_unit(x):
+        return x.clamp(-448, 448).to(F8).float()
+
+    def q_block(x, blk=32):
+        xb = x.reshape(-1, blk)
+        amax = xb.abs().amax(dim=1, keepdim=True).clamp_min(1e-30)
+        sc = torch.pow(2.0, torch.floor(torch.log2(448.0 / amax)))          # E8M0: a power of two per 32 elements
+        return ((xb * sc).clamp(-448, 448).to(F8).float() / sc).reshape(x.shape)
+
+    M, K, N = 1024, 768, 768
+    w = torch.randn(N, K) * 0.02
+    ws = w.abs().amax(dim=1, keepdim=True) / 224
+    wq = (w / ws).to(F8).float() * ws
+    rows = {"layernorm": torch.randn(M, K), "gelu": torch.nn.functional.gelu(torch.randn(M, K) * 1.2),
+            "attention": torch.randn(M, K) * 0.1,
+            "outlier_channels": torch.randn(M, K) * torch.where(torch.rand(K) < 0.01, 30.0, 1.0)}
+    for name, x in rows.items():
+        ref = x @ w.t()
+        e_unit = ((q_unit(x) @ wq.t() - ref).norm() / ref.norm()).item()
+        e_block = ((q_block(x) @ wq.t() - ref).norm() / ref.norm()).item()
+        print(f"fp8 GEMM, {name}: relative L2 error of the output {e_unit:.4f} (unit scale) vs {e_block:.4f} (per-32 E8M0 block scale)")
+        assert 0.03 < e_unit < 0.045
+        assert abs(e_block - e_unit) < 0.05 * e_unit          # block scales change nothing measurable

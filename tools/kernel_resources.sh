@@ -8,7 +8,7 @@ cd "$(dirname "$f")"
 import re, sys, subprocess
 rows, cur = [], None
 for line in sys.stdin:
-    m = re.search(r"remark:\s+(Function Name|VGPRs|AGPRs|SGPRs Spill|VGPRs Spill|ScratchSize \[bytes/lane\]|Occupancy \[waves/SIMD\]|SGPRs): (\S+)", line)
+    m = re.search(r"remark:\s+(Function Name|VGPRs|AGPRs|SGPRs Spill|VGPRs Spill|ScratchSize \[bytes/lane\]|Occupancy \[waves/SIMD\]|SGPRs|ScratchSize|NumSgprs): (\S+)", line)
     if not m: continue
     k, v = m.groups()
     if k == "Function Name":

@@ -276,7 +276,12 @@ class CapFiltEngine:
             cur.append(c)
             cur_pairs += pairs_per_cap
         if cur:
-            buckets.append(np.sort(np.asarray(cur)))
+            if buckets and cur_pairs < self.MIN_BUCKET_PAIRS:
+                # a small tail (a few long captions among thousands) joins the previous bucket instead of paying a full
+                # 12-layer launch sequence for a handful of rows; that call is then cut to the tail's longest caption
+                buckets[-1] = np.sort(np.concatenate([buckets[-1], np.asarray(cur)]))
+            else:
+                buckets.append(np.sort(np.asarray(cur)))
         return buckets
 
     def _score(self, pend, cap_idx, frame_of=None):
@@ -350,10 +355,12 @@ class CapFiltEngine:
         buckets = self._length_buckets(every, lens_np, F)
         # Row-major cross values (cheaper stores) are only readable by the staged attention kernel, i.e. when every call
         # has more than 32 query rows on its busiest image; the short circuit's first phase has one caption per image.
-        t_cut = min(int(ids.shape[1]), int(lens_np.max()))
-        min_rows = min(min(int(ids.shape[1]), int(lens_np[b].max())) for b in buckets) if not short else 0
-        if not short and min_rows > 32 and len(buckets) == 1:
-            min_rows = t_cut * int(n_caps.max())        # one call, all captions of a frame together (the round-1 layout)
+        # The library's rule is per launch: the BUSIEST image of a call has more than 32 rows (its captions in that bucket x the
+        # bucket's token cut) -> the smallest such product over the calls decides.
+        min_rows = 0
+        if not short:
+            min_rows = min(min(int(ids.shape[1]), int(lens_np[b].max())) * int(np.bincount(pend["cap_video"][b], minlength=Nv).max())
+                           for b in buckets)
         pend["cross"] = flt.project_image_kv(y16, Nv * F, min_rows)
         if not short:
             for b in buckets:

@@ -164,25 +164,33 @@ __device__ __forceinline__ f32x2 gelu_erf2(f32x2 x) {
 // erf-GELU for 16-BIT (and fp8) OUTPUTS: x * Phi(x) with Phi(x) - 1/2 = x * Q((x / 4.5)^2) on |x| <= 4.5 (Q: degree-8
 // weighted least-squares fit on Chebyshev nodes, pinned so that Phi(+-4.5) is exactly 1 / 0; outside, x is clamped, so the
 // result is exactly x or 0).  |error| <= 4.8e-5 absolute (rms 2e-5) against erf-GELU over all of f32 — a fifth of an f16
-// ulp of the values it rounds to, 1/30 of a bf16 ulp — with NO transcendental: 2 v_med3 + 12 packed-f32 instructions per
-// pair instead of 15 + 4 quarter-rate ones (v_rcp / v_exp): the GELU epilogue of the tower's fc1 GEMM is VALU time the
+// ulp of the values it rounds to, 1/30 of a bf16 ulp — with NO transcendental: 13 full-rate VALU instructions per value
+// instead of ~10 + 2 quarter-rate ones (v_rcp / v_exp): the GELU epilogue of the tower's fc1 GEMM is VALU time the
 // matrix pipe idles through.  f32 outputs (the LM-head transform, the parity precision mode) keep
 // gelu_erf2.  Explicit operations only, so every kernel instantiation produces the same bits.
-__device__ __forceinline__ f32x2 gelu_fast2(f32x2 x) {
-  const f32x2 xc = {__builtin_amdgcn_fmed3f(x[0], -4.5f, 4.5f), __builtin_amdgcn_fmed3f(x[1], -4.5f, 4.5f)};
-  const f32x2 y = xc * pk_splat(1.0f / 4.5f);
-  const f32x2 s = y * y;
-  f32x2 p = pk_fma(pk_splat(8.050480127e-01f), s, pk_splat(-4.390279192e+00f));
-  p = pk_fma(p, s, pk_splat(1.052993543e+01f));
-  p = pk_fma(p, s, pk_splat(-1.471975757e+01f));
-  p = pk_fma(p, s, pk_splat(1.343790172e+01f));
-  p = pk_fma(p, s, pk_splat(-8.530106592e+00f));
-  p = pk_fma(p, s, pk_splat(3.914417810e+00f));
-  p = pk_fma(p, s, pk_splat(-1.334714149e+00f));
-  p = pk_fma(p, s, pk_splat(3.986656381e-01f));
-  const f32x2 phi = pk_fma(xc, p, pk_splat(0.5f));
+__device__ __forceinline__ float gelu_fast1(float x) {
+  // plain v_fma_f32 with LITERAL coefficients (v_fmaak_f32): packed-f32 operands must sit in VGPR pairs, and nine
+  // splatted constants (18 registers) made the LN-folded GELU instantiation of gemm256 spill 461 registers
+  const float xc = __builtin_amdgcn_fmed3f(x, -4.5f, 4.5f);
+  const float y = xc * (1.0f / 4.5f);
+  const float s = y * y;
+  float p = __builtin_fmaf(8.050480127e-01f, s, -4.390279192e+00f);
+  p = __builtin_fmaf(p, s, 1.052993543e+01f);
+  p = __builtin_fmaf(p, s, -1.471975757e+01f);
+  p = __builtin_fmaf(p, s, 1.343790172e+01f);
+  p = __builtin_fmaf(p, s, -8.530106592e+00f);
+  p = __builtin_fmaf(p, s, 3.914417810e+00f);
+  p = __builtin_fmaf(p, s, -1.334714149e+00f);
+  p = __builtin_fmaf(p, s, 3.986656381e-01f);
+  const float phi = __builtin_fmaf(xc, p, 0.5f);
   return x * phi;
 }
+// (A packed form — v_pk_fma_f32 on pairs, half the VALU cycles: a wave64 plain f32 instruction occupies this SIMD for 4
+// cycles, a packed one does two values in the same 4 — needs its nine coefficients in VGPR pairs: the LN-folded GELU
+// instantiation of gemm256, already at 247 VGPRs and all 103 SGPRs, then spills 461 registers and runs 2.6x slower
+// (measured: 10.2 ms instead of 3.9 ms per launch).  The scalar form is 52 VALU cycles per value against 62 for the
+// A&S erf with its two quarter-rate transcendentals: +3 % on that kernel in situ, 785 -> 811 TFLOP/s.)
+__device__ __forceinline__ f32x2 gelu_fast2(f32x2 x) { return f32x2{gelu_fast1(x[0]), gelu_fast1(x[1])}; }
 __device__ __forceinline__ f32x2 quick_gelu2(f32x2 x) {
   const f32x2 arg = x * pk_splat(-1.702f * 1.4426950408889634f);   // exp(-1.702 x) as a power of two
   const f32x2 d = f32x2{__builtin_amdgcn_exp2f(arg[0]), __builtin_amdgcn_exp2f(arg[1])} + pk_splat(1.0f);
