@@ -266,7 +266,7 @@ def time_steps(step, n):
     return (time.perf_counter() - t0) / n
 
 
-def secondary_measurements(args, cap, flt, clip, step, frames, dev, parity_file, log):
+def secondary_measurements(args, cap, flt, clip, step, frames, dev, parity_file, log, engine=None):
     """After the timed region (rank 0, N = 1): the numbers the headline does not carry.  Everything here re-packs the
     models' weights for another operand type / precision mode, so it runs last."""
     from vidil_amd.blip import DecoderSession
@@ -305,6 +305,16 @@ def secondary_measurements(args, cap, flt, clip, step, frames, dev, parity_file,
                          "asserted_tol": asserted}
 
     record(f"timed_dtype_{args.dtype}", tol[args.dtype])
+    # ---- the same step with the ITM short circuit (identical kept lists: max_filter is an any() over the frames)
+    if engine is not None and not args.itm_short_circuit and engine.config.get("filter_mode", "max_filter") != "avg_filter":
+        engine.config["itm_short_circuit"] = True
+        step()
+        dts = time_steps(step, max(2, min(args.steps, 3)))
+        out["secondary"]["itm_short_circuit"] = {
+            "value": round(Nv * F / dts, 2), "unit": "frames/s", "ms_per_step": round(dts * 1e3, 3), "itm_pairs_per_step": engine.last_stats["itm_pairs"],
+            "note": "a caption is scored on the frame it came from first, on the other frames only if it failed there; same kept "
+                    "lists as `value` (tests/test_models_gpu.py::test_itm_short_circuit...), not the headline schedule"}
+        engine.config["itm_short_circuit"] = False
     # ---- the same step on f16 operands (plain mode): the type the parity statement is written for
     if args.dtype != "f16":
         free_sessions()
@@ -549,7 +559,7 @@ def main():
         parity_file = os.path.join(tempfile.gettempdir(), f"vidil_bench_parity_{os.getpid()}.npy")
         result["cpu_baseline"] = cpu_baseline(args, parity_file=parity_file)
     if rank == 0 and world == 1 and not args.no_secondary:
-        result.update(secondary_measurements(args, cap, flt, clip, step, frames, dev, parity_file, log))
+        result.update(secondary_measurements(args, cap, flt, clip, step, frames, dev, parity_file, log, engine=engine))
     if rank == 0:
         result["statement"] = (f"value: {args.dtype} operands, plain precision mode — the throughput configuration (BASELINE configs[1]); the "
                                "parity statement 'caption logits within 1e-3' holds as an absolute bound in the parity precision "

@@ -132,7 +132,7 @@ def test_vit_fp8_tower_vs_fp32_oracle_measured_deviation():
     cos = torch.nn.functional.cosine_similarity(y8.flatten(1), ref.flatten(1), dim=1).min().item()
     print(f"ViT-B/16 output vs fp32 oracle: relative L2 error f16 {rel16:.2e}, fp8 tower {rel8:.2e}; min cosine (fp8) {cos:.5f}")
     assert rel16 < 1e-3
-    assert rel8 < 0.15 and cos > 0.99            # 3-bit mantissas through 48 GEMMs: a throughput mode, not a parity mode
+    assert rel8 < 0.10 and cos > 0.995           # 3-bit mantissas through 48 GEMMs (measured 0.068 / 0.9977): a throughput mode
 
 
 def test_fp8_tower_accuracy_contract_over_32_videos():
@@ -218,9 +218,12 @@ def test_fp8_tower_accuracy_contract_over_32_videos():
     assert rec["itm_dp_mean"] < FP8_ITM_DP_MEAN and rec["itm_dp_max"] < FP8_ITM_DP_MAX
     assert rec["top5_overlap"] > FP8_TOP5_OVERLAP
     assert same_caps >= FP8_MIN_SAME_CAPTIONS * NV * F
+    assert flips <= 0.02 * NV * F
 
 
 # the contract of the fp8 tower mode (measured on MI355X, random-init ViT-B/16 / MED / CLIP ViT-B/32; see the test above)
-FP8_ITM_DP_MEAN, FP8_ITM_DP_MAX = 0.05, 0.35
-FP8_TOP5_OVERLAP = 0.6
-FP8_MIN_SAME_CAPTIONS = 0.05
+# measured (round 3): ITM |dp| max 0.010 / mean 0.0052, 0 of 256 keep / drop decisions flipped, top-5 overlap 0.942, 69 of 256
+# free-running captions identical (random-init weights: near-flat token distributions), ViT output rel-L2 0.068
+FP8_ITM_DP_MEAN, FP8_ITM_DP_MAX = 0.015, 0.04
+FP8_TOP5_OVERLAP = 0.88
+FP8_MIN_SAME_CAPTIONS = 0.15

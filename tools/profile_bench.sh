@@ -2,7 +2,7 @@
 # rocprofv3 kernel trace + PMC passes of the SAME bench.py command; summaries are copied to profiles/ by hand.
 # usage (on the GPU box, via gpurun): bash tools/profile_bench.sh <tag> [bench args...]
 TAG=${1:-r1}; shift
-ARGS=${@:---steps 2 --warmup 1 --no-cpu-baseline}
+ARGS=${@:---steps 2 --warmup 1 --no-cpu-baseline --no-secondary}
 R=$GRAFT_REPO_ROOT
 OUT=$R/gpurun_out/prof_$TAG
 mkdir -p $OUT
