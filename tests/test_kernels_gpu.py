@@ -333,6 +333,39 @@ def test_attention(Bq, H, Nq, Nk, kv_group, causal, use_len):
     assert torch.allclose(got, ref, rtol=3e-3, atol=3e-3), (got - ref).abs().max()
 
 
+@pytest.mark.parametrize("Bq,H,Nq,Nk,kv_group", [(3, 4, 197, 197, 1), (6, 4, 3, 197, 3), (2, 4, 20, 30, 1), (2, 4, 300, 577, 1)])
+def test_attention_online_softmax_on_spiked_scores(Bq, H, Nq, Nk, kv_group):
+    """The online softmax's running maximum on data that makes it move late and often: rows whose score against ONE key in
+    the last tile is 20-60 above all others, rows that grow a little at every tile, ordinary rows — every output against an
+    fp64 softmax of the same 16-bit operands (staged, direct and one-wave kernels).  (Round 3 tried a deferred-rescale /
+    exp2 / packed-add form of the tile softmax with this test as its guard: bit-different, equally correct, and NOT
+    faster — the staged kernel is bound by its K/V staging latency, not by VALU — so the kernel stayed as it was.)"""
+    k = _k()
+    Bk = Bq // kv_group
+    NP = (Nk + 15) // 16 * 16
+    g = torch.Generator().manual_seed(77)
+    q = (_rand(Bq, H, Nq, 64, seed=30) * 0.125)
+    kk = _rand(Bk, H, Nk, 64, seed=31)
+    v = _rand(Bk, H, Nk, 64, seed=32)
+    # spikes: key (Nk - 7) aligned with a multiple of some queries -> raw score 20 .. 60 in the last tile(s)
+    for b in range(Bq):
+        for t in range(0, Nq, 3):
+            kk[b // kv_group, :, Nk - 7] = q[b, :, t] / q[b, :, t].norm(dim=-1, keepdim=True) * (25.0 + 10.0 * (t % 4)) / 0.125 / 8
+    # ramps: keys whose scores rise by ~0.5 per tile for every query (sub-threshold growth at every tile)
+    kk[:, :, ::32] *= torch.linspace(0.2, 2.5, kk[:, :, ::32].shape[2])[None, None, :, None]
+    q16, k16, v16 = q.half(), kk.half(), v.half()
+    vt = torch.zeros((Bk, H, 64, NP), dtype=torch.float16)
+    vt[..., k.vt_columns(Nk)] = v16.transpose(-1, -2)
+    out = torch.zeros(Bq * Nq, H * 64, dtype=torch.float16, device=DEV)
+    k.attention(q16.to(DEV), k16.to(DEV), vt.to(DEV), out, Bq=Bq, H=H, Nq=Nq, Nk=Nk, Tq_cap=Nq, Tk_cap=Nk, NP=NP, kv_group=kv_group)
+    s = q16.double() @ k16.double().repeat_interleave(kv_group, 0).transpose(-1, -2)
+    assert s.max().item() > 15.0                                   # the spikes are there
+    ref = (torch.softmax(s, -1) @ v16.double().repeat_interleave(kv_group, 0)).permute(0, 2, 1, 3).reshape(Bq * Nq, H * 64)
+    got = out.double().cpu()
+    assert torch.isfinite(got).all()
+    assert torch.allclose(got, ref, rtol=3e-3, atol=3e-3), (got - ref).abs().max()
+
+
 @pytest.mark.parametrize("B,H,T,big", [(3, 12, 197, False), (2, 4, 577, False), (260, 12, 197, True)])
 def test_row_major_v_from_qkv_gemm_through_staged_attention(B, H, T, big):
     """NP = 0: the QKV GEMM (small-tile and 256x256 kernels) stores V like K, the LDS-staged attention transposes it

@@ -9,7 +9,32 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from vidil_amd import kernels as K  # noqa: E402
 
 
+def vit(B):
+    """Encoder self-attention of a ViT-B/16 tower (197 tokens, 12 heads, V row-major): the staged kernel."""
+    H, T = 12, 197
+    dev = "cuda"
+    torch.manual_seed(0)
+    q = (torch.randn(B, H, T, 64, device=dev) * 0.125).half()
+    k = torch.randn(B, H, T, 64, device=dev).half()
+    v = torch.randn(B, H, T, 64, device=dev).half()
+    o = torch.empty(B * T, H * 64, dtype=torch.float16, device=dev)
+    fn = lambda: K.attention(q, k, v, o, Bq=B, H=H, Nq=T, Nk=T, Tq_cap=T, Tk_cap=T, NP=0)  # noqa: E731
+    for _ in range(3):
+        fn()
+    torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(20):
+        fn()
+    e1.record()
+    torch.cuda.synchronize()
+    t = e0.elapsed_time(e1) / 20 * 1e-3
+    print(f"vit self-attention images={B} {t * 1e6:8.1f} us  {4.0 * B * H * T * T * 64 / t / 1e12:.1f} TFLOP/s  {3 * B * H * T * 64 * 2 * 2 / t / 1e12:.2f} TB/s (Q, K, V in + O out)")
+
+
 def main():
+    if len(sys.argv) > 1 and sys.argv[1] == "vit":
+        return vit(int(sys.argv[2]) if len(sys.argv) > 2 else 3584)
     B = int(sys.argv[1]) if len(sys.argv) > 1 else 3072        # images
     beams, H, Te = 3, 12, 197
     cap = int(sys.argv[2]) if len(sys.argv) > 2 else 0            # key capacity of the buffers (0: tight)
