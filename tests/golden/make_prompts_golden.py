@@ -90,7 +90,53 @@ def prompt_string_cases():
             cfg_out["request_body"] = dict(cfg_out["request_body"], prompt="")
             runs.append(dict(visual_tokens=vt, filtered=filt, unfiltered=unf, qa=qa if task == "qa" else None, asr=asr, config=cfg_out,
                              lines=lines, idx=idx))
-    json.dump(dict(cases=cases, fixed_prefix_runs=runs), open(os.path.join(HERE, "prompt_strings_golden.json"), "w"), indent=0)
+    # the random-prefix generator: few-shot example selection (get_prompt_prefix) + its own save_prompt_lines
+    import contextlib
+    import io
+
+    import generate_prompts_random_prefix as gr
+
+    rruns = []
+    for task, permutate, shot, seed in (("caption", -1, 3, 42), ("qa", -1, 2, 7), ("vlep", -1, 3, 5), ("caption", 2, 3, 11), ("qa", 3, 3, 1)):
+        tvt = {f"t{i}": synth(500 + i, 8, 5) for i in range(9) if i != 4}         # t4: an id without visual tokens
+        for i, o in enumerate(tvt.values()):
+            o["caption"] = [f"gt caption {i} a.", f"gt caption {i} b"] if i % 2 else f" single gt {i} "
+        ids = sorted(f"t{i}" for i in range(9))
+        tf = {f"t{i}": [f"train cap {i} {j}." for j in range(1 + i % 3)] for i in (0, 1, 2, 3, 5, 7)}
+        tu = {f"t{i}": [f"train raw {i} {j}" for j in range(4)] for i in (0, 1, 2, 3, 5, 6, 7)}
+        # (with permutations requested every chosen video must yield an example — the script indexes the shuffled
+        #  permutations blindly — so only the plain runs exercise the "skip a video without annotation" path)
+        qa = {f"t{i}": [dict(question=f"tq{i}-{j}?", answer=f"ta{i}-{j}") for j in range(1 + i % 2)]
+              for i in ((0, 1, 2, 3, 5, 6, 8) if permutate == -1 else range(9))}
+        if permutate != -1:
+            tf = {f"t{i}": [f"train cap {i} {j}." for j in range(1 + i % 3)] for i in range(9)}
+        long_line = "word " * 60
+        asr = {"t0": ["hi", "there "], "t1": [], "t2": [" so, ", "what?", long_line, long_line, long_line, long_line, "late"], "t5": ["x"],
+               "v0": ["test hi"], "v1": []}
+        vt = {f"v{i}": synth(700 + i, 8, 4) for i in range(4)}
+        filt = {f"v{i}": [f"cap {i} {j}." for j in range(2 + i)] for i in (0, 1, 3)}
+        unf = {f"v{i}": [f"raw {i} {j}" for j in range(5)] for i in range(4)}
+        tqa = {"v0": [dict(question="q0?", answer="a0")], "v1": [dict(question="q1?", answer="a1"), dict(question="q1b?", answer="a1b")]}
+        with tempfile.TemporaryDirectory() as d:
+            cfg = dict(base, prompt_task=task, add_events=False, add_scenes=False, caption_all_video=True, permutate=permutate,
+                       output_path=os.path.join(d, "out_q.jsonl"),
+                       request_body=dict(engine="text-davinci-002", prompt="", n=1, temperature=0.0, max_tokens=64, top_p=1,
+                                         frequency_penalty=0, presence_penalty=0))
+            cfg_in = {k: (dict(v) if isinstance(v, dict) else v) for k, v in cfg.items() if k != "output_path"}
+            with contextlib.redirect_stdout(io.StringIO()):
+                prefixes = gr.get_prompt_prefix(copy.deepcopy(tvt), tf, tu, ids, "INSTRUCTION LINE", cfg, qa if task == "qa" else None, asr, shot, seed)
+            chosen = json.load(open(os.path.join(d, "out_q__chosen_samples.json")))
+            # the script then writes the queries with the user's flags and each prefix
+            cfg2 = dict(cfg, add_original_caption=False, add_answer=False)
+            with contextlib.redirect_stdout(io.StringIO()):
+                gr.save_prompt_lines(copy.deepcopy(vt), filt, unf, Prompt(prefixes[0], seed=seed), cfg2, tqa if task == "qa" else None, asr)
+            lines = open(cfg["output_path"]).read().splitlines()
+            idx = json.load(open(os.path.join(d, "out_q__idx_2_videoid.json")))
+        rruns.append(dict(train_visual_tokens=tvt, train_filtered=tf, train_unfiltered=tu, training_video_ids=ids, qa=qa if task == "qa" else None,
+                          asr=asr, config=cfg_in, shot=shot, seed=seed, prefixes=prefixes, chosen=chosen,
+                          visual_tokens=vt, filtered=filt, unfiltered=unf, test_qa=tqa if task == "qa" else None, lines=lines, idx=idx))
+    json.dump(dict(cases=cases, fixed_prefix_runs=runs, random_prefix_runs=rruns), open(os.path.join(HERE, "prompt_strings_golden.json"), "w"), indent=0)
+    print("wrote", len(rruns), "random-prefix runs")
     print("wrote", len(cases), "construct_prompt cases,", len(runs), "fixed-prefix runs;",
           sum(c["error"] is not None for c in cases), "of the cases are errors")
 

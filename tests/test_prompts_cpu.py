@@ -76,3 +76,29 @@ def test_list_templates_refuse_what_the_reference_tables_lack():
             render_list(bad, "static")
     with pytest.raises(NotImplementedError):
         render_list(["a"], "bullet")
+
+
+def test_random_prefix_example_selection_and_lines_match_the_reference_script():
+    """generate_prompts_random_prefix.py run here on seeded inputs (tests/golden/make_prompts_golden.py): the few-shot
+    prefix — videos drawn with the global `random` seeded as the script seeds it, ground truth filled in, optional shuffled
+    permutations — its `__chosen_samples.json`, and the query lines written with that prefix (vlep subtitles trimmed and
+    capped at 1,024 characters, empty subtitle lists, videos without annotation skipped) vs vidil_amd.prompts."""
+    import copy
+
+    from vidil_amd.prompts import Prompt, random_prefix_examples, random_prefix_prompt_lines
+
+    g = json.load(open(os.path.join(ROOT, "tests", "golden", "prompt_strings_golden.json")))
+    runs = g["random_prefix_runs"]
+    assert len(runs) == 5 and {r["config"]["prompt_task"] for r in runs} == {"caption", "qa", "vlep"}
+    for r in runs:
+        cfg = copy.deepcopy(r["config"])
+        prefixes, chosen = random_prefix_examples(copy.deepcopy(r["train_visual_tokens"]), r["train_filtered"], r["train_unfiltered"],
+                                                  r["training_video_ids"], "INSTRUCTION LINE", cfg, r["qa"], r["asr"], shot=r["shot"], seed=r["seed"])
+        assert prefixes == r["prefixes"], (r["config"]["prompt_task"], r["seed"])
+        assert chosen == r["chosen"]
+        cfg2 = dict(cfg, add_original_caption=False, add_answer=False)
+        lines, idx = random_prefix_prompt_lines(copy.deepcopy(r["visual_tokens"]), r["filtered"], r["unfiltered"], Prompt(prefixes[0], seed=r["seed"]),
+                                                cfg2, r["test_qa"], r["asr"])
+        assert lines == r["lines"]
+        assert {str(k): (list(v) if isinstance(v, tuple) else v) for k, v in idx.items()} == r["idx"]
+    assert any(len(r["prefixes"]) > 1 for r in runs)          # the permutation branch ran

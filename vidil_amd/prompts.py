@@ -189,3 +189,106 @@ def fixed_prefix_prompt_lines(visual_tokens, frame_captions_filtered, frame_capt
             lines.append(json.dumps(body))
             line_to_video[len(lines) - 1] = video_name
     return lines, line_to_video
+
+
+def _subtitle_text(subs, task):
+    """ASR lines -> one string (generate_prompts_random_prefix.py:60-81,143-164): an empty list becomes 'no subtitle.'; the
+    vlep task strips every line, closes it with '.' unless it already ends in punctuation or a quote, and stops once
+    1,024 characters are reached; the other tasks join the lines as they are."""
+    if subs == []:
+        return "no subtitle."
+    if task != "vlep":
+        return " ".join(subs)
+    out, total = [], 0
+    for sub in subs:
+        sub = sub.strip()
+        if not sub.endswith((".", ",", "?", ";", "!", ":", "'", '"')):
+            sub += "."
+        out.append(sub)
+        total += len(sub)
+        if total >= 1024:
+            break
+    return " ".join(out)
+
+
+def random_prefix_examples(train_visual_tokens, train_frame_captions_filtered, train_frame_captions_unfiltered, training_video_ids,
+                           instruction_line, config, video_2_question_answer_pairs=None, video_2_asr=None, shot=5, seed=42):
+    """The few-shot prefix of generate_prompts_random_prefix.py:16-134 (``get_prompt_prefix``) without its file output:
+    ``shot`` distinct training videos drawn with ``random.choice`` on the GLOBAL generator seeded with ``seed`` (after a
+    throw-away ``Prompt("", seed)``, as the script does), each rendered by ``construct_prompt`` with the ground truth filled
+    in by the caller's config (add_original_caption / add_answer), joined under the instruction line; ``permutate`` > 0
+    yields that many shuffled orders of the examples.  Returns (list of prefix strings, chosen examples as the script's
+    ``__chosen_samples.json`` holds them).  Videos whose captions are missing are skipped exactly like there."""
+    import itertools
+    import random
+
+    dummy = Prompt("", seed=seed)
+    random.seed(seed)
+    chosen = []
+    while len(chosen) != shot:
+        cand = random.choice(training_video_ids)
+        if cand in train_visual_tokens and cand not in chosen:
+            chosen.append(cand)
+    picked, examples = {}, []
+    task = config["prompt_task"]
+    for video_name in chosen:
+        obj = train_visual_tokens[video_name]
+        captions = train_frame_captions_filtered
+        if video_name not in train_frame_captions_filtered:
+            if not config["caption_all_video"] or video_name not in train_frame_captions_unfiltered:
+                continue
+            captions = train_frame_captions_unfiltered
+        asr = None
+        if video_2_asr is not None and video_name in video_2_asr:
+            asr = _subtitle_text(video_2_asr[video_name], task)
+        if task == "qa":
+            if video_name not in video_2_question_answer_pairs:
+                continue
+            item = random.choice(video_2_question_answer_pairs[video_name])
+            text = dummy.construct_prompt(video_name, obj, captions, config, item["question"], item["answer"], asr)
+            picked[video_name] = {"question": item["question"], "answer": item["answer"]}
+        elif task in ("caption", "vlep"):
+            text = dummy.construct_prompt(video_name, obj, captions, config, question=None, answer=None, asr=asr)
+            marker = "Video Caption:" if task == "caption" else "What is likely to happen next?"
+            picked[video_name] = [text.split(marker)[-1].strip()]
+        else:
+            raise UnboundLocalError("prompt_task must be 'qa', 'caption' or 'vlep'")       # the reference's failure
+        examples.append(text)
+    if config["permutate"] == -1:
+        return ["\n\n".join([instruction_line] + examples) + "\n\n"], picked
+    orders = list(itertools.permutations(examples))
+    random.shuffle(orders)
+    return ["\n\n".join([instruction_line] + list(orders[i])) + "\n\n" for i in range(config["permutate"])], picked
+
+
+def random_prefix_prompt_lines(visual_tokens, frame_captions_filtered, frame_captions_unfiltered, prompt, config,
+                               video_2_question_answer_pairs=None, video_2_asr=None):
+    """``save_prompt_lines`` of generate_prompts_random_prefix.py:136-210 without its file output: the loop of
+    ``fixed_prefix_prompt_lines`` with that script's subtitle handling (vlep: trimmed and capped at 1,024 characters)."""
+    import json
+
+    lines, line_to_video = [], {}
+    task = config["prompt_task"]
+    for video_name, obj in visual_tokens.items():
+        captions = frame_captions_filtered
+        if video_name not in frame_captions_filtered:
+            if not config["caption_all_video"] or video_name not in frame_captions_unfiltered:
+                continue
+            captions = frame_captions_unfiltered
+        asr = None
+        if video_2_asr is not None and video_name in video_2_asr:
+            asr = _subtitle_text(video_2_asr[video_name], task)
+        if task == "qa":
+            if video_name not in video_2_question_answer_pairs:
+                continue
+            for qidx, item in enumerate(video_2_question_answer_pairs[video_name]):
+                body = config["request_body"]
+                body["prompt"] = prompt.construct_prompt(video_name, obj, captions, config, item["question"], item["answer"], asr)
+                lines.append(json.dumps(body))
+                line_to_video[len(lines) - 1] = (video_name, qidx)
+        else:
+            body = config["request_body"]
+            body["prompt"] = prompt.construct_prompt(video_name, obj, captions, config, question=None, answer=None, asr=asr)
+            lines.append(json.dumps(body))
+            line_to_video[len(lines) - 1] = video_name
+    return lines, line_to_video
