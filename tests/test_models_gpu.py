@@ -1090,3 +1090,42 @@ def test_config4_vit_large_16_frames_end_to_end_vs_oracle_pipeline():
           f"{ranks - masked}/{ranks} at the youcook2 category sizes")
     assert masked <= 0.6 * ranks, (masked, ranks)
     assert got["aggregated_tokens"] == tokens_ref.aggregate_frame_tokens(got["frame_tokens"])
+
+
+def test_ontology_text_embeddings_at_the_full_vg_count(full_models):
+    """The one-off ontology embedding (run_visual_tokenization.py:83-96,198-214): 42,759 prompts through the CLIP text
+    tower in batches of 512 by `get_text_embeddings_clip` — unit-norm rows, a row's embedding independent of the batch it
+    sat in (bitwise), and equal to the fp32 oracle on a sample."""
+    import time
+
+    from oracle import clip_ref
+    from vidil_amd.visual_tokenization import get_text_embeddings_clip
+
+    clip, sd = full_models["clip"], full_models["sd_clip"]
+    n, L = 42759, 12
+    g = torch.Generator().manual_seed(21)
+    ids = torch.randint(1000, 40000, (n, L), generator=g)
+    ids[:, 0] = 49406
+    lens = torch.randint(4, L + 1, (n,), generator=g)
+    for t in range(L):
+        ids[lens <= t + 1, t] = 49407                      # EOS at position len-1, EOS-padded after it (CLIP pads with EOS)
+    texts = list(range(n))
+
+    def tokenize(batch):
+        rows = torch.tensor(batch)
+        return dict(input_ids=ids[rows], attention_mask=(torch.arange(L)[None, :] < lens[rows][:, None]).long())
+
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    emb = get_text_embeddings_clip(clip, tokenize, texts, DEV, batch=512)
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    print(f"ontology text embeddings: {n} prompts in {dt:.2f} s (incl. first-call packing)")
+    assert emb.shape == (n, 512) and torch.isfinite(emb).all()
+    assert torch.allclose(emb.norm(dim=-1), torch.ones(n, device=DEV), atol=1e-5)
+    sample = torch.tensor([0, 1, 511, 512, 513, 20000, 42758])
+    alone = clip.encode_text(ids[sample].to(DEV), (torch.arange(L)[None, :] < lens[sample][:, None]).long())
+    assert torch.equal(alone, emb[sample.to(DEV)])
+    with torch.no_grad():
+        ref = clip_ref.text_embeds(sd, ids[sample], (torch.arange(L)[None, :] < lens[sample][:, None]).long())
+    assert (alone.cpu() - ref).abs().max().item() < 1e-3

@@ -188,8 +188,12 @@ __device__ __forceinline__ float gelu_fast1(float x) {
 // (A packed form — v_pk_fma_f32 on pairs, half the VALU cycles: a wave64 plain f32 instruction occupies this SIMD for 4
 // cycles, a packed one does two values in the same 4 — needs its nine coefficients in VGPR pairs: the LN-folded GELU
 // instantiation of gemm256, already at 247 VGPRs and all 103 SGPRs, then spills 461 registers and runs 2.6x slower
-// (measured: 10.2 ms instead of 3.9 ms per launch).  The scalar form is 52 VALU cycles per value against 62 for the
-// A&S erf with its two quarter-rate transcendentals: +3 % on that kernel in situ, 785 -> 811 TFLOP/s.)
+// (measured: 10.2 ms instead of 3.9 ms per launch).  Three more placements of the packed form were compiled — coefficients
+// defined opaquely inside the epilogue so that they cannot be hoisted across the main loop, scheduling barriers between
+// the pairs, the activation moved to the point where a value is converted for its store instead of updating the
+// accumulator tuples in place — all spill 361 registers (fp8 instantiation: 304) in the epilogue region.  The scalar form
+// is 52 VALU cycles per value against 62 for the A&S erf with its two quarter-rate transcendentals: +3 % on that kernel
+// in situ, 785 -> 811 TFLOP/s.)
 __device__ __forceinline__ f32x2 gelu_fast2(f32x2 x) { return f32x2{gelu_fast1(x[0]), gelu_fast1(x[1])}; }
 __device__ __forceinline__ f32x2 quick_gelu2(f32x2 x) {
   const f32x2 arg = x * pk_splat(-1.702f * 1.4426950408889634f);   // exp(-1.702 x) as a power of two
