@@ -881,8 +881,10 @@ def test_end_to_end_three_videos_vs_oracle_pipeline_at_the_vg_ontology_size(full
         assert got["aggregated_tokens"] == agg and set(agg.keys()) == set(CATEGORIES)
     print(f"e2e: {checked}/{Nv * F} free-running captions equal the fp32 oracle's; visual-token ranks compared exactly "
           f"{ranks - masked}/{ranks} (the rest lie within {GAP} of a neighbour in the oracle's own scores)")
-    assert checked >= (Nv * F) // 2, checked      # most free-running captions equal the fp32 oracle's
-    assert masked <= 0.6 * ranks, (masked, ranks)
+    # measured: 24 of 24 free-running captions equal the fp32 oracle's (every decisive frame is asserted above; two
+    # near-tie flips of 24 are allowed), 199 of 480 ranks undecided by the oracle's own score gaps
+    assert checked >= Nv * F - 2, checked
+    assert masked <= 0.45 * ranks, (masked, ranks)
     f_out, u_out = collect_outputs(items)
     assert list(u_out.keys()) == ["video0", "video1", "video2"]
 

@@ -256,3 +256,57 @@ def test_parity_mode_is_refused_with_fp8_and_off_by_default():
     set_compute_dtype("fp8", v)
     with pytest.raises(ValueError):
         v.parity
+
+
+def test_parity_mode_itm_logits_and_capfilt_decisions_vs_oracle():
+    """The filter side of CapFilt in the parity precision mode (BLIP_ITM.itm_pairs takes the whole-stack route on
+    error-compensated operands): ITM logits of (frame, caption) pairs with padding against the fp32 oracle
+    (models/blip_itm.py:41-58, models/med.py BertModel) — 1e-4 where the plain f16 path is asserted at 2e-3 — and a small
+    CapFiltEngine run whose captions and kept lists equal the oracle pipeline's."""
+    from oracle import clip_ref, med_ref, pipeline_ref, vit_ref
+    from vidil_amd.blip import BLIP_Decoder
+    from vidil_amd.blip_itm import BLIP_ITM
+    from vidil_amd.capfilt import CapFiltEngine
+    from vidil_amd.packing import set_compute_dtype, set_parity_mode
+    from vidil_amd.tokenizer import SyntheticBertTokenizer
+
+    torch.manual_seed(0)
+    tok = SyntheticBertTokenizer()
+    cap = BLIP_Decoder(image_size=224, vit="base", tokenizer=tok).eval()
+    itm = BLIP_ITM(image_size=224, vit="base", tokenizer=tok).eval()
+    perturb_(cap, 100)
+    perturb_(itm, 101)
+    sd_cap = {k: v.clone() for k, v in cap.state_dict().items()}
+    sd_itm = {k: v.clone() for k, v in itm.state_dict().items()}
+    cap, itm = cap.to(DEV), itm.to(DEV)
+    set_compute_dtype("f16", cap, itm)
+    set_parity_mode(True, cap, itm)
+    # ---- ITM logits of 4 frames x their captions (different lengths -> padding) through the reference call shape
+    F = 4
+    u8 = synthetic_frames(1, F, first_video=3)[0]
+    x = clip_ref.preprocess_u8(u8)
+    captions = ["w2000 w2001 w2002", "w3000 w3001 w3002 w3003 w3004 w3005 w3006", "a picture of w4000", "w5000 " * 12]
+    got = itm(x.to(DEV), captions, match_head="itm").cpu()
+    with torch.no_grad():
+        y_ref = vit_ref.vit_forward(sd_itm, x)
+        ids, lens = itm.tokenize(captions)
+        ref = med_ref.itm_logits(sd_itm, y_ref, ids.long(), (torch.arange(ids.shape[1])[None, :] < lens[:, None]).long())
+    e = (got - ref).abs().max().item()
+    print(f"parity mode ITM logits vs fp32 oracle: max|d| {e:.2e} (plain f16 path: asserted 2e-3)")
+    assert e < 2e-4
+    # ---- a CapFiltEngine run in parity mode: captions and kept lists of the oracle pipeline
+    cfg = dict(caption=True, filter=True, filter_generated_only=True, keep_original_caption=False, threshold=0.4,
+               filter_mode="max_filter", generation_mode="beam", image_size=224, vit="base")
+    eng = CapFiltEngine(cfg, DEV, captioner=cap, filterer=itm)
+    Nv, Fv = 2, 4
+    frames = synthetic_frames(Nv, Fv, first_video=11)
+    items = [dict(video_id=f"video{v}", text=[]) for v in range(Nv)]
+    eng.process(items, torch.from_numpy(frames).to(DEV))
+    prompt = cap.prompt_ids(1, "cpu")[0].long().numpy()
+    for v in range(Nv):
+        xv = clip_ref.preprocess_u8(frames[v])
+        caps_ref = pipeline_ref.caption_video(sd_cap, xv, prompt, tok, cap.prompt)
+        assert eng.last_frame_captions[v * Fv:(v + 1) * Fv] == caps_ref, v
+        kept, probs = pipeline_ref.filter_video(sd_itm, xv, items[v]["unfiltered_text"], tok, 0.4, return_probs=True)
+        if all(abs(float(np.max(p)) - 0.4) > 1e-4 for p in probs):
+            assert items[v]["text"] == kept, v

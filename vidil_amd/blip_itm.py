@@ -16,7 +16,7 @@ import torch.nn as nn
 from . import kernels as K
 from .blip import create_vit, load_checkpoint, resolve_med_config
 from .med import BertConfig, BertModel
-from .packing import PackedCache, require_cuda, v32, w16
+from .packing import PackedCache, require_cuda, v32, w3, w16
 from .tokenizer import init_tokenizer, refuse_synthetic_with_checkpoint
 
 ITM_MAX_LENGTH = 35  # models/blip_itm.py:46
@@ -37,7 +37,10 @@ class BLIP_ITM(PackedCache, nn.Module):
         self.itm_head = nn.Linear(text_width, 2)
 
     def _pack(self):
-        return dict(itm_w=w16(self.itm_head.weight, dtype=self.cdt), itm_b=v32(self.itm_head.bias))
+        p = dict(itm_w=w16(self.itm_head.weight, dtype=self.cdt), itm_b=v32(self.itm_head.bias), parity=self.parity)
+        if p["parity"]:          # parity precision mode: [W_hi | W_hi | W_lo] against the [hi | lo | hi] rows of the [CLS] states
+            p["itm_w3"] = w3(self.itm_head.weight, dtype=self.cdt)
+        return p
 
     def parameters_for_fingerprint(self):
         return [self.itm_head.weight, self.itm_head.bias]
@@ -96,10 +99,23 @@ class BLIP_ITM(PackedCache, nn.Module):
         if pair_text is not None:
             pair_text = pair_text.to(dev).to(torch.int64).contiguous()
         P = ids.shape[0] if pair_text is None else pair_text.numel()
+        p = self.packed()
+        if p["parity"]:
+            # parity precision mode (packing.set_parity_mode): every pair through ALL layers on all of its tokens with
+            # error-compensated GEMM operands (BertModel.encode -> _run_layers_parity) — no [CLS]-only last layer, no
+            # shared text front: a statement about results, not the throughput schedule
+            if pair_text is not None:
+                ids, lens = ids.index_select(0, pair_text).contiguous(), lens.index_select(0, pair_text).contiguous()
+            h32, _ = te.encode(ids, lens, cross, cross_index=image_index, cross_groups=group_start, cross_max_group=max_group)
+            C = te.config.hidden_size
+            cls32 = h32.view(P, ids.shape[1], C)[:, 0].contiguous()
+            a3 = K.split3(cls32, torch.empty((P, 3 * C), dtype=p["itm_w"].dtype, device=dev))
+            out = torch.empty((P, 2), dtype=torch.float32, device=dev)
+            K.gemm(a3, p["itm_w3"], p["itm_b"], out=out)
+            return out
         # only token 0 feeds the itm_head: the last layer runs on the [CLS] rows alone (BertModel.encode_cls)
         _, c16 = te.encode_cls(ids, lens, cross, cross_index=image_index, cross_groups=group_start,
                                cross_max_group=max_group, pair_text=pair_text)
-        p = self.packed()
         out = torch.empty((P, 2), dtype=torch.float32, device=dev)
         K.gemm(c16, p["itm_w"], p["itm_b"], out=out)
         return out

@@ -324,8 +324,9 @@ class BertModel(PackedCache, nn.Module):
         cdt = h16.dtype
         if p["parity"]:
             if self_done_first or stop_after_self or n_layers is not None:
-                raise K.VidilHipError("run_layers: the parity precision mode covers the caption decoder (and plain encode); "
-                                      "encode_cls' split schedules are not built for it")
+                raise K.VidilHipError("run_layers: the parity precision mode runs whole stacks (the caption decoder, "
+                                      "BertModel.encode); encode_cls' split schedules are not built for it — BLIP_ITM.itm_pairs "
+                                      "takes the encode() route in that mode")
             return self._run_layers_parity(p, h32, h16, rows=rows, T=T, self_k=self_k, self_vt=self_vt, t_off=t_off,
                                            Tk_cap=Tk_cap, NPs=NPs, causal=causal, kv_len=kv_len, cross=cross,
                                            cross_index=cross_index, cross_group=cross_group, cross_groups=cross_groups,
@@ -436,8 +437,10 @@ class BertModel(PackedCache, nn.Module):
             K.layernorm(tmp, d["ao_g"], d["ao_bt"], eps, out16=h3, out32=h32, split3=True)
             if cross is not None:
                 K.gemm(h3, d["cq_w3"], d["cq_b"], heads=dict(q=q, T=T, H=H, part0=0, Tq_cap=T, q_scale=0.125))
-                K.attention(q, cross.k[i], cross.vt[i], o3, Bq=rows, H=H, Nq=T, Nk=cross.Te, Tq_cap=T,
-                            Tk_cap=cross.Tk_cap, NP=cross.NP, kv_group=cross_group, kv_index=cross_index,
+                # (project_cross_kv(last_layer_vt=True) keeps the LAST layer's values in a V^T buffer of their own)
+                last = i == len(p["layers"]) - 1 and cross.last_vt is not None
+                K.attention(q, cross.k[i], cross.last_vt if last else cross.vt[i], o3, Bq=rows, H=H, Nq=T, Nk=cross.Te, Tq_cap=T,
+                            Tk_cap=cross.Tk_cap, NP=cross.last_NP if last else cross.NP, kv_group=cross_group, kv_index=cross_index,
                             group_start=cross_groups, max_group=cross_max_group, kv_tiled=cross.tiled, split3=True)
                 K.gemm(o3, d["co_w3"], d["co_b"], out=tmp, resid=h32)
                 K.layernorm(tmp, d["co_g"], d["co_bt"], eps, out16=h3, out32=h32, split3=True)
