@@ -279,7 +279,14 @@ class BLIP_Decoder(nn.Module):
             st = None                              # parameters changed since the capture (e.g. a checkpoint was loaded)
         if st is None:
             if len(cache) >= 8:
-                cache.clear()
+                # make room: the compact sessions first (each holds its own cross K/V, arena and step graphs — roughly
+                # +1.6x of a main session's memory over the four bucket sizes — and is cheap to rebuild), the main
+                # sessions of other shapes only if that was not enough; a main session's captured graphs then survive
+                # the arrival of a new shape
+                for k_ in [k_ for k_ in cache if isinstance(k_[-1], tuple)]:
+                    del cache[k_]
+                if len(cache) >= 8:
+                    cache.clear()
             # (the shared prompt pass has P query rows per image, a decode step nb)
             st = cache[key] = dict(sess=DecoderSession(dec, enc16, B, nb, max_length, tiled_cross=P <= 32 and nb <= 32),
                                    bufs=K.BeamBuffers(B, nb, max_length, dev), graphs={}, pool=None, calls=0, packs=packs,
