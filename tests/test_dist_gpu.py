@@ -103,6 +103,33 @@ def test_two_ranks_on_one_gpu_through_the_engines_equal_single_process(tmp_path)
     assert list(toks.keys()) == [f"video{i}" for i in range(5)] and len(toks["video4"]["frame_tokens"]) == 4
 
 
+def test_rccl_backend_with_a_single_rank_runs_the_device_side_collectives(tmp_path):
+    """What a one-GPU box CAN execute of the RCCL branch: backend "nccl" with world size 1 — process-group creation on the
+    device, `barrier(device_ids=...)`, the size all_gather and the max-reduce of `vidil_amd.dist` on DEVICE buffers (the
+    peer-to-peer send / recv of gather_json needs a second GPU: next test).  Outputs equal the un-distributed run's."""
+    out0, out1 = str(tmp_path / "plain"), str(tmp_path / "nccl1")
+    _run(1, out0)
+    _run(1, out1, backend="nccl")
+    for name in ("video_text_CapFilt.json", "video_text_Cap.json", "visual_tokens.json"):
+        assert open(os.path.join(out0, name)).read() == open(os.path.join(out1, name)).read(), name
+    probe = r"""
+import os, sys, torch
+sys.path.insert(0, %r)
+from vidil_amd import dist as vdist
+rank, world, local = vdist.init_distributed_mode(backend="nccl")
+assert (rank, world) == (0, 1) and torch.distributed.get_backend() == "nccl"
+assert vdist._comm_device().type == "cuda"
+assert vdist.gather_json({"a": [1, 2, 3]}) == [{"a": [1, 2, 3]}]
+assert vdist.max_over_ranks(1.25) == 1.25
+vdist.barrier()
+print("nccl-single-rank-ok")
+""" % ROOT
+    env = dict(os.environ, RANK="0", WORLD_SIZE="1", LOCAL_RANK="0", MASTER_ADDR="127.0.0.1", MASTER_PORT=str(_free_port()),
+               HSA_ENABLE_IPC_MODE_LEGACY="0")
+    r = subprocess.run([sys.executable, "-c", probe], env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0 and "nccl-single-rank-ok" in r.stdout, (r.stdout[-1000:], r.stderr[-3000:])
+
+
 def test_one_rank_per_gpu_over_rccl_equals_single_process(tmp_path):
     """The RCCL branch of vidil_amd.dist (backend "nccl": sizes all_gather'ed and JSON bytes sent / received as DEVICE
     buffers over xGMI, barrier pinned to the rank's device): 2 ranks (4 when the node has them), one per GPU, through both
