@@ -1,5 +1,5 @@
-// gemm_epilogue.h — operand traits (Mma<T>) and helpers shared by the 256x256 kernel (gemm256.hip) and
-// the 128x256 two-workgroups-per-CU kernel (gemm128x256.hip).  The accumulators come out of v_mfma_f32_32x32x*
+// gemm_epilogue.h — operand traits (Mma<T>) and helpers of the 256x256 kernel (gemm256.hip; also used by the experimental
+// kernels under tools/experiments/).  The accumulators come out of v_mfma_f32_32x32x*
 // with SWAPPED operands (D = W_frag · A_frag^T):
 //   acc[it][j][rq*4+e]: row = m_w + it*32 + (lane & 31) ; col = n_w + j*32 + rq*8 + (lane >> 5)*4 + e
 // so a lane owns 4 consecutive output columns of one row, and every store path below first transposes through the
