@@ -269,6 +269,10 @@ class CLIPModel(PackedCache, nn.Module):
         return (self.fuse_layernorm, self.fp8)
 
     def _pack(self):
+        if self.parity:
+            raise NotImplementedError("the parity precision mode covers the BLIP captioner and filter (caption logits / ITM "
+                                      "decisions); the CLIP towers feed an exact-f32 scan whose top-k is compared rank by rank "
+                                      "instead (DESIGN.md §4) — do not set_parity_mode() a CLIPModel")
         vm, tm = self.vision_model, self.text_model
         D = self.config.vision_config.hidden_size
         c = self.cdt
