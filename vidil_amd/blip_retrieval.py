@@ -33,6 +33,8 @@ class BLIP_Retrieval(BLIP_ITM):
         self.queue_size, self.momentum, self.negative_all_rank = queue_size, momentum, negative_all_rank
 
     def _pack(self):
+        if self.parity:
+            raise NotImplementedError("the parity precision mode is built for BLIP_Decoder and BLIP_ITM, not for the retrieval heads")
         p = super()._pack()
         p.update(vp_w=w16(self.vision_proj.weight, dtype=self.cdt), vp_b=v32(self.vision_proj.bias),
                  tp_w=w16(self.text_proj.weight, dtype=self.cdt), tp_b=v32(self.text_proj.bias))
