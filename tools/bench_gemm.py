@@ -12,10 +12,16 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from vidil_amd import kernels as K  # noqa: E402
 
 
-def timeit(fn, iters=20):
-    for _ in range(3):
-        fn()
-    torch.cuda.synchronize()
+def timeit(fn, iters=40, warm_s=0.25):
+    """The shader clock takes ~60 launches (~40 ms) of a big GEMM to ramp from idle: the first 20-launch block of a cold GPU
+    reads 775 TFLOP/s where the settled one reads 930 (tools/experiments/exp_fc2_bistable.py).  Warm up by TIME, not by count,
+    so that two kernels timed one after the other are compared at the same clock."""
+    import time
+    t0 = time.time()
+    while time.time() - t0 < warm_s:
+        for _ in range(5):
+            fn()
+        torch.cuda.synchronize()
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     e0.record()
     for _ in range(iters):

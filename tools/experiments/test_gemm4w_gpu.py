@@ -1,0 +1,195 @@
+"""The 4-wave GEMM kernel (csrc/gemm4w.hip: 256x256 tiles over four waves with 128x128 register blocks, one continuous
+K-tile stream) must be BIT-IDENTICAL to the 8-wave kernel (gemm256.hip) — same k order per output element, same epilogue
+arithmetic — for every epilogue of the hot path, both 16-bit operand types, ragged M / N, 2 to 48 K-tiles.
+Reference ops: nn.Linear calls of models/vit.py:35-41,72,84 and models/med.py:153-171,236,301,314."""
+import os
+
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda"
+
+
+def _k():
+    from vidil_amd import kernels
+    return kernels
+
+
+def _rand(*shape, scale=1.0, seed=0):
+    g = torch.Generator(device="cpu").manual_seed(seed)
+    return torch.randn(*shape, generator=g) * scale
+
+
+def both(k, fn, *a, **kw):
+    """Run the same GEMM through gemm256 (VIDIL_GEMM4W=0) and through gemm4w (VIDIL_GEMM4W=1)."""
+    old = os.environ.get("VIDIL_GEMM4W")
+    try:
+        os.environ["VIDIL_GEMM4W"] = "0"
+        ref = fn()
+        os.environ["VIDIL_GEMM4W"] = "1"
+        got = fn()
+    finally:
+        if old is None:
+            os.environ.pop("VIDIL_GEMM4W", None)
+        else:
+            os.environ["VIDIL_GEMM4W"] = old
+    return ref, got
+
+
+def _row_partials(x32):
+    M, D = x32.shape
+    xs = x32.view(M, D // 64, 64)
+    return torch.stack([xs.sum(-1), (xs * xs).sum(-1)], dim=-1).contiguous()
+
+
+SHAPES = [(256 * 300, 768, 128), (256 * 8 + 5, 256 * 8, 192), (197 * 130 + 37, 768, 768), (197 * 40 + 3, 3072, 768), (197 * 130, 768, 3072), (256 * 90, 832, 512), (197 * 70, 2304, 2304)]
+
+
+@pytest.mark.parametrize("dtype", [torch.float16, torch.bfloat16])
+@pytest.mark.parametrize("M,N,K", SHAPES)
+def test_gemm4w_16bit_and_f32_outputs_equal_gemm256(dtype, M, N, K):
+    k = _k()
+    a = _rand(M, K, seed=1).to(dtype).to(DEV)
+    w = _rand(N, K, scale=0.05, seed=2).to(dtype).to(DEV)
+    bias = _rand(N, seed=3).to(DEV)
+    for act in (k.ACT_NONE, k.ACT_GELU_ERF, k.ACT_QUICK_GELU):
+        ref, got = both(k, lambda: k.gemm(a, w, bias, out=torch.empty(M, N, dtype=dtype, device=DEV), act=act), a, w, bias, act=act)
+        assert torch.equal(ref, got), (act, (ref.float() - got.float()).abs().max())
+    x0 = _rand(M, N, seed=4).to(DEV)
+
+    def run():
+        x = x0.clone()
+        k.gemm(a, w, bias, out=x, resid=x)
+        return x
+    ref, got = both(k, run, a, w, bias, out=x0, resid=x0)
+    assert torch.equal(ref, got)
+    # torch reference on a row sample (f32 accumulate over 16-bit operands)
+    rows = torch.tensor([0, 1, 255, 256, M // 2, M - 2, M - 1], device=DEV)
+    want = a[rows].float() @ w.float().t() + bias + x0[rows]
+    assert torch.allclose(got[rows], want, rtol=1e-4, atol=2e-3 * (K / 768) ** 0.5)
+    if N % 64 == 0:
+        x16 = torch.zeros(M, N, dtype=dtype, device=DEV)
+        st = torch.zeros(M, N // 64, 2, device=DEV)
+
+        def run_stats():
+            x = x0.clone()
+            x16.zero_()
+            st.zero_()
+            k.gemm(a, w, bias, out=x, resid=x, out16=x16, ln_stats_out=st)
+            return torch.cat([x.view(-1), x16.float().view(-1), st.view(-1)])
+        ref, got = both(k, run_stats, a, w, bias, out=x0, resid=x0, out16=x16, ln_stats_out=st)
+        assert torch.equal(ref, got)
+
+
+@pytest.mark.parametrize("dtype", [torch.float16, torch.bfloat16])
+def test_gemm4w_layernorm_fold_consumers_and_residual_layernorm_equal_gemm256(dtype):
+    from vidil_amd.packing import fold_layernorm
+
+    k = _k()
+    M, D, N = 197 * 60 + 11, 768, 3072
+    x = _rand(M, D, seed=10) * 1.5
+    x[:, 5] += 9.0
+    x[::7] += 2.0
+    g, bt = _rand(D, seed=11) * 0.2 + 1.0, _rand(D, seed=12) * 0.2
+    wf, bf, cs = fold_layernorm(_rand(N, D, scale=0.03, seed=13), _rand(N, seed=14) * 0.1, g, bt, dtype)
+    x16 = x.to(dtype).to(DEV)
+    st = _row_partials(x).to(DEV)
+    wf, bf, cs = wf.to(DEV), bf.to(DEV), cs.to(DEV)
+    for act in (k.ACT_GELU_ERF, k.ACT_NONE):
+        ref, got = both(k, lambda: k.gemm(x16, wf, bf, act=act, ln=(cs, 1e-6, st)), x16, wf, bf, act=act, ln=(cs, 1e-6, st))
+        assert torch.equal(ref, got)
+    # folded QKV with the per-head scatter: V row-major (towers), V^T and fragment-tiled K/V
+    B, T, H = 60, 197, 12
+    Mq = B * T
+    wq, bq, csq = fold_layernorm(_rand(3 * D, D, scale=0.03, seed=15), _rand(3 * D, seed=16) * 0.1, g, bt, dtype)
+    wq, bq, csq = wq.to(DEV), bq.to(DEV), csq.to(DEV)
+    xq, stq = x16[:Mq].contiguous(), st[:Mq].contiguous()
+    for layout in ("rowmajor", "vt", "tiled"):
+        q = torch.zeros(B, H, T, 64, dtype=dtype, device=DEV)
+        kk = torch.zeros(B, H, 224 if layout == "tiled" else T, 64, dtype=dtype, device=DEV)
+        if layout == "rowmajor":
+            v = torch.zeros(B, H, T, 64, dtype=dtype, device=DEV)
+            hd = dict(q=q, k=kk, vt=v, T=T, H=H, part0=0, t_off=0, Tq_cap=T, Tk_cap=T, NP=0, q_scale=0.125)
+        elif layout == "vt":
+            v = torch.zeros(B, H, 64, 208, dtype=dtype, device=DEV)
+            hd = dict(q=q, k=kk, vt=v, T=T, H=H, part0=0, t_off=0, Tq_cap=T, Tk_cap=T, NP=208, q_scale=0.125)
+        else:
+            v = torch.zeros(B, H, 224, 64, dtype=dtype, device=DEV)
+            hd = dict(q=q, k=kk, vt=v, T=T, H=H, part0=0, t_off=0, Tq_cap=T, Tk_cap=224, tiled=True, q_scale=0.125)
+
+        def run():
+            q.zero_(); kk.zero_(); v.zero_()
+            k.gemm(xq, wq, bq, heads=hd, ln=(csq, 1e-6, stq))
+            return torch.cat([q.float().view(-1), kk.float().view(-1), v.float().view(-1)])
+        ref, got = both(k, run, xq, wq, bq, heads=hd, ln=(csq, 1e-6, stq))
+        assert torch.equal(ref, got), layout
+    # residual LayerNorm epilogue (post-LN text stack)
+    Nr, Kr = 768, 768
+    Mr = 35 * 700 + 9
+    u = _rand(Mr, Nr, seed=20) * 1.3
+    u[:, 11] += 7.0
+    gr, br = (_rand(Nr, seed=21) * 0.2 + 1.0).to(DEV), (_rand(Nr, seed=22) * 0.2).to(DEV)
+    a = _rand(Mr, Kr, seed=23).to(dtype).to(DEV)
+    w, b = _rand(Nr, Kr, scale=0.03, seed=24).to(dtype).to(DEV), (_rand(Nr, seed=25) * 0.1).to(DEV)
+    st_in = _row_partials(u).to(DEV)
+    xx = u.to(DEV)
+    x16o = torch.zeros(Mr, Nr, dtype=dtype, device=DEV)
+    sto = torch.zeros(Mr, Nr // 64, 2, device=DEV)
+
+    def run_rln():
+        xx.copy_(u)
+        x16o.zero_(); sto.zero_()
+        k.gemm(a, w, b, out=xx, resid=xx, out16=x16o, ln_stats_out=sto, rln=(gr, br, 1e-12, st_in))
+        return torch.cat([xx.view(-1), x16o.float().view(-1), sto.view(-1)])
+    ref, got = both(k, run_rln, a, w, b, out=xx, resid=xx, out16=x16o, ln_stats_out=sto, rln=(gr, br, 1e-12, st_in))
+    assert torch.equal(ref, got)
+
+
+def test_gemm4w_patch_epilogue_and_plain_heads_equal_gemm256():
+    k = _k()
+    B, P, D, Kp = 140, 196, 768, 768
+    a = _rand(B * P, Kp, seed=30).half().to(DEV)
+    w = _rand(D, Kp, scale=0.05, seed=31).half().to(DEV)
+    bias = _rand(D, seed=32).to(DEV)
+    pos = _rand(P + 1, D, seed=33).to(DEV)
+    x = torch.zeros(B * (P + 1), D, device=DEV)
+
+    def run():
+        x.zero_()
+        k.gemm(a, w, bias, patch=dict(out=x, pos=pos, tpi=P))
+        return x.clone()
+    ref, got = both(k, run, a, w, bias, patch=dict(out=x, pos=pos, tpi=P))
+    assert torch.equal(ref, got)
+    # un-folded cross K|V projection into fragment tiles (the captioner's image K/V)
+    T, H = 197, 12
+    Bk = 120
+    ak = _rand(Bk * T, D, seed=34).half().to(DEV)
+    wk = _rand(2 * D, D, scale=0.05, seed=35).half().to(DEV)
+    bk = _rand(2 * D, seed=36).to(DEV)
+    kk = torch.zeros(Bk, H, 224, 64, dtype=torch.float16, device=DEV)
+    v = torch.zeros(Bk, H, 224, 64, dtype=torch.float16, device=DEV)
+    hd = dict(k=kk, vt=v, T=T, H=H, part0=1, t_off=0, Tk_cap=224, tiled=True)
+
+    def run_kv():
+        kk.zero_(); v.zero_()
+        k.gemm(ak, wk, bk, heads=hd)
+        return torch.cat([kk.float().view(-1), v.float().view(-1)])
+    ref, got = both(k, run_kv, ak, wk, bk, heads=hd)
+    assert torch.equal(ref, got)
+
+
+def test_gemm4w_repeated_launches_are_deterministic_and_race_free():
+    """The two wave groups hand stream elements over through one barrier per K-tile: 20 launches of a shape with many
+    tiles per workgroup and an odd tile count give the same bits every time, and the right ones."""
+    k = _k()
+    M, N, K = 256 * 131 + 77, 1152, 768
+    a = _rand(M, K, seed=40).half().to(DEV)
+    w = _rand(N, K, scale=0.05, seed=41).half().to(DEV)
+    bias = _rand(N, seed=42).to(DEV)
+    os.environ["VIDIL_GEMM4W"] = "1"
+    first = k.gemm(a, w, bias, act=k.ACT_GELU_ERF)
+    for _ in range(20):
+        assert torch.equal(k.gemm(a, w, bias, act=k.ACT_GELU_ERF), first)
+    want = torch.nn.functional.gelu(a[-300:].float() @ w.float().t() + bias)
+    assert torch.allclose(first[-300:].float(), want, rtol=3e-3, atol=3e-3)

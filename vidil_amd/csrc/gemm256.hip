@@ -471,7 +471,15 @@ static int launch256_fp8(const vidil_gemm_args& a, hipStream_t s) {
   }
 }
 
+int vidil_gemm4w_launch(const vidil_gemm_args& a, hipStream_t s);   // gemm4w.hip; -1000: variant not built there
+
 int vidil_gemm256_launch(const vidil_gemm_args& a, hipStream_t s) {
+  const char* e4w = getenv("VIDIL_GEMM4W");
+  const bool use4w = e4w && atoi(e4w) != 0;
+  if (use4w) {
+    const int rc = vidil_gemm4w_launch(a, s);
+    if (rc != -1000) return rc;
+  }
   if (a.dtype == VIDIL_DT_FP8) return a.dtype16 == VIDIL_DT_BF16 ? launch256_fp8<bf16>(a, s) : launch256_fp8<f16>(a, s);
   if (a.dtype == VIDIL_DT_BF16) return launch256_dispatch<bf16>(a, s);
   return launch256_dispatch<f16>(a, s);

@@ -1,0 +1,414 @@
+// gemm4w.hip — the large-M GEMM of the hot path, second generation: C[M,N] = A[M,K] · W[N,K]^T, 256x256x(128 B) tiles
+// over FOUR waves (one per SIMD), each owning a 128x128 block of the tile in 256 accumulator registers.
+//
+// Why (round 3): with warm clocks the library GEMM beats the 8-wave kernel (gemm256.hip) by 10 % at K = 768
+// and by 38 % at K = 8192, and its main loop is exactly this shape.  What the shape buys over 8 waves x (128x64):
+//   * LDS fragment traffic per K-tile drops from 8 x 24 KiB to 4 x 32 KiB (a 128x128 register block reuses every
+//     fragment 4 times instead of 2 / 4);
+//   * one instruction stream per SIMD: the matrix pipe never arbitrates between two waves, and the schedule below is
+//     written once, in program order: every MFMA is followed by at most one LDS read or one LDS-DMA piece;
+//   * 2 barriers per K-tile (2,048 matrix-pipe cycles) instead of 4;
+//   * the K-tile stream is CONTINUOUS across output tiles: the DMA head runs two K-tiles ahead of the MFMAs and walks
+//     straight into the next output tile, so a tile's first K-tiles land during the previous tile's last iterations and
+//     its epilogue (no per-tile prologue bubble, no re-fetch of clamped tiles past the end).
+//
+// LDS (160 KiB, all of it): ring of 2 K-tiles x 4 half-tiles (A rows 0-127 / 128-255, W rows 0-127 / 128-255) of 16 KiB,
+// layout as in gemm256.hip (128-B rows, 16-B slot XOR (row>>1)&7, filled by global_load_lds_dwordx4); then 4 x 8 KiB of
+// private epilogue scratch (the ring is never idle here, so the transposition cannot borrow it).
+//
+// One iteration = one K-tile = 16*KS MFMAs per wave, fragments of the tile's first half of k-steps (S0) already in
+// registers:
+//     MFMAs of S0      | after each of the first ones: one fragment read of S1 (second half of k-steps, same tile)
+//     ...              | lgkmcnt(0); BARRIER A: every wave has tile g in registers -> its ring buffer is free
+//     ...              | 16 DMA pieces of tile g+2 into that buffer, one per 64 matrix-pipe cycles
+//     MFMAs of S1      | ...
+//     ...              | vmcnt(pieces of g+2 in flight); BARRIER B: tile g+1 (issued one iteration ago) is in LDS
+//     ...              | fragment reads of S0 of tile g+1
+// (A fragment register is overwritten only after the last MFMA that reads it has been issued; DMA of tile g+2 lands
+// about 1.1 iterations ~ 1 us after it is issued — gemm256 gave it two half-periods, 0.4 us.)
+#include <type_traits>
+#include <utility>
+
+#include "common.h"
+#include "gemm_epilogue.h"
+
+#define VIDIL_EPI_LAZY 1   // gemm_epilogue.inc: bias / activation applied per stored quad, not to all accumulators up front
+
+namespace {
+
+constexpr int SLOT = 16384;       // one half-tile: 128 rows x 128 B
+constexpr int BUF = 4 * SLOT;      // one K-tile: A0, A1, W0, W1
+constexpr int RING_BYTES = 2 * BUF;
+constexpr int LDS_BYTES = RING_BYTES + 4 * 8192;
+
+// compile-time loop: the body sees its index as a constant expression (accumulators and fragments are register arrays —
+// every index into them must be static)
+template <class F, int... Is>
+__device__ __forceinline__ void static_for_impl(F&& f, std::integer_sequence<int, Is...>) {
+  (f(std::integral_constant<int, Is>{}), ...);
+}
+template <int N, class F>
+__device__ __forceinline__ void static_for(F&& f) {
+  static_for_impl(static_cast<F&&>(f), std::make_integer_sequence<int, N>{});
+}
+
+__device__ __forceinline__ void glds16(const void* g, char* lds) {
+  __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)g,
+                                   (__attribute__((address_space(3))) void*)lds, 16, 0, 0);
+}
+
+template <typename T, typename TO, int EPI, int ACT, bool FOLD, bool STATS, bool RLN>
+__global__ __launch_bounds__(256) void gemm4w_kernel(const vidil_gemm_args p) {
+  constexpr bool ROWSTAT = FOLD || RLN;
+  static_assert(!(FOLD && RLN), "a GEMM normalises either its A rows or its residual rows");
+  static_assert(!RLN || EPI == VIDIL_EPI_F32, "the residual exists in the f32 epilogue only");
+  using f16 = TO;
+  using f16x4 = typename Elt<TO>::x4;
+  using f16x8 = typename Elt<TO>::x8;
+  using Frag = typename Mma<T>::Frag;
+  constexpr int KS = Mma<T>::KS;
+  constexpr int ESZ = sizeof(T);
+  constexpr int KT = 128 / ESZ;
+  static_assert(!FOLD || ESZ == 2, "the LayerNorm fold reads 16-bit A fragments");
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int grp = wave >> 1;   // A half: output rows grp*128 ..
+  const int wc2 = wave & 1;    // W half: output columns wc2*128 ..
+  const int hi = lane >> 5, l31 = lane & 31;
+
+  const int M = p.M, N = p.N, K = p.K;
+  const int lda = p.lda > 0 ? p.lda : K;
+  const int tiles_n = (N + 255) >> 8;
+  const int tiles_m = (M + 255) >> 8;
+  // persistent workgroups, XCD-contiguous tile ranges: as gemm256.hip
+  int logical, remaining;
+  const int tile_step = gridDim.x >= 8 ? (gridDim.x >> 3) : 1;
+  {
+    const int nblk = tiles_m * tiles_n;
+    const int bid = blockIdx.x;
+    const int xcd = bid & 7, q = nblk >> 3, r = nblk & 7, slot = bid >> 3;
+    logical = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + slot;
+    remaining = (xcd < r ? q + 1 : q) - slot;
+  }
+  if (remaining <= 0) return;
+  const int nk = K / KT;
+
+  // ---- the DMA head: two K-tiles ahead of the MFMAs, walking this workgroup's tile sequence --------------------------
+  // A thread's 16-B chunk of piece (half-tile hf, instruction i) is row hf*128 + i*32 + (tid >> 3) of the head tile, byte
+  // column c16 of the K-tile.  Only the row (tid >> 3) and c16 live in registers; the offset of a piece is formed when it is
+  // issued — min(row, last valid row) * row pitch + c16, three VALU operations beside 64 cycles of MFMA — on top of a
+  // UNIFORM 64-bit base (the address form `global_load_lds_dwordx4 v_off, s[base:base+1]`).  Sixteen precomputed offsets
+  // (the gemm256 way) were the registers this kernel could not afford: they spilled, and a spill reload in front of a DMA
+  // piece is an `s_waitcnt vmcnt(0)` — a full drain of the stream.
+  int h_r0, h_c16;
+  {
+    const int r0 = tid >> 3, sl = tid & 7;
+    h_r0 = r0;
+    h_c16 = (sl ^ ((r0 >> 1) & 7)) * 16;     // (rows 32 apart share the swizzle)
+  }
+  const char* hbaseA = (const char*)p.A;    // first row of the head tile's A panel / W panel
+  const char* hbaseW = (const char*)p.W;
+  int h_limA = 0, h_limW = 0;               // last valid row of the panel, relative to its first
+  int h_logical = logical, h_remaining = remaining, h_kt = 0, h_buf = 0;
+  bool h_live = true;    // false once the stream has run past the workgroup's last K-tile: the head then keeps re-fetching
+  //                        that last K-tile into the free buffer (two wasted K-tiles per WORKGROUP) so that every
+  //                        iteration issues its 16 pieces unconditionally and the counted waits stay uniform
+  const uint32_t pitchA = (uint32_t)lda * ESZ, pitchW = (uint32_t)K * ESZ;
+  auto head_setup = [&](int lt) {
+    const int tile_m = lt / tiles_n;
+    const int tile_n = lt - tile_m * tiles_n;
+    const int hm0 = tile_m << 8, hn0 = tile_n << 8;
+    hbaseA = (const char*)p.A + (size_t)hm0 * pitchA;
+    hbaseW = (const char*)p.W + (size_t)hn0 * pitchW;
+    h_limA = M - 1 - hm0;
+    h_limW = N - 1 - hn0;
+  };
+  head_setup(logical);
+  // piece pc (0..15) of the head's K-tile: slots W0, W1, A0, A1 in that order, 4 instructions of 4 KiB each
+  auto issue_piece = [&](int pc) {
+    const int sl = pc >> 2, i = pc & 3;
+    char* dst = smem + h_buf * BUF + (sl < 2 ? 2 + sl : sl - 2) * SLOT + i * 4096 + wave * 1024;
+    const int row = h_r0 + (sl & 1) * 128 + i * 32;
+    if (sl < 2) {
+      const int rr = row < h_limW ? row : h_limW;
+      glds16(hbaseW + (size_t)(h_kt * 128) + (uint32_t)(rr * (int)pitchW + h_c16), dst);
+    } else {
+      const int rr = row < h_limA ? row : h_limA;
+      glds16(hbaseA + (size_t)(h_kt * 128) + (uint32_t)(rr * (int)pitchA + h_c16), dst);
+    }
+  };
+  auto head_advance = [&]() {
+    h_buf ^= 1;
+    if (h_live && ++h_kt == nk) {
+      if (h_remaining > tile_step) {
+        h_kt = 0;
+        h_logical += tile_step;
+        h_remaining -= tile_step;
+        head_setup(h_logical);
+      } else {
+        h_kt = nk - 1;
+        h_live = false;
+      }
+    }
+  };
+
+  f32x16 accA[4][2], accB[4][2];   // output columns 0-63 / 64-127 of the wave's block
+#define ACC(i, j) ((j) < 2 ? accA[i][(j) & 1] : accB[i][(j) & 1])
+  float st_s[4], st_ss[4];
+  f32x2 st_raw[4][4];
+
+  const int sw = (l31 >> 1) & 7;
+  const int a_off = grp * SLOT + l31 * 128;
+  const int w_off = (2 + wc2) * SLOT + l31 * 128;
+  Frag fa[KS][4], fw[KS][4];
+  constexpr int KH = KS / 2;           // k-steps per fragment set
+  constexpr int NM = 16 * KS;          // MFMAs per K-tile per wave
+  constexpr int NFR = KH * 8;          // fragments per set
+  constexpr int STEP = ESZ == 2 ? 2 : 1;            // MFMAs per DMA piece (64 matrix-pipe cycles either way)
+  constexpr int T_A = ESZ == 2 ? 21 : 10;           // barrier A goes after this MFMA
+  constexpr int T_B = T_A + 16 * STEP;              // barrier B goes after this MFMA
+  static_assert(T_B < NM - 2 && NFR <= T_A, "schedule");
+  auto read_frag = [&](const char* buf, int ks, int r) {     // r: 0-3 = W column tiles, 4-7 = A row tiles
+    if (r < 4) fw[ks][r] = Mma<T>::load(buf + w_off + r * 4096, ks, hi, sw);
+    else fa[ks][r - 4] = Mma<T>::load(buf + a_off + (r - 4) * 4096, ks, hi, sw);
+  };
+
+  // ---- start of the stream: tiles 0 and 1, then S0 of tile 0 ------------------------------------------------------
+#pragma unroll
+  for (int pc = 0; pc < 16; ++pc) issue_piece(pc);
+  head_advance();
+#pragma unroll
+  for (int pc = 0; pc < 16; ++pc) issue_piece(pc);
+  head_advance();
+  asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
+  __builtin_amdgcn_s_barrier();
+  int cb = 0;   // ring buffer of the tile the MFMAs are on
+
+  for (;;) {   // ======================================================================== one output tile
+    const int tile_m = logical / tiles_n;
+    const int tile_n = logical - tile_m * tiles_n;
+    const int m0 = tile_m << 8, n0 = tile_n << 8;
+    if constexpr (ROWSTAT) {
+      // this wave's share of the producer's row partials (the two waves of a row group and their half-waves take every
+      // fourth part): issued here, summed after the main loop
+      const int nparts = (FOLD ? K : N) >> 6;   // <= 16
+      const f32x2* stats_in = (const f32x2*)p.ln_stats;
+      const int part0 = wc2 + 2 * hi;
+#pragma unroll
+      for (int it = 0; it < 4; ++it) {
+        int row = m0 + grp * 128 + it * 32 + l31;
+        row = row < M ? row : M - 1;
+#pragma unroll
+        for (int q = 0; q < 4; ++q)
+          st_raw[it][q] = part0 + 4 * q < nparts ? stats_in[(size_t)row * nparts + part0 + 4 * q] : f32x2{0.f, 0.f};
+      }
+    }
+
+    // S0 of the tile's first K-tile (landed and visible since barrier B of the previous iteration / the start of the
+    // stream).  Not fetched ahead across the epilogue: 64 live registers there cost more than this exposed LDS latency.
+    static_for<NFR>([&](auto f_tag) {
+      constexpr int f = decltype(f_tag)::value;
+      read_frag(smem + cb * BUF, f / 8, f % 8);
+    });
+    auto iteration = [&](auto first_tag, auto last_tag) {
+      constexpr bool FIRST = decltype(first_tag)::value;   // first K-tile of an output tile: its first k-step starts from zero
+      constexpr bool LAST = decltype(last_tag)::value;     // last K-tile: no fragment reads for a next one
+      const char* const buf = smem + cb * BUF;
+      const char* const nbuf = smem + (cb ^ 1) * BUF;
+      static_for<NM>([&](auto n_tag) {
+        constexpr int n = decltype(n_tag)::value;
+        constexpr int ks = n >> 4, i = (n >> 2) & 3, j = n & 3;
+        if constexpr (FIRST && ks == 0) {
+          const f32x16 zero = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+          ACC(i, j) = Mma<T>::mma(fw[ks][j], fa[ks][i], zero);
+        } else {
+          ACC(i, j) = Mma<T>::mma(fw[ks][j], fa[ks][i], ACC(i, j));
+        }
+        if constexpr (n < NFR) read_frag(buf, KH + n / 8, n % 8);               // S1 of this tile
+        if constexpr (n == T_A) {
+          __builtin_amdgcn_s_waitcnt(0xC07F);                                    // lgkmcnt(0)
+          __builtin_amdgcn_s_barrier();
+        }
+        if constexpr (n > T_A && n <= T_B && (n - T_A - 1) % STEP == 0) {
+          constexpr int pc = (n - T_A - 1) / STEP;
+          issue_piece(pc);
+          if constexpr (pc == 15) head_advance();
+        }
+        if constexpr (n == T_B + 1) {
+          asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
+          __builtin_amdgcn_s_barrier();
+        }
+        if constexpr (n > T_B + 1 && !LAST) {                                    // S0 of the next K-tile
+          constexpr int SLOTS = NM - T_B - 2;
+          constexpr int PER = (NFR + SLOTS - 1) / SLOTS;
+          constexpr int s = n - T_B - 2;
+          static_for<PER>([&](auto q_tag) {
+            constexpr int f = s * PER + decltype(q_tag)::value;
+            if constexpr (f < NFR) read_frag(nbuf, f / 8, f % 8);
+          });
+        }
+        __builtin_amdgcn_sched_barrier(0);
+      });
+      cb ^= 1;
+    };
+    if (nk == 1) {
+      iteration(std::true_type{}, std::true_type{});
+    } else {
+      iteration(std::true_type{}, std::false_type{});
+      for (int u = 2; u < nk; ++u) iteration(std::false_type{}, std::false_type{});
+      iteration(std::false_type{}, std::true_type{});
+    }
+
+    if constexpr (ROWSTAT) {
+      // row statistics, in gemm256's summation order (the two kernels agree bit for bit): half-wave (wc2, hi) plays
+      // gemm256's wave w = wc2 + 2*hi — parts {w, w+8} then {w+4, w+12} — and the four per-"wave" sums meet in LDS (the
+      // start of the epilogue scratch; a second barrier keeps wave 0's transposition from overwriting it under a late
+      // reader) and are added in the order w = 0..3
+      f32x2* stats = (f32x2*)(smem + RING_BYTES);
+#pragma unroll
+      for (int it = 0; it < 4; ++it) {
+        const float s = (st_raw[it][0][0] + st_raw[it][2][0]) + (st_raw[it][1][0] + st_raw[it][3][0]);
+        const float ss = (st_raw[it][0][1] + st_raw[it][2][1]) + (st_raw[it][1][1] + st_raw[it][3][1]);
+        stats[(grp * 4 + wc2 + 2 * hi) * 128 + it * 32 + l31] = f32x2{s, ss};
+      }
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      __builtin_amdgcn_s_barrier();
+      const float inv_k = 1.0f / (float)(FOLD ? K : N);
+#pragma unroll
+      for (int it = 0; it < 4; ++it) {
+        float s = 0.f, ss = 0.f;
+#pragma unroll
+        for (int w = 0; w < 4; ++w) {
+          const f32x2 v = stats[(grp * 4 + w) * 128 + it * 32 + l31];
+          s += v[0];
+          ss += v[1];
+        }
+        const float mean = s * inv_k;
+        float var = ss * inv_k - mean * mean;
+        var = var > 0.f ? var : 0.f;
+        const float rstd = 1.0f / sqrtf(var + p.ln_eps);
+        st_s[it] = rstd;
+        st_ss[it] = mean * rstd;
+      }
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      __builtin_amdgcn_s_barrier();
+    }
+
+    // ================================================================================ epilogue: two 128x64 halves
+    const int m_w = m0 + grp * 128;
+    char* const ep = smem + RING_BYTES + wave * 8192;
+#if defined(VIDIL_4W_ABLATE) && VIDIL_4W_ABLATE == 1
+    if (p.M > 0) {   // developer ablation: no epilogue (one dword per lane keeps the accumulators alive)
+      float s = 0.f;
+#pragma unroll
+      for (int it = 0; it < 4; ++it)
+#pragma unroll
+        for (int j = 0; j < 2; ++j) s += accA[it][j][0] + accB[it][j][5];
+      if (s == 123.456f) ((float*)p.out)[lane] = s;
+    } else
+#endif
+    {
+    // The epilogue's lane-dependent address arithmetic is tile-invariant; hoisted out of the tile loop it would sit in
+    // ~100 registers across the main loop and be spilled — and a spill reload between global stores costs an
+    // `s_waitcnt vmcnt(0)`, i.e. a wait for every store issued so far (measured: 11 us per tile instead of 4).  A fresh
+    // lane id per tile from volatile asm pins that arithmetic inside the epilogue.
+    int lane_e;
+    asm volatile("v_mbcnt_lo_u32_b32 %0, -1, 0\n\tv_mbcnt_hi_u32_b32 %0, -1, %0" : "=v"(lane_e));
+    const int lane = lane_e, hi = lane_e >> 5, l31 = lane_e & 31;
+#if defined(VIDIL_4W_ABLATE) && VIDIL_4W_ABLATE == 2
+    const int M = p.M > 0 ? 0 : 1;    // developer ablation: the whole epilogue except its global stores (every row is "past M")
+#endif
+    {
+      const int n_w = n0 + wc2 * 128;
+      do {
+#define acc accA
+#include "gemm_epilogue.inc"
+#undef acc
+      } while (0);
+    }
+    {
+      const int n_w = n0 + wc2 * 128 + 64;
+      do {
+#define acc accB
+#include "gemm_epilogue.inc"
+#undef acc
+      } while (0);
+    }
+    }
+    if (remaining <= tile_step) break;
+    logical += tile_step;
+    remaining -= tile_step;
+    // No drain of the epilogue's stores here: they share vmcnt with the LDS-DMA stream, and a counted wait with stores
+    // still pending is merely conservative (loads complete in order among themselves, so "at most 16 operations
+    // outstanding" still implies every DMA piece older than the newest 16 has landed; pending stores only make the
+    // wait stricter).  The first MFMAs of the next tile run while this tile's stores are acknowledged.
+  }
+#undef ACC
+}
+
+template <typename T, int EPI, int ACT, bool FOLD = false, typename TO = T, bool STATS = false, bool RLN = false>
+int launch4w(const vidil_gemm_args& a, hipStream_t s) {
+  static bool attr_set = false;
+  auto kern = gemm4w_kernel<T, TO, EPI, ACT, FOLD, STATS, RLN>;
+  if (!attr_set) {
+    hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES);
+    if (e != hipSuccess) {
+      vidil_set_error("gemm4w: hipFuncSetAttribute failed: %s", hipGetErrorString(e));
+      return VIDIL_ELAUNCH;
+    }
+    attr_set = true;
+  }
+  static int num_cu = 0;
+  if (num_cu == 0) {
+    int dev = 0, n = 0;
+    if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n < 8)
+      n = 256;
+    num_cu = n & ~7;
+  }
+  int cus = num_cu;
+  if (const char* e = getenv("VIDIL_GEMM_CUS")) {
+    const int v = atoi(e) & ~7;
+    if (v >= 8 && v < cus) cus = v;
+  }
+  const int ntiles = ((a.M + 255) / 256) * ((a.N + 255) / 256);
+  const int tiles = ntiles >= cus ? cus : (ntiles >= 8 ? (ntiles & ~7) : ntiles);
+  hipLaunchKernelGGL(kern, dim3(tiles), dim3(256), LDS_BYTES, s, a);
+  VIDIL_CHECK_LAUNCH("gemm4w");
+  return VIDIL_OK;
+}
+
+template <typename T>
+int launch4w_dispatch(const vidil_gemm_args& a, hipStream_t s) {
+  if (a.ln_fold) {
+    if (a.epi == VIDIL_EPI_HEADS) return launch4w<T, VIDIL_EPI_HEADS, VIDIL_ACT_NONE, true>(a, s);
+    if (a.act == VIDIL_ACT_NONE) return launch4w<T, VIDIL_EPI_F16, VIDIL_ACT_NONE, true>(a, s);
+    if (a.act == VIDIL_ACT_GELU_ERF) return launch4w<T, VIDIL_EPI_F16, VIDIL_ACT_GELU_ERF, true>(a, s);
+    return launch4w<T, VIDIL_EPI_F16, VIDIL_ACT_QUICK_GELU, true>(a, s);
+  }
+  switch (a.epi) {
+    case VIDIL_EPI_F16:
+      if (a.act == VIDIL_ACT_NONE) return launch4w<T, VIDIL_EPI_F16, VIDIL_ACT_NONE>(a, s);
+      if (a.act == VIDIL_ACT_GELU_ERF) return launch4w<T, VIDIL_EPI_F16, VIDIL_ACT_GELU_ERF>(a, s);
+      return launch4w<T, VIDIL_EPI_F16, VIDIL_ACT_QUICK_GELU>(a, s);
+    case VIDIL_EPI_F32:
+      if (a.rln_gamma) return launch4w<T, VIDIL_EPI_F32, VIDIL_ACT_NONE, false, T, true, true>(a, s);
+      if (a.ln_stats_out) return launch4w<T, VIDIL_EPI_F32, VIDIL_ACT_NONE, false, T, true>(a, s);
+      if (a.act == VIDIL_ACT_NONE) return launch4w<T, VIDIL_EPI_F32, VIDIL_ACT_NONE>(a, s);
+      if (a.act == VIDIL_ACT_GELU_ERF) return launch4w<T, VIDIL_EPI_F32, VIDIL_ACT_GELU_ERF>(a, s);
+      return launch4w<T, VIDIL_EPI_F32, VIDIL_ACT_QUICK_GELU>(a, s);
+    case VIDIL_EPI_HEADS:
+      return launch4w<T, VIDIL_EPI_HEADS, VIDIL_ACT_NONE>(a, s);
+    default:
+      return launch4w<T, VIDIL_EPI_PATCH, VIDIL_ACT_NONE>(a, s);
+  }
+}
+
+}  // namespace
+
+int vidil_gemm4w_launch(const vidil_gemm_args& a, hipStream_t s) {
+  if (a.dtype == VIDIL_DT_FP8) return -1000;
+  if (a.dtype == VIDIL_DT_BF16) return launch4w_dispatch<bf16>(a, s);
+  return launch4w_dispatch<f16>(a, s);
+}
