@@ -195,6 +195,34 @@ __device__ __forceinline__ float gelu_fast1(float x) {
 // is 52 VALU cycles per value against 62 for the A&S erf with its two quarter-rate transcendentals: +3 % on that kernel
 // in situ, 785 -> 811 TFLOP/s.)
 __device__ __forceinline__ f32x2 gelu_fast2(f32x2 x) { return f32x2{gelu_fast1(x[0]), gelu_fast1(x[1])}; }
+// The same polynomial on a PAIR with packed-f32 arithmetic (v_pk_mul_f32 / v_pk_fma_f32: two values per 4-cycle issue) —
+// the same IEEE operations per element as gelu_fast1, so the results are bit-identical.  For kernels with registers to
+// spare for the nine splatted coefficients (gemm4w.hip's epilogue; gemm256's LN-folded GELU instantiation spilled 461
+// registers on it).  Only the clamp stays scalar (no packed min / max on gfx950).
+// NP pairs are evaluated in LOCKSTEP (every Horner step for all pairs before the next step): a wave alone on its SIMD
+// has nobody to fill the dependent-issue gaps of one serial chain (each packed step waits for the previous one), so the
+// instruction-level parallelism has to be in the program order.
+template <int NP>
+__device__ __forceinline__ void gelu_fast2p_n(f32x2 (&x)[NP]) {
+  f32x2 xc[NP], s[NP], p[NP];
+#pragma unroll
+  for (int i = 0; i < NP; ++i) xc[i] = f32x2{__builtin_amdgcn_fmed3f(x[i][0], -4.5f, 4.5f), __builtin_amdgcn_fmed3f(x[i][1], -4.5f, 4.5f)};
+#pragma unroll
+  for (int i = 0; i < NP; ++i) s[i] = xc[i] * pk_splat(1.0f / 4.5f);
+#pragma unroll
+  for (int i = 0; i < NP; ++i) s[i] = s[i] * s[i];
+#pragma unroll
+  for (int i = 0; i < NP; ++i) p[i] = pk_fma(pk_splat(8.050480127e-01f), s[i], pk_splat(-4.390279192e+00f));
+  constexpr float C[7] = {1.052993543e+01f, -1.471975757e+01f, 1.343790172e+01f, -8.530106592e+00f, 3.914417810e+00f, -1.334714149e+00f, 3.986656381e-01f};
+#pragma unroll
+  for (int k = 0; k < 7; ++k)
+#pragma unroll
+    for (int i = 0; i < NP; ++i) p[i] = pk_fma(p[i], s[i], pk_splat(C[k]));
+#pragma unroll
+  for (int i = 0; i < NP; ++i) p[i] = pk_fma(xc[i], p[i], pk_splat(0.5f));
+#pragma unroll
+  for (int i = 0; i < NP; ++i) x[i] = x[i] * p[i];
+}
 __device__ __forceinline__ f32x2 quick_gelu2(f32x2 x) {
   const f32x2 arg = x * pk_splat(-1.702f * 1.4426950408889634f);   // exp(-1.702 x) as a power of two
   const f32x2 d = f32x2{__builtin_amdgcn_exp2f(arg[0]), __builtin_amdgcn_exp2f(arg[1])} + pk_splat(1.0f);

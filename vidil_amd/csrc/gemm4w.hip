@@ -157,7 +157,7 @@ __global__ __launch_bounds__(256) void gemm4w_kernel(const vidil_gemm_args p) {
   f32x16 accA[4][2], accB[4][2];   // output columns 0-63 / 64-127 of the wave's block
 #define ACC(i, j) ((j) < 2 ? accA[i][(j) & 1] : accB[i][(j) & 1])
   float st_s[4], st_ss[4];
-  f32x2 st_raw[4][4];
+  f32x2 st_raw[4][4], st_sum[4];
 
   const int sw = (l31 >> 1) & 7;
   const int a_off = grp * SLOT + l31 * 128;
@@ -190,22 +190,6 @@ __global__ __launch_bounds__(256) void gemm4w_kernel(const vidil_gemm_args p) {
     const int tile_m = logical / tiles_n;
     const int tile_n = logical - tile_m * tiles_n;
     const int m0 = tile_m << 8, n0 = tile_n << 8;
-    if constexpr (ROWSTAT) {
-      // this wave's share of the producer's row partials (the two waves of a row group and their half-waves take every
-      // fourth part): issued here, summed after the main loop
-      const int nparts = (FOLD ? K : N) >> 6;   // <= 16
-      const f32x2* stats_in = (const f32x2*)p.ln_stats;
-      const int part0 = wc2 + 2 * hi;
-#pragma unroll
-      for (int it = 0; it < 4; ++it) {
-        int row = m0 + grp * 128 + it * 32 + l31;
-        row = row < M ? row : M - 1;
-#pragma unroll
-        for (int q = 0; q < 4; ++q)
-          st_raw[it][q] = part0 + 4 * q < nparts ? stats_in[(size_t)row * nparts + part0 + 4 * q] : f32x2{0.f, 0.f};
-      }
-    }
-
     // S0 of the tile's first K-tile (landed and visible since barrier B of the previous iteration / the start of the
     // stream).  Not fetched ahead across the epilogue: 64 live registers there cost more than this exposed LDS latency.
     static_for<NFR>([&](auto f_tag) {
@@ -236,9 +220,56 @@ __global__ __launch_bounds__(256) void gemm4w_kernel(const vidil_gemm_args p) {
           issue_piece(pc);
           if constexpr (pc == 15) head_advance();
         }
+        if constexpr (ROWSTAT && LAST && n == 0) {
+          // this half-wave's share of the producer's row partials (half-wave (wc2, hi) takes parts w, w+4, w+8, w+12 with
+          // w = wc2 + 2*hi): issued at the top of the LAST K-tile (carried from the top of the output tile they were spilled
+          // across the main loop), ahead of this iteration's DMA pieces, and summed behind barrier B below — where
+          // "at most 16 operations in flight" already implies they have arrived, so no wait drains the DMA stream for them
+          const int nparts = (FOLD ? K : N) >> 6;   // <= 16
+          const f32x2* stats_in = (const f32x2*)p.ln_stats;
+          int lane_s;   // (a fresh lane id: values derived from the kernel's own would be spilled across the main loop, and
+          //               their reload HERE would be an `s_waitcnt vmcnt(0)` in the middle of the DMA stream)
+          asm volatile("v_mbcnt_lo_u32_b32 %0, -1, 0\n\tv_mbcnt_hi_u32_b32 %0, -1, %0" : "=v"(lane_s));
+          const int hi = lane_s >> 5, l31 = lane_s & 31;
+          const int part0 = wc2 + 2 * hi;
+#pragma unroll
+          for (int it = 0; it < 4; ++it) {
+            int row = m0 + grp * 128 + it * 32 + l31;
+            row = row < M ? row : M - 1;
+            // (straight-line loads, the part index clamped: parts past the end are masked where the sums are taken —
+            //  a load in an exec-masked block would be waited for with vmcnt(0), draining the DMA stream mid-iteration)
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+              const int part = part0 + 4 * q;
+              // (the load itself in inline asm: the compiler waits for a load it knows about with vmcnt(0) once LDS-DMA
+              //  pieces are in flight beside it — it does not count across the two kinds — and that drains the stream;
+              //  the wait that covers these loads is barrier B's vmcnt(16), they are older than its 16 pieces)
+              const f32x2* src = stats_in + (size_t)row * nparts + (part < nparts ? part : nparts - 1);
+              asm volatile("global_load_dwordx2 %0, %1, off" : "=v"(st_raw[it][q]) : "v"(src));
+            }
+          }
+        }
         if constexpr (n == T_B + 1) {
+          // tile g+1 has landed once nothing older than this iteration's 16 DMA pieces is in flight
           asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
           __builtin_amdgcn_s_barrier();
+        }
+        if constexpr (ROWSTAT && LAST && n == T_B + 2) {
+          // the half-wave's sums, in gemm256's order: parts {w, w+8} then {w+4, w+12}; parts past the end count as zero
+          int lane_s;
+          asm volatile("v_mbcnt_lo_u32_b32 %0, -1, 0\n\tv_mbcnt_hi_u32_b32 %0, -1, %0" : "=v"(lane_s));
+          const int nparts = (FOLD ? K : N) >> 6;
+          const int part0 = wc2 + 2 * (lane_s >> 5);
+#pragma unroll
+          for (int it = 0; it < 4; ++it) {
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+              asm volatile("" : "+v"(st_raw[it][q]));   // (the loaded value exists from here on: behind barrier B's wait)
+              if (part0 + 4 * q >= nparts) st_raw[it][q] = f32x2{0.f, 0.f};
+            }
+            st_sum[it] = f32x2{(st_raw[it][0][0] + st_raw[it][2][0]) + (st_raw[it][1][0] + st_raw[it][3][0]),
+                               (st_raw[it][0][1] + st_raw[it][2][1]) + (st_raw[it][1][1] + st_raw[it][3][1])};
+          }
         }
         if constexpr (n > T_B + 1 && !LAST) {                                    // S0 of the next K-tile
           constexpr int SLOTS = NM - T_B - 2;
@@ -261,6 +292,13 @@ __global__ __launch_bounds__(256) void gemm4w_kernel(const vidil_gemm_args p) {
       iteration(std::false_type{}, std::true_type{});
     }
 
+    // Everything after the main loop works from a FRESH lane id (volatile asm): its lane-dependent address arithmetic is
+    // tile-invariant, and hoisted out of the tile loop it would sit in ~100 registers across the main loop and be spilled
+    // — a spill reload between global stores (or right after the loop, with DMA in flight) costs an `s_waitcnt vmcnt(0)`,
+    // i.e. a wait for every store / DMA piece issued so far (measured: 11 us per tile instead of 4).
+    int lane_e;
+    asm volatile("v_mbcnt_lo_u32_b32 %0, -1, 0\n\tv_mbcnt_hi_u32_b32 %0, -1, %0" : "=v"(lane_e));
+    const int lane = lane_e, hi = lane_e >> 5, l31 = lane_e & 31;
     if constexpr (ROWSTAT) {
       // row statistics, in gemm256's summation order (the two kernels agree bit for bit): half-wave (wc2, hi) plays
       // gemm256's wave w = wc2 + 2*hi — parts {w, w+8} then {w+4, w+12} — and the four per-"wave" sums meet in LDS (the
@@ -268,11 +306,7 @@ __global__ __launch_bounds__(256) void gemm4w_kernel(const vidil_gemm_args p) {
       // reader) and are added in the order w = 0..3
       f32x2* stats = (f32x2*)(smem + RING_BYTES);
 #pragma unroll
-      for (int it = 0; it < 4; ++it) {
-        const float s = (st_raw[it][0][0] + st_raw[it][2][0]) + (st_raw[it][1][0] + st_raw[it][3][0]);
-        const float ss = (st_raw[it][0][1] + st_raw[it][2][1]) + (st_raw[it][1][1] + st_raw[it][3][1]);
-        stats[(grp * 4 + wc2 + 2 * hi) * 128 + it * 32 + l31] = f32x2{s, ss};
-      }
+      for (int it = 0; it < 4; ++it) stats[(grp * 4 + wc2 + 2 * hi) * 128 + it * 32 + l31] = st_sum[it];
       asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
       __builtin_amdgcn_s_barrier();
       const float inv_k = 1.0f / (float)(FOLD ? K : N);
@@ -310,13 +344,6 @@ __global__ __launch_bounds__(256) void gemm4w_kernel(const vidil_gemm_args p) {
     } else
 #endif
     {
-    // The epilogue's lane-dependent address arithmetic is tile-invariant; hoisted out of the tile loop it would sit in
-    // ~100 registers across the main loop and be spilled — and a spill reload between global stores costs an
-    // `s_waitcnt vmcnt(0)`, i.e. a wait for every store issued so far (measured: 11 us per tile instead of 4).  A fresh
-    // lane id per tile from volatile asm pins that arithmetic inside the epilogue.
-    int lane_e;
-    asm volatile("v_mbcnt_lo_u32_b32 %0, -1, 0\n\tv_mbcnt_hi_u32_b32 %0, -1, %0" : "=v"(lane_e));
-    const int lane = lane_e, hi = lane_e >> 5, l31 = lane_e & 31;
 #if defined(VIDIL_4W_ABLATE) && VIDIL_4W_ABLATE == 2
     const int M = p.M > 0 ? 0 : 1;    // developer ablation: the whole epilogue except its global stores (every row is "past M")
 #endif
