@@ -1,6 +1,8 @@
-"""The 4-wave GEMM kernel (csrc/gemm4w.hip: 256x256 tiles over four waves with 128x128 register blocks, one continuous
-K-tile stream) must be BIT-IDENTICAL to the 8-wave kernel (gemm256.hip) — same k order per output element, same epilogue
-arithmetic — for every epilogue of the hot path, both 16-bit operand types, ragged M / N, 2 to 48 K-tiles.
+"""The two 256x256 GEMM kernels of the library — gemm4w.hip (four waves with 128x128 register blocks, one continuous K-tile
+stream, lazily evaluated packed epilogue) and gemm256.hip (eight waves, staggered groups) — must be BIT-IDENTICAL: same k
+order per output element, same epilogue arithmetic (gemm_epilogue.inc in its two forms), same LayerNorm statistics order —
+for every epilogue of the hot path, both 16-bit operand types, ragged M / N, 2 to 48 K-tiles.  The dispatch
+(vidil_gemm256_variant) may then pick either by speed alone; $VIDIL_GEMM4W = 0 / 1 forces one.
 Reference ops: nn.Linear calls of models/vit.py:35-41,72,84 and models/med.py:153-171,236,301,314."""
 import os
 
@@ -179,7 +181,7 @@ def test_gemm4w_patch_epilogue_and_plain_heads_equal_gemm256():
     assert torch.equal(ref, got)
 
 
-def test_gemm4w_repeated_launches_are_deterministic_and_race_free():
+def test_gemm4w_repeated_launches_are_deterministic_and_race_free(monkeypatch):
     """The two wave groups hand stream elements over through one barrier per K-tile: 20 launches of a shape with many
     tiles per workgroup and an odd tile count give the same bits every time, and the right ones."""
     k = _k()
@@ -187,7 +189,8 @@ def test_gemm4w_repeated_launches_are_deterministic_and_race_free():
     a = _rand(M, K, seed=40).half().to(DEV)
     w = _rand(N, K, scale=0.05, seed=41).half().to(DEV)
     bias = _rand(N, seed=42).to(DEV)
-    os.environ["VIDIL_GEMM4W"] = "1"
+    monkeypatch.setenv("VIDIL_GEMM4W", "1")
+    assert k.gemm_kernel_name(a, w, bias, act=k.ACT_GELU_ERF).startswith("gemm4w_kernel")
     first = k.gemm(a, w, bias, act=k.ACT_GELU_ERF)
     for _ in range(20):
         assert torch.equal(k.gemm(a, w, bias, act=k.ACT_GELU_ERF), first)

@@ -758,7 +758,7 @@ def test_gemm_layernorm_fold_consumer_vs_torch(dtype, M, D, N, act):
     code = dict(gelu=k.ACT_GELU_ERF, quick=k.ACT_QUICK_GELU, none=k.ACT_NONE)[act]
     st = _row_partials(x16.float()).to(DEV)
     out = k.gemm(x16.to(DEV), wf.to(DEV), bf.to(DEV), act=code, ln=(cs.to(DEV), 1e-6, st))
-    assert k.gemm_kernel_name(x16.to(DEV), wf.to(DEV), bf.to(DEV), act=code, ln=(cs.to(DEV), 1e-6, st)).startswith("gemm256_kernel")
+    assert k.gemm_kernel_name(x16.to(DEV), wf.to(DEV), bf.to(DEV), act=code, ln=(cs.to(DEV), 1e-6, st)).startswith(("gemm256_kernel", "gemm4w_kernel"))
     # reference: exact LayerNorm of the SAME 16-bit stream values, fp32 weights
     pre = torch.nn.functional.layer_norm(x16.float(), (D,), g, bt, 1e-6) @ w.t() + b
     ref = dict(gelu=torch.nn.functional.gelu(pre), quick=pre * torch.sigmoid(1.702 * pre), none=pre)[act]

@@ -23,6 +23,7 @@ void vidil_set_error(const char* fmt, ...);
 // gemm256.hip: the 256x256 8-wave kernel for large problems (dispatched from vidil_gemm_f16)
 bool vidil_gemm256_eligible(const vidil_gemm_args& a, bool any_size = false);
 int vidil_gemm256_launch(const vidil_gemm_args& a, hipStream_t s);
+const char* vidil_gemm256_variant(const vidil_gemm_args& a);   // "gemm256_kernel" or "gemm4w_kernel": which of the two runs it
 
 #define VIDIL_REQUIRE(cond, ...)                \
   do {                                          \

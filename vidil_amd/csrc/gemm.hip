@@ -497,8 +497,8 @@ extern "C" int vidil_gemm_kernel_name(const vidil_gemm_args* args, char* buf_hos
   const char* t = args->dtype == VIDIL_DT_FP8 ? "fp8" : t16;                 // the spelling rocprofv3 demangles to
   const int act = (args->epi == VIDIL_EPI_F16 || args->epi == VIDIL_EPI_F32 || args->epi == VIDIL_EPI_F8) ? args->act : 0;
   const char* stats = (args->ln_stats_out && args->epi == VIDIL_EPI_F32) ? "true" : "false";
-  if (c.big) snprintf(buf_host, n, "gemm256_kernel<%s, %s, %d, %d, %s, %s, %s>", t, t16, args->epi, act, args->ln_fold ? "true" : "false",
-                      stats, args->rln_gamma ? "true" : "false");
+  if (c.big) snprintf(buf_host, n, "%s<%s, %s, %d, %d, %s, %s, %s>", vidil_gemm256_variant(*args), t, t16, args->epi, act,
+                      args->ln_fold ? "true" : "false", stats, args->rln_gamma ? "true" : "false");
   else snprintf(buf_host, n, "gemm_kernel<%s, %d, %d, %d, %d, %d>", t, c.bm, c.bn, c.st, args->epi, act);
   return VIDIL_OK;
 }

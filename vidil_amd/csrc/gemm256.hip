@@ -473,10 +473,33 @@ static int launch256_fp8(const vidil_gemm_args& a, hipStream_t s) {
 
 int vidil_gemm4w_launch(const vidil_gemm_args& a, hipStream_t s);   // gemm4w.hip; -1000: variant not built there
 
+// Which of the two 256x256 kernels runs a problem (both produce the same bits — tests/test_gemm4w_gpu.py).  The 4-wave
+// kernel (gemm4w.hip) has the faster main loop (-13 % per K-tile) and a continuous K-tile stream, the 8-wave kernel hides
+// memory latency in its epilogue with two waves per SIMD and starts up faster: measured on the same box inside the
+// bench (profiles/r3_gemm4w_ab.md), gemm4w wins on the LN-folded consumers (-7 % on fc1 + GELU), the f32 + residual +
+// row-partials producer (-4 %) and the per-head scatter (-2..3 %) once there are a few tiles per CU, and loses on the
+// residual-LayerNorm and plain f32 epilogues and on small grids.  $VIDIL_GEMM4W = 0 / 1 forces one kernel (developer).
+static bool prefer_4w(const vidil_gemm_args& a) {
+  if (const char* e = getenv("VIDIL_GEMM4W")) return atoi(e) != 0;
+  if (a.dtype == VIDIL_DT_FP8) return false;
+  const long tiles = (long)((a.M + 255) / 256) * ((a.N + 255) / 256);
+  if (tiles < 512) return false;
+  if (a.ln_fold) return true;
+  switch (a.epi) {
+    case VIDIL_EPI_F16:
+    case VIDIL_EPI_HEADS:
+      return true;
+    case VIDIL_EPI_F32:
+      return a.ln_stats_out != nullptr && a.rln_gamma == nullptr;
+    default:
+      return false;
+  }
+}
+
+const char* vidil_gemm256_variant(const vidil_gemm_args& a) { return prefer_4w(a) ? "gemm4w_kernel" : "gemm256_kernel"; }
+
 int vidil_gemm256_launch(const vidil_gemm_args& a, hipStream_t s) {
-  const char* e4w = getenv("VIDIL_GEMM4W");
-  const bool use4w = e4w && atoi(e4w) != 0;
-  if (use4w) {
+  if (prefer_4w(a)) {
     const int rc = vidil_gemm4w_launch(a, s);
     if (rc != -1000) return rc;
   }
