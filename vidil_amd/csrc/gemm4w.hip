@@ -131,6 +131,9 @@ __global__ __launch_bounds__(256) void gemm4w_kernel(const vidil_gemm_args p) {
     const int sl = pc >> 2, i = pc & 3;
     char* dst = smem + h_buf * BUF + (sl < 2 ? 2 + sl : sl - 2) * SLOT + i * 4096 + wave * 1024;
     const int row = h_r0 + (sl & 1) * 128 + i * 32;
+#if defined(VIDIL_4W_ABLATE) && (VIDIL_4W_ABLATE & 4)
+    if (p.M > 0) return;     // developer ablation: no DMA (the MFMAs run on whatever LDS holds)
+#endif
     if (sl < 2) {
       const int rr = row < h_limW ? row : h_limW;
       glds16(hbaseW + (size_t)(h_kt * 128) + (uint32_t)(rr * (int)pitchW + h_c16), dst);
@@ -171,6 +174,9 @@ __global__ __launch_bounds__(256) void gemm4w_kernel(const vidil_gemm_args p) {
   constexpr int T_B = T_A + 16 * STEP;              // barrier B goes after this MFMA
   static_assert(T_B < NM - 2 && NFR <= T_A, "schedule");
   auto read_frag = [&](const char* buf, int ks, int r) {     // r: 0-3 = W column tiles, 4-7 = A row tiles
+#if defined(VIDIL_4W_ABLATE) && (VIDIL_4W_ABLATE & 8)
+    if (p.M > 0) return;     // developer ablation: no fragment reads
+#endif
     if (r < 4) fw[ks][r] = Mma<T>::load(buf + w_off + r * 4096, ks, hi, sw);
     else fa[ks][r - 4] = Mma<T>::load(buf + a_off + (r - 4) * 4096, ks, hi, sw);
   };
@@ -333,7 +339,7 @@ __global__ __launch_bounds__(256) void gemm4w_kernel(const vidil_gemm_args p) {
     // ================================================================================ epilogue: two 128x64 halves
     const int m_w = m0 + grp * 128;
     char* const ep = smem + RING_BYTES + wave * 8192;
-#if defined(VIDIL_4W_ABLATE) && VIDIL_4W_ABLATE == 1
+#if defined(VIDIL_4W_ABLATE) && (VIDIL_4W_ABLATE & 1)
     if (p.M > 0) {   // developer ablation: no epilogue (one dword per lane keeps the accumulators alive)
       float s = 0.f;
 #pragma unroll
@@ -344,7 +350,7 @@ __global__ __launch_bounds__(256) void gemm4w_kernel(const vidil_gemm_args p) {
     } else
 #endif
     {
-#if defined(VIDIL_4W_ABLATE) && VIDIL_4W_ABLATE == 2
+#if defined(VIDIL_4W_ABLATE) && (VIDIL_4W_ABLATE & 2)
     const int M = p.M > 0 ? 0 : 1;    // developer ablation: the whole epilogue except its global stores (every row is "past M")
 #endif
     {
