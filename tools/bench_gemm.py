@@ -43,7 +43,7 @@ def calibrate(dev, M, dtypes=(torch.float16, torch.bfloat16)):
             t_own = timeit(lambda: K.gemm(a, w, None, out=o))
             f = 2.0 * m * n * k / 1e12
             print(f"calibrate {str(dt)[6:]:8s} {name:5s} M={m:6d} N={n:5d} K={k:4d}  hipBLASLt {t_lib * 1e6:8.1f} us {f / t_lib:7.1f} TFLOP/s"
-                  f"   gemm256 {t_own * 1e6:8.1f} us {f / t_own:7.1f} TFLOP/s   ratio {t_lib / t_own:5.2f}")
+                  f"   {K.gemm_kernel_name(a, w, None, out=o).split('_kernel')[0]:7s} {t_own * 1e6:8.1f} us {f / t_own:7.1f} TFLOP/s   ratio {t_lib / t_own:5.2f}")
 
 
 def main():
