@@ -196,3 +196,24 @@ def test_gemm4w_repeated_launches_are_deterministic_and_race_free(monkeypatch):
         assert torch.equal(k.gemm(a, w, bias, act=k.ACT_GELU_ERF), first)
     want = torch.nn.functional.gelu(a[-300:].float() @ w.float().t() + bias)
     assert torch.allclose(first[-300:].float(), want, rtol=3e-3, atol=3e-3)
+
+
+def test_gemm4w_rows_times_k_beyond_2_to_the_31(monkeypatch):
+    """709,200 rows x K = 3072: M * K = 2.18e9 elements.  The 4-wave kernel addresses A as a uniform 64-bit row-panel base
+    plus an unsigned 32-bit byte offset inside the panel (256 rows x 6 KiB here); rows on both sides of the 2^31-element
+    line are checked against torch, and the whole output against gemm256."""
+    k = _k()
+    M, N, K = 197 * 3600, 256, 3072
+    g = torch.Generator(device=DEV).manual_seed(5)
+    a = (torch.randn(M, K, generator=g, device=DEV) * 0.5).half()
+    w = (torch.randn(N, K, generator=g, device=DEV) * 0.05).half()
+    bias = torch.randn(N, generator=g, device=DEV)
+    monkeypatch.setenv("VIDIL_GEMM4W", "1")
+    assert k.gemm_kernel_name(a, w, bias).startswith("gemm4w_kernel")
+    out = k.gemm(a, w, bias)
+    for lo in (0, 349_000, 699_040, M - 300):           # 699,051 is the first row past 2^31 elements
+        rows = slice(lo, lo + 300)
+        want = a[rows].float() @ w.float().t() + bias
+        assert torch.allclose(out[rows].float(), want, rtol=2e-3, atol=2e-2), lo
+    monkeypatch.setenv("VIDIL_GEMM4W", "0")
+    assert torch.equal(k.gemm(a, w, bias), out)

@@ -136,10 +136,10 @@ __global__ __launch_bounds__(256) void gemm4w_kernel(const vidil_gemm_args p) {
 #endif
     if (sl < 2) {
       const int rr = row < h_limW ? row : h_limW;
-      glds16(hbaseW + (size_t)(h_kt * 128) + (uint32_t)(rr * (int)pitchW + h_c16), dst);
+      glds16(hbaseW + (size_t)(h_kt * 128) + ((uint32_t)rr * pitchW + (uint32_t)h_c16), dst);   // (< 2^32: vidil_gemm256_eligible)
     } else {
       const int rr = row < h_limA ? row : h_limA;
-      glds16(hbaseA + (size_t)(h_kt * 128) + (uint32_t)(rr * (int)pitchA + h_c16), dst);
+      glds16(hbaseA + (size_t)(h_kt * 128) + ((uint32_t)rr * pitchA + (uint32_t)h_c16), dst);
     }
   };
   auto head_advance = [&]() {
