@@ -477,8 +477,9 @@ int vidil_gemm4w_launch(const vidil_gemm_args& a, hipStream_t s);   // gemm4w.hi
 // kernel (gemm4w.hip) has the faster main loop (-13 % per K-tile) and a continuous K-tile stream, the 8-wave kernel hides
 // memory latency in its epilogue with two waves per SIMD and starts up faster: measured on the same box inside the
 // bench (profiles/r3_gemm4w_ab.md), gemm4w wins on the LN-folded consumers (-7 % on fc1 + GELU), the f32 + residual +
-// row-partials producer (-4 %) and the per-head scatter (-2..3 %) once there are a few tiles per CU, and loses on the
-// residual-LayerNorm and plain f32 epilogues and on small grids.  $VIDIL_GEMM4W = 0 / 1 forces one kernel (developer).
+// row-partials producers (-4..5 %, with or without the residual LayerNorm) and the per-head scatter (-2..3 %) once there
+// are a couple of tiles per CU, and loses on the plain f32 epilogue (+7 %) and on small grids (and is not built for fp8
+// operands).  $VIDIL_GEMM4W = 0 / 1 forces one kernel (developer).
 static bool prefer_4w(const vidil_gemm_args& a) {
   if (const char* e = getenv("VIDIL_GEMM4W")) return atoi(e) != 0;
   if (a.dtype == VIDIL_DT_FP8) return false;
@@ -490,7 +491,7 @@ static bool prefer_4w(const vidil_gemm_args& a) {
     case VIDIL_EPI_HEADS:
       return true;
     case VIDIL_EPI_F32:
-      return a.ln_stats_out != nullptr && a.rln_gamma == nullptr;
+      return a.ln_stats_out != nullptr;    // (the LN-fold producers, with or without a residual LayerNorm; plain f32: gemm256)
     default:
       return false;
   }
