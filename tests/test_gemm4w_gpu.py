@@ -217,3 +217,25 @@ def test_gemm4w_rows_times_k_beyond_2_to_the_31(monkeypatch):
         assert torch.allclose(out[rows].float(), want, rtol=2e-3, atol=2e-2), lo
     monkeypatch.setenv("VIDIL_GEMM4W", "0")
     assert torch.equal(k.gemm(a, w, bias), out)
+
+
+@pytest.mark.parametrize("D,N", [(1024, 4096), (512, 2048), (320, 1280)])
+def test_gemm4w_layernorm_fold_at_other_widths_equals_gemm256(D, N):
+    """ViT-L (1024: 16 row partials per row — every part slot of a half-wave in use), 512 and a width whose partial count
+    (5) is not a multiple of 4 (the masked slots of the statistics exchange)."""
+    from vidil_amd.packing import fold_layernorm
+
+    k = _k()
+    dtype = torch.bfloat16
+    M = 256 * 150 + 33
+    x = _rand(M, D, seed=50) * 1.5
+    x[:, 3] += 6.0
+    g, bt = _rand(D, seed=51) * 0.2 + 1.0, _rand(D, seed=52) * 0.2
+    wf, bf, cs = fold_layernorm(_rand(N, D, scale=0.03, seed=53), _rand(N, seed=54) * 0.1, g, bt, dtype)
+    x16 = x.to(dtype).to(DEV)
+    st = _row_partials(x16.float().cpu()).to(DEV)
+    wf, bf, cs = wf.to(DEV), bf.to(DEV), cs.to(DEV)
+    ref, got = both(k, lambda: k.gemm(x16, wf, bf, act=k.ACT_GELU_ERF, ln=(cs, 1e-6, st)))
+    assert torch.equal(ref, got)
+    want = torch.nn.functional.gelu(torch.nn.functional.layer_norm(x16[:500].float().cpu(), (D,), g, bt, 1e-6) @ _rand(N, D, scale=0.03, seed=53).t() + _rand(N, seed=54) * 0.1)
+    assert torch.allclose(got[:500].float().cpu(), want, rtol=3e-2, atol=3e-2)
