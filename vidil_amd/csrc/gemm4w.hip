@@ -170,7 +170,10 @@ __global__ __launch_bounds__(256) void gemm4w_kernel(const vidil_gemm_args p) {
   constexpr int NM = 16 * KS;          // MFMAs per K-tile per wave
   constexpr int NFR = KH * 8;          // fragments per set
   constexpr int STEP = ESZ == 2 ? 2 : 1;            // MFMAs per DMA piece (64 matrix-pipe cycles either way)
-  constexpr int T_A = ESZ == 2 ? 21 : 10;           // barrier A goes after this MFMA
+#ifndef VIDIL_4W_TA
+#define VIDIL_4W_TA 21
+#endif
+  constexpr int T_A = ESZ == 2 ? VIDIL_4W_TA : 10;  // barrier A goes after this MFMA (developer sweep: -DVIDIL_4W_TA=17..29)
   constexpr int T_B = T_A + 16 * STEP;              // barrier B goes after this MFMA
   static_assert(T_B < NM - 2 && NFR <= T_A, "schedule");
   auto read_frag = [&](const char* buf, int ks, int r) {     // r: 0-3 = W column tiles, 4-7 = A row tiles
