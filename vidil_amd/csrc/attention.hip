@@ -47,6 +47,8 @@ struct AttnP {
                                // 2: error-compensated rows [hi | lo | hi] in three planes ldo/3 apart (VIDIL_DT_SPLIT3)
   int tiled;                   // K and V in 32-key fragment tiles (common.h: ktile_off / vtile_off); direct kernel only
   int rb;                      // staged kernel, single key chunk: rounds of NW row blocks per workgroup (launch_lds)
+  int ostage;                  // staged kernel: 2 KiB of LDS per wave behind K / V^T for the output transposition (launch_lds:
+                               // only where two workgroups per CU still fit with it)
 };
 
 constexpr int KROW = 72;  // halfs per K row in LDS (64 + 8 pad)
@@ -190,6 +192,44 @@ __device__ __forceinline__ void store_rows(const AttnP<T>& p, const RowInfo& ri,
                        (f16)(O[dt][rq * 4 + 3] * inv)};
       *(f16x4*)(og + dt * 32 + rq * 8) = v;
     }
+}
+
+// The 16-bit rows of a wave's 32 x 64 output block, TRANSPOSED through 2 KiB of wave-private LDS so that the global
+// stores are 16 B per lane and 64 contiguous bytes per row (store_rows above writes 8 B per lane with consecutive lanes
+// 1.5 KB apart: 512 partial-sector writes per block — compiled out, the staged tower kernel ran 18 % faster).  Two
+// passes of 32 d each; the 16-byte chunk index is XORed with (row >> 1) & 3 (no bank conflicts either way).  Rows of a
+// block may belong to different query batches: a row's destination offset and validity come from the lane that owns it.
+template <typename T>
+__device__ __forceinline__ void store_rows_lds(const AttnP<T>& p, const RowInfo& ri, int h, const f32x16 (&O)[2], float inv, char* scratch) {
+  using f16 = T;
+  using f16x4 = typename Elt<T>::x4;
+  using f16x8 = typename Elt<T>::x8;
+  const int lane = threadIdx.x & 63;
+  const int hi = lane >> 5, l31 = lane & 31;
+  // element offset of this lane's row (valid rows only) — fetched below by the lanes that store that row
+  const long long own = ri.valid ? (long long)(((size_t)ri.qb * p.Nq + ri.t) * p.ldo + h * 64) : -1;
+  long long dst[2];
+#pragma unroll
+  for (int i = 0; i < 2; ++i) {
+    const int r = i * 16 + (lane >> 2);
+    const int lo = __shfl((int)(own & 0xffffffffLL), r, 64), hi32 = __shfl((int)(own >> 32), r, 64);
+    dst[i] = ((long long)hi32 << 32) | (unsigned int)lo;
+  }
+#pragma unroll
+  for (int dt = 0; dt < 2; ++dt) {
+#pragma unroll
+    for (int rq = 0; rq < 4; ++rq) {
+      const f16x4 v = {(f16)(O[dt][rq * 4 + 0] * inv), (f16)(O[dt][rq * 4 + 1] * inv), (f16)(O[dt][rq * 4 + 2] * inv),
+                       (f16)(O[dt][rq * 4 + 3] * inv)};
+      *(f16x4*)(scratch + l31 * 64 + ((rq ^ ((l31 >> 1) & 3)) << 4) + hi * 8) = v;
+    }
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      const int r = i * 16 + (lane >> 2), c = lane & 3;
+      const f16x8 v = *(const f16x8*)(scratch + r * 64 + ((c ^ ((r >> 1) & 3)) << 4));
+      if (dst[i] >= 0) *(f16x8*)(p.out + dst[i] + dt * 32 + c * 8) = v;
+    }
+  }
 }
 
 // ------------------------------------------------------------------ LDS-staged kernel
@@ -408,7 +448,10 @@ __global__ __launch_bounds__(NW * 64, NW == 8 ? 4 : 2) void attn_lds_kernel(cons
     }
     if (!active) break;
     l += __shfl_xor(l, 32, 64);
-    store_rows(p, ri, h, O, l > 0.f ? 1.0f / l : 0.f);
+    if (p.out_mode == 0 && p.ostage)   // (uniform) plain 16-bit rows: through the wave's LDS scratch, 16-B / 64-B-per-row stores
+      store_rows_lds(p, ri, h, O, l > 0.f ? 1.0f / l : 0.f, smem + NKEY * KROW * 2 + 64 * VROW * 2 + wave * 2048);
+    else
+      store_rows(p, ri, h, O, l > 0.f ? 1.0f / l : 0.f);
   }
 }
 
@@ -639,7 +682,10 @@ __global__ __launch_bounds__(64) void attn_wave_kernel(const AttnP<T> p) {
 
 template <typename T, int NKT, int NW>
 int launch_lds(const AttnP<T>& p, int max_rows, hipStream_t s) {
-  constexpr int smem = NKT * 32 * KROW * 2 + 64 * (NKT * 32 + 8) * 2;
+  constexpr int smem_kv = NKT * 32 * KROW * 2 + 64 * (NKT * 32 + 8) * 2;
+  // + 2 KiB per wave for the output transposition (store_rows_lds) where a second workgroup still fits beside it
+  constexpr bool ostage = 2 * (smem_kv + NW * 2048) <= 160 * 1024;
+  constexpr int smem = smem_kv + (ostage ? NW * 2048 : 0);
   static bool attr_set = false;
   auto kern = attn_lds_kernel<T, NKT, NW>;
   if (!attr_set) {
@@ -654,6 +700,7 @@ int launch_lds(const AttnP<T>& p, int max_rows, hipStream_t s) {
   // image with NW = 8): a second round in the same workgroup instead of a second workgroup that would stage the
   // unit's K/V again for a handful of rows
   AttnP<T> q = p;
+  q.ostage = (ostage && p.ldo % 8 == 0 && ((uintptr_t)p.out & 15) == 0) ? 1 : 0;   // (16-byte stores)
   q.rb = (p.Nk <= NKT * 32 && max_rows > NW * 32 && max_rows <= NW * 32 + NW * 16) ? 2 : 1;
   dim3 grid((max_rows + NW * 32 * q.rb - 1) / (NW * 32 * q.rb), p.H, p.n_kv);
   hipLaunchKernelGGL(kern, grid, dim3(NW * 64), smem, s, q);
