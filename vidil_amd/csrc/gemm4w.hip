@@ -1,8 +1,8 @@
 // gemm4w.hip — the large-M GEMM of the hot path, second generation: C[M,N] = A[M,K] · W[N,K]^T, 256x256x(128 B) tiles
 // over FOUR waves (one per SIMD), each owning a 128x128 block of the tile in 256 accumulator registers.
 //
-// Why (round 3): with warm clocks the library GEMM beats the 8-wave kernel (gemm256.hip) by 10 % at K = 768
-// and by 38 % at K = 8192, and its main loop is exactly this shape.  What the shape buys over 8 waves x (128x64):
+// Why (round 3): with warm clocks the library GEMM beats the 8-wave kernel (gemm256.hip) by 7-15 % on the
+// path's shapes and by 38 % at K = 8192, and its main loop is exactly this shape.  What the shape buys over 8 waves x (128x64):
 //   * LDS fragment traffic per K-tile drops from 8 x 24 KiB to 4 x 32 KiB (a 128x128 register block reuses every
 //     fragment 4 times instead of 2 / 4);
 //   * one instruction stream per SIMD: the matrix pipe never arbitrates between two waves, and the schedule below is
@@ -10,7 +10,7 @@
 //   * 2 barriers per K-tile (2,048 matrix-pipe cycles) instead of 4;
 //   * the K-tile stream is CONTINUOUS across output tiles: the DMA head runs two K-tiles ahead of the MFMAs and walks
 //     straight into the next output tile, so a tile's first K-tiles land during the previous tile's last iterations and
-//     its epilogue (no per-tile prologue bubble, no re-fetch of clamped tiles past the end).
+//     its epilogue (no per-tile prologue bubble; only the workgroup's very last two K-tiles are fetched twice).
 //
 // LDS (160 KiB, all of it): ring of 2 K-tiles x 4 half-tiles (A rows 0-127 / 128-255, W rows 0-127 / 128-255) of 16 KiB,
 // layout as in gemm256.hip (128-B rows, 16-B slot XOR (row>>1)&7, filled by global_load_lds_dwordx4); then 4 x 8 KiB of
@@ -22,10 +22,17 @@
 //     ...              | lgkmcnt(0); BARRIER A: every wave has tile g in registers -> its ring buffer is free
 //     ...              | 16 DMA pieces of tile g+2 into that buffer, one per 64 matrix-pipe cycles
 //     MFMAs of S1      | ...
-//     ...              | vmcnt(pieces of g+2 in flight); BARRIER B: tile g+1 (issued one iteration ago) is in LDS
-//     ...              | fragment reads of S0 of tile g+1
+//     ...              | vmcnt(16); BARRIER B: tile g+1 (issued one iteration ago) is in LDS
+//     ...              | fragment reads of S0 of tile g+1 (not in a tile's last iteration: the next output tile reads
+//                      |   its first fragments after the epilogue — 64 registers less to carry across it)
 // (A fragment register is overwritten only after the last MFMA that reads it has been issued; DMA of tile g+2 lands
 // about 1.1 iterations ~ 1 us after it is issued — gemm256 gave it two half-periods, 0.4 us.)
+//
+// One wave per SIMD has nobody to cover its stalls, so the rest of the file is about not having any: no `s_waitcnt
+// vmcnt(0)` while DMA or stores are in flight (which is what hipcc emits for a spill reload, for an ordinary load beside
+// LDS-DMA, and at the end of an exec-masked block containing a load — see the comments at head_setup, issue_piece, the
+// row partials and the lane ids), and instruction-level parallelism written into the program order of the epilogue
+// (gemm_epilogue.inc under VIDIL_EPI_LAZY).  Results are bit-identical to gemm256's (tests/test_gemm4w_gpu.py).
 #include <type_traits>
 #include <utility>
 
