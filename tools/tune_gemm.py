@@ -12,13 +12,18 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from vidil_amd import kernels as K  # noqa: E402
 
 CONFIGS = ["default", "128x128x2", "128x128x3", "128x128x4", "128x64x2", "128x64x3", "128x64x4", "64x64x2", "64x64x3",
-           "64x64x4"]
+           "64x64x4", "128x256x2", "128x256x3"]
+if os.environ.get("VIDIL_TUNE_CONFIGS"):
+    CONFIGS = os.environ["VIDIL_TUNE_CONFIGS"].split(",")
 
 
 def timeit(fn, iters=30):
-    for _ in range(3):
-        fn()
-    torch.cuda.synchronize()
+    import time
+    t0 = time.time()
+    while time.time() - t0 < 0.1:       # (warm clocks: tools/bench_gemm.py has the story)
+        for _ in range(5):
+            fn()
+        torch.cuda.synchronize()
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     e0.record()
     for _ in range(iters):

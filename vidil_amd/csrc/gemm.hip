@@ -34,7 +34,7 @@ __device__ __forceinline__ void wait_vm() {
 
 // waves along N: the 128x128 tile runs on 8 waves (2 x 4, two per SIMD, 64x32 outputs each) so that one workgroup
 // already overlaps LDS-DMA issue with MFMAs; the smaller tiles use 4 waves (2 x 2) and rely on co-resident workgroups
-constexpr int waves_n(int bm, int bn) { return (bm == 128 && bn == 128) ? 4 : 2; }
+constexpr int waves_n(int bm, int bn) { return (bm == 128 && bn >= 128) ? 4 : 2; }
 
 template <typename T, int BM, int BN, int ST, int EPI, int ACT>
 __global__ __launch_bounds__(2 * waves_n(BM, BN) * 64) void gemm_kernel(const vidil_gemm_args p) {
@@ -358,6 +358,7 @@ int pick_tile(const vidil_gemm_args& a, hipStream_t s) {
   VIDIL_TRY(128, 128, 2) VIDIL_TRY(128, 128, 3) VIDIL_TRY(128, 64, 2) VIDIL_TRY(64, 64, 3)
 #ifdef VIDIL_GEMM_TUNE
   VIDIL_TRY(128, 128, 4) VIDIL_TRY(128, 64, 3) VIDIL_TRY(128, 64, 4) VIDIL_TRY(64, 64, 2) VIDIL_TRY(64, 64, 4)
+  VIDIL_TRY(128, 256, 2) VIDIL_TRY(128, 256, 3)
 #endif
 #undef VIDIL_TRY
   vidil_set_error("gemm: no kernel for tile %dx%dx%d", c.bm, c.bn, c.st);
