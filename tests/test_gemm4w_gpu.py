@@ -239,3 +239,42 @@ def test_gemm4w_layernorm_fold_at_other_widths_equals_gemm256(D, N):
     assert torch.equal(ref, got)
     want = torch.nn.functional.gelu(torch.nn.functional.layer_norm(x16[:500].float().cpu(), (D,), g, bt, 1e-6) @ _rand(N, D, scale=0.03, seed=53).t() + _rand(N, seed=54) * 0.1)
     assert torch.allclose(got[:500].float().cpu(), want, rtol=3e-2, atol=3e-2)
+
+
+@pytest.mark.parametrize("dtype", [torch.float16, torch.bfloat16])
+@pytest.mark.parametrize("M,N,K", [(10752, 768, 768), (10752, 768, 3072), (128 * 70 + 5, 768, 192), (9999, 832, 512)])
+def test_gemm4w_128_row_tile_form_equals_the_other_kernels(monkeypatch, dtype, M, N, K):
+    """The 128 x 256-tile form of gemm4w (mid-size grids: the decode steps' projections and FFN at ~10^4 beam rows) against
+    whatever serves the problem without it (the small-tile kernel or gemm256 — themselves bit-identical): f32 + residual,
+    16-bit with and without activations, the per-head Q scatter; ragged M and N."""
+    k = _k()
+    a = _rand(M, K, seed=1).to(dtype).to(DEV)
+    w = _rand(N, K, scale=0.05, seed=2).to(dtype).to(DEV)
+    bias = _rand(N, seed=3).to(DEV)
+    x0 = _rand(M, N, seed=4).to(DEV)
+    H = 12
+
+    def run_all():
+        outs = []
+        x = x0.clone()
+        k.gemm(a, w, bias, out=x, resid=x)
+        outs.append(x)
+        for act in (k.ACT_NONE, k.ACT_GELU_ERF, k.ACT_QUICK_GELU):
+            outs.append(k.gemm(a, w, bias, act=act).float())
+        outs.append(k.gemm(a, w, None).float())
+        if N == H * 64:
+            q = torch.zeros(M, H, 1, 64, dtype=dtype, device=DEV)
+            k.gemm(a, w, bias, heads=dict(q=q, T=1, H=H, part0=0, t_off=0, Tq_cap=1, q_scale=0.125))
+            outs.append(q.float().view(M, -1))
+        return outs
+
+    monkeypatch.setenv("VIDIL_GEMM4W128", "0")
+    assert "gemm4w_kernel" not in k.gemm_kernel_name(a, w, bias, out=x0, resid=x0) or not k.gemm_kernel_name(a, w, bias, out=x0, resid=x0).endswith(", 2>")
+    ref = run_all()
+    monkeypatch.setenv("VIDIL_GEMM4W128", "1")
+    assert k.gemm_kernel_name(a, w, bias, out=x0, resid=x0).startswith("gemm4w_kernel") and k.gemm_kernel_name(a, w, bias, out=x0, resid=x0).endswith(", 2>")
+    got = run_all()
+    for r, g in zip(ref, got):
+        assert torch.equal(r, g)
+    want = a[-200:].float() @ w.float().t() + bias + x0[-200:]
+    assert torch.allclose(got[0][-200:], want, rtol=1e-4, atol=2e-3 * (K / 768) ** 0.5 + 1e-3)

@@ -24,6 +24,8 @@ void vidil_set_error(const char* fmt, ...);
 bool vidil_gemm256_eligible(const vidil_gemm_args& a, bool any_size = false);
 int vidil_gemm256_launch(const vidil_gemm_args& a, hipStream_t s);
 const char* vidil_gemm256_variant(const vidil_gemm_args& a);   // "gemm256_kernel" or "gemm4w_kernel": which of the two runs it
+bool vidil_gemm4w128_wanted(const vidil_gemm_args& a);          // the 128 x 256-tile form of gemm4w (mid-size grids)
+int vidil_gemm4w128_launch(const vidil_gemm_args& a, hipStream_t s);
 
 #define VIDIL_REQUIRE(cond, ...)                \
   do {                                          \

@@ -325,6 +325,7 @@ TileChoice choose_tile(const vidil_gemm_args& a) {
   }();
   const bool forced_big = a.ln_fold || a.out16 || a.ln_stats_out || a.dtype == VIDIL_DT_FP8;   // (check_args)
   if (forced_big) return {1, 256, 256, 2};
+  if (allow256 && a.epi != VIDIL_EPI_ARENA && vidil_gemm4w128_wanted(a)) return {2, 128, 256, 2};
   if (allow256 && a.epi != VIDIL_EPI_ARENA && vidil_gemm256_eligible(a)) return {1, 256, 256, 2};
 #ifdef VIDIL_GEMM_TUNE
   // developer builds only: VIDIL_GEMM_TILE=<BM>x<BN>x<ST> forces one configuration
@@ -352,6 +353,12 @@ TileChoice choose_tile(const vidil_gemm_args& a) {
 template <typename T, int EPI, int ACT>
 int pick_tile(const vidil_gemm_args& a, hipStream_t s) {
   const TileChoice c = choose_tile(a);
+  if (c.big == 2) {
+    const int rc = vidil_gemm4w128_launch(a, s);
+    if (rc != -1000) return rc;
+    vidil_set_error("gemm: the 128x256 kernel is not built for epilogue %d", a.epi);
+    return VIDIL_EUNSUP;
+  }
   if (c.big) return vidil_gemm256_launch(a, s);
 #define VIDIL_TRY(BM_, BN_, ST_) \
   if (c.bm == BM_ && c.bn == BN_ && c.st == ST_) return launch<T, BM_, BN_, ST_, EPI, ACT>(a, s);
@@ -498,8 +505,13 @@ extern "C" int vidil_gemm_kernel_name(const vidil_gemm_args* args, char* buf_hos
   const char* t = args->dtype == VIDIL_DT_FP8 ? "fp8" : t16;                 // the spelling rocprofv3 demangles to
   const int act = (args->epi == VIDIL_EPI_F16 || args->epi == VIDIL_EPI_F32 || args->epi == VIDIL_EPI_F8) ? args->act : 0;
   const char* stats = (args->ln_stats_out && args->epi == VIDIL_EPI_F32) ? "true" : "false";
-  if (c.big) snprintf(buf_host, n, "%s<%s, %s, %d, %d, %s, %s, %s>", vidil_gemm256_variant(*args), t, t16, args->epi, act,
-                      args->ln_fold ? "true" : "false", stats, args->rln_gamma ? "true" : "false");
+  if (c.big) {
+    const char* kn = c.big == 2 ? "gemm4w_kernel" : vidil_gemm256_variant(*args);
+    if (kn[4] == '4') snprintf(buf_host, n, "%s<%s, %s, %d, %d, %s, %s, %s, %d>", kn, t, t16, args->epi, act, args->ln_fold ? "true" : "false",
+                               stats, args->rln_gamma ? "true" : "false", c.big == 2 ? 2 : 4);      // (gemm4w: + its row-tile count)
+    else snprintf(buf_host, n, "%s<%s, %s, %d, %d, %s, %s, %s>", kn, t, t16, args->epi, act, args->ln_fold ? "true" : "false", stats,
+                  args->rln_gamma ? "true" : "false");
+  }
   else snprintf(buf_host, n, "gemm_kernel<%s, %d, %d, %d, %d, %d>", t, c.bm, c.bn, c.st, args->epi, act);
   return VIDIL_OK;
 }

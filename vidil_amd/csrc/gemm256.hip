@@ -382,7 +382,7 @@ int launch256(const vidil_gemm_args& a, hipStream_t s) {
     if (v >= 8 && v < cus) cus = v;
   }
   const int ntiles = ((a.M + 255) / 256) * ((a.N + 255) / 256);
-  const int tiles = !(kPersistent<EPI> && sizeof(T) == 2 && !RLN) ? ntiles : ntiles >= cus ? cus : (ntiles >= 8 ? (ntiles & ~7) : ntiles);
+  const int tiles = !(kPersistent<EPI> && sizeof(T) == 2 && !RLN) ? ntiles : ntiles >= cus ? cus : (ntiles >= 8 ? ((ntiles + 7) & ~7) : ntiles);   // (rounded UP: gemm4w.hip launch4w)
   hipLaunchKernelGGL(kern, dim3(tiles), dim3(512), lds, s, a);
   VIDIL_CHECK_LAUNCH("gemm256");
   return VIDIL_OK;
@@ -471,7 +471,7 @@ static int launch256_fp8(const vidil_gemm_args& a, hipStream_t s) {
   }
 }
 
-int vidil_gemm4w_launch(const vidil_gemm_args& a, hipStream_t s);   // gemm4w.hip; -1000: variant not built there
+int vidil_gemm4w_launch(const vidil_gemm_args& a, hipStream_t s, int tm);   // gemm4w.hip (tm: 4 = 256-row tiles, 2 = 128-row); -1000: variant not built there
 
 // Which of the two 256x256 kernels runs a problem (both produce the same bits — tests/test_gemm4w_gpu.py).  The 4-wave
 // kernel (gemm4w.hip) has the faster main loop (-13 % per K-tile) and a continuous K-tile stream, the 8-wave kernel hides
@@ -500,9 +500,27 @@ static bool prefer_4w(const vidil_gemm_args& a) {
 
 const char* vidil_gemm256_variant(const vidil_gemm_args& a) { return prefer_4w(a) ? "gemm4w_kernel" : "gemm256_kernel"; }
 
+// The 128 x 256-tile form of gemm4w for problems with too few 256 x 256 tiles to fill the chip but about one 128 x 256
+// tile per CU or more (the decode steps' projections and FFN at ~10^4 beam rows): 16-bit operands, plain epilogues.
+// Measured against the small-tile kernel at 10,752 rows (tools/experiments/gemm4w128_ab.py; all three kernels bit-identical):
+// N = 768, K = 3072 (decode fc2) 61.7 -> 53.6 us, N = K = 768 with GELU / heads 23.4 -> 18.4, with the f32 residual 24.3 -> 24.0;
+// where gemm256 is eligible (>= 160 tiles of 256 x 256) or K is a few tiles it loses, so it is not chosen there.
+bool vidil_gemm4w128_wanted(const vidil_gemm_args& a) {
+  const char* e = getenv("VIDIL_GEMM4W128");                    // (developer: 0 never, 1 whenever it can run)
+  const int mode = e ? atoi(e) : -1;
+  if (mode == 0 || a.dtype == VIDIL_DT_FP8 || a.ln_fold || a.ln_stats_out || a.rln_gamma || a.out16) return false;
+  if (!(a.epi == VIDIL_EPI_F16 || a.epi == VIDIL_EPI_HEADS || (a.epi == VIDIL_EPI_F32 && a.act == VIDIL_ACT_NONE))) return false;
+  if (!vidil_gemm256_eligible(a, true)) return false;        // (alignment / stride / offset-range rules are the same)
+  if (mode == 1) return true;
+  const long t256 = (long)((a.M + 255) / 256) * ((a.N + 255) / 256);
+  const long t128 = (long)((a.M + 127) / 128) * ((a.N + 255) / 256);
+  return t256 < 160 && t128 >= 200 && a.K >= 512;
+}
+int vidil_gemm4w128_launch(const vidil_gemm_args& a, hipStream_t s) { return vidil_gemm4w_launch(a, s, 2); }
+
 int vidil_gemm256_launch(const vidil_gemm_args& a, hipStream_t s) {
   if (prefer_4w(a)) {
-    const int rc = vidil_gemm4w_launch(a, s);
+    const int rc = vidil_gemm4w_launch(a, s, 4);
     if (rc != -1000) return rc;
   }
   if (a.dtype == VIDIL_DT_FP8) return a.dtype16 == VIDIL_DT_BF16 ? launch256_fp8<bf16>(a, s) : launch256_fp8<f16>(a, s);

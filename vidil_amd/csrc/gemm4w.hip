@@ -40,13 +40,17 @@
 #include "gemm_epilogue.h"
 
 #define VIDIL_EPI_LAZY 1   // gemm_epilogue.inc: bias / activation applied per stored quad, not to all accumulators up front
+#define VIDIL_EPI_NIT TM   // ... over the TM 32-row tiles of a wave's block
 
 namespace {
 
 constexpr int SLOT = 16384;       // one half-tile: 128 rows x 128 B
-constexpr int BUF = 4 * SLOT;      // one K-tile: A0, A1, W0, W1
-constexpr int RING_BYTES = 2 * BUF;
-constexpr int LDS_BYTES = RING_BYTES + 4 * 8192;
+// TM = 32-row tiles per wave: 4 -> 256 x 256 output tiles (A0, A1, W0, W1 per K-tile), 2 -> 128 x 256 tiles (A0, W0, W1:
+// the form for problems with too few 256 x 256 tiles to fill the chip — 10,752 decode rows x 768 columns are 126 of
+// those but 252 of these; the library picks the same tile there)
+template <int TM> constexpr int kBuf = (TM == 4 ? 4 : 3) * SLOT;
+template <int TM> constexpr int kRing = 2 * kBuf<TM>;
+template <int TM> constexpr int kLds = kRing<TM> + 4 * 8192;
 
 // compile-time loop: the body sees its index as a constant expression (accumulators and fragments are register arrays —
 // every index into them must be static)
@@ -64,8 +68,13 @@ __device__ __forceinline__ void glds16(const void* g, char* lds) {
                                    (__attribute__((address_space(3))) void*)lds, 16, 0, 0);
 }
 
-template <typename T, typename TO, int EPI, int ACT, bool FOLD, bool STATS, bool RLN>
+template <typename T, typename TO, int EPI, int ACT, bool FOLD, bool STATS, bool RLN, int TM = 4>
 __global__ __launch_bounds__(256) void gemm4w_kernel(const vidil_gemm_args p) {
+  static_assert(TM == 4 || TM == 2, "256- or 128-row output tiles");
+  static_assert(TM == 4 || !(FOLD || RLN), "the 128-row form is built without the row-statistics epilogues");
+  constexpr int BUF = kBuf<TM>, RING_BYTES = kRing<TM>;
+  constexpr int MSH = TM == 4 ? 8 : 7;           // log2 of the tile's rows
+  constexpr int NPIECE = TM == 4 ? 16 : 12;      // LDS-DMA instructions per K-tile per wave
   constexpr bool ROWSTAT = FOLD || RLN;
   static_assert(!(FOLD && RLN), "a GEMM normalises either its A rows or its residual rows");
   static_assert(!RLN || EPI == VIDIL_EPI_F32, "the residual exists in the f32 epilogue only");
@@ -88,7 +97,7 @@ __global__ __launch_bounds__(256) void gemm4w_kernel(const vidil_gemm_args p) {
   const int M = p.M, N = p.N, K = p.K;
   const int lda = p.lda > 0 ? p.lda : K;
   const int tiles_n = (N + 255) >> 8;
-  const int tiles_m = (M + 255) >> 8;
+  const int tiles_m = (M + (1 << MSH) - 1) >> MSH;
   // persistent workgroups, XCD-contiguous tile ranges: as gemm256.hip
   int logical, remaining;
   const int tile_step = gridDim.x >= 8 ? (gridDim.x >> 3) : 1;
@@ -126,17 +135,19 @@ __global__ __launch_bounds__(256) void gemm4w_kernel(const vidil_gemm_args p) {
   auto head_setup = [&](int lt) {
     const int tile_m = lt / tiles_n;
     const int tile_n = lt - tile_m * tiles_n;
-    const int hm0 = tile_m << 8, hn0 = tile_n << 8;
+    const int hm0 = tile_m << MSH, hn0 = tile_n << 8;
     hbaseA = (const char*)p.A + (size_t)hm0 * pitchA;
     hbaseW = (const char*)p.W + (size_t)hn0 * pitchW;
     h_limA = M - 1 - hm0;
     h_limW = N - 1 - hn0;
   };
   head_setup(logical);
-  // piece pc (0..15) of the head's K-tile: slots W0, W1, A0, A1 in that order, 4 instructions of 4 KiB each
+  // piece pc (0 .. NPIECE-1) of the head's K-tile: half-tiles W0, W1, A0 (, A1) in that order, 4 instructions of 4 KiB each;
+  // LDS slots of a K-tile buffer: A0 (, A1), W0, W1
+  constexpr int WSLOT = TM == 4 ? 2 : 1;
   auto issue_piece = [&](int pc) {
     const int sl = pc >> 2, i = pc & 3;
-    char* dst = smem + h_buf * BUF + (sl < 2 ? 2 + sl : sl - 2) * SLOT + i * 4096 + wave * 1024;
+    char* dst = smem + h_buf * BUF + (sl < 2 ? WSLOT + sl : sl - 2) * SLOT + i * 4096 + wave * 1024;
     const int row = h_r0 + (sl & 1) * 128 + i * 32;
 #if defined(VIDIL_4W_ABLATE) && (VIDIL_4W_ABLATE & 4)
     if (p.M > 0) return;     // developer ablation: no DMA (the MFMAs run on whatever LDS holds)
@@ -164,53 +175,55 @@ __global__ __launch_bounds__(256) void gemm4w_kernel(const vidil_gemm_args p) {
     }
   };
 
-  f32x16 accA[4][2], accB[4][2];   // output columns 0-63 / 64-127 of the wave's block
+  f32x16 accA[TM][2], accB[TM][2];   // output columns 0-63 / 64-127 of the wave's (32*TM) x 128 block
 #define ACC(i, j) ((j) < 2 ? accA[i][(j) & 1] : accB[i][(j) & 1])
   float st_s[4], st_ss[4];
   f32x2 st_raw[4][4], st_sum[4];
 
   const int sw = (l31 >> 1) & 7;
-  const int a_off = grp * SLOT + l31 * 128;
-  const int w_off = (2 + wc2) * SLOT + l31 * 128;
-  Frag fa[KS][4], fw[KS][4];
+  const int a_off = (TM == 4 ? grp * SLOT : grp * 8192) + l31 * 128;    // (TM == 2: rows grp*64 .. of the one A half-tile)
+  const int w_off = (WSLOT + wc2) * SLOT + l31 * 128;
+  Frag fa[KS][TM], fw[KS][4];
   constexpr int KH = KS / 2;           // k-steps per fragment set
-  constexpr int NM = 16 * KS;          // MFMAs per K-tile per wave
-  constexpr int NFR = KH * 8;          // fragments per set
-  constexpr int STEP = ESZ == 2 ? 2 : 1;            // MFMAs per DMA piece (64 matrix-pipe cycles either way)
+  constexpr int NKS = 4 * TM;          // MFMAs per k-step per wave
+  constexpr int NM = NKS * KS;         // MFMAs per K-tile per wave
+  constexpr int NFK = 4 + TM;          // fragments per k-step: 4 W column tiles, TM A row tiles
+  constexpr int NFR = KH * NFK;        // fragments per set
+  constexpr int STEP = (ESZ == 2 && TM == 4) ? 2 : 1;   // MFMAs per DMA piece
 #ifndef VIDIL_4W_TA
 #define VIDIL_4W_TA 21
 #endif
-  constexpr int T_A = ESZ == 2 ? VIDIL_4W_TA : 10;  // barrier A goes after this MFMA (developer sweep: -DVIDIL_4W_TA=17..29)
-  constexpr int T_B = T_A + 16 * STEP;              // barrier B goes after this MFMA
+  constexpr int T_A = TM == 2 ? NFR + 1 : (ESZ == 2 ? VIDIL_4W_TA : 10);   // barrier A goes after this MFMA (developer sweep: -DVIDIL_4W_TA=17..29)
+  constexpr int T_B = T_A + NPIECE * STEP;          // barrier B goes after this MFMA
   static_assert(T_B < NM - 2 && NFR <= T_A, "schedule");
   auto read_frag = [&](const char* buf, int ks, int r) {     // r: 0-3 = W column tiles, 4-7 = A row tiles
 #if defined(VIDIL_4W_ABLATE) && (VIDIL_4W_ABLATE & 8)
     if (p.M > 0) return;     // developer ablation: no fragment reads
 #endif
     if (r < 4) fw[ks][r] = Mma<T>::load(buf + w_off + r * 4096, ks, hi, sw);
-    else fa[ks][r - 4] = Mma<T>::load(buf + a_off + (r - 4) * 4096, ks, hi, sw);
+    else if (r - 4 < TM) fa[ks][r - 4] = Mma<T>::load(buf + a_off + (r - 4) * 4096, ks, hi, sw);
   };
 
   // ---- start of the stream: tiles 0 and 1, then S0 of tile 0 ------------------------------------------------------
 #pragma unroll
-  for (int pc = 0; pc < 16; ++pc) issue_piece(pc);
+  for (int pc = 0; pc < NPIECE; ++pc) issue_piece(pc);
   head_advance();
 #pragma unroll
-  for (int pc = 0; pc < 16; ++pc) issue_piece(pc);
+  for (int pc = 0; pc < NPIECE; ++pc) issue_piece(pc);
   head_advance();
-  asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
+  asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NPIECE) : "memory");
   __builtin_amdgcn_s_barrier();
   int cb = 0;   // ring buffer of the tile the MFMAs are on
 
   for (;;) {   // ======================================================================== one output tile
     const int tile_m = logical / tiles_n;
     const int tile_n = logical - tile_m * tiles_n;
-    const int m0 = tile_m << 8, n0 = tile_n << 8;
+    const int m0 = tile_m << MSH, n0 = tile_n << 8;
     // S0 of the tile's first K-tile (landed and visible since barrier B of the previous iteration / the start of the
     // stream).  Not fetched ahead across the epilogue: 64 live registers there cost more than this exposed LDS latency.
     static_for<NFR>([&](auto f_tag) {
       constexpr int f = decltype(f_tag)::value;
-      read_frag(smem + cb * BUF, f / 8, f % 8);
+      read_frag(smem + cb * BUF, f / NFK, f % NFK);
     });
     auto iteration = [&](auto first_tag, auto last_tag) {
       constexpr bool FIRST = decltype(first_tag)::value;   // first K-tile of an output tile: its first k-step starts from zero
@@ -219,14 +232,14 @@ __global__ __launch_bounds__(256) void gemm4w_kernel(const vidil_gemm_args p) {
       const char* const nbuf = smem + (cb ^ 1) * BUF;
       static_for<NM>([&](auto n_tag) {
         constexpr int n = decltype(n_tag)::value;
-        constexpr int ks = n >> 4, i = (n >> 2) & 3, j = n & 3;
+        constexpr int ks = n / NKS, i = (n >> 2) % TM, j = n & 3;
         if constexpr (FIRST && ks == 0) {
           const f32x16 zero = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
           ACC(i, j) = Mma<T>::mma(fw[ks][j], fa[ks][i], zero);
         } else {
           ACC(i, j) = Mma<T>::mma(fw[ks][j], fa[ks][i], ACC(i, j));
         }
-        if constexpr (n < NFR) read_frag(buf, KH + n / 8, n % 8);               // S1 of this tile
+        if constexpr (n < NFR) read_frag(buf, KH + n / NFK, n % NFK);           // S1 of this tile
         if constexpr (n == T_A) {
           __builtin_amdgcn_s_waitcnt(0xC07F);                                    // lgkmcnt(0)
           __builtin_amdgcn_s_barrier();
@@ -234,7 +247,7 @@ __global__ __launch_bounds__(256) void gemm4w_kernel(const vidil_gemm_args p) {
         if constexpr (n > T_A && n <= T_B && (n - T_A - 1) % STEP == 0) {
           constexpr int pc = (n - T_A - 1) / STEP;
           issue_piece(pc);
-          if constexpr (pc == 15) head_advance();
+          if constexpr (pc == NPIECE - 1) head_advance();
         }
         if constexpr (ROWSTAT && LAST && n == 0) {
           // this half-wave's share of the producer's row partials (half-wave (wc2, hi) takes parts w, w+4, w+8, w+12 with
@@ -267,7 +280,7 @@ __global__ __launch_bounds__(256) void gemm4w_kernel(const vidil_gemm_args p) {
         }
         if constexpr (n == T_B + 1) {
           // tile g+1 has landed once nothing older than this iteration's 16 DMA pieces is in flight
-          asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
+          asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NPIECE) : "memory");
           __builtin_amdgcn_s_barrier();
         }
         if constexpr (ROWSTAT && LAST && n == T_B + 2) {
@@ -293,7 +306,7 @@ __global__ __launch_bounds__(256) void gemm4w_kernel(const vidil_gemm_args p) {
           constexpr int s = n - T_B - 2;
           static_for<PER>([&](auto q_tag) {
             constexpr int f = s * PER + decltype(q_tag)::value;
-            if constexpr (f < NFR) read_frag(nbuf, f / 8, f % 8);
+            if constexpr (f < NFR) read_frag(nbuf, f / NFK, f % NFK);
           });
         }
         __builtin_amdgcn_sched_barrier(0);
@@ -347,13 +360,13 @@ __global__ __launch_bounds__(256) void gemm4w_kernel(const vidil_gemm_args p) {
     }
 
     // ================================================================================ epilogue: two 128x64 halves
-    const int m_w = m0 + grp * 128;
+    const int m_w = m0 + grp * (32 * TM);
     char* const ep = smem + RING_BYTES + wave * 8192;
 #if defined(VIDIL_4W_ABLATE) && (VIDIL_4W_ABLATE & 1)
     if (p.M > 0) {   // developer ablation: no epilogue (one dword per lane keeps the accumulators alive)
       float s = 0.f;
 #pragma unroll
-      for (int it = 0; it < 4; ++it)
+      for (int it = 0; it < TM; ++it)
 #pragma unroll
         for (int j = 0; j < 2; ++j) s += accA[it][j][0] + accB[it][j][5];
       if (s == 123.456f) ((float*)p.out)[lane] = s;
@@ -391,10 +404,11 @@ __global__ __launch_bounds__(256) void gemm4w_kernel(const vidil_gemm_args p) {
 #undef ACC
 }
 
-template <typename T, int EPI, int ACT, bool FOLD = false, typename TO = T, bool STATS = false, bool RLN = false>
+template <typename T, int EPI, int ACT, bool FOLD = false, typename TO = T, bool STATS = false, bool RLN = false, int TM = 4>
 int launch4w(const vidil_gemm_args& a, hipStream_t s) {
   static bool attr_set = false;
-  auto kern = gemm4w_kernel<T, TO, EPI, ACT, FOLD, STATS, RLN>;
+  auto kern = gemm4w_kernel<T, TO, EPI, ACT, FOLD, STATS, RLN, TM>;
+  constexpr int LDS_BYTES = kLds<TM>;
   if (!attr_set) {
     hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES);
     if (e != hipSuccess) {
@@ -415,8 +429,10 @@ int launch4w(const vidil_gemm_args& a, hipStream_t s) {
     const int v = atoi(e) & ~7;
     if (v >= 8 && v < cus) cus = v;
   }
-  const int ntiles = ((a.M + 255) / 256) * ((a.N + 255) / 256);
-  const int tiles = ntiles >= cus ? cus : (ntiles >= 8 ? (ntiles & ~7) : ntiles);
+  const int ntiles = ((a.M + 64 * TM - 1) / (64 * TM)) * ((a.N + 255) / 256);
+  // (fewer tiles than CUs: one workgroup per tile — the count rounded UP to the XCD multiple, the spare workgroups find
+  //  their XCD's range empty and leave; rounded down, a few workgroups would run two tiles and double the launch's time)
+  const int tiles = ntiles >= cus ? cus : (ntiles >= 8 ? ((ntiles + 7) & ~7) : ntiles);
   hipLaunchKernelGGL(kern, dim3(tiles), dim3(256), LDS_BYTES, s, a);
   VIDIL_CHECK_LAUNCH("gemm4w");
   return VIDIL_OK;
@@ -450,8 +466,29 @@ int launch4w_dispatch(const vidil_gemm_args& a, hipStream_t s) {
 
 }  // namespace
 
-int vidil_gemm4w_launch(const vidil_gemm_args& a, hipStream_t s) {
+// the 128 x 256-tile form: plain epilogues only (the decode steps' projections and FFN, mid-size grids)
+template <typename T>
+int launch4w128_dispatch(const vidil_gemm_args& a, hipStream_t s) {
+  if (a.ln_fold || a.ln_stats_out || a.rln_gamma) return -1000;
+  switch (a.epi) {
+    case VIDIL_EPI_F16:
+      if (a.act == VIDIL_ACT_NONE) return launch4w<T, VIDIL_EPI_F16, VIDIL_ACT_NONE, false, T, false, false, 2>(a, s);
+      if (a.act == VIDIL_ACT_GELU_ERF) return launch4w<T, VIDIL_EPI_F16, VIDIL_ACT_GELU_ERF, false, T, false, false, 2>(a, s);
+      return launch4w<T, VIDIL_EPI_F16, VIDIL_ACT_QUICK_GELU, false, T, false, false, 2>(a, s);
+    case VIDIL_EPI_F32:
+      if (a.act == VIDIL_ACT_NONE) return launch4w<T, VIDIL_EPI_F32, VIDIL_ACT_NONE, false, T, false, false, 2>(a, s);
+      return -1000;
+    case VIDIL_EPI_HEADS:
+      return launch4w<T, VIDIL_EPI_HEADS, VIDIL_ACT_NONE, false, T, false, false, 2>(a, s);
+    default:
+      return -1000;
+  }
+}
+
+// tm: 4 = 256 x 256 tiles, 2 = 128 x 256 tiles.  -1000: the variant is not built here.
+int vidil_gemm4w_launch(const vidil_gemm_args& a, hipStream_t s, int tm) {
   if (a.dtype == VIDIL_DT_FP8) return -1000;
+  if (tm == 2) return a.dtype == VIDIL_DT_BF16 ? launch4w128_dispatch<bf16>(a, s) : launch4w128_dispatch<f16>(a, s);
   if (a.dtype == VIDIL_DT_BF16) return launch4w_dispatch<bf16>(a, s);
   return launch4w_dispatch<f16>(a, s);
 }
