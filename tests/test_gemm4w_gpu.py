@@ -278,3 +278,42 @@ def test_gemm4w_128_row_tile_form_equals_the_other_kernels(monkeypatch, dtype, M
         assert torch.equal(r, g)
     want = a[-200:].float() @ w.float().t() + bias + x0[-200:]
     assert torch.allclose(got[0][-200:], want, rtol=1e-4, atol=2e-3 * (K / 768) ** 0.5 + 1e-3)
+
+
+@pytest.mark.parametrize("dtype", [torch.float16, torch.bfloat16])
+@pytest.mark.parametrize("T,stride", [(1, 1), (4, 3)])
+def test_arena_epilogue_on_the_256_row_kernels(monkeypatch, dtype, T, stride):
+    """EPI_ARENA (Q rows + K / V rows appended to the beam-search KV arena: include/vidil_hip.h) through gemm256, gemm4w
+    and gemm4w's 128-row form — the decode steps' self-attention Q|K|V projection at ~10^4 beam rows used to run on the
+    small-tile kernel only.  Expected values: the f32 GEMM (+ bias) rounded as the epilogue rounds (Q scaled by q_scale)."""
+    k = _k()
+    H, D = 12, 768
+    nseq = 10752 // T
+    M = nseq * T
+    a = _rand(M, D, seed=1).to(dtype).to(DEV)
+    w = _rand(3 * D, D, scale=0.05, seed=2).to(dtype).to(DEV)
+    bias = _rand(3 * D, seed=3).to(DEV)
+    t_off, Tcap = 5, 16
+    rows = (nseq - 1) * stride + 1
+    f32 = k.gemm(a, w, bias, out_dtype=torch.float32)
+    qs = 0.125
+    want_q = (f32[:, :D] * qs).to(dtype)
+    want_k, want_v = f32[:, D:2 * D].to(dtype), f32[:, 2 * D:].to(dtype)
+    names = set()
+    for env in (dict(VIDIL_GEMM4W="0", VIDIL_GEMM4W128="0"), dict(VIDIL_GEMM4W="1", VIDIL_GEMM4W128="0"), dict(VIDIL_GEMM4W128="1")):
+        for kk in ("VIDIL_GEMM4W", "VIDIL_GEMM4W128"):
+            monkeypatch.delenv(kk, raising=False)
+        for kk, vv in env.items():
+            monkeypatch.setenv(kk, vv)
+        q = torch.zeros(M, D, dtype=dtype, device=DEV)
+        ka = torch.zeros(Tcap, rows, D, dtype=dtype, device=DEV)
+        va = torch.zeros(Tcap, rows, D, dtype=dtype, device=DEV)
+        ar = dict(q=q, k=ka, v=va, T=T, H=H, part0=0, t_off=t_off, arena_rows=rows, slot_stride=stride, Tcap=Tcap, q_scale=qs)
+        names.add(k.gemm_kernel_name(a, w, bias, arena=ar).split("<")[0] + k.gemm_kernel_name(a, w, bias, arena=ar)[-4:])
+        k.gemm(a, w, bias, arena=ar)
+        assert torch.equal(q, want_q)
+        got_k = ka[t_off:t_off + T, ::stride].permute(1, 0, 2).reshape(M, D)
+        got_v = va[t_off:t_off + T, ::stride].permute(1, 0, 2).reshape(M, D)
+        assert torch.equal(got_k, want_k) and torch.equal(got_v, want_v)
+        assert ka[:t_off].abs().sum() == 0 and ka[t_off + T:].abs().sum() == 0
+    assert len(names) == 3, names

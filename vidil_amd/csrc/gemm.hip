@@ -325,8 +325,8 @@ TileChoice choose_tile(const vidil_gemm_args& a) {
   }();
   const bool forced_big = a.ln_fold || a.out16 || a.ln_stats_out || a.dtype == VIDIL_DT_FP8;   // (check_args)
   if (forced_big) return {1, 256, 256, 2};
-  if (allow256 && a.epi != VIDIL_EPI_ARENA && vidil_gemm4w128_wanted(a)) return {2, 128, 256, 2};
-  if (allow256 && a.epi != VIDIL_EPI_ARENA && vidil_gemm256_eligible(a)) return {1, 256, 256, 2};
+  if (allow256 && vidil_gemm4w128_wanted(a)) return {2, 128, 256, 2};
+  if (allow256 && vidil_gemm256_eligible(a)) return {1, 256, 256, 2};
 #ifdef VIDIL_GEMM_TUNE
   // developer builds only: VIDIL_GEMM_TILE=<BM>x<BN>x<ST> forces one configuration
   if (const char* e = getenv("VIDIL_GEMM_TILE")) {

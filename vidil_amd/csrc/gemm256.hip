@@ -48,7 +48,7 @@ __device__ __forceinline__ void glds16(const void* g, char* lds) {
 // The per-head scatter epilogue (EPI_HEADS) is launched one tile per workgroup: its V^T tiles end in 128 narrow
 // stores per lane whose drain the next tile would have to wait for, and the extra live state spills registers.
 template <int EPI>
-constexpr bool kPersistent = EPI != VIDIL_EPI_HEADS;
+constexpr bool kPersistent = EPI != VIDIL_EPI_HEADS && EPI != VIDIL_EPI_ARENA;
 
 #ifdef VIDIL_GEMM_PROBE
 // developer build only (make EXTRA=-DVIDIL_GEMM_PROBE, tools/probe_gemm_clock.py): shader cycles and 100-MHz
@@ -422,6 +422,8 @@ bool vidil_gemm256_eligible(const vidil_gemm_args& a, bool any_size) {
       return a.N % 4 == 0 && a.ldo % 4 == 0 && al16(a.out) && al16(a.pos);
     case VIDIL_EPI_HEADS:
       return (!a.q || al16(a.q)) && (!a.k || al16(a.k)) && ((a.NP != 0 && !a.kv_tiled) || !a.vt || al16(a.vt));
+    case VIDIL_EPI_ARENA:      // (rows of H*64 16-bit values: 128-byte multiples)
+      return (!a.q || al16(a.q)) && (!a.k || al16(a.k)) && (!a.vt || al16(a.vt));
     default:
       return false;
   }
@@ -448,6 +450,8 @@ static int launch256_dispatch(const vidil_gemm_args& a, hipStream_t s) {
       return launch256<T, VIDIL_EPI_F32, VIDIL_ACT_QUICK_GELU>(a, s);
     case VIDIL_EPI_HEADS:
       return launch256<T, VIDIL_EPI_HEADS, VIDIL_ACT_NONE>(a, s);
+    case VIDIL_EPI_ARENA:
+      return launch256<T, VIDIL_EPI_ARENA, VIDIL_ACT_NONE>(a, s);
     default:
       return launch256<T, VIDIL_EPI_PATCH, VIDIL_ACT_NONE>(a, s);
   }
@@ -490,6 +494,7 @@ static bool prefer_4w(const vidil_gemm_args& a) {
   switch (a.epi) {
     case VIDIL_EPI_F16:
     case VIDIL_EPI_HEADS:
+    case VIDIL_EPI_ARENA:
       return true;
     case VIDIL_EPI_F32:
       return a.ln_stats_out != nullptr;    // (the LN-fold producers, with or without a residual LayerNorm; plain f32: gemm256)
@@ -509,7 +514,8 @@ bool vidil_gemm4w128_wanted(const vidil_gemm_args& a) {
   const char* e = getenv("VIDIL_GEMM4W128");                    // (developer: 0 never, 1 whenever it can run)
   const int mode = e ? atoi(e) : -1;
   if (mode == 0 || a.dtype == VIDIL_DT_FP8 || a.ln_fold || a.ln_stats_out || a.rln_gamma || a.out16) return false;
-  if (!(a.epi == VIDIL_EPI_F16 || a.epi == VIDIL_EPI_HEADS || (a.epi == VIDIL_EPI_F32 && a.act == VIDIL_ACT_NONE))) return false;
+  if (!(a.epi == VIDIL_EPI_F16 || a.epi == VIDIL_EPI_HEADS || a.epi == VIDIL_EPI_ARENA || (a.epi == VIDIL_EPI_F32 && a.act == VIDIL_ACT_NONE)))
+    return false;
   if (!vidil_gemm256_eligible(a, true)) return false;        // (alignment / stride / offset-range rules are the same)
   if (mode == 1) return true;
   const long t256 = (long)((a.M + 255) / 256) * ((a.N + 255) / 256);

@@ -459,6 +459,8 @@ int launch4w_dispatch(const vidil_gemm_args& a, hipStream_t s) {
       return launch4w<T, VIDIL_EPI_F32, VIDIL_ACT_QUICK_GELU>(a, s);
     case VIDIL_EPI_HEADS:
       return launch4w<T, VIDIL_EPI_HEADS, VIDIL_ACT_NONE>(a, s);
+    case VIDIL_EPI_ARENA:
+      return launch4w<T, VIDIL_EPI_ARENA, VIDIL_ACT_NONE>(a, s);
     default:
       return launch4w<T, VIDIL_EPI_PATCH, VIDIL_ACT_NONE>(a, s);
   }
@@ -480,6 +482,8 @@ int launch4w128_dispatch(const vidil_gemm_args& a, hipStream_t s) {
       return -1000;
     case VIDIL_EPI_HEADS:
       return launch4w<T, VIDIL_EPI_HEADS, VIDIL_ACT_NONE, false, T, false, false, 2>(a, s);
+    case VIDIL_EPI_ARENA:
+      return launch4w<T, VIDIL_EPI_ARENA, VIDIL_ACT_NONE, false, T, false, false, 2>(a, s);
     default:
       return -1000;
   }
