@@ -488,7 +488,7 @@ static bool prefer_4w(const vidil_gemm_args& a) {
   if (const char* e = getenv("VIDIL_GEMM4W")) return atoi(e) != 0;
   if (a.dtype == VIDIL_DT_FP8) return false;
   const long tiles = (long)((a.M + 255) / 256) * ((a.N + 255) / 256);
-  static const long min_tiles = [] { const char* e = getenv("VIDIL_GEMM4W_MIN_TILES"); return e ? atol(e) : 512L; }();   // (developer sweep: 128 measured -0.3 % in the bench — small grids start faster on gemm256)
+  static const long min_tiles = [] { const char* e = getenv("VIDIL_GEMM4W_MIN_TILES"); return e ? atol(e) : 384L; }();   // (developer sweep, whole bench, same box: 512 -> 5,112, 384 -> 5,120, 320 -> 5,094, 128 -> 5,050 frames/s — small grids start faster on gemm256)
   if (tiles < min_tiles) return false;
   if (a.ln_fold) return true;
   switch (a.epi) {
