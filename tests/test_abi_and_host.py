@@ -75,6 +75,17 @@ def test_argument_validation_without_a_gpu():
     g.A, g.W, g.out, g.M, g.N, g.K, g.ldo, g.epi, g.dtype = 16, 16, 16, 201728, 768, 768, 768, 1, 1
     buf = ctypes.create_string_buffer(128)
     assert lib.vidil_gemm_kernel_name(ctypes.byref(g), buf, 128) == 0 and buf.value == b"gemm256_kernel<__bf16, __bf16, 1, 0, false, false, false>"
+    # ... the dispatch between the library's GEMM kernels (round 3; all of them produce the same bits — tests/test_gemm4w_gpu.py):
+    # the plain f32 epilogue stays on the 8-wave kernel (above); 16-bit outputs of a big grid go to the 4-wave kernel;
+    # a mid-size grid (10,752 decode rows x 768 columns: 126 tiles of 256^2, 252 of 128 x 256) to its 128-row-tile form;
+    # a small problem to the small-tile kernel
+    import os
+    if not any(k in os.environ for k in ("VIDIL_GEMM4W", "VIDIL_GEMM4W128", "VIDIL_GEMM256", "VIDIL_GEMM4W_MIN_TILES")):
+        g.epi = 0
+        assert lib.vidil_gemm_kernel_name(ctypes.byref(g), buf, 128) == 0 and buf.value == b"gemm4w_kernel<__bf16, __bf16, 0, 0, false, false, false, 4>"
+        g.M, g.epi = 10752, 1
+        assert lib.vidil_gemm_kernel_name(ctypes.byref(g), buf, 128) == 0 and buf.value == b"gemm4w_kernel<__bf16, __bf16, 1, 0, false, false, false, 2>"
+        g.epi = 1
     g.M, g.dtype = 3072, 0
     assert lib.vidil_gemm_kernel_name(ctypes.byref(g), buf, 128) == 0 and buf.value.startswith(b"gemm_kernel<_Float16, ")
     g.dtype = 5
