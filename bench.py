@@ -369,14 +369,29 @@ def secondary_measurements(args, cap, flt, clip, step, frames, dev, parity_file,
     return out
 
 
+def launch_ranks(n):
+    """Re-run this command line as ``n`` ranks of one node (rendezvous on 127.0.0.1, a free port)."""
+    import socket
+    import subprocess
+
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")     # (dmabuf IPC: what RCCL needs on this driver)
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n}", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    raise SystemExit(subprocess.run(cmd, env=env).returncode)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=5)
     ap.add_argument("--warmup", type=int, default=2)
-    # 384 videos = 3072 frames per step: 605,184 ViT rows = 2364 row tiles of 256, i.e. 27.7 rounds of 256-tile
-    # workgroups on the N = 768 GEMMs (98.9 % of the last round filled; 128 videos give 9.23 rounds = 92 %), and
-    # 9216 beam rows per decode step (measured: 128 -> 3.7k, 192 -> 3.8-3.95k, 384 -> 4.1k, 576 -> 3.9k frames/s)
+    # 448 videos = 3,584 frames per step: 706,048 ViT rows = exactly 2,758 row tiles of 256 (every batch that is a multiple of
+    # 32 videos fills its last round of 256-row tiles), 10,752 beam rows per decode step (measured on one box: 384 -> 4,838,
+    # 416 -> 4,845, 448 -> 4,918, 480 -> 4,855, 512 -> 4,873, 640 -> 4,836 frames/s; DESIGN.md §5)
     ap.add_argument("--videos-per-step", type=int, default=448)
     ap.add_argument("--frames", type=int, default=8, help="frames per video (config 4: 16)")
     ap.add_argument("--dtype", choices=["f16", "bf16", "fp8"], default="bf16",
@@ -417,10 +432,15 @@ def main():
     if args.gpus > torch.cuda.device_count() and not one_device:
         raise SystemExit(f"--gpus {args.gpus} but this node has {torch.cuda.device_count()} GPU(s): one rank per GPU over RCCL "
                          "(VIDIL_BENCH_SMOKE_ONE_DEVICE=1 runs the launch path with every rank on cuda:0 over gloo)")
+    if args.gpus > 1 and "RANK" not in os.environ:
+        # `python bench.py --gpus N` by itself: become the launcher — one rank per GPU under torch.distributed.run (what
+        # pipeline/scripts/run_frame_captioning_and_visual_tokenization.sh:37,48 does for the reference's drivers), same
+        # arguments, rank 0's JSON line on this process's stdout, its exit code as ours
+        return launch_ranks(args.gpus)
     backend = "gloo" if one_device else "nccl"
     rank, world, local = vdist.init_distributed_mode(backend=backend) if args.gpus > 1 else (0, 1, 0)
     if args.gpus > 1 and world != args.gpus:
-        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}; launch with torch.distributed.run")
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
     if one_device:
         local = 0
     torch.cuda.set_device(local)

@@ -8,6 +8,11 @@ if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
 
+# the kernel-selection switches ($VIDIL_GEMM4W ...) are cached per process by the library unless this is set (core.hip):
+# several tests flip them between launches
+os.environ.setdefault("VIDIL_DEV_ENV", "1")
+
+
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
 

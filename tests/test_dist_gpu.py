@@ -105,8 +105,9 @@ def test_two_ranks_on_one_gpu_through_the_engines_equal_single_process(tmp_path)
 
 def test_rccl_backend_with_a_single_rank_runs_the_device_side_collectives(tmp_path):
     """What a one-GPU box CAN execute of the RCCL branch: backend "nccl" with world size 1 — process-group creation on the
-    device, `barrier(device_ids=...)`, the size all_gather and the max-reduce of `vidil_amd.dist` on DEVICE buffers (the
-    peer-to-peer send / recv of gather_json needs a second GPU: next test).  Outputs equal the un-distributed run's."""
+    device, `barrier(device_ids=...)`, BOTH all_gathers of gather_json (sizes, then the padded payload bytes: since round 4
+    the gather has no peer-to-peer half, so the code an 8-GPU job takes is exactly the code that runs here) and the
+    max-reduce of `vidil_amd.dist` on DEVICE buffers.  Outputs equal the un-distributed run's."""
     out0, out1 = str(tmp_path / "plain"), str(tmp_path / "nccl1")
     _run(1, out0)
     _run(1, out1, backend="nccl")
@@ -131,7 +132,7 @@ print("nccl-single-rank-ok")
 
 
 def test_one_rank_per_gpu_over_rccl_equals_single_process(tmp_path):
-    """The RCCL branch of vidil_amd.dist (backend "nccl": sizes all_gather'ed and JSON bytes sent / received as DEVICE
+    """The RCCL branch of vidil_amd.dist (backend "nccl": sizes, then the padded JSON bytes all_gather'ed as DEVICE
     buffers over xGMI, barrier pinned to the rank's device): 2 ranks (4 when the node has them), one per GPU, through both
     engines and both writers; the merged files equal the single-process ones byte for byte."""
     import torch
@@ -177,3 +178,35 @@ def test_bench_gpus_2_one_device_smoke(tmp_path):
     os.makedirs(os.path.join(ROOT, "gpurun_out"), exist_ok=True)
     with open(os.path.join(ROOT, "gpurun_out", "bench_gpus2_one_device_smoke.log"), "w") as f:
         f.write("$ VIDIL_BENCH_SMOKE_ONE_DEVICE=1 " + " ".join(cmd[1:]) + "\n" + r.stdout + "\n---- stderr ----\n" + r.stderr[-3000:])
+
+
+def _json_lines(text):
+    return [l for l in text.splitlines() if l.startswith("{")]
+
+
+def test_bench_launches_itself_for_gpus_1_and_gpus_2():
+    """`python bench.py --gpus N` exactly as the driver types it — no RANK in the environment, no external
+    launcher.  N = 1 runs in-process; N = 2 makes bench.py re-run itself under torch.distributed.run (one-device smoke flag
+    on this 1-GPU box: both ranks on cuda:0 over Gloo; on a multi-GPU node the same command is one rank per GPU over RCCL).
+    One JSON line from rank 0, n_gpus = N, exit code 0."""
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    env["HSA_ENABLE_IPC_MODE_LEGACY"] = "0"
+    common = ["--steps", "1", "--warmup", "0", "--videos-per-step", "16", "--no-cpu-baseline", "--no-secondary"]
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "1"] + common, env=env, cwd=ROOT,
+                       capture_output=True, text=True, timeout=1200)
+    assert r.returncode == 0, (r.stdout[-2000:], r.stderr[-4000:])
+    lines = _json_lines(r.stdout)
+    assert len(lines) == 1 and json.loads(lines[0])["n_gpus"] == 1
+    import torch
+    if torch.cuda.device_count() < 2:
+        env["VIDIL_BENCH_SMOKE_ONE_DEVICE"] = "1"
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2"] + common, env=env, cwd=ROOT,
+                       capture_output=True, text=True, timeout=1800)
+    assert r.returncode == 0, (r.stdout[-2000:], r.stderr[-4000:])
+    lines = _json_lines(r.stdout)
+    assert len(lines) == 1, r.stdout
+    rec = json.loads(lines[0])
+    assert rec["n_gpus"] == 2 and rec["scaling"] == "weak" and rec["value"] > 0
+    os.makedirs(os.path.join(ROOT, "gpurun_out"), exist_ok=True)
+    with open(os.path.join(ROOT, "gpurun_out", "bench_gpus2_self_launch.log"), "w") as f:
+        f.write("$ python bench.py --gpus 2 " + " ".join(common) + "\n" + r.stdout + "\n---- stderr ----\n" + r.stderr[-3000:])

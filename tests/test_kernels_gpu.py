@@ -850,3 +850,53 @@ def test_layernorm_fold_does_not_depend_on_the_batch_size():
     big = k.gemm(x16, wf.to(DEV), bf.to(DEV), act=k.ACT_GELU_ERF, ln=(cs.to(DEV), 1e-6, st))
     small = k.gemm(x16[:591].contiguous(), wf.to(DEV), bf.to(DEV), act=k.ACT_GELU_ERF, ln=(cs.to(DEV), 1e-6, st[:591].contiguous()))
     assert torch.equal(big[:591], small)
+
+
+# ------------------------------------------------------------------------------- the polynomial GELU of 16-bit outputs
+def _all_16bit_values(dtype, lim):
+    bits = torch.arange(0, 1 << 16, dtype=torch.int32).to(torch.int16)
+    v = bits.view(dtype)
+    v = v[torch.isfinite(v.float()) & (v.float().abs() <= lim)]
+    return v
+
+
+@pytest.mark.parametrize("dtype,abs_bound,one_ulp_above", [(torch.float16, 4.5e-5, 1.0 / 16), (torch.bfloat16, 2.0e-4, 1.0 / 32)])
+def test_polynomial_gelu_of_16bit_outputs_vs_erf_gelu(dtype, abs_bound, one_ulp_above):
+    """the transcendental-free GELU that the GEMM epilogues apply to 16-bit outputs (csrc/common.h GeluPoly) against
+    erf-GELU in float64 on EVERY 16-bit input: absolute error (the bound the header states), error in output ulps where the
+    value is not tiny, exact saturation outside the fitted range — through the small-tile kernel and, on a tall problem,
+    through the 256-row kernels, which must agree with it bit for bit."""
+    k = _k()
+    x = torch.cat([_all_16bit_values(dtype, 16.0), torch.tensor([100.0, -100.0, 3.0e4, -3.0e4], dtype=dtype)])
+    n = x.numel()
+    K, N = 512, 256
+    a = torch.zeros(n, K, dtype=dtype)
+    a[:, 0] = x
+    w = torch.zeros(N, K, dtype=dtype)
+    w[:, 0] = 1.0
+    y = k.gemm(a.to(DEV), w.to(DEV), None, out_dtype=dtype, act=k.ACT_GELU_ERF)
+    reps = (256 * 400 + n - 1) // n                              # >= 384 tiles of 256 x 256: the 4-wave kernel's territory
+    a_tall = a.repeat(reps, 1).to(DEV)
+    assert "gemm4w" in k.gemm_kernel_name(a_tall, w.to(DEV), None, out_dtype=dtype, act=k.ACT_GELU_ERF)
+    y_tall = k.gemm(a_tall, w.to(DEV), None, out_dtype=dtype, act=k.ACT_GELU_ERF)
+    torch.cuda.synchronize()
+    y = y.cpu()
+    assert torch.equal(y.view(torch.int16), y[:, :1].expand(-1, N).contiguous().view(torch.int16))
+    assert torch.equal(y_tall.cpu().view(reps, n, N).view(torch.int16), y.view(torch.int16).expand(reps, -1, -1)), \
+        "the 256-row kernel's GELU differs from the small-tile kernel's"
+    got = y[:, 0].double()
+    xd = x.double()
+    ref = xd * 0.5 * (1.0 + torch.erf(xd / math.sqrt(2.0)))
+    ref16 = ref.to(dtype).double()
+    mant = 10 if dtype == torch.float16 else 7
+    ulp = torch.pow(2.0, torch.floor(torch.log2(ref.abs().clamp_min(2.0 ** -14))) - mant)
+    err = (got - ref).abs()
+    assert bool((err <= abs_bound + 0.5 * ulp).all()), f"max |gelu_poly - erf-GELU| beyond the rounding: {(err - 0.5 * ulp).max():.3e}"
+    big = ref.abs() >= one_ulp_above
+    ulps = ((got - ref16).abs() / ulp)
+    assert float(ulps[big].max()) <= 1.0, f"{float(ulps[big].max())} ulps at |gelu| >= {one_ulp_above}"
+    far = xd.abs() >= 8.0
+    assert torch.equal(got[far & (xd > 0)], xd[far & (xd > 0)]) and bool((got[far & (xd < 0)] == 0).all())
+    small = ~big & (xd.abs() <= 4.5)
+    print(f"\n{dtype}: max abs err (after rounding) {float(err.max()):.2e}; max ulps where |gelu| < {one_ulp_above}: "
+          f"{float(ulps[small].max()):.1f} at x = {float(xd[small][ulps[small].argmax()]):.3f}")

@@ -310,3 +310,82 @@ def test_parity_mode_itm_logits_and_capfilt_decisions_vs_oracle():
         kept, probs = pipeline_ref.filter_video(sd_itm, xv, items[v]["unfiltered_text"], tok, 0.4, return_probs=True)
         if all(abs(float(np.max(p)) - 0.4) > 1e-4 for p in probs):
             assert items[v]["text"] == kept, v
+
+
+# ------------------------------------------------------------------------------- CLIP in the parity mode (round 4)
+@pytest.fixture(scope="module")
+def parity_clip():
+    from vidil_amd.clip import CLIPModel
+    from vidil_amd.packing import set_compute_dtype, set_parity_mode
+
+    torch.manual_seed(0)
+    clip = CLIPModel().eval()
+    perturb_(clip, 102)
+    sd = {k: v.clone() for k, v in clip.state_dict().items()}
+    clip = clip.to(DEV)
+    set_compute_dtype("f16", clip)
+    set_parity_mode(True, clip)
+    return clip, sd
+
+
+def test_parity_mode_clip_embeddings_vs_fp32_oracle(parity_clip):
+    """CLIP ViT-B/32 image embeddings and text embeddings (run_visual_tokenization.py:83-96,135-143: HF CLIPModel
+    image_embeds / text_embeds, unit norm) with both towers on error-compensated operands, against the fp32 oracle
+    (oracle/clip_ref.py, itself pinned to transformers' CLIPModel): 2e-5 where the plain 16-bit tower is asserted at 5e-4."""
+    from oracle import clip_ref
+
+    clip, sd = parity_clip
+    u8 = synthetic_frames(1, 8, first_video=5)[0]
+    x = clip_ref.preprocess_u8(u8)
+    with torch.no_grad():
+        ref = clip_ref.image_embeds(sd, x)
+    got = clip.encode_image_u8(torch.from_numpy(u8).to(DEV)).cpu()
+    e_img = (got - ref).abs().max().item()
+    got_f32 = clip.encode_image(x.to(DEV)).cpu()
+    g = torch.Generator().manual_seed(7)
+    ids = torch.randint(1000, 40000, (6, 12), generator=g)
+    ids[:, 0] = 49406
+    for r, n in enumerate((5, 7, 9, 11, 12, 6)):
+        ids[r, n - 1] = 49407
+        ids[r, n:] = 0
+    mask = (torch.arange(12)[None, :] < torch.tensor([5, 7, 9, 11, 12, 6])[:, None]).long()
+    with torch.no_grad():
+        tref = clip_ref.text_embeds(sd, ids, mask)
+    tgot = clip.encode_text(ids.to(DEV), mask.to(DEV)).cpu()
+    e_txt = (tgot - tref).abs().max().item()
+    print(f"parity-mode CLIP ViT-B/32 vs fp32 oracle: image embeds max|d| {e_img:.2e} (f32 entry point {(got_f32 - ref).abs().max().item():.2e}), "
+          f"text embeds {e_txt:.2e}  (plain 16-bit towers: asserted 5e-4)")
+    assert e_img < 2e-5 and e_txt < 2e-5 and (got_f32 - ref).abs().max().item() < 2e-5
+    assert (got.norm(dim=-1) - 1).abs().max().item() < 1e-5
+
+
+def test_parity_mode_visual_token_indices_end_to_end_equal_the_reference_form(parity_clip):
+    """BASELINE: "top-k visual-token indices bit-exact" — END TO END, frames -> CLIP tower -> ontology scan -> per-frame
+    top-5 per category, against the reference FORM on the fp32 oracle's embeddings (`image_embeds @ text_embeds.t()` +
+    `np.argsort(score)[::-1][:5]`, run_visual_tokenization.py:276,298-308), at config 1's shape per video (8 frames) and
+    the vg ontology sizes (19,958 / 15,026 / 365 / 7,410 classes).  With the tower in the parity mode what separates the
+    device's scores from the oracle's is the fp32 summation order (~3e-5 over 42k classes), so a rank is compared exactly
+    unless the ORACLE's own adjacent scores are closer than that — and that mask is bounded at 5 % (round 3, 16-bit tower:
+    gap 1.5e-3, 41 % masked)."""
+    from oracle import clip_ref
+    from test_models_gpu import _compare_visual_tokens_rank_by_rank, _ontology
+    from vidil_amd.visual_tokenization import VisualTokenizer
+
+    clip, sd = parity_clip
+    Nv, F = 3, 8
+    u8 = synthetic_frames(Nv, F, first_video=7)
+    emb, texts = _ontology(sizes=dict(objects=19958, attributes=15026, scenes=365, verbs=7410))
+    cfg = dict(topk_visualize=5)
+    vt = VisualTokenizer(cfg, clip, texts, emb, DEV)
+    toks = vt.process([f"video{v}" for v in range(Nv)], torch.from_numpy(u8).to(DEV), [[] for _ in range(Nv)])
+    GAP = 3e-5
+    ranks = masked = 0
+    for v in range(Nv):
+        with torch.no_grad():
+            ie = clip_ref.image_embeds(sd, clip_ref.preprocess_u8(u8[v]))
+        r, m = _compare_visual_tokens_rank_by_rank(toks[f"video{v}"], ie, emb, texts, F, GAP)
+        ranks += r
+        masked += m
+    print(f"parity-mode e2e visual tokens: {ranks - masked}/{ranks} ranks compared exactly and equal "
+          f"({masked} lie within {GAP} of a neighbour in the oracle's own scores)")
+    assert masked <= 0.05 * ranks, (masked, ranks)

@@ -7,6 +7,7 @@ Prints: ViT time on n CUs alone, decode time on n CUs alone, and both together f
 """
 import ctypes
 import os
+os.environ.setdefault("VIDIL_DEV_ENV", "1")   # the library caches its developer switches per process otherwise
 import sys
 import time
 

@@ -4,6 +4,7 @@ Needs a library built with -DVIDIL_GEMM_TUNE (make EXTRA=-DVIDIL_GEMM_TUNE), whi
 VIDIL_GEMM_TILE=<BM>x<BN>x<ST>.  Usage: python tools/tune_gemm.py [rows ...]
 """
 import os
+os.environ.setdefault("VIDIL_DEV_ENV", "1")   # the library caches its developer switches per process otherwise
 import sys
 
 import torch

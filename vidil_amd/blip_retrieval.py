@@ -31,10 +31,14 @@ class BLIP_Retrieval(BLIP_ITM):
                          vit_ckpt_layer=vit_ckpt_layer, embed_dim=embed_dim, tokenizer=tokenizer)
         self.temp = nn.Parameter(0.07 * torch.ones([]))      # models/blip_retrieval.py:66 (unused at inference)
         self.queue_size, self.momentum, self.negative_all_rank = queue_size, momentum, negative_all_rank
+        # the retrieval heads have no parity form: pin this model (and its towers) to the plain mode so that the process-wide
+        # $VIDIL_PARITY default — meant for the captioner, the filter and CLIP — leaves it working
+        from .packing import set_parity_mode
+        set_parity_mode(False, self)
 
     def _pack(self):
-        if self.parity:
-            raise NotImplementedError("the parity precision mode is built for BLIP_Decoder and BLIP_ITM, not for the retrieval heads")
+        if self.__dict__.get("_parity"):     # (explicitly switched on for THIS model)
+            raise NotImplementedError("the parity precision mode is built for BLIP_Decoder, BLIP_ITM and CLIPModel, not for the retrieval heads")
         p = super()._pack()
         p.update(vp_w=w16(self.vision_proj.weight, dtype=self.cdt), vp_b=v32(self.vision_proj.bias),
                  tp_w=w16(self.text_proj.weight, dtype=self.cdt), tp_b=v32(self.text_proj.bias))

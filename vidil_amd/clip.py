@@ -19,7 +19,7 @@ import torch
 import torch.nn as nn
 
 from . import kernels as K
-from .packing import FP8, PackedCache, fold_layernorm, require_cuda, v32, w8, w16, w16_patch
+from .packing import FP8, PackedCache, fold_layernorm, require_cuda, v32, w3, w3_patch, w8, w16, w16_patch
 
 CLIP_MEAN = (0.48145466, 0.4578275, 0.40821073)
 CLIP_STD = (0.26862954, 0.26130258, 0.27577711)
@@ -119,14 +119,20 @@ class _TextModel(nn.Module):
         self.final_layer_norm = nn.LayerNorm(cfg.hidden_size, eps=cfg.layer_norm_eps)
 
 
-def _pack_layers(encoder, c, fuse=False, fp8=False):
+def _pack_layers(encoder, c, fuse=False, fp8=False, parity=False):
     """fuse: LayerNorm folded into the QKV / fc1 GEMMs (layer_norm2 everywhere, layer_norm1 from layer 1 on: layer
-    0's input is written by a stand-alone LayerNorm / embedding kernel, not by a residual GEMM)."""
+    0's input is written by a stand-alone LayerNorm / embedding kernel, not by a residual GEMM).
+    parity: [W_hi | W_hi | W_lo] operands of the error-compensated GEMMs (packing.set_parity_mode)."""
     out = []
     for i, l in enumerate(encoder.layers):
         a = l.self_attn
         extra = {}
-        if fp8:     # fp8 tower mode (see vit.VisionTransformer._run_blocks_fp8)
+        if parity:
+            extra["qkv_w3"] = w3(a.q_proj.weight, a.k_proj.weight, a.v_proj.weight, dtype=c)
+            extra["o_w3"] = w3(a.out_proj.weight, dtype=c)
+            extra["fc1_w3"] = w3(l.mlp.fc1.weight, dtype=c)
+            extra["fc2_w3"] = w3(l.mlp.fc2.weight, dtype=c)
+        elif fp8:     # fp8 tower mode (see vit.VisionTransformer._run_blocks_fp8)
             extra["qkv_w8"], extra["qkv_s"] = w8(a.q_proj.weight, a.k_proj.weight, a.v_proj.weight)
             extra["o_w8"], extra["o_s"] = w8(a.out_proj.weight)
             extra["fc1_w8"], extra["fc1_s"] = w8(l.mlp.fc1.weight)
@@ -164,6 +170,26 @@ def _run_layers(layers, x, B, T, H, eps, *, causal=False, kv_len=None):
     hid = torch.empty((M, layers[0]["fc1_w"].shape[0]), dtype=cdt, device=dev)
     heads = dict(q=q, k=k, vt=vt, T=T, H=H, part0=0, t_off=0, Tq_cap=T, Tk_cap=T, NP=NP, q_scale=0.125)
     n = len(layers)
+    if "qkv_w3" in layers[0]:
+        # Parity precision mode (round 4; as vit.VisionTransformer._run_blocks_parity): every GEMM on error-compensated
+        # operands — LayerNorm and attention write [hi | lo | hi] rows (VIDIL_DT_SPLIT3), the quick-GELU output goes through
+        # f32 and vidil_split3_f32, weights are [W_hi | W_hi | W_lo], K tripled.  Q / K / V and the softmax probabilities
+        # are still rounded to 16 bits inside the attention kernels.
+        Dh = layers[0]["fc1_w"].shape[0]
+        a3 = torch.empty((M, 3 * D), dtype=cdt, device=dev)
+        o3 = torch.empty((M, 3 * D), dtype=cdt, device=dev)
+        hid32 = torch.empty((M, Dh), dtype=torch.float32, device=dev)
+        hid3 = torch.empty((M, 3 * Dh), dtype=cdt, device=dev)
+        for l in layers:
+            K.layernorm(x, l["n1g"], l["n1b"], eps, out16=a3, split3=True)
+            K.gemm(a3, l["qkv_w3"], l["qkv_b"], heads=heads)
+            K.attention(q, k, vt, o3, Bq=B, H=H, Nq=T, Nk=T, Tq_cap=T, Tk_cap=T, NP=NP, causal=causal, kv_len=kv_len, split3=True)
+            K.gemm(o3, l["o_w3"], l["o_b"], out=x, resid=x)
+            K.layernorm(x, l["n2g"], l["n2b"], eps, out16=a3, split3=True)
+            K.gemm(a3, l["fc1_w3"], l["fc1_b"], out=hid32, act=K.ACT_QUICK_GELU)
+            K.split3(hid32, hid3)
+            K.gemm(hid3, l["fc2_w3"], l["fc2_b"], out=x, resid=x)
+        return x
     stats = torch.empty((M, D // 64, 2), dtype=torch.float32, device=dev) if "fc1_f" in layers[0] else None
     if "qkv_w8" in layers[0] and T > 32:
         xn8 = torch.empty((M, D), dtype=FP8, device=dev)
@@ -266,26 +292,31 @@ class CLIPModel(PackedCache, nn.Module):
                 nn.init.zeros_(m.bias)
 
     def pack_flags(self):
-        return (self.fuse_layernorm, self.fp8)
+        return (self.fuse_layernorm, self.fp8, self.parity)
 
     def _pack(self):
-        if self.parity:
-            raise NotImplementedError("the parity precision mode covers the BLIP captioner and filter (caption logits / ITM "
-                                      "decisions); the CLIP towers feed an exact-f32 scan whose top-k is compared rank by rank "
-                                      "instead (DESIGN.md §4) — do not set_parity_mode() a CLIPModel")
         vm, tm = self.vision_model, self.text_model
         D = self.config.vision_config.hidden_size
         c = self.cdt
-        return dict(
+        par = self.parity
+        extra = {}
+        if par:
+            # parity precision mode (round 4: packing.set_parity_mode(True, clip) / $VIDIL_PARITY): both towers and both
+            # projections on error-compensated operands, so that the embeddings the exact-f32 ontology scan reads carry the
+            # fp32 reference's values to ~1e-6 and its top-k indices can be compared END TO END (tests/test_parity_mode_gpu.py)
+            extra = dict(pe_w3=w3_patch(vm.embeddings.patch_embedding.weight, c), vproj3=w3(self.visual_projection.weight, dtype=c),
+                         tproj3=w3(self.text_projection.weight, dtype=c))
+        return dict(extra, parity=par,
             pe_w=w16_patch(vm.embeddings.patch_embedding.weight, c),
             cls=v32(vm.embeddings.class_embedding), pos=v32(vm.embeddings.position_embedding.weight).view(-1, D),
             pre_g=v32(vm.pre_layrnorm.weight), pre_b=v32(vm.pre_layrnorm.bias),
             post_g=v32(vm.post_layernorm.weight), post_b=v32(vm.post_layernorm.bias),
-            vproj=w16(self.visual_projection.weight, dtype=c), vlayers=_pack_layers(vm.encoder, c, self.fuse_layernorm, self.fp8),
+            vproj=w16(self.visual_projection.weight, dtype=c),
+            vlayers=_pack_layers(vm.encoder, c, self.fuse_layernorm and not par, self.fp8 and not par, par),
             tok=v32(tm.embeddings.token_embedding.weight).view(self.config.text_config.vocab_size, -1),
             tpos=v32(tm.embeddings.position_embedding.weight).view(self.config.text_config.max_position_embeddings, -1),
             fin_g=v32(tm.final_layer_norm.weight), fin_b=v32(tm.final_layer_norm.bias),
-            tproj=w16(self.text_projection.weight, dtype=c), tlayers=_pack_layers(tm.encoder, c))
+            tproj=w16(self.text_projection.weight, dtype=c), tlayers=_pack_layers(tm.encoder, c, parity=par))
 
     # ------------------------------------------------------------------ vision tower
     def _vision_from_patches(self, patches16, B, pooled=False):
@@ -296,18 +327,19 @@ class CLIPModel(PackedCache, nn.Module):
         T = P + 1
         dev = patches16.device
         cdt = patches16.dtype
+        par = p["parity"]          # (then patches16 holds [hi | lo | hi] rows: see the callers)
         x = torch.empty((B * T, D), dtype=torch.float32, device=dev)
-        K.gemm(patches16, p["pe_w"], None, patch=dict(out=x, pos=p["pos"], tpi=P))
+        K.gemm(patches16, p["pe_w3"] if par else p["pe_w"], None, patch=dict(out=x, pos=p["pos"], tpi=P))
         K.set_cls_row(x, p["cls"], p["pos"], B, T, D)
         K.layernorm(x, p["pre_g"], p["pre_b"], vc.layer_norm_eps, out32=x)
         _run_layers(p["vlayers"], x, B, T, H, vc.layer_norm_eps)
-        pooled16 = torch.empty((B, D), dtype=cdt, device=dev)
+        pooled16 = torch.empty((B, (3 if par else 1) * D), dtype=cdt, device=dev)
         pooled32 = torch.empty((B, D), dtype=torch.float32, device=dev) if pooled else None
         K.layernorm(x, p["post_g"], p["post_b"], vc.layer_norm_eps, M=B, D=D, x_stride=T * D, out16=pooled16,
-                    out32=pooled32)
+                    out32=pooled32, split3=par)
         if pooled:
             return pooled32
-        emb = K.gemm(pooled16, p["vproj"], None, out_dtype=torch.float32)
+        emb = K.gemm(pooled16, p["vproj3"] if par else p["vproj"], None, out_dtype=torch.float32)
         return K.l2_normalize_rows(emb)
 
     @torch.no_grad()
@@ -315,7 +347,7 @@ class CLIPModel(PackedCache, nn.Module):
         """pixel_values f32 [F,3,S,S] (already normalised) -> unit-norm f32 [F,P]."""
         require_cuda(pixel_values, "CLIPModel.encode_image")
         ps = self.config.vision_config.patch_size
-        patches = K.patchify_f32(pixel_values.contiguous().float(), ps, dtype=self.cdt)
+        patches = K.patchify_f32(pixel_values.contiguous().float(), ps, dtype=self.cdt, split3=self.parity)
         return self._vision_from_patches(patches, pixel_values.shape[0])
 
     @torch.no_grad()
@@ -323,7 +355,7 @@ class CLIPModel(PackedCache, nn.Module):
         """uint8 [F,S,S,3] frames already at the model resolution; fused /255 + CLIP normalisation."""
         require_cuda(frames_u8, "CLIPModel.encode_image_u8")
         ps = self.config.vision_config.patch_size
-        patches = K.patchify_u8(frames_u8.contiguous(), ps, CLIP_MEAN, CLIP_STD, dtype=self.cdt)
+        patches = K.patchify_u8(frames_u8.contiguous(), ps, CLIP_MEAN, CLIP_STD, dtype=self.cdt, split3=self.parity)
         return self._vision_from_patches(patches, frames_u8.shape[0])
 
     @torch.no_grad()
@@ -333,7 +365,7 @@ class CLIPModel(PackedCache, nn.Module):
         (data/video_pretrain_dataset.py:199-202)."""
         require_cuda(frames_u8, "CLIPModel.pooled_image_u8")
         ps = self.config.vision_config.patch_size
-        patches = K.patchify_u8(frames_u8.contiguous(), ps, CLIP_MEAN, CLIP_STD, dtype=self.cdt)
+        patches = K.patchify_u8(frames_u8.contiguous(), ps, CLIP_MEAN, CLIP_STD, dtype=self.cdt, split3=self.parity)
         return self._vision_from_patches(patches, frames_u8.shape[0], pooled=True)
 
     # ------------------------------------------------------------------ text tower
@@ -361,9 +393,10 @@ class CLIPModel(PackedCache, nn.Module):
             pos = (ids32 == tc.eos_token_id).to(torch.int32).argmax(dim=-1)
         rows = (torch.arange(N, device=dev) * L + pos).to(torch.int32)
         sel = K.gather_rows(x, rows)
-        pooled16 = torch.empty((N, D), dtype=cdt, device=dev)
-        K.layernorm(sel, p["fin_g"], p["fin_b"], tc.layer_norm_eps, out16=pooled16)
-        emb = K.gemm(pooled16, p["tproj"], None, out_dtype=torch.float32)
+        par = p["parity"]
+        pooled16 = torch.empty((N, (3 if par else 1) * D), dtype=cdt, device=dev)
+        K.layernorm(sel, p["fin_g"], p["fin_b"], tc.layer_norm_eps, out16=pooled16, split3=par)
+        emb = K.gemm(pooled16, p["tproj3"] if par else p["tproj"], None, out_dtype=torch.float32)
         return K.l2_normalize_rows(emb)
 
     def forward(self, input_ids=None, pixel_values=None, attention_mask=None, **_):

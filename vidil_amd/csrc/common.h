@@ -14,11 +14,14 @@ typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 typedef float f32x2 __attribute__((ext_vector_type(2)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));
+typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
 
 #define VIDIL_WAVE 64
 
 // error plumbing ------------------------------------------------------------
 void vidil_set_error(const char* fmt, ...);
+const char* vidil_dev_env(const char* name);   // core.hip: developer overrides, read once per process (live under $VIDIL_DEV_ENV)
 
 // gemm256.hip: the 256x256 8-wave kernel for large problems (dispatched from vidil_gemm_f16)
 bool vidil_gemm256_eligible(const vidil_gemm_args& a, bool any_size = false);
@@ -164,65 +167,70 @@ __device__ __forceinline__ f32x2 gelu_erf2(f32x2 x) {
   const f32x2 er = {copysignf(y[0], xs[0]), copysignf(y[1], xs[1])};
   return (x * pk_splat(0.5f)) * (er + pk_splat(1.0f));
 }
-// erf-GELU for 16-BIT (and fp8) OUTPUTS: x * Phi(x) with Phi(x) - 1/2 = x * Q((x / 4.5)^2) on |x| <= 4.5 (Q: degree-8
-// weighted least-squares fit on Chebyshev nodes, pinned so that Phi(+-4.5) is exactly 1 / 0; outside, x is clamped, so the
-// result is exactly x or 0).  |error| <= 4.8e-5 absolute (rms 2e-5) against erf-GELU over all of f32 — a fifth of an f16
-// ulp of the values it rounds to, 1/30 of a bf16 ulp — with NO transcendental: 13 full-rate VALU instructions per value
-// instead of ~10 + 2 quarter-rate ones (v_rcp / v_exp): the GELU epilogue of the tower's fc1 GEMM is VALU time the
-// matrix pipe idles through.  f32 outputs (the LM-head transform, the parity precision mode) keep
-// gelu_erf2.  Explicit operations only, so every kernel instantiation produces the same bits.
+// erf-GELU for 16-BIT (and fp8) OUTPUTS, transcendental-free: x * Phi(x) with
+//     Phi(x) = clamp(1/2 + x * Q(x^2), 0, 1),
+// Q a minimax polynomial (absolute error of x * Phi(x), LP fit on [-R, R]; tools/fit_gelu.py prints these coefficients
+// and the error tables quoted here).  The clamp is the [0, 1] output modifier of the last fma, so nothing clamps x: past R
+// the odd polynomial x * Q(x^2) runs monotonically through +-1/2 (even degree in x^2, positive leading coefficient) and
+// the result is exactly x or -0 — checked for every f32 magnitude up to overflow of x^2 (inf * 0 = NaN only for x = -inf).
+// Degree by OUTPUT type — the polynomial only has to be invisible under the rounding of the value it feeds:
+//   f16  (11 significant bits): degree 8, R = 4.25: |error| <= 4.3e-5 absolute over all of f32 (rms 1.1e-5 on |x| < 4);
+//   bf16 ( 8 significant bits): degree 6, R = 4.00: |error| <= 1.9e-4 (rms 1.3e-4): a twentieth of a bf16 ulp at 1.
+// These are ABSOLUTE bounds: in the negative tail, where erf-GELU itself is ~1e-4 (x < -3.8), the relative error reaches
+// 100 % (the value is then worth 1/10 of an f16 ulp of the fc2 inputs that matter); tests/test_kernels_gpu.py bounds both the
+// absolute error and the error in output ulps over every 16-bit input.  Instruction count per PAIR of values (what the
+// epilogue of a one-wave-per-SIMD kernel pays for, DESIGN.md §3 "Round 4"): 1 mul + deg fma + 1 fma.clamp + 1 mul = 11 / 9
+// packed instructions, against 2 v_med3 + 12 for round 3's clamped degree-8 form.  f32 outputs (the LM-head transform, the
+// parity precision mode) keep gelu_erf2.  Explicit IEEE operations only — the scalar and the packed forms below produce
+// the same bits in every kernel instantiation.
+template <typename TO> struct GeluPoly;
+template <> struct GeluPoly<f16> {
+  static constexpr int DEG = 8;
+  static constexpr float q[9] = {3.988192516e-01f, -6.619034771e-02f, 9.718823738e-03f, -1.079092217e-03f, 8.849158500e-05f,
+                                 -5.147754456e-06f, 1.986294828e-07f, -4.515713104e-09f, 4.547582994e-11f};
+};
+template <> struct GeluPoly<bf16> {
+  static constexpr int DEG = 6;
+  static constexpr float q[7] = {3.978833846e-01f, -6.457313509e-02f, 8.772395999e-03f, -8.140167550e-04f, 4.795563103e-05f,
+                                 -1.598607122e-06f, 2.278152054e-08f};
+};
+template <typename TO>
 __device__ __forceinline__ float gelu_fast1(float x) {
-  // plain v_fma_f32 with LITERAL coefficients (v_fmaak_f32): packed-f32 operands must sit in VGPR pairs, and nine
-  // splatted constants (18 registers) made the LN-folded GELU instantiation of gemm256 spill 461 registers
-  const float xc = __builtin_amdgcn_fmed3f(x, -4.5f, 4.5f);
-  const float y = xc * (1.0f / 4.5f);
-  const float s = y * y;
-  float p = __builtin_fmaf(8.050480127e-01f, s, -4.390279192e+00f);
-  p = __builtin_fmaf(p, s, 1.052993543e+01f);
-  p = __builtin_fmaf(p, s, -1.471975757e+01f);
-  p = __builtin_fmaf(p, s, 1.343790172e+01f);
-  p = __builtin_fmaf(p, s, -8.530106592e+00f);
-  p = __builtin_fmaf(p, s, 3.914417810e+00f);
-  p = __builtin_fmaf(p, s, -1.334714149e+00f);
-  p = __builtin_fmaf(p, s, 3.986656381e-01f);
-  const float phi = __builtin_fmaf(xc, p, 0.5f);
+  using P = GeluPoly<TO>;
+  const float s = x * x;
+  float p = __builtin_fmaf(P::q[P::DEG], s, P::q[P::DEG - 1]);
+#pragma unroll
+  for (int k = P::DEG - 2; k >= 0; --k) p = __builtin_fmaf(p, s, P::q[k]);
+  const float phi = __builtin_amdgcn_fmed3f(__builtin_fmaf(x, p, 0.5f), 0.f, 1.f);   // (-> v_fma_f32 ... clamp)
   return x * phi;
 }
-// (A packed form — v_pk_fma_f32 on pairs, half the VALU cycles: a wave64 plain f32 instruction occupies this SIMD for 4
-// cycles, a packed one does two values in the same 4 — needs its nine coefficients in VGPR pairs: the LN-folded GELU
-// instantiation of gemm256, already at 247 VGPRs and all 103 SGPRs, then spills 461 registers and runs 2.6x slower
-// (measured: 10.2 ms instead of 3.9 ms per launch).  Three more placements of the packed form were compiled — coefficients
-// defined opaquely inside the epilogue so that they cannot be hoisted across the main loop, scheduling barriers between
-// the pairs, the activation moved to the point where a value is converted for its store instead of updating the
-// accumulator tuples in place — all spill 361 registers (fp8 instantiation: 304) in the epilogue region.  The scalar form
-// is 52 VALU cycles per value against 62 for the A&S erf with its two quarter-rate transcendentals: +3 % on that kernel
-// in situ, 785 -> 811 TFLOP/s.)
-__device__ __forceinline__ f32x2 gelu_fast2(f32x2 x) { return f32x2{gelu_fast1(x[0]), gelu_fast1(x[1])}; }
-// The same polynomial on a PAIR with packed-f32 arithmetic (v_pk_mul_f32 / v_pk_fma_f32: two values per 4-cycle issue) —
-// the same IEEE operations per element as gelu_fast1, so the results are bit-identical.  For kernels with registers to
-// spare for the nine splatted coefficients (gemm4w.hip's epilogue; gemm256's LN-folded GELU instantiation spilled 461
-// registers on it).  Only the clamp stays scalar (no packed min / max on gfx950).
-// NP pairs are evaluated in LOCKSTEP (every Horner step for all pairs before the next step): a wave alone on its SIMD
-// has nobody to fill the dependent-issue gaps of one serial chain (each packed step waits for the previous one), so the
-// instruction-level parallelism has to be in the program order.
-template <int NP>
+template <typename TO>
+__device__ __forceinline__ f32x2 gelu_fast2(f32x2 x) { return f32x2{gelu_fast1<TO>(x[0]), gelu_fast1<TO>(x[1])}; }
+// clamp(a * b + 1/2, 0, 1) on a pair: v_pk_fma_f32 with the output modifier (no builtin reaches it for packed f32; the
+// scalar form above is folded into `v_fma_f32 ... clamp` by the compiler — the same arithmetic)
+__device__ __forceinline__ f32x2 pk_fma_half_clamp(f32x2 a, f32x2 b) {
+  f32x2 d;
+  asm("v_pk_fma_f32 %0, %1, %2, 0.5 op_sel_hi:[1,1,0] clamp" : "=v"(d) : "v"(a), "v"(b));
+  return d;
+}
+// The same polynomial on PAIRS with packed-f32 arithmetic (v_pk_mul_f32 / v_pk_fma_f32: two values per issue slot) — the
+// same IEEE operations per element as gelu_fast1, so the results are bit-identical.  NP pairs are evaluated in LOCKSTEP
+// (every Horner step for all pairs before the next step): a wave alone on its SIMD has nobody to fill the dependent-issue
+// gaps of one serial chain, so the instruction-level parallelism has to be in the program order.
+template <typename TO, int NP>
 __device__ __forceinline__ void gelu_fast2p_n(f32x2 (&x)[NP]) {
-  f32x2 xc[NP], s[NP], p[NP];
+  using P = GeluPoly<TO>;
+  f32x2 s[NP], p[NP];
 #pragma unroll
-  for (int i = 0; i < NP; ++i) xc[i] = f32x2{__builtin_amdgcn_fmed3f(x[i][0], -4.5f, 4.5f), __builtin_amdgcn_fmed3f(x[i][1], -4.5f, 4.5f)};
+  for (int i = 0; i < NP; ++i) s[i] = x[i] * x[i];
 #pragma unroll
-  for (int i = 0; i < NP; ++i) s[i] = xc[i] * pk_splat(1.0f / 4.5f);
+  for (int i = 0; i < NP; ++i) p[i] = pk_fma(pk_splat(P::q[P::DEG]), s[i], pk_splat(P::q[P::DEG - 1]));
 #pragma unroll
-  for (int i = 0; i < NP; ++i) s[i] = s[i] * s[i];
+  for (int k = P::DEG - 2; k >= 0; --k)
 #pragma unroll
-  for (int i = 0; i < NP; ++i) p[i] = pk_fma(pk_splat(8.050480127e-01f), s[i], pk_splat(-4.390279192e+00f));
-  constexpr float C[7] = {1.052993543e+01f, -1.471975757e+01f, 1.343790172e+01f, -8.530106592e+00f, 3.914417810e+00f, -1.334714149e+00f, 3.986656381e-01f};
+    for (int i = 0; i < NP; ++i) p[i] = pk_fma(p[i], s[i], pk_splat(P::q[k]));
 #pragma unroll
-  for (int k = 0; k < 7; ++k)
-#pragma unroll
-    for (int i = 0; i < NP; ++i) p[i] = pk_fma(p[i], s[i], pk_splat(C[k]));
-#pragma unroll
-  for (int i = 0; i < NP; ++i) p[i] = pk_fma(xc[i], p[i], pk_splat(0.5f));
+  for (int i = 0; i < NP; ++i) p[i] = pk_fma_half_clamp(x[i], p[i]);
 #pragma unroll
   for (int i = 0; i < NP; ++i) x[i] = x[i] * p[i];
 }

@@ -1,5 +1,7 @@
 // core.hip — error reporting and ABI bookkeeping for libvidil_hip.so.
 #include <stdarg.h>
+#include <stdlib.h>
+#include <string.h>
 #include "common.h"
 
 static thread_local char g_err[512] = "";
@@ -9,6 +11,29 @@ void vidil_set_error(const char* fmt, ...) {
   va_start(ap, fmt);
   vsnprintf(g_err, sizeof(g_err), fmt, ap);
   va_end(ap);
+}
+
+// Developer overrides ($VIDIL_GEMM4W, $VIDIL_GEMM4W128, $VIDIL_GEMM_CUS ...) are consulted on every GEMM launch, including
+// launches being captured into the decode steps' graphs: each is looked up in the environment ONCE per process and
+// remembered — unless $VIDIL_DEV_ENV is set when the first one is asked for: the tests and tools that flip these
+// switches between launches set it, and then every query is a live getenv.
+const char* vidil_dev_env(const char* name) {
+  static const bool live = getenv("VIDIL_DEV_ENV") != nullptr;
+  if (live) return getenv(name);
+  struct Slot { const char* name; const char* val; bool known; };
+  static Slot slots[16] = {};
+  static int n = 0;
+  for (int i = 0; i < n; ++i)
+    if (slots[i].name == name || strcmp(slots[i].name, name) == 0) return slots[i].known ? slots[i].val : nullptr;
+  const char* v = getenv(name);
+  if (n < 16) {   // (launches come from one host thread per process: DESIGN.md §1 "Threading")
+    slots[n].name = name;
+    slots[n].val = v ? strdup(v) : nullptr;
+    slots[n].known = v != nullptr;
+    ++n;
+    return slots[n - 1].val;
+  }
+  return v;
 }
 
 extern "C" const char* vidil_last_error(void) { return g_err; }

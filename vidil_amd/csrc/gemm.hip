@@ -190,7 +190,7 @@ __global__ __launch_bounds__(2 * waves_n(BM, BN) * 64) void gemm_kernel(const vi
 #pragma unroll
       for (int r = 0; r < 16; r += 2) {
         f32x2 v = {acc[i][j][r] + bias, acc[i][j][r + 1] + bias};
-        if constexpr (ACT == VIDIL_ACT_GELU_ERF) v = EPI == VIDIL_EPI_F32 ? gelu_erf2(v) : gelu_fast2(v);   // (as gemm_epilogue.inc)
+        if constexpr (ACT == VIDIL_ACT_GELU_ERF) v = EPI == VIDIL_EPI_F32 ? gelu_erf2(v) : gelu_fast2<T>(v);   // (as gemm_epilogue.inc)
         if constexpr (ACT == VIDIL_ACT_QUICK_GELU) v = quick_gelu2(v);
         acc[i][j][r] = v[0];
         acc[i][j][r + 1] = v[1];
@@ -329,7 +329,7 @@ TileChoice choose_tile(const vidil_gemm_args& a) {
   if (allow256 && vidil_gemm256_eligible(a)) return {1, 256, 256, 2};
 #ifdef VIDIL_GEMM_TUNE
   // developer builds only: VIDIL_GEMM_TILE=<BM>x<BN>x<ST> forces one configuration
-  if (const char* e = getenv("VIDIL_GEMM_TILE")) {
+  if (const char* e = vidil_dev_env("VIDIL_GEMM_TILE")) {
     int bm = 0, bn = 0, st = 0;
     if (sscanf(e, "%dx%dx%d", &bm, &bn, &st) == 3) return {0, bm, bn, st};
   }

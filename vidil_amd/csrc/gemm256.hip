@@ -377,7 +377,7 @@ int launch256(const vidil_gemm_args& a, hipStream_t s) {
   }
   // persistent grid: one workgroup per CU (a multiple of 8 so every XCD gets the same number), never more than tiles
   int cus = num_cu;
-  if (const char* e = getenv("VIDIL_GEMM_CUS")) {      // developer: a stream confined to fewer CUs by a CU mask (tools/exp_cu_mask.py)
+  if (const char* e = vidil_dev_env("VIDIL_GEMM_CUS")) {      // developer: a stream confined to fewer CUs by a CU mask (tools/exp_cu_mask.py)
     const int v = atoi(e) & ~7;
     if (v >= 8 && v < cus) cus = v;
   }
@@ -485,7 +485,8 @@ int vidil_gemm4w_launch(const vidil_gemm_args& a, hipStream_t s, int tm);   // g
 // are a couple of tiles per CU, and loses on the plain f32 epilogue (+7 %) and on small grids (and is not built for fp8
 // operands).  $VIDIL_GEMM4W = 0 / 1 forces one kernel (developer).
 static bool prefer_4w(const vidil_gemm_args& a) {
-  if (const char* e = getenv("VIDIL_GEMM4W")) return atoi(e) != 0;
+  if (a.epi == VIDIL_EPI_HEADS && a.T < 8) return false;   // (the 4-wave scatter steps (image, token) by 8 rows: gemm_epilogue.inc)
+  if (const char* e = vidil_dev_env("VIDIL_GEMM4W")) return atoi(e) != 0;
   if (a.dtype == VIDIL_DT_FP8) return false;
   const long tiles = (long)((a.M + 255) / 256) * ((a.N + 255) / 256);
   static const long min_tiles = [] { const char* e = getenv("VIDIL_GEMM4W_MIN_TILES"); return e ? atol(e) : 384L; }();   // (developer sweep, whole bench, same box: 512 -> 5,112, 384 -> 5,120, 320 -> 5,094, 128 -> 5,050 frames/s — small grids start faster on gemm256)
@@ -511,9 +512,10 @@ const char* vidil_gemm256_variant(const vidil_gemm_args& a) { return prefer_4w(a
 // N = 768, K = 3072 (decode fc2) 61.7 -> 53.6 us, N = K = 768 with GELU / heads 23.4 -> 18.4, with the f32 residual 24.3 -> 24.0;
 // where gemm256 is eligible (>= 160 tiles of 256 x 256) or K is a few tiles it loses, so it is not chosen there.
 bool vidil_gemm4w128_wanted(const vidil_gemm_args& a) {
-  const char* e = getenv("VIDIL_GEMM4W128");                    // (developer: 0 never, 1 whenever it can run)
+  const char* e = vidil_dev_env("VIDIL_GEMM4W128");                    // (developer: 0 never, 1 whenever it can run)
   const int mode = e ? atoi(e) : -1;
   if (mode == 0 || a.dtype == VIDIL_DT_FP8 || a.ln_fold || a.ln_stats_out || a.rln_gamma || a.out16) return false;
+  if (a.epi == VIDIL_EPI_HEADS && a.T < 8) return false;
   if (!(a.epi == VIDIL_EPI_F16 || a.epi == VIDIL_EPI_HEADS || a.epi == VIDIL_EPI_ARENA || (a.epi == VIDIL_EPI_F32 && a.act == VIDIL_ACT_NONE)))
     return false;
   if (!vidil_gemm256_eligible(a, true)) return false;        // (alignment / stride / offset-range rules are the same)

@@ -148,6 +148,10 @@ __global__ __launch_bounds__(256) void gemm4w_kernel(const vidil_gemm_args p) {
   auto issue_piece = [&](int pc) {
     const int sl = pc >> 2, i = pc & 3;
     char* dst = smem + h_buf * BUF + (sl < 2 ? WSLOT + sl : sl - 2) * SLOT + i * 4096 + wave * 1024;
+    // (h_r0 made opaque at every piece: otherwise the compiler forms the eight row indices h_r0 + {0, 32, .. 224} once,
+    //  keeps them across the tile loop and — when the epilogue needs the registers — spills them; their reloads then sit
+    //  between the DMA pieces of an iteration, each one a VMEM load to be waited for)
+    asm volatile("" : "+v"(h_r0));
     const int row = h_r0 + (sl & 1) * 128 + i * 32;
 #if defined(VIDIL_4W_ABLATE) && (VIDIL_4W_ABLATE & 4)
     if (p.M > 0) return;     // developer ablation: no DMA (the MFMAs run on whatever LDS holds)
@@ -425,7 +429,7 @@ int launch4w(const vidil_gemm_args& a, hipStream_t s) {
     num_cu = n & ~7;
   }
   int cus = num_cu;
-  if (const char* e = getenv("VIDIL_GEMM_CUS")) {
+  if (const char* e = vidil_dev_env("VIDIL_GEMM_CUS")) {
     const int v = atoi(e) & ~7;
     if (v >= 8 && v < cus) cus = v;
   }
@@ -440,6 +444,15 @@ int launch4w(const vidil_gemm_args& a, hipStream_t s) {
 
 template <typename T>
 int launch4w_dispatch(const vidil_gemm_args& a, hipStream_t s) {
+#ifdef VIDIL_4W_DEV_ONE   // developer builds (ISA inspection): one instantiation, VIDIL_4W_DEV_ONE = 1 fc1 (LN fold + GELU), 2 f32 + residual + row partials, 3 LN-folded heads, 4 = 2 + residual LayerNorm, 5 plain heads, 6 plain 16-bit
+  if constexpr (VIDIL_4W_DEV_ONE == 1) return launch4w<T, VIDIL_EPI_F16, VIDIL_ACT_GELU_ERF, true>(a, s);
+  if constexpr (VIDIL_4W_DEV_ONE == 2) return launch4w<T, VIDIL_EPI_F32, VIDIL_ACT_NONE, false, T, true>(a, s);
+  if constexpr (VIDIL_4W_DEV_ONE == 3) return launch4w<T, VIDIL_EPI_HEADS, VIDIL_ACT_NONE, true>(a, s);
+  if constexpr (VIDIL_4W_DEV_ONE == 4) return launch4w<T, VIDIL_EPI_F32, VIDIL_ACT_NONE, false, T, true, true>(a, s);
+  if constexpr (VIDIL_4W_DEV_ONE == 5) return launch4w<T, VIDIL_EPI_HEADS, VIDIL_ACT_NONE>(a, s);
+  if constexpr (VIDIL_4W_DEV_ONE == 6) return launch4w<T, VIDIL_EPI_F16, VIDIL_ACT_NONE>(a, s);
+  return -1000;
+#else
   if (a.ln_fold) {
     if (a.epi == VIDIL_EPI_HEADS) return launch4w<T, VIDIL_EPI_HEADS, VIDIL_ACT_NONE, true>(a, s);
     if (a.act == VIDIL_ACT_NONE) return launch4w<T, VIDIL_EPI_F16, VIDIL_ACT_NONE, true>(a, s);
@@ -464,6 +477,7 @@ int launch4w_dispatch(const vidil_gemm_args& a, hipStream_t s) {
     default:
       return launch4w<T, VIDIL_EPI_PATCH, VIDIL_ACT_NONE>(a, s);
   }
+#endif
 }
 
 }  // namespace
@@ -471,6 +485,9 @@ int launch4w_dispatch(const vidil_gemm_args& a, hipStream_t s) {
 // the 128 x 256-tile form: plain epilogues only (the decode steps' projections and FFN, mid-size grids)
 template <typename T>
 int launch4w128_dispatch(const vidil_gemm_args& a, hipStream_t s) {
+#ifdef VIDIL_4W_DEV_ONE
+  return -1000;
+#else
   if (a.ln_fold || a.ln_stats_out || a.rln_gamma) return -1000;
   switch (a.epi) {
     case VIDIL_EPI_F16:
@@ -487,6 +504,7 @@ int launch4w128_dispatch(const vidil_gemm_args& a, hipStream_t s) {
     default:
       return -1000;
   }
+#endif
 }
 
 // tm: 4 = 256 x 256 tiles, 2 = 128 x 256 tiles.  -1000: the variant is not built here.
@@ -494,5 +512,8 @@ int vidil_gemm4w_launch(const vidil_gemm_args& a, hipStream_t s, int tm) {
   if (a.dtype == VIDIL_DT_FP8) return -1000;
   if (tm == 2) return a.dtype == VIDIL_DT_BF16 ? launch4w128_dispatch<bf16>(a, s) : launch4w128_dispatch<f16>(a, s);
   if (a.dtype == VIDIL_DT_BF16) return launch4w_dispatch<bf16>(a, s);
+#ifdef VIDIL_4W_DEV_ONE
+  return -1000;
+#endif
   return launch4w_dispatch<f16>(a, s);
 }

@@ -22,6 +22,40 @@ __device__ __forceinline__ float row16_sum(float v) {
   return row_ror_add<1>(v);
 }
 
+// A raw buffer descriptor (stride 0: byte offsets, range-checked against `bytes`) over [base, base + bytes).  The base
+// is passed through v_readfirstlane: it is wave-uniform by construction wherever this is used, but under the SGPR
+// pressure of the big GEMM kernels the compiler otherwise leaves descriptor words in VGPRs and wraps every buffer
+// instruction in a "waterfall" loop (readfirstlane x 4, compare, exec-mask — a dozen instructions per access).
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t uniform_rsrc(const void* base, uint32_t bytes) {
+  const uint64_t a = (uint64_t)base;
+  const uint32_t lo = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)a);
+  const uint32_t hi = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)(a >> 32));
+  const uint32_t n = (uint32_t)__builtin_amdgcn_readfirstlane((int)bytes);
+  return __builtin_amdgcn_make_buffer_rsrc((void*)(((uint64_t)hi << 32) | lo), 0, (int)n, 0x00020000);
+}
+
+// 16 x 16 REDUCE-SCATTER over a DPP row: every lane brings 16 values; lane i of each 16 leaves with value i summed over
+// the 16 lanes.  Four halving stages — a lane keeps the half of its values that its partner's side of the row does not
+// own, and adds the partner's copy of them — over the pairings row_mirror (i <-> 15 - i: splits on bit 3),
+// row_half_mirror (i <-> 7 - i within 8: bit 2), quad_perm [2,3,0,1] (bit 1), quad_perm [1,0,3,2] (bit 0): 15 DPP adds
+// and 30 selects, against 4 DPP moves + 4 adds for EACH of the 16 values as separate all-reduces.  The summation order is
+// fixed (a property of this function), so every kernel that uses it produces the same bits.
+template <int CTRL>
+__device__ __forceinline__ float dpp_f32(float v) {
+  return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), CTRL, 0xF, 0xF, false));
+}
+__device__ __forceinline__ float row16_reduce_scatter(const float (&v)[16], int lane) {
+  const bool b3 = (lane & 8) != 0, b2 = (lane & 4) != 0, b1 = (lane & 2) != 0, b0 = (lane & 1) != 0;
+  float w8[8], w4[4], w2[2];
+#pragma unroll
+  for (int k = 0; k < 8; ++k) w8[k] = (b3 ? v[k + 8] : v[k]) + dpp_f32<0x140>(b3 ? v[k] : v[k + 8]);
+#pragma unroll
+  for (int k = 0; k < 4; ++k) w4[k] = (b2 ? w8[k + 4] : w8[k]) + dpp_f32<0x141>(b2 ? w8[k] : w8[k + 4]);
+#pragma unroll
+  for (int k = 0; k < 2; ++k) w2[k] = (b1 ? w4[k + 2] : w4[k]) + dpp_f32<0x4E>(b1 ? w4[k] : w4[k + 2]);
+  return (b0 ? w2[1] : w2[0]) + dpp_f32<0xB1>(b0 ? w2[0] : w2[1]);
+}
+
 // What the main loop needs to know about the operand type: a 128-byte LDS row holds one K-tile (64 x 16-bit or
 // 128 x fp8), consumed in KS MFMA k-steps; a fragment is the lane's share of one k-step of one 32-row tile.
 template <typename T>

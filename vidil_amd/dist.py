@@ -97,11 +97,14 @@ def _comm_device():
 
 
 def gather_json(obj):
-    """Gather one JSON-serialisable object per rank TO RANK 0 (rank order); other ranks get None.
+    """Gather one JSON-serialisable object per rank (rank order); rank 0 gets the list, other ranks get None.
 
-    Sizes first (all_gather of one int64), then the payloads: rank 0 posts one receive per peer sized to that peer's
-    payload and the peers send — nothing is padded, nothing lands on ranks that do not need it.  RCCL (backend 'nccl')
-    moves device buffers over xGMI; Gloo moves host buffers."""
+    Two collectives and nothing else: an ``all_gather`` of the payload sizes (one int64 per rank), then ONE ``all_gather`` of
+    the UTF-8 bytes padded to the longest payload.  RCCL (backend 'nccl') moves device buffers over xGMI as a ring
+    all-gather, Gloo moves host buffers.  Round 4: this replaces a per-peer ``send`` / ``recv`` pair — the same code path
+    now runs for every world size including 1, so what an 8-GPU job executes is what the one-GPU box has already executed
+    (tests/test_dist_gpu.py); the price is that the padded payloads (a few KB per video: tens of MB for a full dataset)
+    land on every rank instead of rank 0 only."""
     if not is_dist_avail_and_initialized():
         return [obj]
     dev = _comm_device()
@@ -111,19 +114,15 @@ def gather_json(obj):
     sizes = [torch.zeros(1, dtype=torch.int64, device=dev) for _ in range(world)]
     dist.all_gather(sizes, size)
     sizes = [int(s.item()) for s in sizes]
+    cap = max(max(sizes), 1)
+    mine = torch.zeros(cap, dtype=torch.uint8)
+    mine[:len(raw)] = torch.frombuffer(bytearray(raw), dtype=torch.uint8)
+    mine = mine.to(dev)
+    bufs = [torch.empty(cap, dtype=torch.uint8, device=dev) for _ in range(world)]
+    dist.all_gather(bufs, mine)
     if rank != 0:
-        if sizes[rank]:
-            dist.send(torch.frombuffer(bytearray(raw), dtype=torch.uint8).to(dev), dst=0)
         return None
-    parts = [obj]
-    for r in range(1, world):
-        if sizes[r] == 0:
-            parts.append(json.loads("null"))
-            continue
-        buf = torch.empty(sizes[r], dtype=torch.uint8, device=dev)
-        dist.recv(buf, src=r)
-        parts.append(json.loads(buf.cpu().numpy().tobytes().decode("utf-8")))
-    return parts
+    return [json.loads(bufs[r][:sizes[r]].cpu().numpy().tobytes().decode("utf-8")) for r in range(world)]
 
 
 def merge_rank_dicts(parts):
