@@ -457,3 +457,27 @@ def test_the_drivers_build_hook_passes():
     import __graft_entry__ as g
 
     g.build()
+
+
+def test_length_buckets_merge_a_small_tail_only_when_the_padding_it_adds_is_cheap():
+    """ADVICE r3 (capfilt._length_buckets): a handful of long captions behind a large bucket of short ones used to be merged
+    into it unconditionally — padding every pair of the large bucket to the long captions' length (+50 % rows on real
+    caption length distributions).  The merge is now decided by the rows it adds."""
+    import numpy as np
+
+    from vidil_amd.capfilt import CapFiltEngine
+
+    eng = CapFiltEngine.__new__(CapFiltEngine)           # (host logic only: no models, no device)
+    F = 8
+    # 3,000 captions of 9-12 tokens (one bucket of 24,000 pairs) + 5 captions of 30 tokens (40 pairs)
+    lens = np.r_[np.random.default_rng(0).integers(9, 13, 3000), np.full(5, 30)].astype(np.int64)
+    idx = np.arange(len(lens))
+    b = eng._length_buckets(idx, lens, F)
+    assert [len(x) for x in b] == [3000, 5], [len(x) for x in b]          # merging would add 3000 * 8 * 18 = 432,000 rows
+    assert np.array_equal(np.sort(np.concatenate(b)), idx)
+    # the same tail behind a bucket that already runs to 28 tokens: 300 captions * 8 * 2 = 4,800 rows -> merged
+    lens2 = np.r_[np.full(300, 28), np.full(5, 30)].astype(np.int64)
+    b2 = eng._length_buckets(np.arange(305), lens2, F)
+    assert [len(x) for x in b2] == [305]
+    # equal lengths (the synthetic benchmark): one bucket, as before
+    assert [len(x) for x in eng._length_buckets(np.arange(100), np.full(100, 20, dtype=np.int64), F)] == [100]

@@ -1,0 +1,106 @@
+"""BASELINE config 1, LITERALLY, as files: 16 synthetic videos x 8 frames 224^2 through the product path —
+FramePipeline (CapFiltEngine + VisualTokenizer) and both writers — and the three JSON documents it leaves on disk
+(video_text_CapFilt.json, video_text_Cap.json: run_video_CapFilt.py:261-291; visual_tokens.json:
+run_visual_tokenization.py:447-463) diffed against goldens the fp32 CPU oracle produced in the build container
+(tests/golden/make_config1_golden.py -> config1_{capfilt,cap,visual_tokens,margins}.json).
+
+The device runs in the parity precision mode (all three models).  The comparison is EXACT outside entries the oracle
+itself flags as undecided — a beam search with two candidates closer than 1e-3, a token rank whose score is closer than
+3e-5 (the fp32 summation-order resolution over 42k classes) to a neighbour — and the flagged entries that actually differ
+are counted and bounded."""
+import json
+import os
+import sys
+
+import pytest
+import torch
+
+from common import ROOT
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda"
+GOLD = os.path.join(ROOT, "tests", "golden")
+CAPTION_GAP, TOKEN_GAP = 1e-3, 3e-5
+
+
+def _gold(name):
+    with open(os.path.join(GOLD, name)) as f:
+        return json.load(f)
+
+
+def test_config1_three_output_files_equal_the_oracle_generated_goldens(tmp_path):
+    sys.path.insert(0, GOLD)
+    import make_config1_golden as G
+    from vidil_amd import capfilt
+    from vidil_amd import visual_tokenization as vtmod
+    from vidil_amd.capfilt import CapFiltEngine
+    from vidil_amd.packing import set_compute_dtype, set_parity_mode
+    from vidil_amd.pipeline import FramePipeline
+    from vidil_amd.visual_tokenization import CATEGORIES, VisualTokenizer
+
+    margins = _gold("config1_margins.json")
+    meta = margins["meta"]
+    tok, cap, itm, clip = G.build_models()
+    sums = dict(cap=G.state_checksum(cap.state_dict()), itm=G.state_checksum(itm.state_dict()), clip=G.state_checksum(clip.state_dict()))
+    if sums != meta["checksums"]:
+        pytest.skip(f"the seeded weights differ from the ones the golden was generated with (torch {torch.__version__} vs "
+                    f"{meta['torch']}): regenerate with tests/golden/make_config1_golden.py")
+    emb, texts = G.ontology()
+    Nv, F = meta["videos"], meta["frames"]
+    from common import synthetic_frames
+    u8 = torch.from_numpy(synthetic_frames(Nv, F)).to(DEV)
+    cap, itm, clip = cap.to(DEV), itm.to(DEV), clip.to(DEV)
+    set_compute_dtype("f16", cap, itm, clip)
+    set_parity_mode(True, cap, itm, clip)
+    cfg = dict(caption=True, filter=True, filter_generated_only=True, keep_original_caption=False, threshold=meta["threshold"],
+               filter_mode="max_filter", generation_mode="beam", do_sentence_tokenization=False, image_size=224, vit="base",
+               topk_visualize=5)
+    eng = CapFiltEngine(cfg, DEV, captioner=cap, filterer=itm)
+    vt = VisualTokenizer(cfg, clip, texts, emb, DEV)
+    items = [dict(video_id=f"video{v}", text=[]) for v in range(Nv)]
+    items, toks = FramePipeline(eng, vt).process(items, u8)
+    out = str(tmp_path / "out")
+    f_out, u_out = capfilt.collect_outputs(items)
+    capfilt.write_outputs(out, f_out, u_out)
+    vtmod.write_outputs(out, toks)
+    got_f = json.load(open(os.path.join(out, "video_text_CapFilt.json")))
+    got_u = json.load(open(os.path.join(out, "video_text_Cap.json")))
+    got_t = json.load(open(os.path.join(out, "visual_tokens.json")))
+    ref_f, ref_u, ref_t = _gold("config1_capfilt.json"), _gold("config1_cap.json"), _gold("config1_visual_tokens.json")
+    vids = [f"video{v}" for v in range(Nv)]
+    assert list(got_u.keys()) == vids == list(ref_u.keys()) and list(got_t.keys()) == vids
+    # ---- captions (video_text_Cap.json) and kept lists (video_text_CapFilt.json)
+    cap_diff = []
+    for v in vids:
+        if got_u[v] != ref_u[v]:
+            assert min(margins["caption_gap"][v]) < CAPTION_GAP, (v, "captions differ although every beam decision had a margin")
+            cap_diff.append(v)
+        else:
+            # same candidate captions -> the filter's decisions must be the oracle's (margins: >= 0.06 from the threshold)
+            assert min(margins["filter_margin"][v]) > 1e-3
+            assert got_f.get(v) == ref_f.get(v), (v, "kept list")
+    assert [k for k in got_f if k not in cap_diff] == [k for k in ref_f if k not in cap_diff]      # order of the filtered file
+    # ---- visual tokens
+    ranks = flagged = differ = 0
+    for v in vids:
+        assert got_t[v]["caption"] == got_u[v]
+        all_equal = True
+        for f in range(F):
+            for key in CATEGORIES:
+                gaps = margins["token_gap"][v][f][key]
+                for r in range(5):
+                    ranks += 1
+                    undecided = gaps[r] < TOKEN_GAP or (r > 0 and gaps[r - 1] < TOKEN_GAP)
+                    same = got_t[v]["frame_tokens"][f][key][r] == ref_t[v]["frame_tokens"][f][key][r]
+                    flagged += int(undecided)
+                    if not same:
+                        assert undecided, (v, f, key, r, "token rank differs although the oracle's scores separate it")
+                        differ += 1
+                        all_equal = False
+        if all_equal:
+            assert got_t[v]["aggregated_tokens"] == ref_t[v]["aggregated_tokens"], v
+    print(f"\nconfig 1 as files: video_text_Cap.json {Nv - len(cap_diff)}/{Nv} videos identical ({len(cap_diff)} differ, all flagged by a "
+          f"beam near-tie < {CAPTION_GAP}); visual_tokens.json {ranks - differ}/{ranks} ranks identical ({flagged} flagged by a score gap "
+          f"< {TOKEN_GAP}, {differ} of them differ)")
+    assert len(cap_diff) <= 2, cap_diff
+    assert flagged <= 0.05 * ranks and differ <= 0.02 * ranks, (flagged, differ, ranks)

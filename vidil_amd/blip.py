@@ -280,13 +280,14 @@ class BLIP_Decoder(nn.Module):
         if st is None:
             if len(cache) >= 8:
                 # make room: the compact sessions first (each holds its own cross K/V, arena and step graphs — roughly
-                # +1.6x of a main session's memory over the four bucket sizes — and is cheap to rebuild), the main
-                # sessions of other shapes only if that was not enough; a main session's captured graphs then survive
-                # the arrival of a new shape
+                # +1.6x of a main session's memory over the four bucket sizes — and is cheap to rebuild); if that was not
+                # enough, the LEAST RECENTLY USED main sessions go, one at a time, until there is room — the sessions a
+                # pipeline alternates between keep their captured step graphs when an eighth shape shows up (ADVICE r2:
+                # this used to be cache.clear())
                 for k_ in [k_ for k_ in cache if isinstance(k_[-1], tuple)]:
                     del cache[k_]
-                if len(cache) >= 8:
-                    cache.clear()
+                while len(cache) >= 8:
+                    del cache[min(cache, key=lambda k_: cache[k_].get("last_used", 0))]
             # (the shared prompt pass has P query rows per image, a decode step nb)
             st = cache[key] = dict(sess=DecoderSession(dec, enc16, B, nb, max_length, tiled_cross=P <= 32 and nb <= 32),
                                    bufs=K.BeamBuffers(B, nb, max_length, dev), graphs={}, pool=None, calls=0, packs=packs,
@@ -294,6 +295,7 @@ class BLIP_Decoder(nn.Module):
                                    n_done_host=torch.zeros((1,), dtype=torch.int32, pin_memory=True))
         else:
             st["sess"].rebind(enc16)
+        self.__dict__["_decode_clock"] = st["last_used"] = self.__dict__.get("_decode_clock", 0) + 1
         st["calls"] += 1
         st["bufs"].reset(prompt)
         # `cur`: the session the loop is driving — the full batch, or (after compaction, below) a smaller session that

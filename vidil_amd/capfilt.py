@@ -259,6 +259,8 @@ class CapFiltEngine:
     LENGTH_EDGES = (8, 12, 16, 20, 24, 28, 35)
     #: a bucket with fewer pairs than this is merged into the next longer one (its GEMMs would not fill the chip)
     MIN_BUCKET_PAIRS = 2048
+    #: ... unless merging a small TAIL bucket would pad the previous bucket's pairs by more rows than this
+    MERGE_MAX_EXTRA_ROWS = 10_000
 
     def _length_buckets(self, cap_idx, lens_np, pairs_per_cap):
         """Split caption indices by token count so that a call's rows are cut to ITS longest caption (the reference pads
@@ -276,12 +278,19 @@ class CapFiltEngine:
             cur.append(c)
             cur_pairs += pairs_per_cap
         if cur:
+            merge = False
             if buckets and cur_pairs < self.MIN_BUCKET_PAIRS:
-                # a small tail (a few long captions among thousands) joins the previous bucket instead of paying a full
-                # 12-layer launch sequence for a handful of rows; that call is then cut to the tail's longest caption
+                # a small tail (a few long captions among thousands) may join the previous bucket instead of paying a full
+                # 12-layer launch sequence for a handful of rows — but that call is then cut to the TAIL's longest caption, so
+                # every pair of the previous bucket is padded up to it: merge on a cost test, the rows the merge
+                # adds against what a launch sequence is worth (~2 ms of launches ~ 10^4 rows of encoder work)
+                prev = buckets[-1]
+                extra_rows = len(prev) * pairs_per_cap * (int(lens_np[np.asarray(cur)].max()) - int(lens_np[prev].max()))
+                merge = extra_rows <= self.MERGE_MAX_EXTRA_ROWS
+            if merge:
                 buckets[-1] = np.sort(np.concatenate([buckets[-1], np.asarray(cur)]))
             else:
-                buckets.append(np.sort(np.asarray(cur)))
+                buckets.append(np.sort(np.asarray(cur)))   # (itm_pairs falls back to its small-call layout for a thin call: min_rows)
         return buckets
 
     def _score(self, pend, cap_idx, frame_of=None):

@@ -106,7 +106,21 @@ class VisionTransformer(PackedCache, nn.Module):
 
     # ------------------------------------------------------------------ packing
     def pack_flags(self):
-        return (self.fuse_layernorm, self.fp8, self.parity)
+        return (self.fuse_layernorm, self.fp8, self.parity, self.parity_last_blocks)
+
+    @property
+    def parity_last_blocks(self):
+        """Parity precision mode, MIXED form (round 4): only the last k blocks run on error-compensated operands, the
+        first depth - k on plain 16-bit operands (unfused LayerNorm kernels + plain GEMMs: both forms meet at the f32
+        residual stream).  None = all blocks (the default).  Rounding errors of the tower accumulate like a random walk over
+        its 48 GEMMs, so compensating the last k of 12 blocks removes ~k/12 of the tower's error variance at ~k/12 of the
+        3x cost — tests/probes/probe_parity_mix.py measures caption-logit error and time for every k."""
+        return self.__dict__.get("_parity_last_blocks")
+
+    def set_parity_last_blocks(self, k):
+        if k is not None and not (0 <= int(k) <= len(self.blocks)):
+            raise ValueError(f"parity_last_blocks must be in 0..{len(self.blocks)}")
+        self.__dict__["_parity_last_blocks"] = None if k is None else int(k)
 
     def _pack(self):
         D = self.embed_dim
@@ -126,8 +140,11 @@ class VisionTransformer(PackedCache, nn.Module):
                 fc2_w=w16(b.mlp.fc2.weight, dtype=c), fc2_b=v32(b.mlp.fc2.bias))
             if self.parity:
                 # parity precision mode (packing.set_parity_mode): [W_hi | W_hi | W_lo] against [x_hi | x_lo | x_hi] rows
-                for name, lin in (("qkv", b.attn.qkv), ("proj", b.attn.proj), ("fc1", b.mlp.fc1), ("fc2", b.mlp.fc2)):
-                    d[name + "_w3"] = w3(lin.weight, dtype=c)
+                # (mixed form: only the last parity_last_blocks blocks; the others keep their plain operands)
+                k_par = self.parity_last_blocks
+                if k_par is None or i >= len(self.blocks) - k_par:
+                    for name, lin in (("qkv", b.attn.qkv), ("proj", b.attn.proj), ("fc1", b.mlp.fc1), ("fc2", b.mlp.fc2)):
+                        d[name + "_w3"] = w3(lin.weight, dtype=c)
             elif self.fp8:
                 # fp8 tower mode: the four big GEMMs on e4m3 operands (weights per-output-row scaled), LayerNorm as
                 # a stand-alone kernel writing fp8 (its output is well scaled; the raw stream is not)
@@ -224,7 +241,21 @@ class VisionTransformer(PackedCache, nn.Module):
         o3 = torch.empty((M, 3 * D), dtype=cdt, device=dev)
         hid32 = torch.empty((M, Dh), dtype=torch.float32, device=dev)
         hid3 = torch.empty((M, 3 * Dh), dtype=cdt, device=dev)
+        plain = [b for b in p["blocks"] if "qkv_w3" not in b]
+        if plain:       # mixed form: the leading blocks on plain 16-bit operands (unfused: LayerNorm kernel + plain GEMM)
+            xn = torch.empty((M, D), dtype=cdt, device=dev)
+            o = torch.empty((M, D), dtype=cdt, device=dev)
+            hid = torch.empty((M, Dh), dtype=cdt, device=dev)
         for b in p["blocks"]:
+            if "qkv_w3" not in b:
+                K.layernorm(x, b["n1g"], b["n1b"], self.ln_eps, out16=xn)
+                K.gemm(xn, b["qkv_w"], b["qkv_b"], heads=heads)
+                K.attention(q, k, vt, o, Bq=B, H=H, Nq=T, Nk=T, Tq_cap=T, Tk_cap=T, NP=NP)
+                K.gemm(o, b["proj_w"], b["proj_b"], out=x, resid=x)
+                K.layernorm(x, b["n2g"], b["n2b"], self.ln_eps, out16=xn)
+                K.gemm(xn, b["fc1_w"], b["fc1_b"], out=hid, act=K.ACT_GELU_ERF)
+                K.gemm(hid, b["fc2_w"], b["fc2_b"], out=x, resid=x)
+                continue
             K.layernorm(x, b["n1g"], b["n1b"], self.ln_eps, out16=a3, split3=True)
             K.gemm(a3, b["qkv_w3"], b["qkv_b"], heads=heads)
             K.attention(q, k, vt, o3, Bq=B, H=H, Nq=T, Nk=T, Tq_cap=T, Tk_cap=T, NP=NP, split3=True)
