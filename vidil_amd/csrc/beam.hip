@@ -4,7 +4,8 @@
 // MinLengthLogitsProcessor), the version models/med.py:7-8 of the reference
 // names; the reference call site is models/blip.py:154-161.
 //
-//   logsoftmax_topk : one workgroup per image; log-softmax of its nb rows,
+//   logsoftmax_topk : one workgroup per image; log-softmax of its nb rows (one
+//                     pass per row: online max / sum of exponentials),
 //                     optional EOS ban, + beam score, sorted top-2nb over
 //                     nb*V candidates (ties -> lower flat index).
 //   beam_update     : one thread per image; BeamSearchScorer.process + the
@@ -80,49 +81,67 @@ __global__ __launch_bounds__(256) void lsm_topk_kernel(const float* __restrict__
       }
     }
   };
+  // ONE pass over the logits per row (round 4; the round-1 form read every row three times: max, sum of exponentials,
+  // candidates — 3.68 GB instead of 1.31 GB per launch at 10,752 x 30,524): every thread keeps an ONLINE softmax state
+  // (running maximum m, sum of exp(x - m), rescaled when the maximum moves) and its K best RAW logits of the row; the
+  // block then combines the states into the row's (max, log-sum-exp), and only the K survivors per thread are turned into
+  // scores `(x - max) - lse + beam_score` and merged into the thread's candidates of the image.  log_softmax is monotone
+  // in x, so a row's best scores are its best logits (ties in the rounded score are ordered by the final merge, which
+  // compares (score, flat index) exactly as before).
+  constexpr float L2E = 1.4426950408889634f;
   for (int beam = 0; beam < NBL; ++beam) {
     const float* row = logits + ((size_t)b * NBL + beam) * V;
-    // pass 1: row max, then sum(exp(x - max)) as torch's log_softmax does (two reductions, vector loads)
-    float m = -INFINITY;
-    if (vec) {
-      for (int i = tid * 4; i < V; i += 1024) {
-        const f32x4 x = *(const f32x4*)(row + i);
-        m = fmaxf(fmaxf(m, fmaxf(x[0], x[1])), fmaxf(x[2], x[3]));
-      }
-    } else {
-      for (int i = tid; i < V; i += 256) m = fmaxf(m, row[i]);
-    }
-    m = block_reduce_max(m, red);
-    float sum = 0.f;
-    if (vec) {
-      for (int i = tid * 4; i < V; i += 1024) {
-        const f32x4 x = *(const f32x4*)(row + i);
-        sum += (expf(x[0] - m) + expf(x[1] - m)) + (expf(x[2] - m) + expf(x[3] - m));
-      }
-    } else {
-      for (int i = tid; i < V; i += 256) sum += expf(row[i] - m);
-    }
-    sum = block_reduce_sum(sum, red);
-    const float lse = logf(sum);
-    const float bs = beam_scores[b * NB + beam];
-    // pass 2: candidates.  A thread's elements arrive in ascending flat index (ties keep the lower index).
-    if (vec) {
-      for (int i = tid * 4; i < V; i += 1024) {
-        const f32x4 x = *(const f32x4*)(row + i);
+    float m = -INFINITY, sum = 0.f;
+    float rs[K];
+    int ri[K];
 #pragma unroll
-        for (int e = 0; e < 4; ++e) {
-          float lp = (x[e] - m) - lse;
-          if (i + e == ban) lp = -INFINITY;
-          consider(lp + bs, beam * V + i + e);
+    for (int j = 0; j < K; ++j) { rs[j] = -INFINITY; ri[j] = 0x7fffffff; }
+    auto consider_raw = [&](float x, int i) {
+      if (better(x, i, rs[K - 1], ri[K - 1])) {
+        rs[K - 1] = x; ri[K - 1] = i;
+#pragma unroll
+        for (int j = K - 1; j > 0; --j) {
+          if (better(rs[j], ri[j], rs[j - 1], ri[j - 1])) {
+            const float t = rs[j]; rs[j] = rs[j - 1]; rs[j - 1] = t;
+            const int x_ = ri[j]; ri[j] = ri[j - 1]; ri[j - 1] = x_;
+          }
         }
+      }
+    };
+    if (vec) {
+      for (int i = tid * 4; i < V; i += 1024) {
+        const f32x4 x = *(const f32x4*)(row + i);
+        const float mx = fmaxf(fmaxf(x[0], x[1]), fmaxf(x[2], x[3]));
+        if (mx > m) {                                   // (m = -inf at first: sum = 0 * 2^-inf = 0)
+          sum *= __builtin_amdgcn_exp2f((m - mx) * L2E);
+          m = mx;
+        }
+        const float ml = m * L2E;
+        sum += (__builtin_amdgcn_exp2f(__builtin_fmaf(x[0], L2E, -ml)) + __builtin_amdgcn_exp2f(__builtin_fmaf(x[1], L2E, -ml))) +
+               (__builtin_amdgcn_exp2f(__builtin_fmaf(x[2], L2E, -ml)) + __builtin_amdgcn_exp2f(__builtin_fmaf(x[3], L2E, -ml)));
+#pragma unroll
+        for (int e = 0; e < 4; ++e)
+          if (i + e != ban) consider_raw(x[e], i + e);  // (the banned token counts in the softmax, never as a candidate)
       }
     } else {
       for (int i = tid; i < V; i += 256) {
-        float lp = (row[i] - m) - lse;
-        if (i == ban) lp = -INFINITY;
-        consider(lp + bs, beam * V + i);
+        const float x = row[i];
+        if (x > m) {
+          sum *= __builtin_amdgcn_exp2f((m - x) * L2E);
+          m = x;
+        }
+        sum += __builtin_amdgcn_exp2f((x - m) * L2E);
+        if (i != ban) consider_raw(x, i);
       }
     }
+    const float M = block_reduce_max(m, red);
+    // (a thread that saw no element has m = -inf, sum = 0: contributes 0)
+    sum = block_reduce_sum(m == -INFINITY ? 0.f : sum * __builtin_amdgcn_exp2f((m - M) * L2E), red);
+    const float lse = logf(sum);
+    const float bs = beam_scores[b * NB + beam];
+#pragma unroll
+    for (int j = 0; j < K; ++j)
+      if (ri[j] != 0x7fffffff) consider((rs[j] - M) - lse + bs, beam * V + ri[j]);
   }
 #pragma unroll
   for (int j = 0; j < K; ++j) { ls[tid * K + j] = ts[j]; li[tid * K + j] = ti[j]; }
