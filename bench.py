@@ -17,8 +17,10 @@ Rank 0 prints ONE JSON line (see README / DESIGN.md §measurement).  Beside the 
   config.algorithmic_gflop_per_frame / whole_path_mfma_frac      SURVEY §8d's algorithmic count (ITM captions at 35 tokens)
   config.executed_gflop_per_frame / executed_mfma_frac           what the launches of the instrumented step really computed
   secondary.f16       the same step on f16 operands (the type of the parity statement), a few steps
+  secondary.fp8       the same step in the fp8 tower mode (config 5's operand type; a throughput mode with an accuracy contract)
   secondary.parity_mode_caption_path   caption path (ViT + beam decode) in the error-compensated "parity" precision mode
   secondary.parity_mode_full_step      the whole step (caption + filter + CLIP / scan) with all three models in that mode
+  secondary.parity_mix_full_step       ... in the cheapest mix that meets both stated tolerances (plain ViT, compensated decoder / CLIP)
   parity              max |caption logit - fp32 CPU oracle| of a 2-frame prompt pass, for the timed dtype, plain f16 and the
                       parity mode, each with the tolerance the test suite asserts for it (computed in the cpu_baseline leg)
   one_off             work outside the metric that a run pays once: the CLIP text tower over the 42,759 ontology prompts
@@ -327,6 +329,26 @@ def secondary_measurements(args, cap, flt, clip, step, frames, dev, parity_file,
                                    "note": "same workload and step as `value`, f16 MFMA operands"}
         log(f"secondary f16: {Nv * F / dt16:.0f} frames/s")
         record("plain_f16", tol["f16"])
+    # ---- the same step in the fp8 tower mode (BASELINE config 5's operand type): e4m3 operands in the towers' four big GEMMs and
+    # the image-side cross K|V projections, 16-bit everywhere else.  A THROUGHPUT mode with an accuracy contract, not a parity
+    # mode (tests/test_fp8_gpu.py bounds it against the f16 path on the same weights)
+    if args.dtype != "fp8":
+        try:
+            free_sessions()
+            set_compute_dtype("fp8", cap, flt, clip)
+            for _ in range(3):
+                step()
+            dt8 = time_steps(step, max(2, min(args.steps, 3)))
+            out["secondary"]["fp8"] = {
+                "value": round(Nv * F / dt8, 2), "unit": "frames/s", "ms_per_step": round(dt8 * 1e3, 3),
+                "note": "same workload and step as `value`, e4m3 MFMA operands in the ViT / CLIP-vision blocks' QKV, proj, fc1, fc2 and the "
+                        "cross K|V projections (v_mfma_scale_f32_32x32x64_f8f6f4, per-output-column weight scales); accuracy contract "
+                        "asserted by tests/test_fp8_gpu.py over 32 videos against the f16 path: ITM |dp| <= 0.04 (measured 0.010), keep / "
+                        "drop flips <= 2 % (0), top-5 visual tokens in common >= 88 % (94 %), ViT rel-L2 <= 0.10 (0.068)"}
+            log(f"secondary fp8: {Nv * F / dt8:.0f} frames/s")
+        except Exception as e:
+            out["secondary"]["fp8"] = {"value": None, "error": f"{type(e).__name__}: {e}"[:300]}
+        set_compute_dtype("f16", cap, flt, clip)
     # ---- caption path in the parity precision mode (error-compensated operands, f16): cost and error
     free_sessions()
     nb = min(Nv, 32)
@@ -358,12 +380,35 @@ def secondary_measurements(args, cap, flt, clip, step, frames, dev, parity_file,
         dtp = time_steps(step, 2)
         out["secondary"]["parity_mode_full_step"] = {
             "value": round(Nv * F / dtp, 2), "unit": "frames/s", "ms_per_step": round(dtp * 1e3, 3),
+            "slowdown_vs_plain_f16": round(dtp / dt16, 3) if args.dtype != "f16" else None,
             "note": "same workload and step as `value` with the captioner, the filter and CLIP in the parity precision mode (f16 "
                     "operands as [hi | lo | hi] x [W_hi | W_hi | W_lo], K tripled in every GEMM): caption logits within 1e-3 absolute, "
                     "ITM logits within 2e-4, visual-token ranks equal to the fp32 reference form (tests/test_parity_mode_gpu.py)"}
         log(f"secondary parity-mode full step: {Nv * F / dtp:.0f} frames/s")
     except Exception as e:      # (a secondary number must not cost the headline line)
         out["secondary"]["parity_mode_full_step"] = {"value": None, "error": f"{type(e).__name__}: {e}"[:300]}
+    set_parity_mode(False, cap, flt, clip)
+    # ---- ... and in the CHEAPEST mix that still meets the two tolerances BASELINE states (tests/probes/probe_parity_mix.py;
+    # tests/test_parity_mode_gpu.py asserts both): captioner = plain ViT + compensated cross K|V / decoder / LM head ("caption
+    # logits within 1e-3" absolute: worst pass 7.6e-4), CLIP compensated ("top-k visual-token indices bit-exact" end to end),
+    # filter plain (its kept lists are decided by margins of >= 0.06 here; nothing is stated for ITM logits)
+    try:
+        free_sessions()
+        set_parity_mode(True, cap, clip)
+        cap.visual_encoder.set_parity_last_blocks(0)
+        for _ in range(3):
+            step()
+        dtm = time_steps(step, 2)
+        out["secondary"]["parity_mix_full_step"] = {
+            "value": round(Nv * F / dtm, 2), "unit": "frames/s", "ms_per_step": round(dtm * 1e3, 3),
+            "slowdown_vs_plain_f16": round(dtm / dt16, 3) if args.dtype != "f16" else None,
+            "note": "same workload and step as `value`; captioner: plain-f16 ViT + error-compensated cross K|V, decoder and LM head "
+                    "(caption logits within 1e-3 absolute on all 16 passes); CLIP tower error-compensated (visual-token ranks equal "
+                    "to the fp32 reference form end to end); filter on plain f16 operands"}
+        log(f"secondary parity-mix full step: {Nv * F / dtm:.0f} frames/s")
+    except Exception as e:
+        out["secondary"]["parity_mix_full_step"] = {"value": None, "error": f"{type(e).__name__}: {e}"[:300]}
+    cap.visual_encoder.set_parity_last_blocks(None)
     set_parity_mode(False, cap, flt, clip)
     free_sessions()
     out["parity"] = parity

@@ -4,10 +4,12 @@ visual_tokens.json): 16 synthetic videos x 8 frames 224^2 (default_rng(1000 + vi
 + CLIP ViT-B/32 visual tokens against an ontology with the vg category sizes (19,958 / 15,026 / 365 / 7,410), computed by the
 fp32 CPU ORACLE (oracle/pipeline_ref.py: the reference's per-video loops) in this build container.
 
-Weights: the product classes' reference init rules under torch.manual_seed(0) + tests/common.perturb_ (no checkpoint can be
-downloaded here) — the golden records a checksum of every state dict; the GPU test rebuilds the same weights and refuses to
-compare if the checksums differ.  Ontology text embeddings: seeded random unit vectors (the CLIP tokenizer's vocabulary is a
-download too), with the duplicate scene row of tests/test_models_gpu._ontology.
+Weights (no checkpoint can be downloaded here): tests/common.portable_init_ — every parameter drawn from numpy's PCG64
+stream, which is bit-identical on every host (torch's seeded CPU normal sampler is NOT: it differs between AVX2 and AVX-512
+machines, i.e. between this container and the GPU box).  The golden records a checksum of every state dict; the GPU test
+rebuilds the weights and refuses to compare if the checksums differ.  Ontology text embeddings: unit vectors from the same
+kind of stream (the CLIP tokenizer's vocabulary is a download too), with one duplicated scene row (314 of the real file's 365
+scene strings are distinct).
 
 Beside the three documents it writes config1_margins.json: for every decision of the oracle, how close it was —
   caption_gap[video][frame]    min gap between adjacent beam candidates over the search (a near-tie may flip on the device)
@@ -31,7 +33,7 @@ ROOT = os.path.dirname(os.path.dirname(HERE))
 sys.path.insert(0, ROOT)
 sys.path.insert(0, os.path.join(ROOT, "tests"))
 
-from common import perturb_, synthetic_frames  # noqa: E402
+from common import portable_init_, synthetic_frames  # noqa: E402
 from oracle import clip_ref, pipeline_ref, tokens_ref  # noqa: E402
 
 VG = dict(objects=19958, attributes=15026, scenes=365, verbs=7410)
@@ -39,13 +41,13 @@ N_VIDEOS, F, THRESHOLD = 16, 8, 0.4
 
 
 def ontology(dim=512, seed=3, sizes=VG):
-    g = torch.Generator().manual_seed(seed)
+    rng = np.random.default_rng(seed)
     emb, texts = {}, {}
     for k, n in sizes.items():
-        e = torch.randn(n, dim, generator=g)
+        e = torch.from_numpy(rng.standard_normal((n, dim), dtype=np.float32))
         emb[k] = e / e.norm(dim=-1, keepdim=True)
         texts[k] = [f"{k}{i}" for i in range(n)]
-    emb["scenes"][10] = emb["scenes"][3]        # duplicate class strings -> exact score ties (314 distinct of 365 in the real file)
+    emb["scenes"][10] = emb["scenes"][3]        # duplicate class strings -> exact score ties
     texts["scenes"][10] = texts["scenes"][3]
     return emb, texts
 
@@ -65,13 +67,12 @@ def build_models():
     from vidil_amd.clip import CLIPModel
     from vidil_amd.tokenizer import SyntheticBertTokenizer
 
-    torch.manual_seed(0)
     tok = SyntheticBertTokenizer()
     cap = BLIP_Decoder(image_size=224, vit="base", tokenizer=tok).eval()
     itm = BLIP_ITM(image_size=224, vit="base", tokenizer=tok).eval()
     clip = CLIPModel().eval()
     for i, m in enumerate((cap, itm, clip)):
-        perturb_(m, 100 + i)
+        portable_init_(m, 100 + i)
     return tok, cap, itm, clip
 
 

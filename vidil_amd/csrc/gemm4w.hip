@@ -71,11 +71,15 @@ __device__ __forceinline__ void glds16(const void* g, char* lds) {
 template <typename T, typename TO, int EPI, int ACT, bool FOLD, bool STATS, bool RLN, int TM = 4>
 __global__ __launch_bounds__(256) void gemm4w_kernel(const vidil_gemm_args p) {
   static_assert(TM == 4 || TM == 2, "256- or 128-row output tiles");
+  constexpr int ESZ_OF_T = sizeof(T);
   static_assert(TM == 4 || !(FOLD || RLN), "the 128-row form is built without the row-statistics epilogues");
   constexpr int BUF = kBuf<TM>, RING_BYTES = kRing<TM>;
   constexpr int MSH = TM == 4 ? 8 : 7;           // log2 of the tile's rows
   constexpr int NPIECE = TM == 4 ? 16 : 12;      // LDS-DMA instructions per K-tile per wave
   constexpr bool ROWSTAT = FOLD || RLN;
+  // 16-bit row epilogues keep their transposition inside the lower 4 KiB of a wave's scratch: the upper 4 KiB receive the
+  // bias / column-sum vectors by LDS-DMA during the last K-tile (gemm_epilogue.inc: VIDIL_EPI_BIAS_LDS)
+  constexpr bool BIAS_LDS = (EPI == VIDIL_EPI_F16 || EPI == VIDIL_EPI_HEADS || EPI == VIDIL_EPI_ARENA) && ESZ_OF_T == 2;
   static_assert(!(FOLD && RLN), "a GEMM normalises either its A rows or its residual rows");
   static_assert(!RLN || EPI == VIDIL_EPI_F32, "the residual exists in the f32 epilogue only");
   using f16 = TO;
@@ -253,6 +257,24 @@ __global__ __launch_bounds__(256) void gemm4w_kernel(const vidil_gemm_args p) {
           issue_piece(pc);
           if constexpr (pc == NPIECE - 1) head_advance();
         }
+        if constexpr (BIAS_LDS && LAST && n == 0) {
+          // The epilogue's per-column vectors — bias, and the folded LayerNorm's column sums — for this wave's 128 columns,
+          // fetched by ONE LDS-DMA instruction (lanes 0-31: bias, lanes 32-63: column sums, 16 B each) into the upper half
+          // of the wave's epilogue scratch while the last K-tile is still being multiplied.  Loaded by the epilogue itself
+          // (16 global loads per 64-column half) they cost an `s_waitcnt vmcnt(0)` — L2 latency, plus a drain of every store
+          // of the previous half and of the DMA stream — twice per tile with the matrix pipe idle.  Older than this
+          // iteration's DMA pieces, so barrier B's counted wait covers it (as for the row partials below).
+          if (p.bias != nullptr || FOLD) {     // (uniform)
+            int lane_s;
+            asm volatile("v_mbcnt_lo_u32_b32 %0, -1, 0\n\tv_mbcnt_hi_u32_b32 %0, -1, %0" : "=v"(lane_s));
+            int col = n0 + wc2 * 128 + (lane_s & 31) * 4;
+            col = col + 4 <= N ? col : N - 4;      // (columns past N are never stored; N >= 4)
+            const float* v0 = p.bias != nullptr ? p.bias : (FOLD ? p.ln_colsum : (const float*)p.W);
+            const float* v1 = FOLD ? p.ln_colsum : v0;
+            const float* src = (lane_s < 32 ? v0 : v1) + col;
+            glds16(src, smem + RING_BYTES + wave * 8192 + 4096);
+          }
+        }
         if constexpr (ROWSTAT && LAST && n == 0) {
           // this half-wave's share of the producer's row partials (half-wave (wc2, hi) takes parts w, w+4, w+8, w+12 with
           // w = wc2 + 2*hi): issued at the top of the LAST K-tile (carried from the top of the output tile they were spilled
@@ -334,21 +356,30 @@ __global__ __launch_bounds__(256) void gemm4w_kernel(const vidil_gemm_args p) {
     const int lane = lane_e, hi = lane_e >> 5, l31 = lane_e & 31;
     if constexpr (ROWSTAT) {
       // row statistics, in gemm256's summation order (the two kernels agree bit for bit): half-wave (wc2, hi) plays
-      // gemm256's wave w = wc2 + 2*hi — parts {w, w+8} then {w+4, w+12} — and the four per-"wave" sums meet in LDS (the
-      // start of the epilogue scratch; a second barrier keeps wave 0's transposition from overwriting it under a late
-      // reader) and are added in the order w = 0..3
-      f32x2* stats = (f32x2*)(smem + RING_BYTES);
+      // gemm256's wave w = wc2 + 2*hi — parts {w, w+8} then {w+4, w+12} — and the four per-"wave" sums meet in LDS and are
+      // added in the order w = 0..3
+      // (1-KiB blocks b = grp * 4 + w, two per wave's scratch, in its UPPER 4 KiB behind the bias / column-sum vectors that
+      //  the last K-tile iteration fetched by LDS-DMA (VIDIL_EPI_BIAS_LDS: + 0 .. 1 KiB): the 16-bit epilogues of the FOLD
+      //  kernels never write there, so no second barrier has to keep their transposition — lower 4 KiB — away from a late
+      //  reader; the next tile's partials are written behind a main loop whose per-K-tile barriers every wave has to pass)
+      auto stats_blk = [&](int b) { return (f32x2*)(smem + RING_BYTES + (b >> 1) * 8192 + 4096 + 1024 + (b & 1) * 1024); };
 #pragma unroll
-      for (int it = 0; it < 4; ++it) stats[(grp * 4 + wc2 + 2 * hi) * 128 + it * 32 + l31] = st_sum[it];
+      for (int it = 0; it < 4; ++it) stats_blk(grp * 4 + wc2 + 2 * hi)[it * 32 + l31] = st_sum[it];
       asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
       __builtin_amdgcn_s_barrier();
-      const float inv_k = 1.0f / (float)(FOLD ? K : N);
+      // (the divisor made opaque: 1 / K is tile-invariant, the compiler hoists it out of the tile loop, finds no register for
+      //  it across the main loop and spills it — and its reload here is a VMEM load waited for with vmcnt(0): a drain of
+      //  the DMA stream and of the previous tile's stores once per tile.  Recomputing the correctly rounded quotient costs
+      //  ten instructions; the bits are those of gemm256's.)
+      int kdiv = FOLD ? K : N;
+      asm volatile("" : "+s"(kdiv));
+      const float inv_k = 1.0f / (float)kdiv;
 #pragma unroll
       for (int it = 0; it < 4; ++it) {
         float s = 0.f, ss = 0.f;
 #pragma unroll
         for (int w = 0; w < 4; ++w) {
-          const f32x2 v = stats[(grp * 4 + w) * 128 + it * 32 + l31];
+          const f32x2 v = stats_blk(grp * 4 + w)[it * 32 + l31];
           s += v[0];
           ss += v[1];
         }
@@ -359,8 +390,10 @@ __global__ __launch_bounds__(256) void gemm4w_kernel(const vidil_gemm_args p) {
         st_s[it] = rstd;
         st_ss[it] = mean * rstd;
       }
-      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-      __builtin_amdgcn_s_barrier();
+      if constexpr (RLN) {   // (the f32 epilogue transposes through ALL 8 KiB of a wave's scratch: late readers first)
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+      }
     }
 
     // ================================================================================ epilogue: two 128x64 halves
@@ -380,8 +413,10 @@ __global__ __launch_bounds__(256) void gemm4w_kernel(const vidil_gemm_args p) {
 #if defined(VIDIL_4W_ABLATE) && (VIDIL_4W_ABLATE & 2)
     const int M = p.M > 0 ? 0 : 1;    // developer ablation: the whole epilogue except its global stores (every row is "past M")
 #endif
+#define VIDIL_EPI_BIAS_LDS 1
     {
       const int n_w = n0 + wc2 * 128;
+      const char* const epb = ep + 4096;            // [bias of columns n_w .. n_w+127 | column sums of the same]: 2 x 512 B
       do {
 #define acc accA
 #include "gemm_epilogue.inc"
@@ -390,6 +425,7 @@ __global__ __launch_bounds__(256) void gemm4w_kernel(const vidil_gemm_args p) {
     }
     {
       const int n_w = n0 + wc2 * 128 + 64;
+      const char* const epb = ep + 4096 + 256;
       do {
 #define acc accB
 #include "gemm_epilogue.inc"
