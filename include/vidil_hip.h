@@ -210,6 +210,51 @@ int vidil_attention(const void* q, const void* k, const void* vt, void* out,
                     void* stream);
 
 /* ------------------------------------------------------------------------ */
+/* Attention in f32 — the attention of the "parity" precision mode (round 4). */
+/* softmax(q k^T * scale) v per head (head_dim 64) in plain f32 arithmetic on  */
+/* f32 Q / K / V that are read IN PLACE from the row-major outputs of the      */
+/* projection GEMMs: element (row, head h, d) of an operand lives at           */
+/* base + row * ld + off + h*64 + d (ld, off multiples of 4; no per-head       */
+/* scatter).  Every GEMM operand of that mode is carried to ~2^-21; the 16-bit */
+/* Q / K / V of vidil_attention were what was left of its error (2.4e-4 of the */
+/* logit scale).  A precision mode, not a throughput path (~1/16 of the MFMA   */
+/* kernels' arithmetic rate).                                                  */
+/*  dense form (anc == NULL): query batch b has rows b*Nq .. b*Nq+Nq-1 of q;   */
+/*   kv batch j has rows j*kv_rows .. j*kv_rows+Nk-1 of k / v; query batches   */
+/*   map to kv batches by kv_group / kv_index / group_start (+ n_kv, max_group)*/
+/*   and keys are masked by kv_len / causal / causal_off exactly as in         */
+/*   vidil_attention.                                                          */
+/*  arena form (anc != NULL, Nq == 1): key j of query row b is row             */
+/*   j*arena_rows + anc[b*anc_ld + j] of k / v (the beam search's append-only  */
+/*   KV arena in f32, vidil_beam_ancestry's table); Nk keys.                   */
+/*  out row (b*Nq + t), column h*64 + d, row stride ldo: out_mode 0 = f32;     */
+/*   out_mode 2 = dtype16 rows as three planes [hi | lo | hi] of ldo/3 columns */
+/*   (what VIDIL_DT_SPLIT3 outputs look like: the next compensated GEMM's A).  */
+/* replaces (in that mode): models/vit.py:75-83; models/med.py:178-220; HF     */
+/* CLIPAttention.                                                              */
+/* ------------------------------------------------------------------------ */
+typedef struct {
+  const float* q;
+  const float* k;
+  const float* v;
+  void* out;
+  int64_t ldq, ldk, ldv, ldo;
+  int32_t q_off, k_off, v_off;
+  int32_t out_mode, dtype16;
+  int32_t Bq, H, Nq, Nk, kv_rows;
+  int32_t kv_group;
+  const int32_t* kv_index;
+  const int32_t* group_start;
+  int32_t n_kv, max_group;
+  const int32_t* kv_len;
+  int32_t causal, causal_off;
+  const int32_t* anc;
+  int32_t anc_ld, arena_rows;
+  float scale;
+} vidil_attn_f32_args;
+int vidil_attention_f32(const vidil_attn_f32_args* args, void* stream);
+
+/* ------------------------------------------------------------------------ */
 /* One separable pass of Pillow's antialiased resize on 8-bit interleaved RGB */
 /* frames (ImagingResampleHorizontal_8bpc / Vertical_8bpc of Pillow's          */
 /* Resample.c): every output byte = clip8((2^21 + sum_i px_i * k_i) >> 22)     */

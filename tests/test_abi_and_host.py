@@ -30,7 +30,7 @@ def test_library_exports_every_declared_symbol():
         assert hasattr(lib, n), f"{n} declared in include/vidil_hip.h but not exported"
     assert set(names) == set(_lib.SIGNATURES), set(names) ^ set(_lib.SIGNATURES)
     assert lib.vidil_num_entry_points() == len(names)
-    assert lib.vidil_abi_version() == 8 == _lib.ABI_VERSION
+    assert lib.vidil_abi_version() == 9 == _lib.ABI_VERSION
 
 
 def test_gemm_args_struct_matches_header_field_order():
@@ -47,6 +47,25 @@ def test_gemm_args_struct_matches_header_field_order():
         for part in decl.split(","):
             fields.append(re.findall(r"([A-Za-z_0-9]+)\s*$", part.strip())[0])
     assert fields == [f[0] for f in GemmArgs._fields_]
+
+
+def test_attn_f32_args_struct_matches_header_field_order():
+    from vidil_amd._lib import AttnF32Args
+
+    src = open(HEADER).read()
+    end = src.index("} vidil_attn_f32_args;")
+    body = src[src.rindex("typedef struct {", 0, end):end]
+    body = re.sub(r"/\*.*?\*/", "", body, flags=re.S)
+    fields = []
+    for decl in body.split("{", 1)[1].split(";"):
+        decl = decl.strip()
+        if not decl:
+            continue
+        for part in decl.split(","):
+            fields.append(re.findall(r"([A-Za-z_0-9]+)\s*$", part.strip())[0])
+    assert fields == [f[0] for f in AttnF32Args._fields_]
+    # types: 64-bit strides / pointers, 32-bit everything else (spot checks of the layout)
+    assert AttnF32Args.ldq.size == 8 and AttnF32Args.q_off.size == 4 and AttnF32Args.scale.size == 4 and AttnF32Args.anc.size == 8
 
 
 def test_argument_validation_without_a_gpu():
@@ -68,6 +87,16 @@ def test_argument_validation_without_a_gpu():
     assert lib.vidil_attention(16, 16, 16, 16, None, None, None, 0, 0, 40, 12, 1, 197, 1, 224, 0, 40, 0, 0, 768, 1, 0, 0, None) == -1
     assert b"at most 32 query rows" in lib.vidil_last_error()
     assert lib.vidil_scan_topk_ws_bytes(128, 42784, 5) > 0
+    # the parity mode's f32 attention: 16-byte aligned rows / head offsets, one query row per batch in the arena form
+    a = _lib.AttnF32Args()
+    assert lib.vidil_attention_f32(ctypes.byref(a), None) == -1 and b"null pointer" in lib.vidil_last_error()
+    a.q = a.k = a.v = a.out = 16
+    a.ldq = a.ldk = a.ldv = 770
+    a.ldo, a.Bq, a.H, a.Nq, a.Nk, a.kv_rows, a.kv_group = 768, 2, 12, 4, 4, 4, 1
+    assert lib.vidil_attention_f32(ctypes.byref(a), None) == -1 and b"16-byte aligned" in lib.vidil_last_error()
+    a.ldq = a.ldk = a.ldv = 2304
+    a.anc, a.anc_ld, a.arena_rows = 16, 20, 6
+    assert lib.vidil_attention_f32(ctypes.byref(a), None) == -1 and b"one query row per batch" in lib.vidil_last_error()
     # unknown operand type codes are argument errors; the kernel-name query follows the dispatch without launching
     assert lib.vidil_attention(16, 16, 16, 16, None, None, None, 0, 0, 1, 12, 4, 64, 4, 64, 64, 1, 0, 0, 768, 0, 7, 7, None) == -1
     assert b"unknown dtype" in lib.vidil_last_error()

@@ -437,3 +437,64 @@ def test_parity_mix_plain_vit_with_compensated_decoder_keeps_caption_logits_with
     finally:
         cap.visual_encoder.set_parity_last_blocks(None)
         cap.__dict__.pop("_decode_state", None)
+
+
+# ------------------------------------------------------------------------------- vidil_attention_f32 (round 4)
+@pytest.mark.parametrize("Bq,H,Nq,Nk,kv_group,causal,use_len", [
+    (3, 12, 197, 197, 1, False, False),     # ViT self-attention, read in place from a [M, 3C] projection output
+    (4, 8, 13, 13, 1, True, True),          # CLIP text tower: causal + kv_len
+    (6, 12, 3, 197, 3, False, False),       # decode cross-attention: 3 beams share an image's K | V
+    (5, 4, 35, 70, 1, False, False),        # two key chunks
+])
+def test_attention_f32_vs_float64(Bq, H, Nq, Nk, kv_group, causal, use_len):
+    k = _k()
+    C = H * 64
+    Bk = Bq // kv_group
+    self_attn = Nq == Nk and kv_group == 1
+    if self_attn:
+        qkv = _rand(Bq * Nq, 3 * C, seed=60).to(DEV)
+        q, kk, v = qkv[:, :C], qkv[:, C:2 * C], qkv[:, 2 * C:]
+    else:
+        q = _rand(Bq * Nq, C, seed=61).to(DEV)
+        kv = _rand(Bk, Nk, 2 * C, seed=62).to(DEV)
+        kk, v = kv[..., :C], kv[..., C:]
+    kv_len = None
+    if use_len:
+        kv_len = torch.tensor([Nk, 5, 9, 1][:Bq], dtype=torch.int32)
+    out32 = torch.zeros(Bq * Nq, C, dtype=torch.float32, device=DEV)
+    out3 = torch.zeros(Bq * Nq, 3 * C, dtype=torch.float16, device=DEV)
+    args = dict(Bq=Bq, H=H, Nq=Nq, Nk=Nk, kv_group=kv_group, causal=causal, kv_len=None if kv_len is None else kv_len.to(DEV))
+    k.attention_f32(q, kk, v, out32, **args)
+    k.attention_f32(q, kk, v, out3, **args)
+    qd = q.double().cpu().view(Bq, Nq, H, 64).permute(0, 2, 1, 3)
+    kd = kk.double().cpu().reshape(Bk, Nk, H, 64).permute(0, 2, 1, 3).repeat_interleave(kv_group, 0)
+    vd = v.double().cpu().reshape(Bk, Nk, H, 64).permute(0, 2, 1, 3).repeat_interleave(kv_group, 0)
+    s = (qd @ kd.transpose(-1, -2)) * 0.125
+    keys = torch.arange(Nk)
+    if causal:
+        s = s.masked_fill(keys[None, :] > torch.arange(Nq)[:, None], float("-inf"))
+    if kv_len is not None:
+        s = s.masked_fill(keys[None, None, None, :] >= kv_len.long()[:, None, None, None], float("-inf"))
+    ref = (torch.softmax(s, -1) @ vd).permute(0, 2, 1, 3).reshape(Bq * Nq, C)
+    e32 = (out32.cpu().double() - ref).abs().max().item()
+    e3 = (_join(out3.cpu()).double() - ref).abs().max().item()
+    assert e32 < 3e-6 and e3 < 5e-6, (e32, e3)        # (the 16-bit MFMA kernels: ~4e-4 on the same data)
+
+
+def test_attention_f32_arena_form_follows_the_ancestry_table():
+    k = _k()
+    R, H, Tcap, n_keys = 12, 12, 20, 7
+    C = H * 64
+    g = torch.Generator().manual_seed(70)
+    arena_k = _rand(Tcap, R, C, seed=71).to(DEV)
+    arena_v = _rand(Tcap, R, C, seed=72).to(DEV)
+    anc = torch.randint(0, R, (R, Tcap), generator=g, dtype=torch.int32)
+    q = _rand(R, 3 * C, seed=73).to(DEV)[:, :C]
+    out = torch.zeros(R, C, dtype=torch.float32, device=DEV)
+    k.attention_f32(q, arena_k, arena_v, out, Bq=R, H=H, Nq=1, Nk=n_keys, anc=anc.to(DEV), arena_rows=R)
+    kk = torch.stack([arena_k.cpu()[torch.arange(n_keys), anc[r, :n_keys].long()] for r in range(R)]).double()   # [R, n_keys, C]
+    vv = torch.stack([arena_v.cpu()[torch.arange(n_keys), anc[r, :n_keys].long()] for r in range(R)]).double()
+    qd = q.cpu().double().view(R, H, 1, 64)
+    s = (qd @ kk.view(R, n_keys, H, 64).permute(0, 2, 3, 1)) * 0.125
+    ref = (torch.softmax(s, -1) @ vv.view(R, n_keys, H, 64).permute(0, 2, 1, 3)).reshape(R, C)
+    assert (out.cpu().double() - ref).abs().max().item() < 3e-6

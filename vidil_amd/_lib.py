@@ -50,6 +50,26 @@ class BeamState(C.Structure):
         "hyp_score", "hyp_len", "hyp_tok", "worst", "n_done")]
 
 
+class AttnF32Args(C.Structure):
+    """Mirror of ``vidil_attn_f32_args`` (include/vidil_hip.h; field order and types are the ABI)."""
+
+    _fields_ = [
+        ("q", C.c_void_p), ("k", C.c_void_p), ("v", C.c_void_p), ("out", C.c_void_p),
+        ("ldq", C.c_int64), ("ldk", C.c_int64), ("ldv", C.c_int64), ("ldo", C.c_int64),
+        ("q_off", C.c_int32), ("k_off", C.c_int32), ("v_off", C.c_int32),
+        ("out_mode", C.c_int32), ("dtype16", C.c_int32),
+        ("Bq", C.c_int32), ("H", C.c_int32), ("Nq", C.c_int32), ("Nk", C.c_int32), ("kv_rows", C.c_int32),
+        ("kv_group", C.c_int32),
+        ("kv_index", C.c_void_p), ("group_start", C.c_void_p),
+        ("n_kv", C.c_int32), ("max_group", C.c_int32),
+        ("kv_len", C.c_void_p),
+        ("causal", C.c_int32), ("causal_off", C.c_int32),
+        ("anc", C.c_void_p),
+        ("anc_ld", C.c_int32), ("arena_rows", C.c_int32),
+        ("scale", C.c_float),
+    ]
+
+
 _i32, _i64, _f32, _p = C.c_int32, C.c_int64, C.c_float, C.c_void_p
 
 # name -> (restype, argtypes); the order/types restate include/vidil_hip.h.
@@ -62,6 +82,7 @@ SIGNATURES = {
     "vidil_layernorm": (_i32, [_p, _i64, _p, _p, _f32, _i32, _i32, _p, _i32, _p, _p]),
     "vidil_split3_f32": (_i32, [_p, _p, _i32, _i32, _i32, _p]),
     "vidil_attention": (_i32, [_p, _p, _p, _p, _p, _p, _p] + [_i32] * 16 + [_p]),
+    "vidil_attention_f32": (_i32, [C.POINTER(AttnF32Args), _p]),
     "vidil_patchify_f32": (_i32, [_p, _p, _i32, _i32, _i32, _i32, _p]),
     "vidil_patchify_u8": (_i32, [_p, _p, _i32, _i32, _i32, C.POINTER(_f32), C.POINTER(_f32), _i32, _p]),
     "vidil_resample_u8": (_i32, [_p, _p] + [_i32] * 6 + [_p, _p, _i32, _i32, _p]),
@@ -88,7 +109,7 @@ class VidilHipError(RuntimeError):
     pass
 
 
-ABI_VERSION = 8      # include/vidil_hip.h as this binding mirrors it (struct layouts, argument lists)
+ABI_VERSION = 9      # include/vidil_hip.h as this binding mirrors it (struct layouts, argument lists)
 
 
 def load():

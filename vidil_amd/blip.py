@@ -101,7 +101,9 @@ class DecoderSession:
         self.tiled_cross = tiled_cross
         self.cross = self.bert.project_cross_kv(enc16, B, Te, tiled=tiled_cross)
         self.Tcap = max_length
-        self.arena = BeamArena(self.L, self.Tcap, self.R, cfg.hidden_size, dev, dtype=enc16.dtype)
+        # (parity precision mode with vidil_attention_f32: the self-attention K / V cache is f32 too)
+        arena_dtype = torch.float32 if getattr(self.cross, "f32", False) else enc16.dtype
+        self.arena = BeamArena(self.L, self.Tcap, self.R, cfg.hidden_size, dev, dtype=arena_dtype)
         self.ws_prefill, self.ws_step = {}, {}
         self.logits = None
 
@@ -117,7 +119,7 @@ class DecoderSession:
         pc = parent.cross
         self.cross = CrossKV(torch.empty((pc.k.shape[0], B) + tuple(pc.k.shape[2:]), dtype=pc.k.dtype, device=pc.k.device),
                              torch.empty((pc.vt.shape[0], B) + tuple(pc.vt.shape[2:]), dtype=pc.vt.dtype, device=pc.vt.device),
-                             B, pc.Te, pc.NP, tiled=pc.tiled, Tk_cap=pc.Tk_cap)
+                             B, pc.Te, pc.NP, tiled=pc.tiled, Tk_cap=pc.Tk_cap, f32=getattr(pc, "f32", False))
         pa = parent.arena
         self.arena = BeamArena(pa.L, pa.Tcap, self.R, pa.k.shape[-1], pa.k.device, dtype=pa.k.dtype)
         self.ws_prefill, self.ws_step = {}, {}

@@ -19,7 +19,7 @@ import torch
 import torch.nn as nn
 
 from . import kernels as K
-from .packing import FP8, PackedCache, fold_layernorm, require_cuda, v32, w3, w3_patch, w8, w16, w16_patch
+from .packing import FP8, PackedCache, fold_layernorm, parity_attention_f32, require_cuda, v32, w3, w3_patch, w8, w16, w16_patch
 
 CLIP_MEAN = (0.48145466, 0.4578275, 0.40821073)
 CLIP_STD = (0.26862954, 0.26130258, 0.27577711)
@@ -180,10 +180,16 @@ def _run_layers(layers, x, B, T, H, eps, *, causal=False, kv_len=None):
         o3 = torch.empty((M, 3 * D), dtype=cdt, device=dev)
         hid32 = torch.empty((M, Dh), dtype=torch.float32, device=dev)
         hid3 = torch.empty((M, 3 * Dh), dtype=cdt, device=dev)
+        f32_attn = parity_attention_f32()
+        qkv32 = torch.empty((M, 3 * D), dtype=torch.float32, device=dev) if f32_attn else None
         for l in layers:
             K.layernorm(x, l["n1g"], l["n1b"], eps, out16=a3, split3=True)
-            K.gemm(a3, l["qkv_w3"], l["qkv_b"], heads=heads)
-            K.attention(q, k, vt, o3, Bq=B, H=H, Nq=T, Nk=T, Tq_cap=T, Tk_cap=T, NP=NP, causal=causal, kv_len=kv_len, split3=True)
+            if f32_attn:    # (Q | K | V stay f32 and row-major: vidil_attention_f32 reads them in place)
+                K.gemm(a3, l["qkv_w3"], l["qkv_b"], out=qkv32)
+                K.attention_f32(qkv32[:, :D], qkv32[:, D:2 * D], qkv32[:, 2 * D:], o3, Bq=B, H=H, Nq=T, Nk=T, causal=causal, kv_len=kv_len)
+            else:
+                K.gemm(a3, l["qkv_w3"], l["qkv_b"], heads=heads)
+                K.attention(q, k, vt, o3, Bq=B, H=H, Nq=T, Nk=T, Tq_cap=T, Tk_cap=T, NP=NP, causal=causal, kv_len=kv_len, split3=True)
             K.gemm(o3, l["o_w3"], l["o_b"], out=x, resid=x)
             K.layernorm(x, l["n2g"], l["n2b"], eps, out16=a3, split3=True)
             K.gemm(a3, l["fc1_w3"], l["fc1_b"], out=hid32, act=K.ACT_QUICK_GELU)

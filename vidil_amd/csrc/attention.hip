@@ -804,3 +804,235 @@ extern "C" int vidil_attention(const void* q, const void* k, const void* vt, voi
     return attention_dispatch<T>(p, nkt, max_rows, Nk, (hipStream_t)stream);
   });
 }
+
+// ====================================================================== f32 attention (parity precision mode only)
+// The error-compensated "parity" mode carries every GEMM operand to ~2^-21, and tests/probes/probe_attention_rounding.py
+// shows that what is then left of the caption-logit error — 2.4e-4 of the logit scale — is exactly the 16-bit rounding of
+// Q / K / V (and of the probabilities) inside the MFMA attention kernels above.  This is the attention of that mode since
+// round 4: plain f32 VALU arithmetic on f32 Q / K / V read IN PLACE from the row-major outputs of the projection GEMMs
+// (element (row, head h, d) at base + row * ld + off + h * 64 + d — no per-head scatter), so the mode's tolerance holds at
+// a trained model's logit scale too.  It is a precision mode, not a throughput path: ~1/16 of the MFMA kernels' arithmetic
+// rate (DESIGN.md §4 states the cost); softmax(q k^T * scale) v with the same grouping / masking forms as vidil_attention.
+//
+//   attn_f32_kernel        one workgroup (4 waves) per (unit, head, block of 32 virtual query rows): 64 keys x 64 dims of K and V
+//                          at a time in LDS (row stride 68 floats: conflict-free ds_read_b128 across keys), each wave owns 8
+//                          rows and works on 4 at once — scores with lane = key, online softmax (wave reductions), then
+//                          P.V with lane = d through a wave-private P buffer.
+//   attn_f32_arena_kernel  decode-step self-attention over an f32 KV arena through the ancestry table (one query row per
+//                          beam row, <= Tcap keys): one wave per (row, head), lane = d, online softmax over the keys.
+namespace {
+
+struct AttnF32P {
+  const float* q;
+  const float* k;
+  const float* v;
+  void* out;
+  long long ldq, ldk, ldv, ldo;
+  int q_off, k_off, v_off;
+  int out_mode;                // 0: f32 rows; 2: 16-bit [hi | lo | hi] rows in three planes ldo / 3 apart (VIDIL_DT_SPLIT3)
+  int dtype16;
+  const int32_t* kv_len;
+  const int32_t* kv_index;
+  const int32_t* group_start;
+  int Bq, H, Nq, Nk, kv_rows, kv_group, causal, causal_off, n_kv;
+  const int32_t* anc;          // arena form
+  int anc_ld, arena_rows;
+  float scale;
+};
+
+template <typename T16>
+__device__ __forceinline__ void store_f32_row(const AttnF32P& p, size_t row, int h, int d, float v) {
+  if (p.out_mode == 0) {
+    ((float*)p.out)[row * p.ldo + h * 64 + d] = v;
+  } else {
+    const long long pl = p.ldo / 3;
+    T16* o = (T16*)p.out + row * p.ldo + h * 64 + d;
+    const T16 hi = Elt<T16>::from_f32(v);
+    const T16 lo = Elt<T16>::from_f32(v - (float)hi);
+    o[0] = hi;
+    o[pl] = lo;
+    o[2 * pl] = hi;
+  }
+}
+
+constexpr int F32_KC = 64;      // keys per staged chunk
+constexpr int F32_LD = 68;      // floats per staged K / V / Q row (64 + 4: ds_read_b128 of consecutive rows hit distinct bank groups)
+constexpr int F32_RB = 32;      // virtual query rows per workgroup
+
+template <typename T16>
+__global__ __launch_bounds__(256) void attn_f32_kernel(const AttnF32P p) {
+  __shared__ __attribute__((aligned(16))) float Ks[F32_KC * F32_LD];
+  __shared__ __attribute__((aligned(16))) float Vs[F32_KC * F32_LD];
+  __shared__ __attribute__((aligned(16))) float Qs[F32_RB * F32_LD];
+  __shared__ __attribute__((aligned(16))) float Ps[4][4][F32_KC];     // [wave][row of the group of 4][key]
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int h = blockIdx.y;
+  int bk, first, count;
+  resolve_unit(p, blockIdx.z, bk, first, count);
+  const int rows = count * p.Nq;
+  const int base = blockIdx.x * F32_RB;
+  if (base >= rows) return;
+  // ---- the block's query rows (pre-scaled), once
+  for (int i = tid; i < F32_RB * 16; i += 256) {
+    const int r = i >> 4, c = i & 15;
+    const RowInfo ri = row_info(p, base + r, first, rows);
+    f32x4 qv = {0.f, 0.f, 0.f, 0.f};
+    if (ri.valid) qv = *(const f32x4*)(p.q + ((size_t)ri.qb * p.Nq + ri.t) * p.ldq + p.q_off + h * 64 + c * 4);
+    *(f32x4*)(Qs + r * F32_LD + c * 4) = qv * p.scale;
+  }
+  // this wave's 8 rows, in two groups of 4: running maximum / sum (lane-uniform) and the output accumulator (lane = d)
+  float m[2][4], l[2][4], acc[2][4];
+  int klim[2][4];
+#pragma unroll
+  for (int g = 0; g < 2; ++g)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      m[g][r] = -INFINITY; l[g][r] = 0.f; acc[g][r] = 0.f;
+      const RowInfo ri = row_info(p, base + wave * 8 + g * 4 + r, first, rows);
+      klim[g][r] = ri.valid ? ri.klim : 0;
+    }
+  const float* kg = p.k + (size_t)bk * p.kv_rows * p.ldk + p.k_off + h * 64;
+  const float* vg = p.v + (size_t)bk * p.kv_rows * p.ldv + p.v_off + h * 64;
+  for (int k0 = 0; k0 < p.Nk; k0 += F32_KC) {
+    __syncthreads();     // (the previous chunk is consumed; the first pass: Qs is written)
+    for (int i = tid; i < F32_KC * 16; i += 256) {
+      const int r = i >> 4, c = i & 15;
+      f32x4 kv = {0.f, 0.f, 0.f, 0.f}, vv = {0.f, 0.f, 0.f, 0.f};
+      if (k0 + r < p.Nk) {
+        kv = *(const f32x4*)(kg + (size_t)(k0 + r) * p.ldk + c * 4);
+        vv = *(const f32x4*)(vg + (size_t)(k0 + r) * p.ldv + c * 4);
+      }
+      *(f32x4*)(Ks + r * F32_LD + c * 4) = kv;
+      *(f32x4*)(Vs + r * F32_LD + c * 4) = vv;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int g = 0; g < 2; ++g) {
+      // ---- scores of 4 rows x 64 keys: lane = key
+      float sc[4] = {0.f, 0.f, 0.f, 0.f};
+      const float* krow = Ks + lane * F32_LD;
+      const float* qrow = Qs + (wave * 8 + g * 4) * F32_LD;
+#pragma unroll 4
+      for (int c = 0; c < 16; ++c) {
+        const f32x4 kv = *(const f32x4*)(krow + c * 4);
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const f32x4 qv = *(const f32x4*)(qrow + r * F32_LD + c * 4);      // (same address in every lane: a broadcast)
+          sc[r] = __builtin_fmaf(qv[0], kv[0], sc[r]);
+          sc[r] = __builtin_fmaf(qv[1], kv[1], sc[r]);
+          sc[r] = __builtin_fmaf(qv[2], kv[2], sc[r]);
+          sc[r] = __builtin_fmaf(qv[3], kv[3], sc[r]);
+        }
+      }
+      // ---- online softmax per row; probabilities of this chunk into the wave's P buffer
+      float alpha[4];
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const float s = (k0 + lane < klim[g][r]) ? sc[r] : -INFINITY;
+        const float mn = fmaxf(m[g][r], wave_max(s));
+        const float msafe = mn == -INFINITY ? 0.f : mn;
+        const float pr = expf(s - msafe);                 // (s = -inf -> 0)
+        alpha[r] = expf(m[g][r] - msafe);                 // (m = -inf -> 0)
+        l[g][r] = l[g][r] * alpha[r] + wave_sum(pr);
+        m[g][r] = mn;
+        Ps[wave][r][lane] = pr;
+      }
+      // ---- P.V of the chunk: lane = d
+#pragma unroll
+      for (int r = 0; r < 4; ++r) acc[g][r] *= alpha[r];
+      for (int j = 0; j < F32_KC; j += 4) {
+        f32x4 pv[4];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) pv[r] = *(const f32x4*)(&Ps[wave][r][j]);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          const float v = Vs[(j + e) * F32_LD + lane];
+#pragma unroll
+          for (int r = 0; r < 4; ++r) acc[g][r] = __builtin_fmaf(pv[r][e], v, acc[g][r]);
+        }
+      }
+    }
+  }
+#pragma unroll
+  for (int g = 0; g < 2; ++g)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const RowInfo ri = row_info(p, base + wave * 8 + g * 4 + r, first, rows);
+      if (!ri.valid) continue;
+      const float inv = l[g][r] > 0.f ? 1.0f / l[g][r] : 0.f;
+      store_f32_row<T16>(p, (size_t)ri.qb * p.Nq + ri.t, h, lane, acc[g][r] * inv);
+    }
+}
+
+template <typename T16>
+__global__ __launch_bounds__(256) void attn_f32_arena_kernel(const AttnF32P p) {
+  const int lane = threadIdx.x & 63;
+  const int unit = blockIdx.x * 4 + (threadIdx.x >> 6);       // (row, head)
+  if (unit >= p.Bq * p.H) return;
+  const int b = unit / p.H, h = unit - b * p.H;
+  const float q = p.q[(size_t)b * p.ldq + p.q_off + h * 64 + lane] * p.scale;
+  float m = -INFINITY, l = 0.f, acc = 0.f;
+  for (int j = 0; j < p.Nk; ++j) {
+    const size_t row = (size_t)j * p.arena_rows + p.anc[(size_t)b * p.anc_ld + j];
+    const float s = wave_sum(q * p.k[row * p.ldk + p.k_off + h * 64 + lane]);
+    const float mn = fmaxf(m, s);
+    const float alpha = expf(m - mn), pr = expf(s - mn);
+    l = l * alpha + pr;
+    acc = __builtin_fmaf(pr, p.v[row * p.ldv + p.v_off + h * 64 + lane], acc * alpha);
+    m = mn;
+  }
+  store_f32_row<T16>(p, (size_t)b, h, lane, acc / l);
+}
+
+}  // namespace
+
+extern "C" int vidil_attention_f32(const vidil_attn_f32_args* a, void* stream) {
+  VIDIL_REQUIRE(a && a->q && a->k && a->v && a->out, "attention_f32: null pointer");
+  VIDIL_REQUIRE(a->Bq > 0 && a->H > 0 && a->Nq > 0 && a->Nk > 0, "attention_f32: bad shape Bq=%d H=%d Nq=%d Nk=%d", a->Bq, a->H, a->Nq, a->Nk);
+  VIDIL_REQUIRE(a->ldq % 4 == 0 && a->ldk % 4 == 0 && a->ldv % 4 == 0 && a->q_off % 4 == 0 && a->k_off % 4 == 0 && a->v_off % 4 == 0 &&
+                    ((uintptr_t)a->q & 15) == 0 && ((uintptr_t)a->k & 15) == 0 && ((uintptr_t)a->v & 15) == 0,
+                "attention_f32: rows and head offsets must be 16-byte aligned");
+  VIDIL_REQUIRE(a->out_mode == 0 || (a->out_mode == 2 && a->ldo % 3 == 0 && a->ldo / 3 >= (long long)a->H * 64 &&
+                                     (a->dtype16 == VIDIL_DT_F16 || a->dtype16 == VIDIL_DT_BF16)),
+                "attention_f32: out_mode 0 (f32 rows) or 2 ([hi | lo | hi] 16-bit rows, ldo = 3 planes)");
+  AttnF32P p;
+  p.q = a->q; p.k = a->k; p.v = a->v; p.out = a->out;
+  p.ldq = a->ldq; p.ldk = a->ldk; p.ldv = a->ldv; p.ldo = a->ldo;
+  p.q_off = a->q_off; p.k_off = a->k_off; p.v_off = a->v_off;
+  p.out_mode = a->out_mode; p.dtype16 = a->dtype16;
+  p.kv_len = a->kv_len; p.kv_index = a->kv_index; p.group_start = a->group_start;
+  p.Bq = a->Bq; p.H = a->H; p.Nq = a->Nq; p.Nk = a->Nk; p.kv_rows = a->kv_rows; p.kv_group = a->kv_group;
+  p.causal = a->causal; p.causal_off = a->causal_off; p.n_kv = a->n_kv;
+  p.anc = a->anc; p.anc_ld = a->anc_ld; p.arena_rows = a->arena_rows; p.scale = a->scale;
+  hipStream_t s = (hipStream_t)stream;
+  const bool bf = a->dtype16 == VIDIL_DT_BF16;
+  if (a->anc != nullptr) {
+    VIDIL_REQUIRE(a->Nq == 1 && a->arena_rows > 0 && a->anc_ld >= a->Nk, "attention_f32: the arena form serves one query row per batch");
+    const int units = a->Bq * a->H;
+    if (bf) hipLaunchKernelGGL(attn_f32_arena_kernel<bf16>, dim3((units + 3) / 4), dim3(256), 0, s, p);
+    else hipLaunchKernelGGL(attn_f32_arena_kernel<f16>, dim3((units + 3) / 4), dim3(256), 0, s, p);
+    VIDIL_CHECK_LAUNCH("attention_f32 (arena)");
+    return VIDIL_OK;
+  }
+  VIDIL_REQUIRE(a->kv_rows >= a->Nk && a->kv_group > 0, "attention_f32: kv_rows=%d < Nk=%d or kv_group=%d", a->kv_rows, a->Nk, a->kv_group);
+  int units, max_rows;
+  if (a->group_start != nullptr) {
+    VIDIL_REQUIRE(a->kv_index == nullptr && a->n_kv > 0 && a->max_group > 0, "attention_f32: group_start needs n_kv and max_group (and no kv_index)");
+    units = a->n_kv;
+    max_rows = a->max_group * a->Nq;
+  } else if (a->kv_index != nullptr) {
+    units = a->Bq;
+    max_rows = a->Nq;
+  } else {
+    VIDIL_REQUIRE(a->Bq % a->kv_group == 0, "attention_f32: Bq=%d not a multiple of kv_group=%d", a->Bq, a->kv_group);
+    units = a->Bq / a->kv_group;
+    max_rows = a->kv_group * a->Nq;
+  }
+  VIDIL_REQUIRE(a->H <= 65535 && units <= 65535, "attention_f32: grid too large (H=%d units=%d)", a->H, units);
+  const dim3 grid((max_rows + F32_RB - 1) / F32_RB, a->H, units);
+  if (bf) hipLaunchKernelGGL(attn_f32_kernel<bf16>, grid, dim3(256), 0, s, p);
+  else hipLaunchKernelGGL(attn_f32_kernel<f16>, grid, dim3(256), 0, s, p);
+  VIDIL_CHECK_LAUNCH("attention_f32");
+  return VIDIL_OK;
+}

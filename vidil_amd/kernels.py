@@ -246,6 +246,56 @@ def attention(q, k, vt, out, *, Bq, H, Nq, Nk, Tq_cap, Tk_cap, NP, kv_group=1, c
     return out
 
 
+def _f32_view(t, what):
+    """(data pointer, row stride in elements) of an f32 tensor whose LAST dim is contiguous and whose leading dims collapse to
+    one row index (a [rows, C] matrix, or a column slice of one)."""
+    from .packing import require_cuda
+    require_cuda(t, what)
+    if t.dtype != torch.float32 or t.stride(-1) != 1:
+        raise VidilHipError(f"{what}: f32 tensor with a contiguous last dimension expected, got {t.dtype} strides {t.stride()}")
+    t2 = t if t.dim() == 2 else t.flatten(0, -2)      # (raises if the leading dims do not collapse without a copy)
+    if t2.data_ptr() != t.data_ptr():
+        raise VidilHipError(f"{what}: leading dimensions do not collapse to rows without a copy")
+    return t2.data_ptr(), t2.stride(0)
+
+
+def attention_f32(q, k, v, out, *, Bq, H, Nq, Nk, kv_rows=None, kv_group=1, causal=False, causal_off=0, kv_len=None, kv_index=None,
+                  group_start=None, max_group=0, scale=0.125, split3=None, anc=None, arena_rows=0):
+    """softmax(q k^T * scale) v in plain f32 (the attention of the parity precision mode; vidil_attention_f32).
+
+    q, k, v: f32 matrices — typically COLUMN SLICES of the row-major output of a projection GEMM (``qkv32[:, :C]``, ``[:, C:2*C]``,
+    ``[:, 2*C:]``): row stride and column offset are taken from the views, head h occupies columns h*64 .. h*64+63.
+    q rows: query batch b at rows b*Nq ..; k / v rows: kv batch j at rows j*kv_rows .. (default kv_rows = Nk).
+    out: f32 [Bq*Nq, H*64], or a 16-bit [Bq*Nq, 3*H*64] tensor receiving [hi | lo | hi] rows (split3 defaults to that case).
+    anc (+ arena_rows): the arena form — Nq == 1, key j of query row b is row j*arena_rows + anc[b][j] of k / v."""
+    a = _lib.AttnF32Args()
+    a.q, a.ldq = _f32_view(q, "attention_f32.q")
+    a.k, a.ldk = _f32_view(k, "attention_f32.k")
+    a.v, a.ldv = _f32_view(v, "attention_f32.v")
+    a.q_off = a.k_off = a.v_off = 0
+    if split3 is None:
+        split3 = out.dtype != torch.float32
+    a.out = _ptr(out, None, "attention_f32.out")
+    a.ldo = out.stride(-2) if out.dim() >= 2 else out.shape[-1]
+    a.out_mode = 2 if split3 else 0
+    a.dtype16 = _dt(out, "attention_f32.out") if split3 else DT_F16
+    a.Bq, a.H, a.Nq, a.Nk = Bq, H, Nq, Nk
+    a.kv_rows = Nk if kv_rows is None else kv_rows
+    a.kv_group = kv_group
+    a.kv_index = _ptr(kv_index, torch.int32, "attention_f32.kv_index")
+    a.group_start = _ptr(group_start, torch.int32, "attention_f32.group_start")
+    a.n_kv = 0 if group_start is None else group_start.numel() - 1
+    a.max_group = max_group
+    a.kv_len = _ptr(kv_len, torch.int32, "attention_f32.kv_len")
+    a.causal, a.causal_off = int(bool(causal)), causal_off
+    a.anc = _ptr(anc, torch.int32, "attention_f32.anc")
+    a.anc_ld = 0 if anc is None else anc.stride(0)
+    a.arena_rows = arena_rows
+    a.scale = float(scale)
+    check(_lib.load().vidil_attention_f32(C.byref(a), _stream()), "attention_f32")
+    return out
+
+
 def resample_u8(src, dst, bounds, coeffs, *, vertical, src_row0=0):
     """One pass of Pillow's 8-bit resize: src u8 [B,in_h,in_w,3] -> dst u8 [B,out_h,out_w,3] (see vidil_resample_u8)."""
     B, in_h, in_w, _ = src.shape

@@ -22,7 +22,7 @@ import torch
 import torch.nn as nn
 
 from . import kernels as K
-from .packing import FP8, PackedCache, fold_layernorm, require_cuda, v32, w3, w8, w16
+from .packing import FP8, PackedCache, fold_layernorm, parity_attention_f32, require_cuda, v32, w3, w8, w16
 
 LN_EPS_DEFAULT = 1e-12
 
@@ -128,8 +128,11 @@ def _init_bert(module, std):
 class CrossKV:
     """Per-image cross-attention keys / values^T of every layer: K [L][B,H,Te,64], VT [L][B,H,64,NP]."""
 
-    def __init__(self, k, vt, B, Te, NP, last_vt=None, last_NP=0, tiled=False, Tk_cap=None):
+    def __init__(self, k, vt, B, Te, NP, last_vt=None, last_NP=0, tiled=False, Tk_cap=None, f32=False):
         self.k, self.vt, self.B, self.Te, self.NP = k, vt, B, Te, NP
+        # f32 (parity precision mode with vidil_attention_f32): k = f32 [L][B, Te, 2C] — the K | V projection GEMM's row-major
+        # output, keys in columns 0..C-1 and values in C..2C-1 — and vt a placeholder [L][B, 1] (same batch axis for adopt())
+        self.f32 = f32
         # tiled: K and V of every layer in 32-key fragment tiles [L][B,H,Tk_cap/32,2048] (vidil_attention kv_tiled)
         self.tiled, self.Tk_cap = tiled, (Te if Tk_cap is None else Tk_cap)
         # optional second copy of the LAST layer's values in V^T layout (see project_cross_kv(last_layer_vt=True))
@@ -256,6 +259,18 @@ class BertModel(PackedCache, nn.Module):
             if enc16.shape[1] != 3 * self.config.encoder_width:
                 raise K.VidilHipError(f"project_cross_kv (parity mode): image tokens must be [hi | lo | hi] rows of width "
                                       f"{3 * self.config.encoder_width}, got {tuple(enc16.shape)}")
+
+            if parity_attention_f32():
+                L, C = len(p["layers"]), self.config.hidden_size
+                dev = enc16.device
+                if out is not None and getattr(out, "f32", False) and (out.B, out.Te) == (B, Te) and out.k.device == dev:
+                    kv32, ph = out.k, out.vt
+                else:
+                    kv32 = torch.empty((L, B, Te, 2 * C), dtype=torch.float32, device=dev)
+                    ph = torch.zeros((L, B, 1), dtype=torch.float32, device=dev)
+                for i, d in enumerate(p["layers"]):
+                    K.gemm(enc16, d["ckv_w3"], d["ckv_b"], out=kv32[i].view(B * Te, 2 * C))
+                return CrossKV(kv32, ph, B, Te, 0, f32=True)
 
             def kv_gemm(d, **heads):
                 K.gemm(enc16, d["ckv_w3"], d["ckv_b"], heads=heads)
@@ -417,8 +432,33 @@ class BertModel(PackedCache, nn.Module):
         Nk = t_off + T
         if arena is not None and T > 1 and t_off != 0:
             raise K.VidilHipError("run_layers: a multi-token block can only be appended to a beam arena at position 0")
+        f32_attn = parity_attention_f32()
+        if f32_attn:
+            # Q | K | V (and the cross query) stay f32 and row-major, the KV arena and the cross K | V are f32:
+            # vidil_attention_f32 reads all of them in place.  (t_off > 0 happens in the arena form only.)
+            if (arena is not None and arena.k.dtype != torch.float32) or (cross is not None and not getattr(cross, "f32", False)):
+                raise K.VidilHipError("run_layers (parity mode, f32 attention): the KV arena / cross K|V of this session were built for "
+                                      "the 16-bit attention kernels — build the DecoderSession / CrossKV under the same $VIDIL_PARITY_ATTN")
+            if t_off != 0 and not (arena is not None and T == 1):
+                raise K.VidilHipError("run_layers (parity mode, f32 attention): cached self-attention keys are served by the arena form only")
+            qkv32 = torch.empty((M, 3 * C), dtype=torch.float32, device=dev)
+            q32 = torch.empty((M, C), dtype=torch.float32, device=dev) if cross is not None else None
         for i, d in enumerate(p["layers"]):
-            if arena is not None and T == 1:
+            if f32_attn:
+                K.gemm(h3, d["qkv_w3"], d["qkv_b"], out=qkv32)
+                if arena is not None and T == 1:
+                    arena.k[i][t_off].copy_(qkv32[:, C:2 * C])          # position t_off, slot = producing beam row
+                    arena.v[i][t_off].copy_(qkv32[:, 2 * C:])
+                    K.attention_f32(qkv32[:, :C], arena.k[i], arena.v[i], o3, Bq=rows, H=H, Nq=1, Nk=Nk, anc=arena.anc,
+                                    arena_rows=arena.rows)
+                else:
+                    K.attention_f32(qkv32[:, :C], qkv32[:, C:2 * C], qkv32[:, 2 * C:], o3, Bq=rows, H=H, Nq=T, Nk=T, causal=causal,
+                                    kv_len=kv_len)
+                    if arena is not None:   # the prompt's K / V in the arena: position t, slot r * arena_slot_stride
+                        blk = qkv32.view(rows, T, 3 * C)
+                        arena.k[i][:T, 0:rows * arena_slot_stride:arena_slot_stride] = blk[:, :, C:2 * C].permute(1, 0, 2)
+                        arena.v[i][:T, 0:rows * arena_slot_stride:arena_slot_stride] = blk[:, :, 2 * C:].permute(1, 0, 2)
+            elif arena is not None and T == 1:
                 K.gemm(h3, d["qkv_w3"], d["qkv_b"],
                        arena=dict(q=q, k=arena.k[i], v=arena.v[i], T=1, H=H, part0=0, t_off=t_off, Tcap=arena.Tcap,
                                   arena_rows=arena.rows, slot_stride=1, q_scale=0.125))
@@ -435,7 +475,14 @@ class BertModel(PackedCache, nn.Module):
                                       arena_rows=arena.rows, slot_stride=arena_slot_stride))
             K.gemm(o3, d["ao_w3"], d["ao_b"], out=tmp, resid=h32)
             K.layernorm(tmp, d["ao_g"], d["ao_bt"], eps, out16=h3, out32=h32, split3=True)
-            if cross is not None:
+            if cross is not None and f32_attn:
+                K.gemm(h3, d["cq_w3"], d["cq_b"], out=q32)
+                kv = cross.k[i]                                         # f32 [B, Te, 2C]: keys | values
+                K.attention_f32(q32, kv[..., :C], kv[..., C:], o3, Bq=rows, H=H, Nq=T, Nk=cross.Te, kv_rows=cross.Te,
+                                kv_group=cross_group, kv_index=cross_index, group_start=cross_groups, max_group=cross_max_group)
+                K.gemm(o3, d["co_w3"], d["co_b"], out=tmp, resid=h32)
+                K.layernorm(tmp, d["co_g"], d["co_bt"], eps, out16=h3, out32=h32, split3=True)
+            elif cross is not None:
                 K.gemm(h3, d["cq_w3"], d["cq_b"], heads=dict(q=q, T=T, H=H, part0=0, Tq_cap=T, q_scale=0.125))
                 # (project_cross_kv(last_layer_vt=True) keeps the LAST layer's values in a V^T buffer of their own)
                 last = i == len(p["layers"]) - 1 and cross.last_vt is not None

@@ -94,6 +94,13 @@ def parity_mode(module=None) -> bool:
     return _parity_default[0] if v is None else v
 
 
+def parity_attention_f32() -> bool:
+    """The parity precision mode's attention: plain f32 (vidil_attention_f32, the default since round 4 — the mode's remaining
+    error WAS the 16-bit Q / K / V of the MFMA attention kernels: tests/probes/probe_attention_rounding.py), or those 16-bit
+    kernels with [hi | lo | hi] outputs as in round 3 ($VIDIL_PARITY_ATTN=16: cheaper, 2.4e-4 of the logit scale)."""
+    return os.environ.get("VIDIL_PARITY_ATTN", "f32") != "16"
+
+
 def w3(*weights, dtype=None):
     """nn.Linear weights (concatenated along N) [N,K] f32 -> 16-bit [N,3K] = [W_hi | W_hi | W_lo] (hi = T16(W), lo =
     T16(W - hi)): the weight side of an error-compensated GEMM whose activation rows are [x_hi | x_lo | x_hi]."""
