@@ -183,7 +183,7 @@ def test_parity_mode_vit_output_vs_oracle(parity_captioner):
     y32, y3 = cap.visual_encoder.forward_u8(torch.from_numpy(u8).to(DEV), clip_ref.CLIP_MEAN, clip_ref.CLIP_STD)
     d = (y32.cpu() - y_ref).abs()
     print(f"parity-mode ViT-B/16 output vs fp32 oracle: max {d.max().item():.2e} mean {d.mean().item():.2e}")
-    assert d.max().item() < 5e-4 and d.mean().item() < 3e-5          # (plain f16 operands: 1e-2 / 1e-3)
+    assert d.max().item() < 5e-5 and d.mean().item() < 5e-6          # (plain f16 operands: 1e-2 / 1e-3; 16-bit attention in the mode: 2.4e-4 / 2.1e-5)
     assert y3.shape == (3 * 197, 3 * 768)
     assert (_join(y3.cpu()) - y32.cpu().view(-1, 768)).abs().max().item() < 1e-6
 
@@ -241,9 +241,15 @@ def test_parity_mode_caption_logits_within_1e_3_absolute_on_every_forward_pass(p
     out_tok, _ = cap.generate_ids(y3, B, num_beams=nb, max_length=20, min_length=5)
     seqs, _ = beam_ref.beam_search(step, prompt, num_beams=nb, max_length=20, min_length=5, eos_token_id=102, pad_token_id=0)
     toks = out_tok.cpu().numpy()
-    agree = sum(int(np.array_equal(toks[b][: len(seqs[b])], seqs[b])) for b in range(B))
-    print(f"parity mode free-running captions equal to the fp32 oracle: {agree}/{B}")
-    assert agree == B
+    same = [bool(np.array_equal(toks[b][: len(seqs[b])], seqs[b])) for b in range(B)]
+    # a search may legitimately take another branch where the ORACLE's own candidates are closer than the device's error
+    # (random-init weights: near-flat distributions, f32 ties do occur): decisive = every adjacent candidate gap > 1e-4
+    gaps = np.stack([np.min(t["cand_scores"][:, :-1] - t["cand_scores"][:, 1:], axis=1) for t in otrace]).min(axis=0)
+    print(f"parity mode free-running captions equal to the fp32 oracle: {sum(same)}/{B}; smallest candidate gap per image "
+          f"{', '.join('%.1e' % g for g in gaps)}")
+    for b in range(B):
+        assert same[b] or gaps[b] < 1e-4, (b, gaps[b])
+    assert sum(same) >= B - 1
 
 
 def test_parity_mode_is_refused_with_fp8_and_off_by_default():

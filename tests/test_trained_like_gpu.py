@@ -5,12 +5,12 @@ max|logit| ~ 2.5, LayerNorm gains ~ 1, residual rows with zero mean.  Here the s
 with 10-50x outlier channels, residual rows ~1 sigma off zero, a [SEP] bias so that searches end at different lengths.
 
 What is asserted, and the SCALE LAW that comes out of it (DESIGN.md §4 quotes the printed table):
-  * parity precision mode: the error is PROPORTIONAL to the logit scale — measured 2.3e-4 .. 2.5e-4 of max|logit| at scales
-    2.0 / 8.0 / 15.7 (random-init statistics: 1.6e-4) — so "within 1e-3" as an ABSOLUTE bound holds up to max|logit| ~ 4 and
-    stops holding above: 1.9e-3 at scale 8, 3.7e-3 at scale 15.7.  What remains in the mode is the 16-bit rounding of Q / K / V
-    and of the softmax probabilities inside the attention kernels (every GEMM operand is carried to 2^-21), and a logit is a
-    768-term dot product of those hidden states with head weights that grow with the scale.  The test asserts the relative law
-    `<= PARITY_REL * scale` at every scale and the absolute 1e-3 where the law allows it;
+  * parity precision mode: the error is PROPORTIONAL to the logit scale.  With the 16-bit MFMA attention kernels of round 3
+    ($VIDIL_PARITY_ATTN=16) it was 2.3e-4 .. 2.5e-4 of max|logit| — "within 1e-3" ABSOLUTE held up to max|logit| ~ 4 and not above
+    (1.9e-3 at scale 8, 3.7e-3 at 15.7) — because every GEMM operand was carried to 2^-21 but Q / K / V were still rounded to 16
+    bits inside the attention kernels (tests/probes/probe_attention_rounding.py reproduces exactly that residual on the CPU).  With
+    the mode's f32 attention (vidil_attention_f32, the default since round 4) it is 8e-6 .. 9e-6 of the scale: 1.4e-4 at
+    max|logit| = 15.7.  The test asserts `<= PARITY_REL * scale` AND the absolute 1e-3 at every scale;
   * plain f16: 1.5e-3 .. 1.6e-3 of the logit scale on these statistics (outlier gains amplify the operand rounding: random-init
     weights give 0.85e-3), asserted at PLAIN_REL;
   * LayerNorm-folded tower vs the unfolded kernels on the same weights: within the fold's budget (DESIGN.md §4);
@@ -26,7 +26,7 @@ from common import ROOT, synthetic_frames, trained_like_
 
 pytestmark = pytest.mark.gpu
 DEV = "cuda"
-PARITY_REL = 3.5e-4       # parity mode: max|d logit| <= PARITY_REL * max|logit|   (measured 2.3e-4 .. 2.5e-4 at scales 2 / 8 / 16)
+PARITY_REL = 3e-5         # parity mode (f32 attention): max|d logit| <= PARITY_REL * max|logit|   (measured 8.3e-6 .. 9.0e-6 at scales 2 / 8 / 16)
 PLAIN_REL = 2.2e-3        # plain f16 operands (measured 1.5e-3 .. 1.6e-3 of the scale; random-init statistics: 0.85e-3)
 
 
@@ -102,8 +102,7 @@ def test_caption_logits_at_trained_like_statistics_plain_and_parity(head_scale):
     print("\ntrained-like statistics: " + json.dumps(rec))
     assert worst_plain <= PLAIN_REL * max(1.0, scale), rec
     assert worst_par <= PARITY_REL * max(1.0, scale), rec
-    if PARITY_REL * scale <= 1e-3:              # where the law allows it, the absolute tolerance of BASELINE.json
-        assert worst_par <= 1e-3, rec
+    assert worst_par <= 1e-3, rec                # the absolute tolerance of BASELINE.json, at every scale tested
 
 
 def test_free_running_captions_with_staggered_endings_equal_the_oracle_at_trained_like_statistics():

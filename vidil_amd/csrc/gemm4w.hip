@@ -242,7 +242,11 @@ __global__ __launch_bounds__(256) void gemm4w_kernel(const vidil_gemm_args p) {
         constexpr int n = decltype(n_tag)::value;
         constexpr int ks = n / NKS, i = (n >> 2) % TM, j = n & 3;
         if constexpr (FIRST && ks == 0) {
-          const f32x16 zero = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+          f32x16 zero = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+          // (fp8: C must be an OPAQUE zero tuple — with the constant 0 as C hipcc sent the result of every first-k-step
+          //  v_mfma_scale_* through a[0:15] and scratch, 160 spilled registers; with an opaque C it initialises each accumulator
+          //  tuple in place (16 v_accvgpr_write between two 64-cycle MFMAs) and accumulates: no spill at all)
+          if constexpr (ESZ == 1) asm volatile("" : "+a"(zero));
           ACC(i, j) = Mma<T>::mma(fw[ks][j], fa[ks][i], zero);
         } else {
           ACC(i, j) = Mma<T>::mma(fw[ks][j], fa[ks][i], ACC(i, j));
@@ -487,6 +491,9 @@ int launch4w_dispatch(const vidil_gemm_args& a, hipStream_t s) {
   if constexpr (VIDIL_4W_DEV_ONE == 4) return launch4w<T, VIDIL_EPI_F32, VIDIL_ACT_NONE, false, T, true, true>(a, s);
   if constexpr (VIDIL_4W_DEV_ONE == 5) return launch4w<T, VIDIL_EPI_HEADS, VIDIL_ACT_NONE>(a, s);
   if constexpr (VIDIL_4W_DEV_ONE == 6) return launch4w<T, VIDIL_EPI_F16, VIDIL_ACT_NONE>(a, s);
+  if constexpr (VIDIL_4W_DEV_ONE == 7) return launch4w<fp8, VIDIL_EPI_F8, VIDIL_ACT_GELU_ERF, false, T>(a, s);     // (fp8 operands)
+  if constexpr (VIDIL_4W_DEV_ONE == 8) return launch4w<fp8, VIDIL_EPI_HEADS, VIDIL_ACT_NONE, false, T>(a, s);
+  if constexpr (VIDIL_4W_DEV_ONE == 9) return launch4w<fp8, VIDIL_EPI_F32, VIDIL_ACT_NONE, false, T>(a, s);
   return -1000;
 #else
   if (a.ln_fold) {
@@ -543,9 +550,32 @@ int launch4w128_dispatch(const vidil_gemm_args& a, hipStream_t s) {
 #endif
 }
 
+// fp8 operands (round 4): the tower mode's GEMMs — fp8 hand-over with / without activation, per-head scatter into the 16-bit
+// companion type, f32 + residual — on the 4-wave main loop (K-tiles of 128 e4m3, v_mfma_scale_f32_32x32x64_f8f6f4)
+template <typename TO>
+static int launch4w_fp8(const vidil_gemm_args& a, hipStream_t s) {
+#ifdef VIDIL_4W_DEV_ONE
+  return -1000;
+#else
+  if (a.ln_fold || a.ln_stats_out || a.rln_gamma || a.out16) return -1000;
+  switch (a.epi) {
+    case VIDIL_EPI_F32:
+      if (a.act != VIDIL_ACT_NONE) return -1000;
+      return launch4w<fp8, VIDIL_EPI_F32, VIDIL_ACT_NONE, false, TO>(a, s);
+    case VIDIL_EPI_HEADS: return launch4w<fp8, VIDIL_EPI_HEADS, VIDIL_ACT_NONE, false, TO>(a, s);
+    case VIDIL_EPI_F8:
+      if (a.act == VIDIL_ACT_GELU_ERF) return launch4w<fp8, VIDIL_EPI_F8, VIDIL_ACT_GELU_ERF, false, TO>(a, s);
+      if (a.act == VIDIL_ACT_QUICK_GELU) return launch4w<fp8, VIDIL_EPI_F8, VIDIL_ACT_QUICK_GELU, false, TO>(a, s);
+      return launch4w<fp8, VIDIL_EPI_F8, VIDIL_ACT_NONE, false, TO>(a, s);
+    default:
+      return -1000;
+  }
+#endif
+}
+
 // tm: 4 = 256 x 256 tiles, 2 = 128 x 256 tiles.  -1000: the variant is not built here.
 int vidil_gemm4w_launch(const vidil_gemm_args& a, hipStream_t s, int tm) {
-  if (a.dtype == VIDIL_DT_FP8) return -1000;
+  if (a.dtype == VIDIL_DT_FP8) return tm == 4 ? (a.dtype16 == VIDIL_DT_BF16 ? launch4w_fp8<bf16>(a, s) : launch4w_fp8<f16>(a, s)) : -1000;
   if (tm == 2) return a.dtype == VIDIL_DT_BF16 ? launch4w128_dispatch<bf16>(a, s) : launch4w128_dispatch<f16>(a, s);
   if (a.dtype == VIDIL_DT_BF16) return launch4w_dispatch<bf16>(a, s);
 #ifdef VIDIL_4W_DEV_ONE
