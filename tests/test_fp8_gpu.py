@@ -38,7 +38,10 @@ def test_gemm_fp8_operands_f32_residual_out(M, N, K):
     n = min(M, 1500)
     ref = (a8[:n].float() @ w8_.float().t()) * ws[None, :] + bias + x0[:n]
     assert torch.allclose(x[:n].cpu(), ref, rtol=2e-4, atol=2e-3), (x[:n].cpu() - ref).abs().max()
-    assert k.gemm_kernel_name(a8.to(DEV), w8_.to(DEV), bias.to(DEV), out=x, resid=x, w_scale=ws.to(DEV)).startswith("gemm256_kernel<fp8")
+    # (a 256-row kernel on fp8 operands whatever the size; since round 4 the 4-wave one from 384 tiles on)
+    name = k.gemm_kernel_name(a8.to(DEV), w8_.to(DEV), bias.to(DEV), out=x, resid=x, w_scale=ws.to(DEV))
+    tiles = ((M + 255) // 256) * ((N + 255) // 256)
+    assert name.startswith("gemm4w_kernel<fp8" if tiles >= 384 else "gemm256_kernel<fp8"), name
 
 
 def test_gemm_fp8_transpose_detecting_and_k_order():

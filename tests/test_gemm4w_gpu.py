@@ -317,3 +317,63 @@ def test_arena_epilogue_on_the_256_row_kernels(monkeypatch, dtype, T, stride):
         assert torch.equal(got_k, want_k) and torch.equal(got_v, want_v)
         assert ka[:t_off].abs().sum() == 0 and ka[t_off + T:].abs().sum() == 0
     assert len(names) == 3, names
+
+
+@pytest.mark.parametrize("dt16", [torch.float16, torch.bfloat16])
+def test_gemm4w_fp8_operands_equal_gemm256(dt16):
+    """Round 4: e4m3 operands on the 4-wave main loop (v_mfma_scale_f32_32x32x64_f8f6f4, K-tiles of 128) — the fp8 tower mode's
+    three epilogues (fp8 hand-over with GELU, per-head scatter into the 16-bit companion type, f32 + residual) through both
+    256-row kernels, bit for bit; ragged M, and the dispatch picks the 4-wave kernel at the tower's size."""
+    from vidil_amd.packing import w8
+
+    k = _k()
+    F8 = torch.float8_e4m3fn
+    B, T, H, D = 130, 197, 12, 768                  # 25,610 rows: 101 row tiles (the last one ragged) x 9 / 12 / 3 column tiles
+    M = B * T
+    a8 = _rand(M, D, seed=80).to(F8).to(DEV)
+    # ---- per-head scatter
+    wq, sq = w8(_rand(3 * D, D, scale=0.03, seed=81))
+    bq = (_rand(3 * D, seed=82) * 0.1).to(DEV)
+
+    def run_heads():
+        q = torch.zeros(B, H, T, 64, dtype=dt16, device=DEV)
+        kk, v = torch.zeros_like(q), torch.zeros_like(q)
+        k.gemm(a8, wq.to(DEV), bq, w_scale=sq.to(DEV),
+               heads=dict(q=q, k=kk, vt=v, T=T, H=H, part0=0, t_off=0, Tq_cap=T, Tk_cap=T, NP=0, q_scale=0.125))
+        return q, kk, v
+
+    ref, got = both(k, run_heads)
+    for r, g in zip(ref, got):
+        assert torch.equal(r.view(torch.int16), g.view(torch.int16))
+    # ---- fc1: GELU, fp8 out
+    w1, s1 = w8(_rand(3072, D, scale=0.03, seed=83))
+    b1 = (_rand(3072, seed=84) * 0.1).to(DEV)
+
+    def run_fc1():
+        hid = torch.zeros(M, 3072, dtype=F8, device=DEV)
+        k.gemm(a8, w1.to(DEV), b1, out=hid, act=k.ACT_GELU_ERF, w_scale=s1.to(DEV), dtype16=dt16)
+        return hid
+
+    ref, got = both(k, run_fc1)
+    assert torch.equal(ref.view(torch.uint8), got.view(torch.uint8))
+    # ---- fc2: f32 + residual (K = 3072)
+    w2, s2 = w8(_rand(D, 3072, scale=0.03, seed=85))
+    b2 = (_rand(D, seed=86) * 0.1).to(DEV)
+    x0 = _rand(M, D, seed=87).to(DEV)
+    hid = got
+
+    def run_fc2():
+        x = x0.clone()
+        k.gemm(hid, w2.to(DEV), b2, out=x, resid=x, w_scale=s2.to(DEV), dtype16=dt16)
+        return x
+
+    ref, got = both(k, run_fc2)
+    assert torch.equal(ref, got)
+    # the dispatch: at the tower's size the 4-wave kernel serves the fp8 GEMMs, small grids stay on the 8-wave kernel
+    big = torch.empty(197 * 512, D, dtype=F8, device=DEV)
+    name = k.gemm_kernel_name(big, w1.to(DEV), b1, out=torch.empty(197 * 512, 3072, dtype=F8, device=DEV), act=k.ACT_GELU_ERF,
+                              w_scale=s1.to(DEV), dtype16=dt16)
+    assert name.startswith("gemm4w_kernel<fp8") or "gemm4w" in name, name
+    name = k.gemm_kernel_name(a8[:197 * 8], w1.to(DEV), b1, out=torch.empty(197 * 8, 3072, dtype=F8, device=DEV), act=k.ACT_GELU_ERF,
+                              w_scale=s1.to(DEV), dtype16=dt16)
+    assert "gemm256" in name, name
