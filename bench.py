@@ -273,7 +273,7 @@ def secondary_measurements(args, cap, flt, clip, step, frames, dev, parity_file,
     """After the timed region (rank 0, N = 1): the numbers the headline does not carry.  Everything here re-packs the
     models' weights for another operand type / precision mode, so it runs last."""
     from vidil_amd.blip import DecoderSession
-    from vidil_amd.packing import set_compute_dtype, set_parity_mode
+    from vidil_amd.packing import set_compute_dtype, set_parity_attention, set_parity_mode
 
     out = {"secondary": {}, "one_off": {}}
     Nv, F = frames.shape[0], frames.shape[1]
@@ -395,6 +395,7 @@ def secondary_measurements(args, cap, flt, clip, step, frames, dev, parity_file,
     try:
         free_sessions()
         set_parity_mode(True, cap, clip)
+        set_parity_attention("16", cap, clip)          # (the mix keeps the MFMA attention kernels: its error is the plain ViT's anyway)
         cap.visual_encoder.set_parity_last_blocks(0)
         for _ in range(3):
             step()
@@ -409,6 +410,7 @@ def secondary_measurements(args, cap, flt, clip, step, frames, dev, parity_file,
     except Exception as e:
         out["secondary"]["parity_mix_full_step"] = {"value": None, "error": f"{type(e).__name__}: {e}"[:300]}
     cap.visual_encoder.set_parity_last_blocks(None)
+    set_parity_attention("f32", cap, clip)
     set_parity_mode(False, cap, flt, clip)
     free_sessions()
     out["parity"] = parity

@@ -406,8 +406,12 @@ def test_parity_mix_plain_vit_with_compensated_decoder_keeps_caption_logits_with
     from oracle import beam_ref, clip_ref, med_ref, vit_ref
     from vidil_amd.blip import DecoderSession
 
+    from vidil_amd.packing import set_parity_attention
+
     cap, sd = parity_captioner
     cap.visual_encoder.set_parity_last_blocks(0)
+    set_parity_attention("16", cap)            # the mix as bench.py times it: MFMA attention kernels (its error is the plain ViT's)
+    cap.__dict__.pop("_decode_state", None)
     try:
         B, nb = 3, 3
         u8 = synthetic_frames(1, B)[0]
@@ -442,6 +446,7 @@ def test_parity_mix_plain_vit_with_compensated_decoder_keeps_caption_logits_with
         assert len(worst) == 16 and max(worst) <= ABS_TOL, worst
     finally:
         cap.visual_encoder.set_parity_last_blocks(None)
+        set_parity_attention("f32", cap)
         cap.__dict__.pop("_decode_state", None)
 
 

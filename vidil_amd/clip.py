@@ -154,7 +154,7 @@ def _pack_layers(encoder, c, fuse=False, fp8=False, parity=False):
     return out
 
 
-def _run_layers(layers, x, B, T, H, eps, *, causal=False, kv_len=None):
+def _run_layers(layers, x, B, T, H, eps, *, causal=False, kv_len=None, f32_attn=True):
     """Pre-LN CLIP encoder layers on the f32 residual stream x [B*T, D] (in place)."""
     dev = x.device
     M, D = x.shape
@@ -180,7 +180,6 @@ def _run_layers(layers, x, B, T, H, eps, *, causal=False, kv_len=None):
         o3 = torch.empty((M, 3 * D), dtype=cdt, device=dev)
         hid32 = torch.empty((M, Dh), dtype=torch.float32, device=dev)
         hid3 = torch.empty((M, 3 * Dh), dtype=cdt, device=dev)
-        f32_attn = parity_attention_f32()
         qkv32 = torch.empty((M, 3 * D), dtype=torch.float32, device=dev) if f32_attn else None
         for l in layers:
             K.layernorm(x, l["n1g"], l["n1b"], eps, out16=a3, split3=True)
@@ -338,7 +337,7 @@ class CLIPModel(PackedCache, nn.Module):
         K.gemm(patches16, p["pe_w3"] if par else p["pe_w"], None, patch=dict(out=x, pos=p["pos"], tpi=P))
         K.set_cls_row(x, p["cls"], p["pos"], B, T, D)
         K.layernorm(x, p["pre_g"], p["pre_b"], vc.layer_norm_eps, out32=x)
-        _run_layers(p["vlayers"], x, B, T, H, vc.layer_norm_eps)
+        _run_layers(p["vlayers"], x, B, T, H, vc.layer_norm_eps, f32_attn=parity_attention_f32(self))
         pooled16 = torch.empty((B, (3 if par else 1) * D), dtype=cdt, device=dev)
         pooled32 = torch.empty((B, D), dtype=torch.float32, device=dev) if pooled else None
         K.layernorm(x, p["post_g"], p["post_b"], vc.layer_norm_eps, M=B, D=D, x_stride=T * D, out16=pooled16,
@@ -392,7 +391,7 @@ class CLIPModel(PackedCache, nn.Module):
         kv_len = None
         if attention_mask is not None:
             kv_len = attention_mask.to(dev).sum(dim=1).to(torch.int32).contiguous()
-        _run_layers(p["tlayers"], x, N, L, H, tc.layer_norm_eps, causal=True, kv_len=kv_len)
+        _run_layers(p["tlayers"], x, N, L, H, tc.layer_norm_eps, causal=True, kv_len=kv_len, f32_attn=parity_attention_f32(self))
         if tc.eos_token_id == 2:
             pos = ids32.argmax(dim=-1)
         else:

@@ -909,6 +909,11 @@ __global__ __launch_bounds__(256) void attn_f32_kernel(const AttnF32P p) {
     __syncthreads();
 #pragma unroll
     for (int g = 0; g < 2; ++g) {
+      // (wave-uniform: a group whose rows are all past the unit's last row, or whose keys of this chunk are all masked, has
+      //  nothing to add — the decode steps' cross-attention has 3 rows per unit: one group of one wave works, and the LDS
+      //  pipe, which bounds this kernel, is left to it)
+      const int kmax = max(max(klim[g][0], klim[g][1]), max(klim[g][2], klim[g][3]));
+      if (kmax <= k0) continue;
       // ---- scores of 4 rows x 64 keys: lane = key
       float sc[4] = {0.f, 0.f, 0.f, 0.f};
       const float* krow = Ks + lane * F32_LD;

@@ -487,12 +487,14 @@ int vidil_gemm4w_launch(const vidil_gemm_args& a, hipStream_t s, int tm);   // g
 static bool prefer_4w(const vidil_gemm_args& a) {
   if (a.epi == VIDIL_EPI_HEADS && a.T < 8) return false;   // (the 4-wave scatter steps (image, token) by 8 rows: gemm_epilogue.inc)
   if (const char* e = vidil_dev_env("VIDIL_GEMM4W")) return atoi(e) != 0;
-  if (a.dtype == VIDIL_DT_FP8) {   // (round 4: the 4-wave main loop takes e4m3 operands too; same grid rule, plain epilogues)
-    const long t8 = (long)((a.M + 255) / 256) * ((a.N + 255) / 256);
-    return t8 >= 384 && (a.epi == VIDIL_EPI_F8 || a.epi == VIDIL_EPI_HEADS || (a.epi == VIDIL_EPI_F32 && a.act == VIDIL_ACT_NONE));
-  }
   const long tiles = (long)((a.M + 255) / 256) * ((a.N + 255) / 256);
-  static const long min_tiles = [] { const char* e = getenv("VIDIL_GEMM4W_MIN_TILES"); return e ? atol(e) : 384L; }();   // (developer sweep, whole bench, same box: 512 -> 5,112, 384 -> 5,120, 320 -> 5,094, 128 -> 5,050 frames/s — small grids start faster on gemm256)
+  static const long min_tiles = [] { const char* e = getenv("VIDIL_GEMM4W_MIN_TILES"); return e ? atol(e) : 384L; }();
+  if (a.dtype == VIDIL_DT_FP8) {   // (round 4: the 4-wave main loop takes e4m3 operands too; same grid rule, plain epilogues;
+    //                                $VIDIL_GEMM4W_FP8=0 keeps the fp8 GEMMs on the 8-wave kernel: the A/B of DESIGN.md §5)
+    static const bool fp8_4w = [] { const char* e = getenv("VIDIL_GEMM4W_FP8"); return !(e && e[0] == '0'); }();
+    return fp8_4w && tiles >= min_tiles &&
+           (a.epi == VIDIL_EPI_F8 || a.epi == VIDIL_EPI_HEADS || (a.epi == VIDIL_EPI_F32 && a.act == VIDIL_ACT_NONE));
+  }   // (developer sweep, whole bench, same box: 512 -> 5,112, 384 -> 5,120, 320 -> 5,094, 128 -> 5,050 frames/s — small grids start faster on gemm256)
   if (tiles < min_tiles) return false;
   if (a.ln_fold) return true;
   switch (a.epi) {

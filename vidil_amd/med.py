@@ -260,7 +260,7 @@ class BertModel(PackedCache, nn.Module):
                 raise K.VidilHipError(f"project_cross_kv (parity mode): image tokens must be [hi | lo | hi] rows of width "
                                       f"{3 * self.config.encoder_width}, got {tuple(enc16.shape)}")
 
-            if parity_attention_f32():
+            if parity_attention_f32(self):
                 L, C = len(p["layers"]), self.config.hidden_size
                 dev = enc16.device
                 if out is not None and getattr(out, "f32", False) and (out.B, out.Te) == (B, Te) and out.k.device == dev:
@@ -432,7 +432,7 @@ class BertModel(PackedCache, nn.Module):
         Nk = t_off + T
         if arena is not None and T > 1 and t_off != 0:
             raise K.VidilHipError("run_layers: a multi-token block can only be appended to a beam arena at position 0")
-        f32_attn = parity_attention_f32()
+        f32_attn = parity_attention_f32(self)
         if f32_attn:
             # Q | K | V (and the cross query) stay f32 and row-major, the KV arena and the cross K | V are f32:
             # vidil_attention_f32 reads all of them in place.  (t_off > 0 happens in the arena form only.)

@@ -74,6 +74,7 @@ def compute_dtype(module=None):
 # probabilities inside the attention kernels (their error averages over the keys).
 _parity_default = [os.environ.get("VIDIL_PARITY", "0") == "1"]
 _warned_bf16_parity = [False]
+_parity_attn_default = ["16" if os.environ.get("VIDIL_PARITY_ATTN", "f32") == "16" else "f32"]
 
 
 def set_parity_mode(on, *modules):
@@ -94,11 +95,27 @@ def parity_mode(module=None) -> bool:
     return _parity_default[0] if v is None else v
 
 
-def parity_attention_f32() -> bool:
-    """The parity precision mode's attention: plain f32 (vidil_attention_f32, the default since round 4 — the mode's remaining
-    error WAS the 16-bit Q / K / V of the MFMA attention kernels: tests/probes/probe_attention_rounding.py), or those 16-bit
-    kernels with [hi | lo | hi] outputs as in round 3 ($VIDIL_PARITY_ATTN=16: cheaper, 2.4e-4 of the logit scale)."""
-    return os.environ.get("VIDIL_PARITY_ATTN", "f32") != "16"
+def set_parity_attention(kind, *modules):
+    """Which attention the parity precision mode of ``modules`` (and their sub-modules) uses: "f32" — vidil_attention_f32,
+    plain f32 arithmetic on f32 Q / K / V: the mode's logits then sit ~1e-5 of the LOGIT SCALE from the fp32 reference (the
+    default; ~1/16 of the MFMA kernels' arithmetic rate) — or "16": the 16-bit MFMA attention kernels with [hi | lo | hi] outputs
+    (round 3's form: 2.4e-4 of the logit scale, because Q / K / V are rounded to 16 bits inside them; what the cheap parity MIX
+    of bench.py uses).  Without modules: the process-wide default ($VIDIL_PARITY_ATTN)."""
+    if kind not in ("f32", "16"):
+        raise ValueError("parity attention: 'f32' or '16'")
+    if not modules:
+        _parity_attn_default[0] = kind
+        return kind
+    for m in modules:
+        for sub in m.modules():
+            sub.__dict__["_parity_attn"] = kind
+    return kind
+
+
+def parity_attention_f32(module=None) -> bool:
+    """True when the parity precision mode of ``module`` runs its attention in f32 (see set_parity_attention)."""
+    v = None if module is None else module.__dict__.get("_parity_attn")
+    return (_parity_attn_default[0] if v is None else v) == "f32"
 
 
 def w3(*weights, dtype=None):

@@ -241,7 +241,7 @@ class VisionTransformer(PackedCache, nn.Module):
         o3 = torch.empty((M, 3 * D), dtype=cdt, device=dev)
         hid32 = torch.empty((M, Dh), dtype=torch.float32, device=dev)
         hid3 = torch.empty((M, 3 * Dh), dtype=cdt, device=dev)
-        f32_attn = parity_attention_f32()
+        f32_attn = parity_attention_f32(self)
         qkv32 = torch.empty((M, 3 * D), dtype=torch.float32, device=dev) if f32_attn else None
         plain = [b for b in p["blocks"] if "qkv_w3" not in b]
         if plain:       # mixed form: the leading blocks on plain 16-bit operands (unfused: LayerNorm kernel + plain GEMM)
