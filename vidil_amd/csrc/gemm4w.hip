@@ -79,7 +79,7 @@ __global__ __launch_bounds__(256) void gemm4w_kernel(const vidil_gemm_args p) {
   constexpr bool ROWSTAT = FOLD || RLN;
   // 16-bit row epilogues keep their transposition inside the lower 4 KiB of a wave's scratch: the upper 4 KiB receive the
   // bias / column-sum vectors by LDS-DMA during the last K-tile (gemm_epilogue.inc: VIDIL_EPI_BIAS_LDS)
-  constexpr bool BIAS_LDS = (EPI == VIDIL_EPI_F16 || EPI == VIDIL_EPI_HEADS || EPI == VIDIL_EPI_ARENA) && ESZ_OF_T == 2;
+  constexpr bool BIAS_LDS = EPI == VIDIL_EPI_F16 || EPI == VIDIL_EPI_HEADS || EPI == VIDIL_EPI_ARENA || EPI == VIDIL_EPI_F8;
   static_assert(!(FOLD && RLN), "a GEMM normalises either its A rows or its residual rows");
   static_assert(!RLN || EPI == VIDIL_EPI_F32, "the residual exists in the f32 epilogue only");
   using f16 = TO;
@@ -268,13 +268,13 @@ __global__ __launch_bounds__(256) void gemm4w_kernel(const vidil_gemm_args p) {
           // (16 global loads per 64-column half) they cost an `s_waitcnt vmcnt(0)` — L2 latency, plus a drain of every store
           // of the previous half and of the DMA stream — twice per tile with the matrix pipe idle.  Older than this
           // iteration's DMA pieces, so barrier B's counted wait covers it (as for the row partials below).
-          if (p.bias != nullptr || FOLD) {     // (uniform)
+          if (p.bias != nullptr || FOLD || ESZ_OF_T == 1) {     // (uniform)
             int lane_s;
             asm volatile("v_mbcnt_lo_u32_b32 %0, -1, 0\n\tv_mbcnt_hi_u32_b32 %0, -1, %0" : "=v"(lane_s));
             int col = n0 + wc2 * 128 + (lane_s & 31) * 4;
             col = col + 4 <= N ? col : N - 4;      // (columns past N are never stored; N >= 4)
-            const float* v0 = p.bias != nullptr ? p.bias : (FOLD ? p.ln_colsum : (const float*)p.W);
-            const float* v1 = FOLD ? p.ln_colsum : v0;
+            const float* v0 = p.bias != nullptr ? p.bias : (FOLD ? p.ln_colsum : (ESZ_OF_T == 1 ? p.w_scale : (const float*)p.W));
+            const float* v1 = FOLD ? p.ln_colsum : (ESZ_OF_T == 1 ? p.w_scale : v0);   // (fp8: the per-column weight scales)
             const float* src = (lane_s < 32 ? v0 : v1) + col;
             glds16(src, smem + RING_BYTES + wave * 8192 + 4096);
           }
