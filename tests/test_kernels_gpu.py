@@ -770,7 +770,8 @@ def test_gemm_layernorm_fold_consumer_vs_torch(dtype, M, D, N, act):
 
 
 @pytest.mark.parametrize("dtype", [torch.float16, torch.bfloat16])
-@pytest.mark.parametrize("M,N,K", [(35 * 9, 768, 768), (18 * 1400 + 7, 768, 3072), (200, 1024, 256)])
+@pytest.mark.parametrize("M,N,K", [(35 * 9, 768, 768), (18 * 1400 + 7, 768, 3072), (200, 1024, 256),
+                                   (197 * 170 + 3, 768, 768)])      # the last: 393 tiles -> the 4-wave kernel, ragged last row tile
 def test_gemm_residual_layernorm_epilogue_vs_torch(dtype, M, N, K):
     """Post-LN stacks: out = LayerNorm(u; gamma, beta) + a W^T + b where u is the previous block's RAW sum (f32, in the
     residual buffer) and its per-row partials come with it (vidil_gemm_args.rln_gamma); the result is left raw again,
@@ -787,25 +788,27 @@ def test_gemm_residual_layernorm_epilogue_vs_torch(dtype, M, N, K):
     x16 = torch.zeros(M, N, dtype=dtype, device=DEV)
     st_out = torch.zeros(M, N // 64, 2, device=DEV)
     kw = dict(out=x, resid=x, out16=x16, ln_stats_out=st_out, rln=(g.to(DEV), bt.to(DEV), 1e-12, st_in))
-    assert k.gemm_kernel_name(a.to(DEV), w.to(DEV), b.to(DEV), **kw).endswith("false, true, true>")
+    name = k.gemm_kernel_name(a.to(DEV), w.to(DEV), b.to(DEV), **kw)
+    assert "false, true, true" in name and name.startswith("gemm4w" if ((M + 255) // 256) * ((N + 255) // 256) >= 384 else "gemm256"), name
     k.gemm(a.to(DEV), w.to(DEV), b.to(DEV), **kw)
     ref = torch.nn.functional.layer_norm(u, (N,), g, bt, 1e-12) + a.float() @ w.float().t() + b
-    n = min(M, 1500)
-    got = x[:n].cpu()
-    assert torch.allclose(got, ref[:n], rtol=1e-4, atol=3e-3), (got - ref[:n]).abs().max()
-    assert torch.equal(x16[:n].cpu(), got.to(dtype))                                   # the 16-bit copy of what was written
-    assert torch.allclose(st_out[:n].cpu(), _row_partials(got), rtol=1e-4, atol=2e-2)   # partials of the NEW raw stream
+    # (the row-statistics epilogues of the 4-wave kernel against a NON-HIP reference directly: every row)
+    got = x.cpu()
+    assert torch.allclose(got, ref, rtol=1e-4, atol=3e-3), (got - ref).abs().max()
+    assert torch.equal(x16.cpu(), got.to(dtype))                                   # the 16-bit copy of what was written
+    assert torch.allclose(st_out.cpu().double(), _row_partials(got.double()), rtol=1e-4, atol=2e-2)   # partials of the NEW raw stream
     # argument errors: the residual LayerNorm without the statistics of the residual, or together with ln_fold
     with pytest.raises(Exception, match="rln"):
         k.gemm(a.to(DEV), w.to(DEV), b.to(DEV), out=x, resid=x, out16=x16, rln=(g.to(DEV), bt.to(DEV), 1e-12, st_in))
 
 
 @pytest.mark.parametrize("dtype", [torch.float16, torch.bfloat16])
-def test_gemm_layernorm_fold_heads_consumer_and_out16_producer(dtype):
+@pytest.mark.parametrize("B", [4, 180])            # 180 images: 417 / 1,251 tiles -> both GEMMs on the 4-wave kernel
+def test_gemm_layernorm_fold_heads_consumer_and_out16_producer(dtype, B):
     from vidil_amd.packing import fold_layernorm
 
     k = _k()
-    B, T, H, D = 4, 197, 12, 768
+    T, H, D = 197, 12, 768
     M, N = B * T, 3 * H * 64
     # producer: the residual GEMM writes the f32 stream AND its 16-bit copy
     a = _rand(M, D, seed=80).to(dtype)

@@ -456,6 +456,9 @@ def test_parity_mix_plain_vit_with_compensated_decoder_keeps_caption_logits_with
     (4, 8, 13, 13, 1, True, True),          # CLIP text tower: causal + kv_len
     (6, 12, 3, 197, 3, False, False),       # decode cross-attention: 3 beams share an image's K | V
     (5, 4, 35, 70, 1, False, False),        # two key chunks
+    (6, 12, 1, 197, 3, False, False),       # 3 rows per unit: the VALU kernel (idle row groups skipped)
+    (2, 4, 300, 300, 1, False, False),      # more than 128 rows per unit: several workgroups of the f32-MFMA kernel
+    (3, 4, 40, 577, 1, True, False),        # causal with more keys than rows (19 key tiles)
 ])
 def test_attention_f32_vs_float64(Bq, H, Nq, Nk, kv_group, causal, use_len):
     k = _k()

@@ -2,11 +2,11 @@
 # copies the summaries of gpurun_out/prof_<tag> (written by tools/profile_bench.sh on the GPU box) into profiles/
 # usage: bash tools/copy_profiles.sh <tag> [name prefix, default r3]      e.g. copy_profiles.sh r3bf16 r3_bf16
 P=gpurun_out/prof_$1
-N=${2:-r3}
+N=${2:-r4}
 { echo "# rocprofv3 --kernel-trace --stats of \`python bench.py $(head -1 $P/cmdline.txt 2>/dev/null) --no-roofline\` (448 videos x 8 frames per step unless the arguments say otherwise, 1 x MI355X)"; echo
   echo "Bench line of the traced run (tracing costs a few %): \`$(cut -c1-260 $P/bench_traced.json)...\`"; echo
   cat $P/kernel_summary.md; echo; echo "## rocprofv3 --stats (t_kernel_stats.csv, top 25)"; echo; echo '```'; head -26 $P/trace/t_kernel_stats.csv | cut -c1-200; echo '```'; } > profiles/${N}_bench_kernel_trace.md
 { echo "# rocprofv3 --pmc passes (FETCH_SIZE / WRITE_SIZE / SQ_* in separate runs, each with --kernel-trace only) of the same bench command"; echo; cat $P/pmc_summary.md; } > profiles/${N}_bench_pmc.md
-if [ "$N" = r3 ]; then cp $P/pmc_traffic.json profiles/pmc_traffic.json; fi
+cp $P/pmc_traffic.json profiles/pmc_traffic.json   # (what bench.py reads `roofline.traffic` from: the latest profile)
 cp $P/pmc_traffic.json profiles/${N}_pmc_traffic.json
 cp $P/bench.json profiles/${N}_bench.json

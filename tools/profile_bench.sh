@@ -15,4 +15,8 @@ rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $OUT/pmc_fetch 
 rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $OUT/pmc_write -o w -- python $R/bench.py $ARGS --no-roofline > /dev/null 2>&1
 rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE --kernel-trace --output-format csv -d $OUT/pmc_sq -o s -- python $R/bench.py $ARGS --no-roofline > /dev/null 2>&1
 python $R/tools/pmc_summary.py $OUT "$ARGS" > $OUT/pmc_summary.md
+# gpurun merges at most 64 MiB back: keep the summaries and the per-kernel stats, drop the raw traces / counter dumps
+find $OUT/trace -type f ! -name "*kernel_stats.csv" -delete 2>/dev/null
+cp $(find $OUT/trace -name "*kernel_stats.csv" | head -1) $OUT/trace/t_kernel_stats.csv 2>/dev/null
+rm -rf $OUT/pmc_fetch $OUT/pmc_write $OUT/pmc_sq
 ls $OUT; head -30 $OUT/kernel_summary.md; cat $OUT/bench.json | cut -c1-400

@@ -970,6 +970,152 @@ __global__ __launch_bounds__(256) void attn_f32_kernel(const AttnF32P p) {
     }
 }
 
+// The same attention on the f32-input MATRIX instruction (v_mfma_f32_32x32x2_f32: exact f32 products and accumulation at the f32
+// vector rate — but each operand value is read from LDS once per 32 x 32 tile instead of once per FMA, which is what bounded
+// the VALU kernel above: ~10x on the towers' shapes).  One workgroup = 4 waves = 4 x 32 virtual query rows of a unit; a wave
+// owns its 32 rows over ALL keys (no merge across waves) in the transposed forms of the 16-bit kernels: S^T = K.Q^T (lane =
+// query row, 16 keys of the tile per lane: the online softmax is lane-local plus one cross-half shuffle) and O^T = V^T.P^T
+// (lane = row, registers = d).  K and V tiles of 32 keys x 64 dims are staged in LDS for the 4 waves (registers -> LDS, the next
+// tile's global loads in flight under the current tile's MFMAs); Q lives in registers (32 per lane).  The k-index of a K.Q^T
+// step s pairs d = s (lanes 0-31) with d = s + 32 (lanes 32-63), so a lane's 32 operands are one contiguous half row
+// (8 ds_read_b128); the k-index of a V^T.P^T step r pairs the keys that the two half-waves hold in accumulator register r,
+// so P needs no permutation.
+constexpr int F32M_LDK = 68, F32M_LDV = 72;     // floats per staged K / V row (bank-conflict-free b128 / b32 fragment reads)
+
+template <typename T16>
+__global__ __launch_bounds__(256) void attn_f32_mfma_kernel(const AttnF32P p) {
+  __shared__ __attribute__((aligned(16))) float Ks[32 * F32M_LDK];
+  __shared__ __attribute__((aligned(16))) float Vs[32 * F32M_LDV];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int hi = lane >> 5, l31 = lane & 31;
+  const int h = blockIdx.y;
+  int bk, first, count;
+  resolve_unit(p, blockIdx.z, bk, first, count);
+  const int rows = count * p.Nq;
+  const int base = blockIdx.x * 128;
+  if (base >= rows) return;
+  const RowInfo ri = row_info(p, base + wave * 32 + l31, first, rows);       // this lane's query row
+  const bool wave_live = base + wave * 32 < rows;                              // (uniform)
+  // Q operand: q[s] = Q[row][hi * 32 + s] * scale
+  float qf[32];
+  {
+    const float* qrow = p.q + ((size_t)ri.qb * p.Nq + ri.t) * p.ldq + p.q_off + h * 64 + hi * 32;
+#pragma unroll
+    for (int c = 0; c < 8; ++c) {
+      const f32x4 v = *(const f32x4*)(qrow + c * 4);        // (row_info clamps invalid rows onto the last valid one)
+      qf[c * 4 + 0] = v[0] * p.scale; qf[c * 4 + 1] = v[1] * p.scale; qf[c * 4 + 2] = v[2] * p.scale; qf[c * 4 + 3] = v[3] * p.scale;
+    }
+  }
+  const float* kg = p.k + (size_t)bk * p.kv_rows * p.ldk + p.k_off + h * 64;
+  const float* vg = p.v + (size_t)bk * p.kv_rows * p.ldv + p.v_off + h * 64;
+  // staging: thread -> (key = tid / 8, two 16-byte chunks c = tid % 8 and c + 8) of the tile, for K and for V
+  const int skey = tid >> 3, sc = tid & 7;
+  f32x4 kr[2], vr[2];
+  auto fetch = [&](int k0) {
+    const int key = k0 + skey;
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+      kr[j] = f32x4{0.f, 0.f, 0.f, 0.f};
+      vr[j] = f32x4{0.f, 0.f, 0.f, 0.f};
+      if (key < p.Nk) {
+        kr[j] = *(const f32x4*)(kg + (size_t)key * p.ldk + (sc + 8 * j) * 4);
+        vr[j] = *(const f32x4*)(vg + (size_t)key * p.ldv + (sc + 8 * j) * 4);
+      }
+    }
+  };
+  float m = -INFINITY, l = 0.f;
+  f32x16 O[2];
+#pragma unroll
+  for (int dt = 0; dt < 2; ++dt)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) O[dt][r] = 0.f;
+  fetch(0);
+  for (int k0 = 0; k0 < p.Nk; k0 += 32) {
+    __syncthreads();                       // every wave is done with the previous tile
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+      *(f32x4*)(Ks + skey * F32M_LDK + (sc + 8 * j) * 4) = kr[j];
+      *(f32x4*)(Vs + skey * F32M_LDV + (sc + 8 * j) * 4) = vr[j];
+    }
+    __syncthreads();
+    if (k0 + 32 < p.Nk) fetch(k0 + 32);    // (in flight under this tile's MFMAs)
+    if (!wave_live) continue;
+    // ---- S^T[key][row] = sum_d K[key][d] Q[row][d]: 32 steps of k = 2 (d = s | s + 32)
+    f32x16 S;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) S[r] = 0.f;
+    const float* kp = Ks + l31 * F32M_LDK + hi * 32;
+#pragma unroll
+    for (int c = 0; c < 8; ++c) {
+      const f32x4 kv = *(const f32x4*)(kp + c * 4);
+      S = __builtin_amdgcn_mfma_f32_32x32x2f32(kv[0], qf[c * 4 + 0], S, 0, 0, 0);
+      S = __builtin_amdgcn_mfma_f32_32x32x2f32(kv[1], qf[c * 4 + 1], S, 0, 0, 0);
+      S = __builtin_amdgcn_mfma_f32_32x32x2f32(kv[2], qf[c * 4 + 2], S, 0, 0, 0);
+      S = __builtin_amdgcn_mfma_f32_32x32x2f32(kv[3], qf[c * 4 + 3], S, 0, 0, 0);
+    }
+    // ---- online softmax: S[r] belongs to key k0 + (r & 3) + 8 * (r >> 2) + 4 * hi of this lane's row
+    float mt = -INFINITY;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int key = k0 + (r & 3) + 8 * (r >> 2) + 4 * hi;
+      if (key >= ri.klim) S[r] = -INFINITY;
+      mt = fmaxf(mt, S[r]);
+    }
+    mt = fmaxf(mt, __shfl_xor(mt, 32, 64));
+    const float mn = fmaxf(m, mt);
+    const float msafe = mn == -INFINITY ? 0.f : mn;
+    const float alpha = expf(m - msafe);
+    float ps = 0.f;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      S[r] = expf(S[r] - msafe);
+      ps += S[r];
+    }
+    ps += __shfl_xor(ps, 32, 64);
+    l = l * alpha + ps;
+    m = mn;
+#pragma unroll
+    for (int dt = 0; dt < 2; ++dt)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) O[dt][r] *= alpha;
+    // ---- O^T[d][row] += sum_key V[key][d] P[row][key]: step r pairs the keys the two half-waves hold in register r
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const float* vp = Vs + ((r & 3) + 8 * (r >> 2) + 4 * hi) * F32M_LDV + l31;
+      O[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(vp[0], S[r], O[0], 0, 0, 0);
+      O[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(vp[32], S[r], O[1], 0, 0, 0);
+    }
+  }
+  if (!wave_live || !ri.valid) return;
+  const float inv = l > 0.f ? 1.0f / l : 0.f;
+  // O[dt][r]: d = dt * 32 + (r & 3) + 8 * (r >> 2) + 4 * hi -> 4 consecutive d per register quad
+  const size_t row = (size_t)ri.qb * p.Nq + ri.t;
+#pragma unroll
+  for (int dt = 0; dt < 2; ++dt)
+#pragma unroll
+    for (int rq = 0; rq < 4; ++rq) {
+      const int d = dt * 32 + rq * 8 + 4 * hi;
+      const f32x4 v = {O[dt][rq * 4 + 0] * inv, O[dt][rq * 4 + 1] * inv, O[dt][rq * 4 + 2] * inv, O[dt][rq * 4 + 3] * inv};
+      if (p.out_mode == 0) {
+        *(f32x4*)((float*)p.out + row * p.ldo + h * 64 + d) = v;
+      } else {
+        using x4 = typename Elt<T16>::x4;
+        const long long pl = p.ldo / 3;
+        T16* o = (T16*)p.out + row * p.ldo + h * 64 + d;
+        x4 vh, vl;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          vh[e] = Elt<T16>::from_f32(v[e]);
+          vl[e] = Elt<T16>::from_f32(v[e] - (float)vh[e]);
+        }
+        *(x4*)o = vh;
+        *(x4*)(o + pl) = vl;
+        *(x4*)(o + 2 * pl) = vh;
+      }
+    }
+}
+
 template <typename T16>
 __global__ __launch_bounds__(256) void attn_f32_arena_kernel(const AttnF32P p) {
   const int lane = threadIdx.x & 63;
@@ -1035,6 +1181,16 @@ extern "C" int vidil_attention_f32(const vidil_attn_f32_args* a, void* stream) {
     max_rows = a->kv_group * a->Nq;
   }
   VIDIL_REQUIRE(a->H <= 65535 && units <= 65535, "attention_f32: grid too large (H=%d units=%d)", a->H, units);
+  // units of more than 8 query rows (the towers, the ITM encoder, prompt passes): the f32-MFMA kernel, 128 rows per workgroup;
+  // a few rows per unit (the decode steps' cross-attention: 3 beams per image): the VALU kernel, which skips idle row groups
+  static const bool allow_mfma = [] { const char* e = getenv("VIDIL_ATTN_F32_MFMA"); return !(e && e[0] == '0'); }();
+  if (allow_mfma && max_rows > 8 && (a->out_mode == 2 ? a->ldo % 12 == 0 : a->ldo % 4 == 0) && ((uintptr_t)a->out & 15) == 0) {   // (16-B / 8-B row stores)
+    const dim3 gridm((max_rows + 127) / 128, a->H, units);
+    if (bf) hipLaunchKernelGGL(attn_f32_mfma_kernel<bf16>, gridm, dim3(256), 0, s, p);
+    else hipLaunchKernelGGL(attn_f32_mfma_kernel<f16>, gridm, dim3(256), 0, s, p);
+    VIDIL_CHECK_LAUNCH("attention_f32 (mfma)");
+    return VIDIL_OK;
+  }
   const dim3 grid((max_rows + F32_RB - 1) / F32_RB, a->H, units);
   if (bf) hipLaunchKernelGGL(attn_f32_kernel<bf16>, grid, dim3(256), 0, s, p);
   else hipLaunchKernelGGL(attn_f32_kernel<f16>, grid, dim3(256), 0, s, p);
