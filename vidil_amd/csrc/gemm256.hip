@@ -484,6 +484,9 @@ int vidil_gemm4w_launch(const vidil_gemm_args& a, hipStream_t s, int tm);   // g
 // row-partials producers (-4..5 %, with or without the residual LayerNorm) and the per-head scatter (-2..3 %) once there
 // are a couple of tiles per CU, and loses on the plain f32 epilogue (+7 %) and on small grids (and is not built for fp8
 // operands).  $VIDIL_GEMM4W = 0 / 1 forces one kernel (developer).
+#ifndef VIDIL_GEMM4W_F32_DEFAULT
+#define VIDIL_GEMM4W_F32_DEFAULT 0
+#endif
 static bool prefer_4w(const vidil_gemm_args& a) {
   if (a.epi == VIDIL_EPI_HEADS && a.T < 8) return false;   // (the 4-wave scatter steps (image, token) by 8 rows: gemm_epilogue.inc)
   if (const char* e = vidil_dev_env("VIDIL_GEMM4W")) return atoi(e) != 0;
@@ -502,8 +505,12 @@ static bool prefer_4w(const vidil_gemm_args& a) {
     case VIDIL_EPI_HEADS:
     case VIDIL_EPI_ARENA:
       return true;
-    case VIDIL_EPI_F32:
-      return a.ln_stats_out != nullptr;    // (the LN-fold producers, with or without a residual LayerNorm; plain f32: gemm256)
+    case VIDIL_EPI_F32: {
+      // the LN-fold producers, with or without a residual LayerNorm: always; the plain f32 epilogue (the parity mode's K-tripled
+      // GEMMs, the LM head): measured per round — round 3: +7 % on gemm256's side; $VIDIL_GEMM4W_F32 = 0 / 1 decides (A/B switch)
+      static const int f32_4w = [] { const char* e = getenv("VIDIL_GEMM4W_F32"); return e ? atoi(e) : VIDIL_GEMM4W_F32_DEFAULT; }();
+      return a.ln_stats_out != nullptr || (f32_4w != 0 && a.act == VIDIL_ACT_NONE);
+    }
     default:
       return false;
   }
