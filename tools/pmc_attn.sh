@@ -12,7 +12,7 @@ for sub in ('sq','sq2'):
     agg=collections.defaultdict(list)
     for f in glob.glob(f'{out}/{sub}/**/*counter_collection.csv', recursive=True):
         for r in csv.DictReader(open(f)):
-            if 'attn_lds' not in r['Kernel_Name']: continue
+            if "attn_lds" not in r["Kernel_Name"] and "attn_stream" not in r["Kernel_Name"]: continue
             agg[r['Counter_Name']].append(float(r['Counter_Value']))
     print(sub, {c: round(sum(x)/len(x)) for c,x in agg.items()}, 'launches', len(next(iter(agg.values()), [])))
 PY

@@ -29,7 +29,10 @@
 // each 16-key block the 4-key groups 1 and 2 are swapped), so a half-wave's 8
 // keys are one contiguous 16-byte read and P feeds the second MFMA without any
 // permute.  NP (the V^T row stride) is a multiple of 16 for that reason.
+#include <type_traits>
+
 #include "common.h"
+#include "gemm_epilogue.h"
 
 namespace {
 
@@ -101,11 +104,27 @@ __device__ __forceinline__ RowInfo row_info(const P& p, int v, int first, int ro
 
 // One key tile of online softmax + P·V for the 32 rows of a wave.
 // S: scores of this tile (S^T layout: lane = row, 16 keys per half-wave).
-template <typename T, typename VFrag>
-__device__ __forceinline__ void softmax_pv_tile(f32x16& S, int key0, int klim, bool need_mask, float& m, float& l,
-                                                f32x16 (&O)[2], VFrag&& vfrag) {
+// MASKED = false: the caller knows (wave-uniformly) that every key of the tile is inside every row's limit — written as
+// a run-time `need_mask` alone the compiler turns the 16 tests into selects that run on every tile (49 of a tile's ~160
+// VALU instructions in the towers' self-attention, whose 197 keys need the mask on the last tile only).
+//
+// The online softmax keeps a REFERENCE value m per row, not the exact running maximum: m moves (and l and O are
+// rescaled) only when a tile's maximum outgrows it by more than kLazy = 5 — decided for the whole wave by one ballot, so
+// on most tiles the 32 accumulator multiplies, the exp of the correction and the dependent chain through them are not
+// executed at all.  Any reference is exact in exact arithmetic (softmax is shift invariant); a stale one lets the
+// probabilities of a tile reach e^5 = 148 instead of 1, far inside the range of the 16-bit operand they are rounded to,
+// and the row sum stays in f32.  p = 2^(s*log2e - m*log2e): one FMA and one v_exp_f32 per score.
+constexpr float kLazy = 5.0f;
+constexpr float kLog2e = 1.44269504088896340736f;
+// Part 1 of a key tile: scores S -> probabilities rounded to T and packed as the two 16-key operands of P.V (pf), with the
+// row's reference m, its sum l and — when the reference moves — the accumulators O brought up to date.
+// FIRST = true (a row block's first tile, the caller's promise): nothing is accumulated yet, so m starts at the tile's
+// maximum and nothing is rescaled; the general form computes exactly the same values there (alpha = 0 on zeros).
+template <typename T, bool MASKED = true, bool FIRST = false>
+__device__ __forceinline__ void softmax_tile(f32x16& S, int key0, int klim, bool need_mask, float& m, float& l, f32x16 (&O)[2],
+                                             typename Elt<T>::x8 (&pf)[2]) {
   const int hi = (threadIdx.x & 63) >> 5;
-  if (need_mask) {
+  if (MASKED && need_mask) {
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
       const int key = key0 + (r & 3) + 8 * (r >> 2) + 4 * hi;
@@ -115,33 +134,58 @@ __device__ __forceinline__ void softmax_pv_tile(f32x16& S, int key0, int klim, b
   float mt = S[0];
 #pragma unroll
   for (int r = 1; r < 16; ++r) mt = fmaxf(mt, S[r]);
+#if !(defined(VIDIL_ATTN_ABLATE) && (VIDIL_ATTN_ABLATE & 32))
   mt = fmaxf(mt, __shfl_xor(mt, 32, 64));
-  const float mn = fmaxf(m, mt);
-  const float msafe = mn == -INFINITY ? 0.f : mn;
-  const float alpha = __expf(m - msafe);  // m == -inf -> 0
+#endif
+  if (FIRST) {
+    m = mt;
+  } else {
+    const bool grow = mt > m + kLazy;            // (m == -inf: true as soon as the row has seen one finite score)
+    if (__builtin_amdgcn_ballot_w64(grow) != 0) {
+      const float mn = grow ? mt : m;            // the two lanes of a row decide alike (mt is shared above)
+      // rows that keep their reference: alpha = 2^0 = 1 exactly; m == -inf (nothing accumulated yet): alpha = 0
+      const float alpha = __builtin_amdgcn_exp2f((m - (mn == -INFINITY ? 0.f : mn)) * kLog2e);
+      l *= alpha;
+      m = mn;
+#pragma unroll
+      for (int dt = 0; dt < 2; ++dt)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) O[dt][r] *= alpha;
+    }
+  }
+  const float mc = (m == -INFINITY ? 0.f : m) * kLog2e;
   float ps = 0.f;
 #pragma unroll
   for (int r = 0; r < 16; ++r) {
-    const float e = __expf(S[r] - msafe);
+#if defined(VIDIL_ATTN_ABLATE) && (VIDIL_ATTN_ABLATE & 16)
+    const float e = S[r] - mc;
+#else
+    const float e = __builtin_amdgcn_exp2f(__builtin_fmaf(S[r], kLog2e, -mc));
+#endif
     S[r] = e;
     ps += e;
   }
-  l = l * alpha + ps;
-  m = mn;
+  l = FIRST ? ps : l + ps;
 #pragma unroll
-  for (int dt = 0; dt < 2; ++dt)
+  for (int hb = 0; hb < 2; ++hb)
 #pragma unroll
-    for (int r = 0; r < 16; ++r) O[dt][r] *= alpha;
+    for (int j = 0; j < 8; ++j) pf[hb][j] = (T)S[hb * 8 + j];
+}
+
+// One key tile of online softmax + P·V for the 32 rows of a wave.
+// S: scores of this tile (S^T layout: lane = row, 16 keys per half-wave).
+template <typename T, bool MASKED = true, typename VFrag>
+__device__ __forceinline__ void softmax_pv_tile(f32x16& S, int key0, int klim, bool need_mask, float& m, float& l,
+                                                f32x16 (&O)[2], VFrag&& vfrag) {
+  typename Elt<T>::x8 pf[2];
+  softmax_tile<T, MASKED>(S, key0, klim, need_mask, m, l, O, pf);
 #pragma unroll
   for (int hb = 0; hb < 2; ++hb) {
-    typename Elt<T>::x8 pf;
-#pragma unroll
-    for (int j = 0; j < 8; ++j) pf[j] = (T)S[hb * 8 + j];
 #pragma unroll
     for (int dt = 0; dt < 2; ++dt) {
       const typename Elt<T>::x8 vf = vfrag(dt, hb);
       // O^T[d][q] += V^T[d][keys] · P^T[keys][q]
-      O[dt] = Elt<T>::mfma32(vf, pf, O[dt]);
+      O[dt] = Elt<T>::mfma32(vf, pf[hb], O[dt]);
     }
   }
 }
@@ -455,6 +499,316 @@ __global__ __launch_bounds__(NW * 64, NW == 8 ? 4 : 2) void attn_lds_kernel(cons
   }
 }
 
+// ------------------------------------------------------------------ streamed kernel (tower self-attention)
+// The towers' self-attention (197 keys, V row-major, one query batch per K/V batch, no masks) is the one big launch of
+// the staged kernel above, and there it waits: global -> registers -> LDS staging, a barrier, the key tiles, the stores —
+// phases of ONE unit that only a second workgroup on the CU overlaps.  This form keeps a workgroup on the CU for many
+// units (unit = (image, head), walked with the grid's stride) and streams their K / V through LDS by LDS-DMA
+// (`global_load_lds_dwordx4`: no staging registers, so the seven computing waves stay at four waves per SIMD):
+//
+//   wave 7 (has no query rows at <= 224 rows) is the producer: a unit's NKT key tiles live in NKT fixed slots (K tile
+//     [32 keys][64] + V tile [32 keys][64]).  The consumers read a K tile one step before its V tile, so the halves of a
+//     unit are "K tiles 0..KA-1 + V tiles 0..KA-2" and the rest: the producer requests the second half of the current unit
+//     right after barrier B1 and the first half of the NEXT unit right after barrier B2, and arrives at each barrier only
+//     after `vmcnt(0)` — it is the only wave that ever waits for the stream.
+//   waves 0-6 own 32 query rows each.  Per unit: B1, K.Q^T of tile 0, then per key tile the softmax (VALU) followed by
+//     ONE block of eight MFMAs — P.V of this tile and K.Q^T of the next, as alternating independent chains — B2 before the
+//     block that first touches the second half; the next unit's Q fragments are requested half a unit ahead (into a
+//     second register set: under load a request takes 3-4 us), the output rows go out transposed through the wave's 2 KiB
+//     of LDS by buffer stores.  Two barriers per unit; between them the waves drift, which is what lets one wave's MFMAs
+//     run under another's softmax.
+//
+// LDS images are what the fragment reads want, chosen through the SOURCE address each DMA lane fetches (the LDS side of
+// a DMA instruction is lane-linear):
+//   K tile: 128-B rows, 16-B slot c of row r at slot c ^ ((r >> 1) & 7) (the GEMMs' swizzle; ds_read_b128, conflict free)
+//   V tile: [d / 16][32 keys][16 d] (32-B rows; the four d-blocks 1152 B apart, so the two a half-wave reads together
+//     sit 32 banks apart): the P.V operand — 8 keys of one d per lane — is read TRANSPOSED by two `ds_read_b64_tr_b16`
+//     (each 16-lane group reads one [4 keys][16 d] block, 128 contiguous bytes; tools/micro/tr16_probe.hip pins the
+//     instruction's lane mapping).  Row-major V needs no key permutation: the S^T accumulator leaves a half-wave the
+//     keys {0-3, 8-11} / {4-7, 12-15} of a 16-key step, which are whole 4-key blocks.
+// Rows past the last key are fetched from the last key's row (finite values; their probabilities are exactly 0).
+// The arithmetic — MFMA order per accumulator, online softmax, key -> k-slot assignment — is the staged kernel's:
+// outputs are bit-identical (tests/test_kernels_gpu.py).  Measured (MI355X, 3,584 images x 12 heads, bf16, same process):
+// 1,090-1,100 us staged -> 900-920 us; `SQ_VALU_MFMA_BUSY` 0.26 -> 0.34 of the kernel's cycles.  What the ablations say
+// (tools/bench_attn_stream.py on -DVIDIL_ATTN_ABLATE builds): arithmetic alone 670 us, + DMA 780-800, + stores 780, all
+// 900-920; LDS bank conflicts are gone (0.07 of the LDS cycles, all in the output transposition), the split point KA, the
+// Q prefetch distance and s_setprio around the MFMA block each move it by < 2 %.
+typedef short s16x4 __attribute__((ext_vector_type(4)));
+
+__device__ __forceinline__ void attn_glds16(const void* g, char* lds) {
+  __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)g,
+                                   (__attribute__((address_space(3))) void*)lds, 16, 0, 0);
+}
+
+// store_rows_lds for the streamed kernel: the same transposition, but every lane takes part in exactly four 16-byte BUFFER
+// stores per block (rows past the unit's last one get an out-of-range offset and are dropped by the range check) — no
+// exec-masked branch around a store, so the number of memory operations between the next unit's Q loads and their first
+// use is a constant and the wait for Q does not become a wait for the stores' acknowledgements.
+// `row_off`: byte offset of this lane's own row inside the unit's output window, or 0x80000000 for a row that does not exist.
+template <typename T>
+__device__ __forceinline__ void store_rows_stream(__amdgpu_buffer_rsrc_t rsrc, uint32_t row_off, const f32x16 (&O)[2], float inv,
+                                                  char* scratch) {
+  using f16 = T;
+  using f16x4 = typename Elt<T>::x4;
+  const int lane = threadIdx.x & 63;
+  const int hi = lane >> 5, l31 = lane & 31;
+  uint32_t dst[2];
+#pragma unroll
+  for (int i = 0; i < 2; ++i) dst[i] = (uint32_t)__shfl((int)row_off, i * 16 + (lane >> 2), 64);
+#pragma unroll
+  for (int dt = 0; dt < 2; ++dt) {
+#pragma unroll
+    for (int rq = 0; rq < 4; ++rq) {
+      const f16x4 v = {(f16)(O[dt][rq * 4 + 0] * inv), (f16)(O[dt][rq * 4 + 1] * inv), (f16)(O[dt][rq * 4 + 2] * inv),
+                       (f16)(O[dt][rq * 4 + 3] * inv)};
+      *(f16x4*)(scratch + l31 * 64 + ((rq ^ ((l31 >> 1) & 3)) << 4) + hi * 8) = v;
+    }
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      const int r = i * 16 + (lane >> 2), c = lane & 3;
+      const u32x4 v = *(const u32x4*)(scratch + r * 64 + ((c ^ ((r >> 1) & 3)) << 4));
+      __builtin_amdgcn_raw_buffer_store_b128(v, rsrc, dst[i] + (uint32_t)((dt * 32 + c * 8) * 2), 0, 0);
+    }
+  }
+}
+
+template <typename T, int NKT>
+__global__ __launch_bounds__(512, 4) void attn_stream_kernel(const AttnP<T> p) {
+  using f16x8 = typename Elt<T>::x8;
+#ifndef VIDIL_ATTN_KA
+#define VIDIL_ATTN_KA ((NKT + 1) / 2)
+#endif
+  constexpr int KA = VIDIL_ATTN_KA;      // key tiles of the first half of a unit (developer sweep: -DVIDIL_ATTN_KA=2..NKT-1)
+  constexpr int VSUB = 1152;             // bytes between the four [32 keys][16 d] blocks of a V tile: 1 KiB + 128, so that
+                                         // the two blocks a half-wave reads together (d 0-15 / 16-31) sit 32 banks apart
+  constexpr int TILE = 4096 + 4 * VSUB;  // K tile 4 KiB + V tile
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int nunits = p.n_kv * p.H;
+  const int nk = p.Nk;
+  const size_t kv_unit = (size_t)p.Tk_cap * 128;     // bytes of one unit's K (or V)
+  const int stride = gridDim.x;
+  int u = blockIdx.x;
+  if (u >= nunits) return;
+
+  if (wave == 7) {
+    // ------------------------------------------------------------------ producer
+    // piece pc of a tile (1 KiB, one DMA instruction): pc 0-3 K rows pc*8 .. pc*8+7, pc 4-7 V columns (pc-4)*16 .. +15
+    auto issue_half = [&](int uu, int kt, int pc0) {     // pc0 = 0: the K tile, 4: the V tile
+      const char* gb = (const char*)(pc0 == 0 ? p.k : p.vt) + (size_t)uu * kv_unit;
+      char* dst = smem + kt * TILE;
+#pragma unroll
+      for (int pc = pc0; pc < pc0 + 4; ++pc) {
+        int r, cb;
+        if (pc < 4) {
+          r = pc * 8 + (lane >> 3);
+          cb = ((lane & 7) ^ ((r >> 1) & 7)) * 16;
+        } else {
+          r = lane >> 1;
+          cb = (pc - 4) * 32 + (lane & 1) * 16;
+        }
+        int key = kt * 32 + r;
+        key = key < nk - 1 ? key : nk - 1;
+#if defined(VIDIL_ATTN_ABLATE) && (VIDIL_ATTN_ABLATE & 1)
+        if (uu != (int)blockIdx.x) continue;     // developer ablation: DMA for a workgroup's first unit only
+#endif
+        attn_glds16(gb + (uint32_t)(key * 128 + cb), dst + (pc < 4 ? pc * 1024 : 4096 + (pc - 4) * VSUB));
+      }
+    };
+    // A K tile is read one step before its V tile (the consumers' pipeline), so the two halves of a slot are free and
+    // needed at different barriers: "first half" = K tiles 0..KA-1 and V tiles 0..KA-2, "second half" = the rest.
+    auto issue_first = [&](int uu) {
+#pragma unroll
+      for (int kt = 0; kt < KA; ++kt) issue_half(uu, kt, 0);
+#pragma unroll
+      for (int kt = 0; kt < KA - 1; ++kt) issue_half(uu, kt, 4);
+    };
+    auto issue_second = [&](int uu) {
+#pragma unroll
+      for (int kt = KA; kt < NKT; ++kt) issue_half(uu, kt, 0);
+#pragma unroll
+      for (int kt = KA - 1; kt < NKT; ++kt) issue_half(uu, kt, 4);
+    };
+    issue_first(u);
+    for (;;) {
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      __builtin_amdgcn_s_barrier();                       // B1: first half of u in LDS; every wave is done with unit u - stride
+      issue_second(u);
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      __builtin_amdgcn_s_barrier();                       // B2: second half of u in LDS; K tiles < KA, V tiles < KA-1 of u are done with
+      u += stride;
+      if (u >= nunits) break;
+      issue_first(u);
+    }
+    return;
+  }
+
+  // -------------------------------------------------------------------- consumers
+  const int hi = lane >> 5, l31 = lane & 31;
+  const int sw = (l31 >> 1) & 7;
+  const int row = wave * 32 + l31;
+  const bool valid = row < p.Nq;
+  const int vc = valid ? row : p.Nq - 1;
+  // transposed V reads: lane t of 16-lane group g supplies row (t >> 2), 8-byte chunk (t & 3) of its group's block
+  const int vlane = ((lane >> 4) & 1) * VSUB + (hi * 4 + ((lane & 15) >> 2)) * 32 + (lane & 3) * 8;
+  char* scratch = smem + NKT * TILE + wave * 2048;
+  f16x8 qf[4];
+  const uint32_t q_off = (uint32_t)(vc * 128 + hi * 16);     // (one register: the unit's base is uniform)
+  // (buffer loads: descriptor + scalar unit offset + one lane register — as a 64-bit lane address the compiler keeps a
+  //  register pair per wave for it and, at 128 registers, spills it)
+  const __amdgpu_buffer_rsrc_t rsrc_q = uniform_rsrc(p.q, (uint32_t)nunits * p.Tq_cap * 128);
+  auto load_q = [&](int uu, f16x8 (&dst)[4]) {
+    const uint32_t ub = (uint32_t)uu * p.Tq_cap * 128;
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks)
+      dst[ks] = __builtin_bit_cast(f16x8, __builtin_amdgcn_raw_buffer_load_b128(rsrc_q, q_off + ks * 32, ub, 0));
+  };
+  const uint32_t row_off = valid ? (uint32_t)row * p.ldo * 2 : 0x80000000u;
+  load_q(u, qf);
+  asm volatile("" ::"v"(qf[0]), "v"(qf[1]), "v"(qf[2]), "v"(qf[3]));   // (arrived: the loop is entered with nothing in flight)
+  // Software pipeline of a row block: the four MFMAs of P.V of tile kt and the four of the NEXT tile's K.Q^T are issued
+  // as one block of alternating, mutually independent chains (O[0], S, O[1], S, ...) right after tile kt's probabilities
+  // are packed — the matrix pipe gets eight back-to-back instructions instead of two dependent chains with a softmax
+  // between them, and tile kt+1's scores are ready when the wave's VALU work on them starts.
+  // fragment reads of one HALF (hb) of a step: V^T of tile kv (both d tiles, keys hb*16 .. +15) and K of tile kk (k-steps
+  // 2*hb, 2*hb+1) — 16 registers; the two halves of a step reuse them (all eight fragments at once do not fit beside the
+  // accumulators, the scores, two sets of Q and the packed probabilities in 128 registers)
+  auto read_k2 = [&](int kt, int h2, f16x8 (&kf)[2]) {
+    const char* ks_ = smem + kt * TILE + l31 * 128;
+#pragma unroll
+    for (int j = 0; j < 2; ++j) kf[j] = *(const f16x8*)(ks_ + ((((h2 * 2 + j) * 2 + hi) ^ sw) << 4));
+  };
+  auto read_v2 = [&](int kt, int hb, f16x8 (&vf)[2]) {     // [dt]
+    const char* vs_ = smem + kt * TILE + 4096 + vlane + hb * 512;
+#pragma unroll
+    for (int dt = 0; dt < 2; ++dt) {
+      const char* a = vs_ + dt * (2 * VSUB);
+      const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(a));
+      const s16x4 hi4 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(a + 256));
+      typedef short s16x8 __attribute__((ext_vector_type(8)));
+      const s16x8 both = __builtin_shufflevector(lo, hi4, 0, 1, 2, 3, 4, 5, 6, 7);
+      vf[dt] = __builtin_bit_cast(f16x8, both);
+    }
+  };
+  const f32x16 zero16 = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+#ifndef VIDIL_ATTN_QAHEAD
+#define VIDIL_ATTN_QAHEAD 2
+#endif
+  constexpr int QAHEAD = VIDIL_ATTN_QAHEAD;               // (developer sweep: 1 .. NKT-2)
+  f16x8 qn[4];
+#ifdef VIDIL_ATTN_TIMING   // developer build: cycles a wave spends at the two barriers / in the store phase / in total -> out
+  uint64_t t_b1 = 0, t_b2 = 0, t_st = 0;
+  const uint64_t t_begin = __builtin_amdgcn_s_memtime();
+#endif
+  for (;;) {
+    float m, l;
+    f32x16 O[2], S;
+    f16x8 pf[2];
+#ifdef VIDIL_ATTN_TIMING
+    const uint64_t tb1 = __builtin_amdgcn_s_memtime();
+#endif
+    __builtin_amdgcn_s_barrier();                         // B1: K tiles 0..KA-1 / V tiles 0..KA-2 of this unit are in LDS
+    asm volatile("" ::: "memory");
+#ifdef VIDIL_ATTN_TIMING
+    t_b1 += __builtin_amdgcn_s_memtime() - tb1;
+#endif
+    // one step: P.V of tile kt (probabilities pf) fused with K.Q^T of tile kt + 1, in two halves of four MFMAs
+    auto fused = [&](int kt, auto first_tag) {
+      constexpr bool FIRST = decltype(first_tag)::value;
+      f16x8 kf[2], vf[2];
+#ifdef VIDIL_ATTN_PRIO
+      __builtin_amdgcn_s_setprio(VIDIL_ATTN_PRIO);
+#endif
+#pragma unroll
+      for (int hb = 0; hb < 2; ++hb) {
+        read_v2(kt, hb, vf);
+        read_k2(kt + 1, hb, kf);
+        O[0] = Elt<T>::mfma32(vf[0], pf[hb], FIRST && hb == 0 ? zero16 : O[0]);
+        S = Elt<T>::mfma32(kf[0], qf[hb * 2], hb == 0 ? zero16 : S);
+        O[1] = Elt<T>::mfma32(vf[1], pf[hb], FIRST && hb == 0 ? zero16 : O[1]);
+        S = Elt<T>::mfma32(kf[1], qf[hb * 2 + 1], S);
+        __builtin_amdgcn_sched_barrier(0);
+      }
+#ifdef VIDIL_ATTN_PRIO
+      __builtin_amdgcn_s_setprio(0);
+#endif
+    };
+    {
+      f16x8 kf[2];
+      read_k2(0, 0, kf);
+      S = Elt<T>::mfma32(kf[0], qf[0], zero16);
+      S = Elt<T>::mfma32(kf[1], qf[1], S);
+      read_k2(0, 1, kf);
+      S = Elt<T>::mfma32(kf[0], qf[2], S);
+      S = Elt<T>::mfma32(kf[1], qf[3], S);
+    }
+    // ---- tile 0: nothing accumulated yet
+    softmax_tile<T, false, true>(S, 0, nk, false, m, l, O, pf);
+    fused(0, std::true_type{});
+    // ---- tiles 1 .. NKT-2 (all keys inside the limit)
+#pragma unroll 1
+    for (int kt = 1; kt < NKT - 1; ++kt) {
+      // (uniform) the next unit's Q, requested a good half unit ahead: under load a request takes 3-4 us to come back — the
+      // time of two or three key tiles — and a wave that waits for its Q at a unit's start holds up the barrier for all.
+      // The last workgroups' last pass re-reads their own unit instead of branching: the operation count stays the same.
+      if (kt == QAHEAD) load_q(u + stride < nunits ? u + stride : u, qn);
+      softmax_tile<T, false>(S, kt * 32, nk, false, m, l, O, pf);
+#ifdef VIDIL_ATTN_TIMING
+      const uint64_t tb2 = __builtin_amdgcn_s_memtime();
+#endif
+      if (kt == KA - 1) __builtin_amdgcn_s_barrier();     // B2: K tiles KA.. / V tiles KA-1.. are in LDS
+      asm volatile("" ::: "memory");
+#ifdef VIDIL_ATTN_TIMING
+      if (kt == KA - 1) t_b2 += __builtin_amdgcn_s_memtime() - tb2;
+#endif
+      fused(kt, std::false_type{});
+    }
+    const int un = u + stride;
+    const int bk = u / p.H, h = u - bk * p.H;
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks) qf[ks] = qn[ks];       // (tile NKT-2 has just released qf)
+    // ---- last tile: the one that may straddle the key count
+    softmax_tile<T, true>(S, (NKT - 1) * 32, nk, true, m, l, O, pf);
+#pragma unroll
+    for (int hb = 0; hb < 2; ++hb) {
+      f16x8 vf[2];
+      read_v2(NKT - 1, hb, vf);
+      O[0] = Elt<T>::mfma32(vf[0], pf[hb], O[0]);
+      O[1] = Elt<T>::mfma32(vf[1], pf[hb], O[1]);
+    }
+    l += __shfl_xor(l, 32, 64);
+    const float inv = l > 0.f ? 1.0f / l : 0.f;
+#ifdef VIDIL_ATTN_TIMING
+    const uint64_t ts0 = __builtin_amdgcn_s_memtime();
+#endif
+#if defined(VIDIL_ATTN_ABLATE) && (VIDIL_ATTN_ABLATE & 2)
+    if (inv == 12345.f)                           // developer ablation: no output stores
+#endif
+    {
+      // the unit's output window: rows bk*Nq .. +Nq-1, this head's 64 columns onwards
+      const __amdgpu_buffer_rsrc_t rsrc = uniform_rsrc(p.out + ((size_t)bk * p.Nq * p.ldo + h * 64), (uint32_t)p.Nq * p.ldo * 2);
+      store_rows_stream<T>(rsrc, row_off, O, inv, scratch);
+    }
+#ifdef VIDIL_ATTN_TIMING
+    t_st += __builtin_amdgcn_s_memtime() - ts0;
+#endif
+    if (un >= nunits) break;
+    u = un;
+  }
+#ifdef VIDIL_ATTN_TIMING
+  if (lane == 0) {
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    uint64_t* dbg = (uint64_t*)p.out + ((size_t)blockIdx.x * 8 + wave) * 4;
+    dbg[0] = __builtin_amdgcn_s_memtime() - t_begin;
+    dbg[1] = t_b1;
+    dbg[2] = t_b2;
+    dbg[3] = t_st;
+  }
+#endif
+}
+
 // ------------------------------------------------------------------ direct (no K/V staging) kernel
 // rows <= 32.  4 waves; wave w handles key tiles w, w+4, ...; partials merged by wave 0.
 template <typename T, int NKT>
@@ -708,8 +1062,50 @@ int launch_lds(const AttnP<T>& p, int max_rows, hipStream_t s) {
   return VIDIL_OK;
 }
 
+// The streamed kernel serves the towers' self-attention: row-major V, one query batch per K/V batch, no length table or
+// causal mask, 129..224 query rows and <= NKT*32 keys, 16-byte aligned operands; everything else stays on the staged kernel.
+template <typename T>
+bool stream_eligible(const AttnP<T>& p, int max_rows) {
+  const char* e = vidil_dev_env("VIDIL_ATTN_STREAM");
+  if (e != nullptr && e[0] == '0') return false;
+  return p.NP == 0 && p.kv_len == nullptr && p.kv_index == nullptr && p.group_start == nullptr && p.kv_group == 1 && !p.causal &&
+         max_rows > 128 && max_rows <= 224 && p.Nk > 192 && !p.tiled && p.out_mode == 0 && p.ldo % 8 == 0 &&
+         (uint64_t)p.Nq * p.ldo * 2 < 0x80000000ull && (uint64_t)p.n_kv * p.H * p.Tq_cap * 128 < 0x100000000ull && (((uintptr_t)p.k | (uintptr_t)p.vt | (uintptr_t)p.q | (uintptr_t)p.out) & 15) == 0;
+}
+
+template <typename T, int NKT>
+int launch_stream(const AttnP<T>& p, hipStream_t s) {
+  constexpr int smem = NKT * (4096 + 4 * 1152) + 8 * 2048;   // (attn_stream_kernel: TILE)
+  static_assert(2 * smem <= 160 * 1024, "two workgroups per CU");
+  static bool attr_set = false;
+  static int n_cu = 0;
+  auto kern = attn_stream_kernel<T, NKT>;
+  if (!attr_set) {
+    hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, smem);
+    int dev = 0;
+    if (e == hipSuccess) e = hipGetDevice(&dev);
+    if (e == hipSuccess) e = hipDeviceGetAttribute(&n_cu, hipDeviceAttributeMultiprocessorCount, dev);
+    if (e != hipSuccess) {
+      vidil_set_error("attention: stream kernel setup failed: %s", hipGetErrorString(e));
+      return VIDIL_ELAUNCH;
+    }
+    attr_set = true;
+  }
+  AttnP<T> q = p;
+  q.ostage = 1;
+  // two resident workgroups per CU, every one walking the same number of units (+-1)
+  const int units = p.n_kv * p.H, slots = 2 * n_cu;
+  const int rounds = (units + slots - 1) / slots;
+  const int grid = (units + rounds - 1) / rounds;
+  hipLaunchKernelGGL(kern, dim3(grid), dim3(512), smem, s, q);
+  VIDIL_CHECK_LAUNCH("attention/stream");
+  return VIDIL_OK;
+}
+
 template <typename T, int NKT>
 int launch_any(const AttnP<T>& p, int max_rows, hipStream_t s) {
+  if constexpr (NKT == 7)
+    if (stream_eligible(p, max_rows)) return launch_stream<T, NKT>(p, s);
   if (max_rows <= 32 && NKT == 1 && !p.tiled) {
     hipLaunchKernelGGL(attn_wave_kernel<T>, dim3(1, p.H, p.n_kv), dim3(64), 0, s, p);
     VIDIL_CHECK_LAUNCH("attention/wave");
