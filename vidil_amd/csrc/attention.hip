@@ -120,7 +120,10 @@ constexpr float kLog2e = 1.44269504088896340736f;
 // row's reference m, its sum l and — when the reference moves — the accumulators O brought up to date.
 // FIRST = true (a row block's first tile, the caller's promise): nothing is accumulated yet, so m starts at the tile's
 // maximum and nothing is rescaled; the general form computes exactly the same values there (alpha = 0 on zeros).
-template <typename T, bool MASKED = true, bool FIRST = false>
+// LAZY = false: the reference is the exact running maximum and the rescale is unconditional — straight-line code for the
+// direct kernel, which is HBM-bound and lives on having every load of a wave in flight before its first MFMA: with the
+// ballot's branch in the tile the compiler drains the loads before it (decode cross-attention 396 -> 493 us per launch).
+template <typename T, bool MASKED = true, bool FIRST = false, bool LAZY = true>
 __device__ __forceinline__ void softmax_tile(f32x16& S, int key0, int klim, bool need_mask, float& m, float& l, f32x16 (&O)[2],
                                              typename Elt<T>::x8 (&pf)[2]) {
   const int hi = (threadIdx.x & 63) >> 5;
@@ -139,6 +142,15 @@ __device__ __forceinline__ void softmax_tile(f32x16& S, int key0, int klim, bool
 #endif
   if (FIRST) {
     m = mt;
+  } else if (!LAZY) {
+    const float mn = fmaxf(m, mt);
+    const float alpha = __builtin_amdgcn_exp2f((m - (mn == -INFINITY ? 0.f : mn)) * kLog2e);   // m == -inf -> 0
+    l *= alpha;
+    m = mn;
+#pragma unroll
+    for (int dt = 0; dt < 2; ++dt)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) O[dt][r] *= alpha;
   } else {
     const bool grow = mt > m + kLazy;            // (m == -inf: true as soon as the row has seen one finite score)
     if (__builtin_amdgcn_ballot_w64(grow) != 0) {
@@ -174,11 +186,11 @@ __device__ __forceinline__ void softmax_tile(f32x16& S, int key0, int klim, bool
 
 // One key tile of online softmax + P·V for the 32 rows of a wave.
 // S: scores of this tile (S^T layout: lane = row, 16 keys per half-wave).
-template <typename T, bool MASKED = true, typename VFrag>
+template <typename T, bool MASKED = true, bool LAZY = true, bool FIRST = false, typename VFrag>
 __device__ __forceinline__ void softmax_pv_tile(f32x16& S, int key0, int klim, bool need_mask, float& m, float& l,
                                                 f32x16 (&O)[2], VFrag&& vfrag) {
   typename Elt<T>::x8 pf[2];
-  softmax_tile<T, MASKED>(S, key0, klim, need_mask, m, l, O, pf);
+  softmax_tile<T, MASKED, FIRST, LAZY>(S, key0, klim, need_mask, m, l, O, pf);
 #pragma unroll
   for (int hb = 0; hb < 2; ++hb) {
 #pragma unroll
@@ -917,7 +929,7 @@ __global__ __launch_bounds__(256) void attn_direct_kernel(const AttnP<T> p) {
       for (int ks = 0; ks < 4; ++ks) S = Elt<T>::mfma32(kf[i][ks], qf[ks], S);
       const bool tail = (kt * 32 + 32) > nk;  // tile reaches past the last key: V^T needs zeroing too
       const bool need_mask = (kt * 32 + 32) > kmin;
-      softmax_pv_tile<T>(S, kt * 32, ri.klim, need_mask, m, l, O, [&](int dt, int hb) {
+      auto vfrag = [&](int dt, int hb) {
         const int blk0 = (kt * 2 + hb) * 16;
         f16x8 v = vf[i][dt][hb];
         if (tail) {
@@ -926,7 +938,10 @@ __global__ __launch_bounds__(256) void attn_direct_kernel(const AttnP<T> p) {
             if (blk0 + 4 * hi + (e & 3) + 8 * (e >> 2) >= nk) v[e] = (f16)0.f;
         }
         return v;
-      });
+      };
+      // (a wave's first tile, known at compile time when one round covers the keys: nothing to rescale)
+      if (ROUNDS == 1 && i == 0) softmax_pv_tile<T, true, false, true>(S, kt * 32, ri.klim, need_mask, m, l, O, vfrag);
+      else softmax_pv_tile<T, true, false>(S, kt * 32, ri.klim, need_mask, m, l, O, vfrag);
     }
     }  // rounds
   }
