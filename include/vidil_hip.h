@@ -177,6 +177,10 @@ int vidil_layernorm(const float* x, int64_t x_stride, const float* gamma,
 /* transposed while it is staged into LDS — allowed when every work unit has   */
 /* more than 32 query rows (the encoder self-attention of the ViT / CLIP       */
 /* towers); the short-query kernels read V^T fragments straight from memory.   */
+/* The towers' own shape (row-major V, one query batch per K/V batch, 129..224 */
+/* rows, 193..224 keys, no kv_len / causal, plain 16-bit output rows, 16-byte   */
+/* aligned operands) runs on a persistent, LDS-DMA-streamed form of the staged */
+/* kernel with bit-identical results (csrc/attention.hip: attn_stream_kernel). */
 /* kv_tiled != 0: `k` and `vt` are FRAGMENT-TILED (vidil_gemm_args.kv_tiled;    */
 /* [Bk][H][Tk_cap/32][2048], NP ignored, Tk_cap % 32 == 0) — allowed when every */
 /* work unit has at most 32 query rows (the cross-attention of the caption      */
