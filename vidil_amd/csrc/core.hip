@@ -17,6 +17,18 @@ void vidil_set_error(const char* fmt, ...) {
 // launches being captured into the decode steps' graphs: each is looked up in the environment ONCE per process and
 // remembered — unless $VIDIL_DEV_ENV is set when the first one is asked for: the tests and tools that flip these
 // switches between launches set it, and then every query is a live getenv.
+// Compute units of the current device, read once (256 on MI355X; also the fallback when no device answers, e.g. the host-only
+// dispatch-name checks).  The tile-count thresholds of the GEMM dispatch are fractions of it: they were tuned as "workgroups
+// per CU", and the persistent grids are sized from the same number.
+int vidil_cu_count() {
+  static const int n = [] {
+    int dev = 0, v = 0;
+    if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || v < 8) v = 256;
+    return v;
+  }();
+  return n;
+}
+
 const char* vidil_dev_env(const char* name) {
   static const bool live = getenv("VIDIL_DEV_ENV") != nullptr;
   if (live) return getenv(name);

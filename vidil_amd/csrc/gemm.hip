@@ -342,11 +342,12 @@ TileChoice choose_tile(const vidil_gemm_args& a) {
   // ~200 128x128 tiles: the 8-wave 128x128 tile, 2-deep ring when two workgroups share a CU, 3-deep when alone
   // (M = 9216, K = 3072: 61 us against 74 us on 128x64; M = 4608: 33 against 43)
   const long n128 = (long)((a.M + 127) / 128) * ((a.N + 127) / 128);
-  if (n128 >= 200 && a.N <= 1024) return {0, 128, 128, n128 > 256 ? 2 : 3};
+  const long cus = vidil_cu_count();          // (the thresholds below are the tuned 200 / 256 / 1280 / 2560 on 256 CUs)
+  if (n128 >= 25 * cus / 32 && a.N <= 1024) return {0, 128, 128, n128 > cus ? 2 : 3};
   const long n64 = (long)((a.M + 63) / 64) * ((a.N + 63) / 64);
-  if (n64 <= 1280) return {0, 64, 64, ST_64x64};
+  if (n64 <= 5 * cus) return {0, 64, 64, ST_64x64};
   const long n128x64 = (long)((a.M + 127) / 128) * ((a.N + 63) / 64);
-  if (n128x64 <= 2560) return {0, 128, 64, ST_128x64};
+  if (n128x64 <= 10 * cus) return {0, 128, 64, ST_128x64};
   return {0, 128, 128, ST_128x128};
 }
 

@@ -400,7 +400,7 @@ extern "C" int vidil_debug_gemm_probe(unsigned long long* out2) {
 // any_size: skip the "enough tiles to fill the chip" test (LN-folded GEMMs always run here, whatever M is).
 bool vidil_gemm256_eligible(const vidil_gemm_args& a, bool any_size) {
   const long tiles = (long)((a.M + 255) / 256) * ((a.N + 255) / 256);
-  if (tiles < 160 && !any_size) return false;      // too few workgroups to fill 256 CUs: small-tile kernel
+  if (tiles < 5L * vidil_cu_count() / 8 && !any_size) return false;      // (160 on 256 CUs) too few workgroups to fill the chip: small-tile kernel
   if (a.K < 128) return false;
   if (a.dtype == VIDIL_DT_FP8 && (a.K % 128 != 0 || (a.lda != 0 && a.lda % 16 != 0))) return false;
   const long lda = a.lda > 0 ? a.lda : a.K;
@@ -491,7 +491,8 @@ static bool prefer_4w(const vidil_gemm_args& a) {
   if (a.epi == VIDIL_EPI_HEADS && a.T < 8) return false;   // (the 4-wave scatter steps (image, token) by 8 rows: gemm_epilogue.inc)
   if (const char* e = vidil_dev_env("VIDIL_GEMM4W")) return atoi(e) != 0;
   const long tiles = (long)((a.M + 255) / 256) * ((a.N + 255) / 256);
-  static const long min_tiles = [] { const char* e = getenv("VIDIL_GEMM4W_MIN_TILES"); return e ? atol(e) : 384L; }();
+  // (1.5 workgroup rounds: 384 tiles on 256 CUs)
+  static const long min_tiles = [] { const char* e = getenv("VIDIL_GEMM4W_MIN_TILES"); return e ? atol(e) : 3L * vidil_cu_count() / 2; }();
   if (a.dtype == VIDIL_DT_FP8) {   // (round 4: the 4-wave main loop takes e4m3 operands too; same grid rule, plain epilogues;
     //                                $VIDIL_GEMM4W_FP8=0 keeps the fp8 GEMMs on the 8-wave kernel: the A/B of DESIGN.md §5)
     static const bool fp8_4w = [] { const char* e = getenv("VIDIL_GEMM4W_FP8"); return !(e && e[0] == '0'); }();
@@ -534,7 +535,7 @@ bool vidil_gemm4w128_wanted(const vidil_gemm_args& a) {
   if (mode == 1) return true;
   const long t256 = (long)((a.M + 255) / 256) * ((a.N + 255) / 256);
   const long t128 = (long)((a.M + 127) / 128) * ((a.N + 255) / 256);
-  return t256 < 160 && t128 >= 200 && a.K >= 512;
+  return t256 < 5L * vidil_cu_count() / 8 && t128 >= 25L * vidil_cu_count() / 32 && a.K >= 512;   // (160 / 200 on 256 CUs)
 }
 int vidil_gemm4w128_launch(const vidil_gemm_args& a, hipStream_t s) { return vidil_gemm4w_launch(a, s, 2); }
 
