@@ -114,7 +114,10 @@ __device__ __forceinline__ RowInfo row_info(const P& p, int v, int first, int ro
 // executed at all.  Any reference is exact in exact arithmetic (softmax is shift invariant); a stale one lets the
 // probabilities of a tile reach e^5 = 148 instead of 1, far inside the range of the 16-bit operand they are rounded to,
 // and the row sum stays in f32.  p = 2^(s*log2e - m*log2e): one FMA and one v_exp_f32 per score.
-constexpr float kLazy = 5.0f;
+#ifndef VIDIL_ATTN_KLAZY
+#define VIDIL_ATTN_KLAZY 5.0f
+#endif
+constexpr float kLazy = VIDIL_ATTN_KLAZY;   // (developer: -DVIDIL_ATTN_KLAZY=0.0f is the exact running maximum)
 constexpr float kLog2e = 1.44269504088896340736f;
 // Part 1 of a key tile: scores S -> probabilities rounded to T and packed as the two 16-key operands of P.V (pf), with the
 // row's reference m, its sum l and — when the reference moves — the accumulators O brought up to date.
