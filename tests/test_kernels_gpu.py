@@ -399,6 +399,34 @@ def test_streamed_tower_attention_equals_the_staged_kernel_and_fp64(B, H, T, dt,
     assert torch.allclose(outs["1"][:nb * T].double(), ref, rtol=tol, atol=tol), (outs["1"][:nb * T].double() - ref).abs().max()
 
 
+@pytest.mark.parametrize("Nq,Nk,Tq_cap,Tk_cap", [(150, 200, 150, 200), (197, 197, 256, 224), (224, 193, 224, 256), (129, 224, 160, 224)])
+def test_streamed_tower_attention_with_unequal_lengths_and_capacities(Nq, Nk, Tq_cap, Tk_cap, monkeypatch):
+    """Query count != key count and buffers with spare capacity (row strides come from the capacities, not the lengths;
+    waves whose 32 rows lie past Nq compute on a clamped row and store nothing): streamed == staged bit for bit, and the
+    rows past Nq of the output buffer stay untouched."""
+    k = _k()
+    B, H = 9, 5
+    q = torch.zeros(B, H, Tq_cap, 64)
+    kk = torch.full((B, H, Tk_cap, 64), float("nan"))
+    v = torch.full((B, H, Tk_cap, 64), float("nan"))
+    q[:, :, :Nq] = _rand(B, H, Nq, 64, seed=150) * 0.125
+    kk[:, :, :Nk] = _rand(B, H, Nk, 64, seed=151)
+    v[:, :, :Nk] = _rand(B, H, Nk, 64, seed=152)
+    q16, k16, v16 = q.half().to(DEV), kk.half().to(DEV), v.half().to(DEV)
+    outs = {}
+    for mode in ("1", "0"):
+        monkeypatch.setenv("VIDIL_ATTN_STREAM", mode)
+        out = torch.full((B * Nq + 3, H * 64), 7.0, dtype=torch.float16, device=DEV)
+        k.attention(q16, k16, v16, out, Bq=B, H=H, Nq=Nq, Nk=Nk, Tq_cap=Tq_cap, Tk_cap=Tk_cap, NP=0)
+        torch.cuda.synchronize()
+        outs[mode] = out
+    assert torch.equal(outs["1"].view(torch.int16), outs["0"].view(torch.int16))
+    assert (outs["1"][B * Nq:] == 7.0).all()
+    s = q16[:, :, :Nq].double() @ k16[:, :, :Nk].double().transpose(-1, -2)
+    ref = (torch.softmax(s, -1) @ v16[:, :, :Nk].double()).permute(0, 2, 1, 3).reshape(B * Nq, H * 64)
+    assert torch.allclose(outs["1"][:B * Nq].double(), ref, rtol=3e-3, atol=3e-3)
+
+
 def test_streamed_tower_attention_is_the_kernel_the_towers_launch():
     """rocprofv3-free check of the dispatch: the launch-name entry point is not available for attention, so count through
     the env switch — with the stream form disabled and enabled the outputs agree (above) and the error text of an
