@@ -624,6 +624,60 @@ def test_logsoftmax_topk(nb, V, ban):
     assert torch.allclose(s.cpu(), rs, rtol=1e-5, atol=1e-5)
 
 
+def test_logsoftmax_topk_on_structured_rows():
+    """Rows built against the candidate filter of `lsm_topk_kernel` (a wave-uniform lower bound of the row's K-th best logit
+    below which elements are skipped): ramps (every element a new maximum, or none after the first), a row whose six best
+    logits all belong to ONE thread's slice (indices 8 + n * 1024) and one where they belong to one wave, constant rows
+    (every score ties: the order is the flat index), near-ties one f32 ulp apart.  Reference: f32 log-softmax + beam score,
+    ordered by (score descending, flat index ascending) — the order of `oracle/beam_ref.py`."""
+    k = _k()
+    B, nb, V = 3, 3, 30524
+    g = torch.Generator().manual_seed(52)
+    rows = torch.zeros(B * nb, V)
+    rows[0] = torch.linspace(-4.0, 6.0, V)
+    rows[1] = torch.linspace(6.0, -4.0, V)
+    rows[2] = 0.5
+    rows[2, 8 + 1024 * torch.arange(7)] = torch.tensor([3.0, 2.5, 2.75, 3.25, 2.9, 3.1, 2.6])     # one thread's slice
+    rows[3] = 1.0
+    rows[4] = 1.0
+    rows[5] = torch.randn(V, generator=g)
+    rows[6] = torch.randn(V, generator=g) * 0.01
+    rows[6, 40 + 4 * torch.arange(8)] = torch.tensor([5.0, 5.5, 4.5, 6.0, 5.25, 4.75, 5.75, 4.9])   # one wave's lanes
+    rows[7] = -2.0
+    base = torch.tensor(3.0)
+    rows[7, [17, 900, 30000, 12345, 4, 29999, 7777]] = torch.stack([base, torch.nextafter(base, torch.tensor(9.0)), base,
+                                                                     torch.nextafter(base, torch.tensor(0.0)), base, base, base])
+    rows[8] = torch.randn(V, generator=g) * 3
+    bs = torch.tensor([0.0, -0.7, -0.2, -1.0, -1.5, -0.1, -0.3, -0.25, -0.9])
+    lp = torch.log_softmax(rows, -1) + bs[:, None]
+    for ban in (-1, 8):
+        c = lp.clone()
+        if ban >= 0:
+            c[:, ban] = float("-inf")
+        c = c.view(B, nb * V).numpy()
+        s, i = k.logsoftmax_topk(rows.to(DEV), bs.to(DEV), B, nb, ban)
+        s, i = s.cpu().numpy(), i.cpu().numpy()
+        for b in range(B):
+            # the device's own scores decide ties the way the oracle's would: check (1) the returned order is sorted by
+            # (score desc, index asc), (2) the returned scores are the row values, (3) nothing better was left out
+            got_s, got_i = s[b], i[b]
+            assert np.allclose(got_s, c[b][got_i], rtol=2e-6, atol=2e-6)
+            key = list(zip(-got_s, got_i))
+            assert key == sorted(key), (b, ban, key)
+            order = np.lexsort((np.arange(nb * V), -c[b]))[:2 * nb]
+            worst = got_s[-1]
+            left_out = [j for j in order if j not in set(got_i.tolist())]
+            assert all(c[b][j] <= worst + 2e-6 for j in left_out), (b, ban, left_out)
+            # where the reference's scores are distinct beyond rounding (next one included), the indices are exactly its own
+            full = np.lexsort((np.arange(nb * V), -c[b]))[:2 * nb + 1]
+            if np.all(np.abs(np.diff(c[b][full])) > 1e-5):
+                assert got_i.tolist() == order.tolist(), (b, ban)
+    # constant rows: every score of beams 0 and 1 ties -> the flat-index order exactly
+    const_img = torch.stack([rows[3], rows[4], rows[3]])
+    s2, i2 = k.logsoftmax_topk(const_img.to(DEV), torch.tensor([-1.0, -1.0, -2.0]).to(DEV), 1, nb, -1)
+    assert i2[0].cpu().tolist() == [0, 1, 2, 3, 4, 5]            # beams 0 and 1 tie everywhere: lowest flat indices first
+
+
 def test_gemm_arena_epilogue():
     """EPI_ARENA: Q rows + K/V rows appended at [position][slot][H*64]; decode step (T=1) and prompt block (T=P)."""
     k = _k()

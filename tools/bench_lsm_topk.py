@@ -8,6 +8,7 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from vidil_amd import kernels as K  # noqa: E402
 
 B, nb, V = int(sys.argv[1]) if len(sys.argv) > 1 else 3584, 3, 30524
+torch.manual_seed(0)
 logits = torch.randn(B * nb, V, device="cuda")
 bs = torch.randn(B * nb, device="cuda")
 for _ in range(3):

@@ -109,7 +109,17 @@ __global__ __launch_bounds__(256) void lsm_topk_kernel(const float* __restrict__
       }
     };
     if (vec) {
-      for (int i = tid * 4; i < V; i += 1024) {
+      // Candidate filter (second half of round 4).  A thread sees ~120 logits of a row, so some lane of a wave has a new
+      // personal best at nearly every element and the (divergent) sorted insertion ran for all of them: ~200 instructions
+      // per 16-byte load, the kernel's bound (2.9 TB/s).  `thr` is a wave-uniform LOWER bound of the row's K-th best logit
+      // — the K-th largest of the lanes' current best candidates, which are K distinct elements of the row — minus a margin
+      // far wider than any pair of logits whose rounded scores could tie: an element below it cannot be among the row's K
+      // best in the (score, index) order of the final merge, so skipping it changes no output (same digests, 459 -> 347 us;
+      // the bound re-derived every 2 / 4 / 8 / 16 loads: 430 / 360 / 347 / 358 us; four loads per thread issued ahead of
+      // their use on top of it: 374 us — slower, left out).
+      float thr = -INFINITY;
+      int it = 0;
+      for (int i = tid * 4; i < V; i += 1024, ++it) {
         const f32x4 x = *(const f32x4*)(row + i);
         const float mx = fmaxf(fmaxf(x[0], x[1]), fmaxf(x[2], x[3]));
         if (mx > m) {                                   // (m = -inf at first: sum = 0 * 2^-inf = 0)
@@ -119,9 +129,23 @@ __global__ __launch_bounds__(256) void lsm_topk_kernel(const float* __restrict__
         const float ml = m * L2E;
         sum += (__builtin_amdgcn_exp2f(__builtin_fmaf(x[0], L2E, -ml)) + __builtin_amdgcn_exp2f(__builtin_fmaf(x[1], L2E, -ml))) +
                (__builtin_amdgcn_exp2f(__builtin_fmaf(x[2], L2E, -ml)) + __builtin_amdgcn_exp2f(__builtin_fmaf(x[3], L2E, -ml)));
+        if (__builtin_amdgcn_ballot_w64(mx >= thr) != 0) {
 #pragma unroll
-        for (int e = 0; e < 4; ++e)
-          if (i + e != ban) consider_raw(x[e], i + e);  // (the banned token counts in the softmax, never as a candidate)
+          for (int e = 0; e < 4; ++e)
+            if (i + e != ban && x[e] >= thr) consider_raw(x[e], i + e);  // (the banned token counts in the softmax, never as a candidate)
+        }
+        if ((it & 7) == 1) {
+          float c = rs[0], t = -INFINITY;
+#pragma unroll
+          for (int r = 0; r < K; ++r) {
+            t = wave_max(c);
+            const unsigned long long holders = __builtin_amdgcn_ballot_w64(c == t);
+            if (holders == 0) break;                     // (NaNs: leave the bound where it is)
+            if ((int)(threadIdx.x & 63) == __builtin_ctzll(holders)) c = -INFINITY;   // one holder leaves per round
+          }
+          const float bound = t - 1e-5f * (fabsf(t) + 64.f);
+          if (bound > thr) thr = bound;                  // (t = -inf while the wave has seen fewer than K elements)
+        }
       }
     } else {
       for (int i = tid; i < V; i += 256) {
