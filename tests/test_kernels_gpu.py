@@ -427,6 +427,31 @@ def test_streamed_tower_attention_with_unequal_lengths_and_capacities(Nq, Nk, Tq
     assert torch.allclose(outs["1"][:B * Nq].double(), ref, rtol=3e-3, atol=3e-3)
 
 
+@pytest.mark.parametrize("dt", ["f16", "bf16"])
+def test_streamed_tower_attention_fp8_output_rows_equal_the_staged_kernel(dt, monkeypatch):
+    """The fp8 tower mode's attention output (e4m3 bytes, the proj GEMM's operand) from the streamed kernel: every byte equals
+    the staged kernel's, rows past the last one untouched."""
+    k = _k()
+    tdt = torch.float16 if dt == "f16" else torch.bfloat16
+    B, H, T = 37, 12, 197
+    q16 = (_rand(B, H, T, 64, seed=160) * 0.125).to(tdt).to(DEV)
+    k16 = _rand(B, H, T, 64, seed=161).to(tdt).to(DEV)
+    v16 = (_rand(B, H, T, 64, seed=162) * 3).to(tdt).to(DEV)
+    outs = {}
+    for mode in ("1", "0"):
+        monkeypatch.setenv("VIDIL_ATTN_STREAM", mode)
+        out = torch.full((B * T + 2, H * 64), 0x55, dtype=torch.uint8, device=DEV).view(torch.float8_e4m3fn)
+        k.attention(q16, k16, v16, out, Bq=B, H=H, Nq=T, Nk=T, Tq_cap=T, Tk_cap=T, NP=0)
+        torch.cuda.synchronize()
+        outs[mode] = out.view(torch.uint8)
+    assert torch.equal(outs["1"], outs["0"])
+    assert (outs["1"][B * T:] == 0x55).all()
+    s = q16[:2].double() @ k16[:2].double().transpose(-1, -2)
+    ref = (torch.softmax(s, -1) @ v16[:2].double()).permute(0, 2, 1, 3).reshape(2 * T, H * 64)
+    got = outs["1"][:2 * T].view(torch.float8_e4m3fn).double()
+    assert torch.allclose(got, ref, rtol=7e-2, atol=2e-2), (got - ref).abs().max()      # (e4m3: 3 mantissa bits)
+
+
 def test_streamed_tower_attention_is_the_kernel_the_towers_launch():
     """rocprofv3-free check of the dispatch: the launch-name entry point is not available for attention, so count through
     the env switch — with the stream form disabled and enabled the outputs agree (above) and the error text of an

