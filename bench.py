@@ -124,6 +124,7 @@ class GemmTimer:
 
     def __init__(self):
         self.records = []
+        self.shapes = []          # (M, N, K) of every record, for --gemm-shapes
 
     def install(self):
         from vidil_amd import kernels as K
@@ -141,6 +142,7 @@ class GemmTimer:
             if "out" not in kw and not (kw.get("heads") or kw.get("patch") or kw.get("arena")):
                 kw = dict(kw, out=r)
             timer.records.append((K.gemm_kernel_name(a, w, bias, **kw), 2.0 * M * N * Kd, e0, e1))
+            timer.shapes.append((M, N, Kd))
             return r
 
         K.gemm = timed
@@ -168,6 +170,19 @@ class GemmTimer:
 
         K.gemm = self._orig
         K.attention, K.beam_attention, K.scan_topk = self._orig_attn, self._orig_battn, self._orig_scan
+
+    def shape_table(self):
+        """Developer (--gemm-shapes): launches, total ms and TFLOP/s per (kernel, M, N, K) of the instrumented step."""
+        torch.cuda.synchronize()
+        agg = {}
+        for (name, flops, e0, e1), shp in zip(self.records, self.shapes):
+            a = agg.setdefault((name, shp), [0, 0.0, 0.0])
+            a[0] += 1
+            a[1] += flops
+            a[2] += e0.elapsed_time(e1) * 1e-3
+        rows = sorted(agg.items(), key=lambda kv: -kv[1][2])
+        return "\n".join(f"{v[2] * 1e3:9.3f} ms {v[0]:5d} x  M={k[1][0]:7d} N={k[1][1]:6d} K={k[1][2]:5d}  {v[1] / v[2] / 1e12:7.1f} TFLOP/s  {k[0]}"
+                         for k, v in rows)
 
     def summary(self):
         torch.cuda.synchronize()
@@ -479,6 +494,7 @@ def main():
     ap.add_argument("--no-secondary", action="store_true", help="skip the secondary f16 / parity-mode / text-tower measurements")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
+    ap.add_argument("--gemm-shapes", action="store_true", help="developer: per-shape table of the instrumented step's GEMM launches on stderr")
     ap.add_argument("--itm-short-circuit", action="store_true",
                     help="secondary number: score a caption on the frame it came from first and on the other frames only if "
                          "it failed there (identical kept lists; the headline scores every pair like the reference)")
@@ -617,6 +633,8 @@ def main():
             st["graphs_ok"] = True
         timer.remove()
         agg = timer.summary()
+        if args.gemm_shapes:
+            print(timer.shape_table(), file=sys.stderr, flush=True)
         key = max(agg, key=lambda k: agg[k][2])
         n, flops, secs = agg[key]
         ach = flops / secs / 1e12
