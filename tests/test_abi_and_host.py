@@ -109,7 +109,10 @@ def test_argument_validation_without_a_gpu():
     # a mid-size grid (10,752 decode rows x 768 columns: 126 tiles of 256^2, 252 of 128 x 256) to its 128-row-tile form;
     # a small problem to the small-tile kernel
     import os
-    if not any(k in os.environ for k in ("VIDIL_GEMM4W", "VIDIL_GEMM4W128", "VIDIL_GEMM256", "VIDIL_GEMM4W_MIN_TILES")):
+    if not any(k in os.environ for k in ("VIDIL_GEMM4W", "VIDIL_GEMM4W128", "VIDIL_GEMM256", "VIDIL_GEMM4W_MIN_TILES", "VIDIL_GEMM4W_F32")):
+        g.K = 3072            # ... unless the reduction is long (round 4: the towers' last fc2, the parity mode's K-tripled GEMMs)
+        assert lib.vidil_gemm_kernel_name(ctypes.byref(g), buf, 128) == 0 and buf.value == b"gemm4w_kernel<__bf16, __bf16, 1, 0, false, false, false, 4>"
+        g.K = 768
         g.epi = 0
         assert lib.vidil_gemm_kernel_name(ctypes.byref(g), buf, 128) == 0 and buf.value == b"gemm4w_kernel<__bf16, __bf16, 0, 0, false, false, false, 4>"
         g.M, g.epi = 10752, 1

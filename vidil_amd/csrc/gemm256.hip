@@ -485,7 +485,7 @@ int vidil_gemm4w_launch(const vidil_gemm_args& a, hipStream_t s, int tm);   // g
 // are a couple of tiles per CU, and loses on the plain f32 epilogue (+7 %) and on small grids (and is not built for fp8
 // operands).  $VIDIL_GEMM4W = 0 / 1 forces one kernel (developer).
 #ifndef VIDIL_GEMM4W_F32_DEFAULT
-#define VIDIL_GEMM4W_F32_DEFAULT 0
+#define VIDIL_GEMM4W_F32_DEFAULT -1   // (-1: by K, see prefer_4w)
 #endif
 static bool prefer_4w(const vidil_gemm_args& a) {
   if (a.epi == VIDIL_EPI_HEADS && a.T < 8) return false;   // (the 4-wave scatter steps (image, token) by 8 rows: gemm_epilogue.inc)
@@ -508,9 +508,11 @@ static bool prefer_4w(const vidil_gemm_args& a) {
       return true;
     case VIDIL_EPI_F32: {
       // the LN-fold producers, with or without a residual LayerNorm: always; the plain f32 epilogue (the parity mode's K-tripled
-      // GEMMs, the LM head): measured per round — round 3: +7 % on gemm256's side; $VIDIL_GEMM4W_F32 = 0 / 1 decides (A/B switch)
+      // GEMMs, the towers' last fc2, the LM head) by K: with 4 output bytes per 2K flop the f32 stores weigh on short reductions —
+      // round 4, same box, whole bench: the last-block fc2 (K = 3072) 1,040 -> 1,160 TFLOP/s on the 4-wave kernel, the LM head
+      // (10,752 x 30,524, K = 768) 838 -> 708.  $VIDIL_GEMM4W_F32 = 0 / 1 forces one kernel (A/B switch).
       static const int f32_4w = [] { const char* e = getenv("VIDIL_GEMM4W_F32"); return e ? atoi(e) : VIDIL_GEMM4W_F32_DEFAULT; }();
-      return a.ln_stats_out != nullptr || (f32_4w != 0 && a.act == VIDIL_ACT_NONE);
+      return a.ln_stats_out != nullptr || (a.act == VIDIL_ACT_NONE && (f32_4w > 0 || (f32_4w < 0 && a.K >= 1536)));
     }
     default:
       return false;
