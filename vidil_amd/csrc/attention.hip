@@ -140,9 +140,7 @@ __device__ __forceinline__ void softmax_tile(f32x16& S, int key0, int klim, bool
   float mt = S[0];
 #pragma unroll
   for (int r = 1; r < 16; ++r) mt = fmaxf(mt, S[r]);
-#if !(defined(VIDIL_ATTN_ABLATE) && (VIDIL_ATTN_ABLATE & 32))
   mt = fmaxf(mt, __shfl_xor(mt, 32, 64));
-#endif
   if (FIRST) {
     m = mt;
   } else if (!LAZY) {
@@ -172,11 +170,7 @@ __device__ __forceinline__ void softmax_tile(f32x16& S, int key0, int klim, bool
   float ps = 0.f;
 #pragma unroll
   for (int r = 0; r < 16; ++r) {
-#if defined(VIDIL_ATTN_ABLATE) && (VIDIL_ATTN_ABLATE & 16)
-    const float e = S[r] - mc;
-#else
     const float e = __builtin_amdgcn_exp2f(__builtin_fmaf(S[r], kLog2e, -mc));
-#endif
     S[r] = e;
     ps += e;
   }
