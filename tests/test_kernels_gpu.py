@@ -149,7 +149,7 @@ def test_gemm256_f16_and_f32(M, N, K):
     assert torch.equal(o_small, o32[sub])
 
 
-def test_gemm256_rows_times_k_beyond_2_to_the_31():
+def test_gemm256_rows_times_k_beyond_2_to_the_31(monkeypatch):
     """A batch of 3,584+ frames makes M * K of the fc2 GEMM (706,048 x 3,072) exceed 2^31 elements: the staging offsets
     are 32-bit but relative to the tile's row panel, so the rows past the 2^31st element must come out right (they did
     not exist for the kernel before: such problems were refused)."""
@@ -159,12 +159,18 @@ def test_gemm256_rows_times_k_beyond_2_to_the_31():
     a = (torch.randn(M, K, generator=g, device=DEV) * 0.5).half()
     w = (torch.randn(N, K, generator=g, device=DEV) * 0.05).half()
     bias = torch.randn(N, generator=g, device=DEV)
-    assert k.gemm_kernel_name(a, w, bias, out_dtype=torch.float32).startswith("gemm256_kernel")
-    out = k.gemm(a, w, bias, out_dtype=torch.float32)
-    for lo in (0, 349_000, 699_040, M - 300):           # 699,051 is the first row past 2^31 elements
-        rows = slice(lo, lo + 300)
-        ref = a[rows].float() @ w.float().t() + bias
-        assert torch.allclose(out[rows], ref, rtol=1e-4, atol=3e-3), (lo, (out[rows] - ref).abs().max().item())
+    # both 256-row kernels (a long reduction with plain f32 outputs goes to the 4-wave one since round 4; $VIDIL_GEMM4W forces either)
+    outs = []
+    for force, name in (("0", "gemm256_kernel"), ("1", "gemm4w_kernel")):
+        monkeypatch.setenv("VIDIL_GEMM4W", force)
+        assert k.gemm_kernel_name(a, w, bias, out_dtype=torch.float32).startswith(name)
+        out = k.gemm(a, w, bias, out_dtype=torch.float32)
+        for lo in (0, 349_000, 699_040, M - 300):           # 699,051 is the first row past 2^31 elements
+            rows = slice(lo, lo + 300)
+            ref = a[rows].float() @ w.float().t() + bias
+            assert torch.allclose(out[rows], ref, rtol=1e-4, atol=3e-3), (name, lo, (out[rows] - ref).abs().max().item())
+        outs.append(out)
+    assert torch.equal(outs[0], outs[1])
 
 
 def test_gemm256_transpose_detecting_and_tails():
