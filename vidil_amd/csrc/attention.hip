@@ -700,7 +700,7 @@ __global__ __launch_bounds__(512, 4) void attn_stream_kernel(const AttnP<T> p) {
     for (int ks = 0; ks < 4; ++ks)
       dst[ks] = __builtin_bit_cast(f16x8, __builtin_amdgcn_raw_buffer_load_b128(rsrc_q, q_off + ks * 32, ub, 0));
   };
-  const uint32_t row_off = valid ? (uint32_t)row * p.ldo * 2 : 0x80000000u;
+  const uint32_t row_off = valid ? (uint32_t)row * p.ldo * (OUT8 ? 1 : 2) : 0x80000000u;   // bytes inside the unit's output window
   load_q(u, qf);
   asm volatile("" ::"v"(qf[0]), "v"(qf[1]), "v"(qf[2]), "v"(qf[3]));   // (arrived: the loop is entered with nothing in flight)
   // Software pipeline of a row block: the four MFMAs of P.V of tile kt and the four of the NEXT tile's K.Q^T are issued
@@ -825,7 +825,7 @@ __global__ __launch_bounds__(512, 4) void attn_stream_kernel(const AttnP<T> p) {
       // the unit's output window: rows bk*Nq .. +Nq-1, this head's 64 columns onwards (out_mode 1: rows of e4m3 bytes)
       if constexpr (OUT8) {
         const __amdgpu_buffer_rsrc_t rsrc = uniform_rsrc((const char*)p.out + ((size_t)bk * p.Nq * p.ldo + h * 64), (uint32_t)p.Nq * p.ldo);
-        store_rows_stream_fp8(rsrc, row_off >> 1, O, inv, scratch);      // (0x80000000 >> 1 is still past any window)
+        store_rows_stream_fp8(rsrc, row_off, O, inv, scratch);
       } else {
         const __amdgpu_buffer_rsrc_t rsrc = uniform_rsrc(p.out + ((size_t)bk * p.Nq * p.ldo + h * 64), (uint32_t)p.Nq * p.ldo * 2);
         store_rows_stream<T>(rsrc, row_off, O, inv, scratch);
@@ -1122,15 +1122,12 @@ int launch_stream(const AttnP<T>& p, hipStream_t s) {
   constexpr int smem = NKT * (4096 + 4 * 1152) + 8 * 2048;   // (attn_stream_kernel: TILE)
   static_assert(2 * smem <= 160 * 1024, "two workgroups per CU");
   static bool attr_set = false;
-  static int n_cu = 0;
+  const int n_cu = vidil_cu_count();
   auto kern16 = attn_stream_kernel<T, NKT, false>;
   auto kern8 = attn_stream_kernel<T, NKT, true>;
   if (!attr_set) {
     hipError_t e = hipFuncSetAttribute((const void*)kern16, hipFuncAttributeMaxDynamicSharedMemorySize, smem);
     if (e == hipSuccess) e = hipFuncSetAttribute((const void*)kern8, hipFuncAttributeMaxDynamicSharedMemorySize, smem);
-    int dev = 0;
-    if (e == hipSuccess) e = hipGetDevice(&dev);
-    if (e == hipSuccess) e = hipDeviceGetAttribute(&n_cu, hipDeviceAttributeMultiprocessorCount, dev);
     if (e != hipSuccess) {
       vidil_set_error("attention: stream kernel setup failed: %s", hipGetErrorString(e));
       return VIDIL_ELAUNCH;
