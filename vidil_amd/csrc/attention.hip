@@ -494,9 +494,10 @@ __global__ __launch_bounds__(NW * 64, NW == 8 ? 4 : 2) void attn_lds_kernel(cons
           S = Elt<T>::mfma32(kf, qf[ks], S);
         }
         const bool need_mask = (k0 + kt * 32 + 32) > kmin;
-        softmax_pv_tile<T>(S, k0 + kt * 32, ri.klim, need_mask, m, l, O, [&](int dt, int hb) {
-          return *(const f16x8*)(Vs + (dt * 32 + l31) * VROW + (kt * 2 + hb) * 16 + 8 * hi);
-        });
+        auto vfrag = [&](int dt, int hb) { return *(const f16x8*)(Vs + (dt * 32 + l31) * VROW + (kt * 2 + hb) * 16 + 8 * hi); };
+        // (a scalar branch to the form without the 16 key tests: as one run-time flag they become selects on every tile)
+        if (need_mask) softmax_pv_tile<T, true>(S, k0 + kt * 32, ri.klim, true, m, l, O, vfrag);
+        else softmax_pv_tile<T, false>(S, k0 + kt * 32, ri.klim, false, m, l, O, vfrag);
       }
     }
     if (!active) break;
