@@ -432,7 +432,7 @@ def secondary_measurements(args, cap, flt, clip, step, frames, dev, parity_file,
     except Exception as e:
         out["secondary"]["parity_mix_full_step"] = {"value": None, "error": f"{type(e).__name__}: {e}"[:300]}
     cap.visual_encoder.set_parity_last_blocks(None)
-    set_parity_attention("f32", cap, clip)
+    set_parity_attention(None, cap, clip)
     set_parity_mode(False, cap, flt, clip)
     free_sessions()
     out["parity"] = parity
@@ -500,6 +500,13 @@ def main():
                          "it failed there (identical kept lists; the headline scores every pair like the reference)")
     ap.add_argument("--decode-streams", type=int, default=1,
                     help="parts of the batch whose beam searches run side by side on their own HIP streams (1 = one search over all images)")
+    ap.add_argument("--precision", choices=["plain", "qualified", "parity"], default="plain",
+                    help="plain: the throughput configuration (default).  qualified: the parity-QUALIFIED configuration — captioner (ViT + "
+                         "cross K|V + decoder + LM head) and CLIP on error-compensated f16 operands with the split-operand attention, "
+                         "filter on plain f16 operands: the cheapest configuration whose caption logits stay within 1e-3 ABSOLUTE of the "
+                         "fp32 reference at a trained model's logit scale and whose visual-token ranks equal the reference form "
+                         "(tests/test_trained_like_gpu.py).  parity: all three models compensated")
+    ap.add_argument("--parity-attn", choices=["f32", "split", "16"], default=None, help="developer: attention kind of the parity mode")
     ap.add_argument("--sequential", action="store_true",
                     help="CapFilt, then visual tokens (the reference's order) instead of vidil_amd.pipeline's interleaving")
     args = ap.parse_args()
@@ -534,7 +541,14 @@ def main():
     dev = torch.device("cuda", local)
 
     t_start = time.perf_counter()
+    if args.precision != "plain":
+        args.dtype = "f16"                       # (the parity precision mode is an f16 statement: hi + lo = 22 significant bits)
     cap, flt, clip, tok = build_models(dev, args.size, args.clip, args.vit, args.dtype)
+    if args.precision != "plain":
+        from vidil_amd.packing import set_parity_attention, set_parity_mode
+        set_parity_mode(True, *((cap, clip) if args.precision == "qualified" else (cap, flt, clip)))
+        if args.parity_attn:
+            set_parity_attention(args.parity_attn, cap, flt, clip)
     onto_embeds, onto_texts = synthetic_ontology(dim=clip.config.projection_dim)
     config = dict(caption=True, filter=True, filter_generated_only=True, keep_original_caption=False,
                   threshold=0.4, filter_mode="max_filter", generation_mode="beam", do_sentence_tokenization=False,

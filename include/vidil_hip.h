@@ -234,6 +234,17 @@ int vidil_attention(const void* q, const void* k, const void* vt, void* out,
 /*  out row (b*Nq + t), column h*64 + d, row stride ldo: out_mode 0 = f32;     */
 /*   out_mode 2 = dtype16 rows as three planes [hi | lo | hi] of ldo/3 columns */
 /*   (what VIDIL_DT_SPLIT3 outputs look like: the next compensated GEMM's A).  */
+/*  arith (ABI 10, round 5): 0 = plain f32 arithmetic (above); 1 = SPLIT-     */
+/*   OPERAND form on the 16-bit matrix instruction: every operand of the two   */
+/*   contractions as hi + lo of dtype16 (22 significant bits for f16), three    */
+/*   MFMAs per contraction (a_hi.b_hi + a_lo.b_hi + a_hi.b_lo, f32 sums), f32  */
+/*   softmax — ~1e-6 of the logit scale from f32 arithmetic at 1/5 of its cost. */
+/*   Dense forms only (the arena form stays f32).  With arith == 1, kv16 != 0:  */
+/*   k and v are NOT f32 rows but the 16-bit FRAGMENT TILES vidil_gemm writes   */
+/*   (heads epilogue, kv_tiled; [n_kv][H][kv_rows/32][2048] of dtype16, kv_rows */
+/*   a multiple of 32): the decode steps' cross-attention, at most 32 query rows */
+/*   per unit — Q (f32, in place) and the probabilities are split, K / V are    */
+/*   what the tiles hold (S = K.Q_lo + K.Q_hi, O = V.P_lo + V.P_hi).            */
 /* replaces (in that mode): models/vit.py:75-83; models/med.py:178-220; HF     */
 /* CLIPAttention.                                                              */
 /* ------------------------------------------------------------------------ */
@@ -255,6 +266,8 @@ typedef struct {
   const int32_t* anc;
   int32_t anc_ld, arena_rows;
   float scale;
+  int32_t arith;   /* 0: f32 arithmetic; 1: split-operand 16-bit MFMA (ABI 10, see above) */
+  int32_t kv16;    /* arith 1 only: k / v are dtype16 fragment tiles [n_kv][H][kv_rows/32][2048] */
 } vidil_attn_f32_args;
 int vidil_attention_f32(const vidil_attn_f32_args* args, void* stream);
 

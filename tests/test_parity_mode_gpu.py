@@ -448,11 +448,12 @@ def test_parity_mix_plain_vit_with_compensated_decoder_keeps_caption_logits_with
         assert len(worst) == 16 and max(worst) <= ABS_TOL, worst
     finally:
         cap.visual_encoder.set_parity_last_blocks(None)
-        set_parity_attention("f32", cap)
+        set_parity_attention(None, cap)
         cap.__dict__.pop("_decode_state", None)
 
 
-# ------------------------------------------------------------------------------- vidil_attention_f32 (round 4)
+# ------------------------------------------------------------------------------- vidil_attention_f32 (round 4; arith 1: round 5)
+@pytest.mark.parametrize("arith", [0, 1])    # 0: f32 arithmetic (f32-input MFMA / VALU); 1: split-operand 16-bit MFMA
 @pytest.mark.parametrize("Bq,H,Nq,Nk,kv_group,causal,use_len", [
     (3, 12, 197, 197, 1, False, False),     # ViT self-attention, read in place from a [M, 3C] projection output
     (4, 8, 13, 13, 1, True, True),          # CLIP text tower: causal + kv_len
@@ -462,7 +463,7 @@ def test_parity_mix_plain_vit_with_compensated_decoder_keeps_caption_logits_with
     (2, 4, 300, 300, 1, False, False),      # more than 128 rows per unit: several workgroups of the f32-MFMA kernel
     (3, 4, 40, 577, 1, True, False),        # causal with more keys than rows (19 key tiles)
 ])
-def test_attention_f32_vs_float64(Bq, H, Nq, Nk, kv_group, causal, use_len):
+def test_attention_f32_vs_float64(Bq, H, Nq, Nk, kv_group, causal, use_len, arith):
     k = _k()
     C = H * 64
     Bk = Bq // kv_group
@@ -479,7 +480,7 @@ def test_attention_f32_vs_float64(Bq, H, Nq, Nk, kv_group, causal, use_len):
         kv_len = torch.tensor([Nk, 5, 9, 1][:Bq], dtype=torch.int32)
     out32 = torch.zeros(Bq * Nq, C, dtype=torch.float32, device=DEV)
     out3 = torch.zeros(Bq * Nq, 3 * C, dtype=torch.float16, device=DEV)
-    args = dict(Bq=Bq, H=H, Nq=Nq, Nk=Nk, kv_group=kv_group, causal=causal, kv_len=None if kv_len is None else kv_len.to(DEV))
+    args = dict(Bq=Bq, H=H, Nq=Nq, Nk=Nk, kv_group=kv_group, causal=causal, kv_len=None if kv_len is None else kv_len.to(DEV), arith=arith)
     k.attention_f32(q, kk, v, out32, **args)
     k.attention_f32(q, kk, v, out3, **args)
     qd = q.double().cpu().view(Bq, Nq, H, 64).permute(0, 2, 1, 3)
@@ -494,7 +495,39 @@ def test_attention_f32_vs_float64(Bq, H, Nq, Nk, kv_group, causal, use_len):
     ref = (torch.softmax(s, -1) @ vd).permute(0, 2, 1, 3).reshape(Bq * Nq, C)
     e32 = (out32.cpu().double() - ref).abs().max().item()
     e3 = (_join(out3.cpu()).double() - ref).abs().max().item()
+    print(f"attention_f32 arith={arith} {Bq}x{H}x{Nq}x{Nk}: max|d| vs float64 {e32:.2e} (f32 rows) {e3:.2e} ([hi | lo | hi] rows)")
     assert e32 < 3e-6 and e3 < 5e-6, (e32, e3)        # (the 16-bit MFMA kernels: ~4e-4 on the same data)
+
+
+@pytest.mark.parametrize("B,nb,Nq,Nk", [(5, 3, 1, 197), (4, 3, 4, 197), (3, 1, 4, 50), (2, 3, 1, 577)])
+def test_attention_f32_split_form_on_16bit_fragment_tiles(B, nb, Nq, Nk):
+    """arith 1 + kv16 (the decode steps' cross-attention of the parity mode, round 5): f32 queries read in place and split into
+    hi + lo, the probabilities split alike, K / V = the 16-bit fragment tiles of the plain path.  Against float64 attention on
+    exactly those stored K / V values: only the split arithmetic is left (~1e-6); against the UNROUNDED K / V the difference is
+    the 16-bit rounding of K / V that tests/probes/probe_precision_design.py prices."""
+    k = _k()
+    from vidil_amd.kernels import kv_tile_offsets
+    H = 12
+    C = H * 64
+    Tc = (Nk + 31) // 32 * 32
+    q = _rand(B * nb * Nq, 3 * C, seed=80).to(DEV)[:, C:2 * C]            # (a column slice: row stride 3C)
+    kf, vf = _rand(B, H, Nk, 64, seed=81), _rand(B, H, Nk, 64, seed=82)
+    k16, v16 = kf.half(), vf.half()
+    ko, vo = kv_tile_offsets(Nk)
+    kt = torch.zeros(B, H, Tc * 64, dtype=torch.float16)
+    vt = torch.zeros(B, H, Tc * 64, dtype=torch.float16)
+    kt[:, :, ko.reshape(-1)] = k16.reshape(B, H, -1)
+    vt[:, :, vo.reshape(-1)] = v16.reshape(B, H, -1)
+    out3 = torch.zeros(B * nb * Nq, 3 * C, dtype=torch.float16, device=DEV)
+    k.attention_f32(q, kt.view(B, H, Tc, 64).to(DEV), vt.view(B, H, Tc, 64).to(DEV), out3, Bq=B * nb, H=H, Nq=Nq, Nk=Nk, kv_rows=Tc,
+                    kv_group=nb, arith=1, kv16=True)
+    qd = q.double().cpu().view(B * nb, Nq, H, 64).permute(0, 2, 1, 3)
+    kd = k16.double().repeat_interleave(nb, 0)
+    vd = v16.double().repeat_interleave(nb, 0)
+    ref = (torch.softmax((qd @ kd.transpose(-1, -2)) * 0.125, -1) @ vd).permute(0, 2, 1, 3).reshape(B * nb * Nq, C)
+    e = (_join(out3.cpu()).double() - ref).abs().max().item()
+    print(f"attention_f32 split / kv16 {B}x{nb}x{Nq}x{Nk}: max|d| vs float64 on the stored K / V {e:.2e}")
+    assert e < 5e-6, e
 
 
 def test_attention_f32_arena_form_follows_the_ancestry_table():

@@ -67,6 +67,7 @@ class AttnF32Args(C.Structure):
         ("anc", C.c_void_p),
         ("anc_ld", C.c_int32), ("arena_rows", C.c_int32),
         ("scale", C.c_float),
+        ("arith", C.c_int32), ("kv16", C.c_int32),
     ]
 
 
@@ -109,7 +110,7 @@ class VidilHipError(RuntimeError):
     pass
 
 
-ABI_VERSION = 9      # include/vidil_hip.h as this binding mirrors it (struct layouts, argument lists)
+ABI_VERSION = 10     # include/vidil_hip.h as this binding mirrors it (struct layouts, argument lists)
 
 
 def load():

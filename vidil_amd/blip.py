@@ -102,7 +102,8 @@ class DecoderSession:
         self.cross = self.bert.project_cross_kv(enc16, B, Te, tiled=tiled_cross)
         self.Tcap = max_length
         # (parity precision mode with vidil_attention_f32: the self-attention K / V cache is f32 too)
-        arena_dtype = torch.float32 if getattr(self.cross, "f32", False) else enc16.dtype
+        from .packing import parity_attention_f32
+        arena_dtype = torch.float32 if (self.bert.parity and parity_attention_f32(self.bert)) else enc16.dtype
         self.arena = BeamArena(self.L, self.Tcap, self.R, cfg.hidden_size, dev, dtype=arena_dtype)
         self.ws_prefill, self.ws_step = {}, {}
         self.logits = None

@@ -19,7 +19,7 @@ import torch
 import torch.nn as nn
 
 from . import kernels as K
-from .packing import FP8, PackedCache, fold_layernorm, parity_attention_f32, require_cuda, v32, w3, w3_patch, w8, w16, w16_patch
+from .packing import FP8, PackedCache, fold_layernorm, parity_attention_arith, parity_attention_f32, require_cuda, v32, w3, w3_patch, w8, w16, w16_patch
 
 CLIP_MEAN = (0.48145466, 0.4578275, 0.40821073)
 CLIP_STD = (0.26862954, 0.26130258, 0.27577711)
@@ -154,7 +154,7 @@ def _pack_layers(encoder, c, fuse=False, fp8=False, parity=False):
     return out
 
 
-def _run_layers(layers, x, B, T, H, eps, *, causal=False, kv_len=None, f32_attn=True):
+def _run_layers(layers, x, B, T, H, eps, *, causal=False, kv_len=None, f32_attn=True, arith=0):
     """Pre-LN CLIP encoder layers on the f32 residual stream x [B*T, D] (in place)."""
     dev = x.device
     M, D = x.shape
@@ -185,7 +185,8 @@ def _run_layers(layers, x, B, T, H, eps, *, causal=False, kv_len=None, f32_attn=
             K.layernorm(x, l["n1g"], l["n1b"], eps, out16=a3, split3=True)
             if f32_attn:    # (Q | K | V stay f32 and row-major: vidil_attention_f32 reads them in place)
                 K.gemm(a3, l["qkv_w3"], l["qkv_b"], out=qkv32)
-                K.attention_f32(qkv32[:, :D], qkv32[:, D:2 * D], qkv32[:, 2 * D:], o3, Bq=B, H=H, Nq=T, Nk=T, causal=causal, kv_len=kv_len)
+                K.attention_f32(qkv32[:, :D], qkv32[:, D:2 * D], qkv32[:, 2 * D:], o3, Bq=B, H=H, Nq=T, Nk=T, causal=causal, kv_len=kv_len,
+                                arith=arith)
             else:
                 K.gemm(a3, l["qkv_w3"], l["qkv_b"], heads=heads)
                 K.attention(q, k, vt, o3, Bq=B, H=H, Nq=T, Nk=T, Tq_cap=T, Tk_cap=T, NP=NP, causal=causal, kv_len=kv_len, split3=True)
@@ -337,7 +338,7 @@ class CLIPModel(PackedCache, nn.Module):
         K.gemm(patches16, p["pe_w3"] if par else p["pe_w"], None, patch=dict(out=x, pos=p["pos"], tpi=P))
         K.set_cls_row(x, p["cls"], p["pos"], B, T, D)
         K.layernorm(x, p["pre_g"], p["pre_b"], vc.layer_norm_eps, out32=x)
-        _run_layers(p["vlayers"], x, B, T, H, vc.layer_norm_eps, f32_attn=parity_attention_f32(self))
+        _run_layers(p["vlayers"], x, B, T, H, vc.layer_norm_eps, f32_attn=parity_attention_f32(self), arith=parity_attention_arith(self))
         pooled16 = torch.empty((B, (3 if par else 1) * D), dtype=cdt, device=dev)
         pooled32 = torch.empty((B, D), dtype=torch.float32, device=dev) if pooled else None
         K.layernorm(x, p["post_g"], p["post_b"], vc.layer_norm_eps, M=B, D=D, x_stride=T * D, out16=pooled16,
@@ -391,7 +392,8 @@ class CLIPModel(PackedCache, nn.Module):
         kv_len = None
         if attention_mask is not None:
             kv_len = attention_mask.to(dev).sum(dim=1).to(torch.int32).contiguous()
-        _run_layers(p["tlayers"], x, N, L, H, tc.layer_norm_eps, causal=True, kv_len=kv_len, f32_attn=parity_attention_f32(self))
+        _run_layers(p["tlayers"], x, N, L, H, tc.layer_norm_eps, causal=True, kv_len=kv_len, f32_attn=parity_attention_f32(self),
+                    arith=parity_attention_arith(self))
         if tc.eos_token_id == 2:
             pos = ids32.argmax(dim=-1)
         else:

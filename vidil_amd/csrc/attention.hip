@@ -52,6 +52,11 @@ struct AttnP {
   int rb;                      // staged kernel, single key chunk: rounds of NW row blocks per workgroup (launch_lds)
   int ostage;                  // staged kernel: 2 KiB of LDS per wave behind K / V^T for the output transposition (launch_lds:
                                // only where two workgroups per CU still fit with it)
+  // direct kernel, split-operand form (vidil_attention_f32 arith = 1 with 16-bit K / V tiles): the queries are f32 rows read in
+  // place — row (qb * Nq + t) * ldq32, head h at column h * 64 — scaled by q_scale and split into hi + lo in the kernel
+  const float* q32;
+  long long ldq32;
+  float q_scale;
 };
 
 constexpr int KROW = 72;  // halfs per K row in LDS (64 + 8 pad)
@@ -195,6 +200,54 @@ __device__ __forceinline__ void softmax_pv_tile(f32x16& S, int key0, int klim, b
       const typename Elt<T>::x8 vf = vfrag(dt, hb);
       // O^T[d][q] += V^T[d][keys] · P^T[keys][q]
       O[dt] = Elt<T>::mfma32(vf, pf[hb], O[dt]);
+    }
+  }
+}
+
+// The same tile with the PROBABILITIES as hi + lo (split-operand form: O += V.P_lo + V.P_hi, the values 16-bit as stored): exact
+// running maximum, straight-line code.
+template <typename T, typename VFrag>
+__device__ __forceinline__ void softmax_pv_tile_psplit(f32x16& S, int key0, int klim, bool need_mask, float& m, float& l,
+                                                       f32x16 (&O)[2], VFrag&& vfrag) {
+  const int hi = (threadIdx.x & 63) >> 5;
+  if (need_mask) {
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int key = key0 + (r & 3) + 8 * (r >> 2) + 4 * hi;
+      if (key >= klim) S[r] = -INFINITY;
+    }
+  }
+  float mt = S[0];
+#pragma unroll
+  for (int r = 1; r < 16; ++r) mt = fmaxf(mt, S[r]);
+  mt = fmaxf(mt, __shfl_xor(mt, 32, 64));
+  const float mn = fmaxf(m, mt);
+  const float mc = (mn == -INFINITY ? 0.f : mn) * kLog2e;
+  const float alpha = __builtin_amdgcn_exp2f(__builtin_fmaf(m, kLog2e, -mc));   // m == -inf -> 0
+  l *= alpha;
+  m = mn;
+#pragma unroll
+  for (int dt = 0; dt < 2; ++dt)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) O[dt][r] *= alpha;
+  typename Elt<T>::x8 ph[2], pl[2];
+  float ps = 0.f;
+#pragma unroll
+  for (int r = 0; r < 16; ++r) {
+    const float e = __builtin_amdgcn_exp2f(__builtin_fmaf(S[r], kLog2e, -mc));
+    ps += e;
+    const T eh = Elt<T>::from_f32(e);
+    ph[r >> 3][r & 7] = eh;
+    pl[r >> 3][r & 7] = Elt<T>::from_f32(e - (float)eh);
+  }
+  l += ps;
+#pragma unroll
+  for (int hb = 0; hb < 2; ++hb) {
+#pragma unroll
+    for (int dt = 0; dt < 2; ++dt) {
+      const typename Elt<T>::x8 vf = vfrag(dt, hb);
+      O[dt] = Elt<T>::mfma32(vf, pl[hb], O[dt]);
+      O[dt] = Elt<T>::mfma32(vf, ph[hb], O[dt]);
     }
   }
 }
@@ -852,7 +905,12 @@ __global__ __launch_bounds__(512, 4) void attn_stream_kernel(const AttnP<T> p) {
 
 // ------------------------------------------------------------------ direct (no K/V staging) kernel
 // rows <= 32.  4 waves; wave w handles key tiles w, w+4, ...; partials merged by wave 0.
-template <typename T, int NKT>
+// QS (split-operand form, the parity precision mode's decode cross-attention): f32 queries split into hi + lo in the kernel and
+// the probabilities split alike — S = K.Q_lo + K.Q_hi, O += V.P_lo + V.P_hi — against the SAME 16-bit K / V tiles.  Which of the
+// four operands need more than 16 bits was measured on the CPU oracle (tests/probes/probe_precision_design.py, trained-like
+// statistics, of the logit scale): Q 1.7e-4, P 6.3e-5, V 2.1e-5, K 1.0e-5 — with Q and P split the 16-bit K / V leave 3.0e-5 where
+// the budget of "1e-3 absolute" at max|logit| = 16 is 6.4e-5, at the byte traffic of the plain kernel (f32 K / V: twice the bytes).
+template <typename T, int NKT, bool QS = false>
 __global__ __launch_bounds__(256) void attn_direct_kernel(const AttnP<T> p) {
   using f16 = T;
   using f16x8 = typename Elt<T>::x8;
@@ -883,8 +941,21 @@ __global__ __launch_bounds__(256) void attn_direct_kernel(const AttnP<T> p) {
   const f16* vg = p.vt + ((size_t)bk * p.H + h) * 64 * (size_t)(p.tiled ? p.Tk_cap : p.NP);
   const int ntiles = (nk + 31) >> 5;
   if (wave < ntiles) {
-    f16x8 qf[4];
-    {
+    f16x8 qf[4], ql[QS ? 4 : 1];
+    if constexpr (QS) {
+      const float* qg = p.q32 + ((size_t)ri.qb * p.Nq + ri.t) * p.ldq32 + h * 64 + hi * 8;
+#pragma unroll
+      for (int ks = 0; ks < 4; ++ks) {
+        const f32x4 a = *(const f32x4*)(qg + ks * 16) * p.q_scale, b = *(const f32x4*)(qg + ks * 16 + 4) * p.q_scale;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          qf[ks][e] = Elt<T>::from_f32(a[e]);
+          ql[ks][e] = Elt<T>::from_f32(a[e] - (float)qf[ks][e]);
+          qf[ks][4 + e] = Elt<T>::from_f32(b[e]);
+          ql[ks][4 + e] = Elt<T>::from_f32(b[e] - (float)qf[ks][4 + e]);
+        }
+      }
+    } else {
       const f16* qg = p.q + (((size_t)ri.qb * p.H + h) * p.Tq_cap + ri.t) * 64 + hi * 8;
 #pragma unroll
       for (int ks = 0; ks < 4; ++ks) qf[ks] = *(const f16x8*)(qg + ks * 16);
@@ -954,6 +1025,10 @@ __global__ __launch_bounds__(256) void attn_direct_kernel(const AttnP<T> p) {
       f32x16 S;
 #pragma unroll
       for (int r = 0; r < 16; ++r) S[r] = 0.f;
+      if constexpr (QS) {
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks) S = Elt<T>::mfma32(kf[i][ks], ql[ks], S);
+      }
 #pragma unroll
       for (int ks = 0; ks < 4; ++ks) S = Elt<T>::mfma32(kf[i][ks], qf[ks], S);
       const bool tail = (kt * 32 + 32) > nk;  // tile reaches past the last key: V^T needs zeroing too
@@ -969,7 +1044,8 @@ __global__ __launch_bounds__(256) void attn_direct_kernel(const AttnP<T> p) {
         return v;
       };
       // (a wave's first tile, known at compile time when one round covers the keys: nothing to rescale)
-      if (ROUNDS == 1 && i == 0) softmax_pv_tile<T, true, false, true>(S, kt * 32, ri.klim, need_mask, m, l, O, vfrag);
+      if constexpr (QS) softmax_pv_tile_psplit<T>(S, kt * 32, ri.klim, need_mask, m, l, O, vfrag);
+      else if (ROUNDS == 1 && i == 0) softmax_pv_tile<T, true, false, true>(S, kt * 32, ri.klim, need_mask, m, l, O, vfrag);
       else softmax_pv_tile<T, true, false>(S, kt * 32, ri.klim, need_mask, m, l, O, vfrag);
     }
     }  // rounds
@@ -998,22 +1074,30 @@ __global__ __launch_bounds__(256) void attn_direct_kernel(const AttnP<T> p) {
       const float inv = lt > 0.f ? 1.0f / lt : 0.f;
       const int g = row / p.Nq;
       const int qb = first + g, t = row - g * p.Nq;
-      f16x8 o8, l8;
+      f16x8 o8, l8, h8;
 #pragma unroll
       for (int e = 0; e < 8; ++e) {
         const int d = db * 8 + e;
         float acc = 0.f;
 #pragma unroll
         for (int w = 0; w < 4; ++w) acc += part_o[w][d][row] * sc[w];
-        o8[e] = (f16)(acc * inv);
-        l8[e] = Elt<T>::from_f32(acc * inv - (float)o8[e]);
+        const float x = acc * inv;
+        o8[e] = (f16)x;             // (plain rows: the compiler may fold the multiply into the conversion — one rounding)
+        // [hi | lo | hi]: hi and the value lo is taken against MUST be the same conversion of the same f32 — with the fold
+        // above hi was RN16(acc . inv) while lo was computed against RN16(RN32(acc . inv)): one element in ~10^4 sits between
+        // the two, and its hi + lo was one f16 ulp off (round 5: tests/test_parity_mode_gpu.py, split form on fragment tiles)
+        const f16 h16 = Elt<T>::from_f32(x);
+        h8[e] = h16;
+        l8[e] = Elt<T>::from_f32(x - (float)h16);
       }
       f16* const og = p.out + ((size_t)qb * p.Nq + t) * p.ldo + h * 64 + db * 8;
-      *(f16x8*)og = o8;
       if (p.out_mode == 2) {       // [hi | lo | hi] planes (VIDIL_DT_SPLIT3)
         const int pl = p.ldo / 3;
+        *(f16x8*)og = h8;
         *(f16x8*)(og + pl) = l8;
-        *(f16x8*)(og + 2 * pl) = o8;
+        *(f16x8*)(og + 2 * pl) = h8;
+      } else {
+        *(f16x8*)og = o8;
       }
     }
   }
@@ -1557,6 +1641,204 @@ __global__ __launch_bounds__(256) void attn_f32_mfma_kernel(const AttnF32P p) {
     }
 }
 
+// ---------------------------------------------------------------------------------------------------------------------
+// SPLIT-OPERAND form (round 5, arith = 1): the same f32 Q / K / V read in place, but every operand of the two contractions is
+// handed to the 16-bit matrix instruction as hi + lo (hi = T16(x), lo = T16(x - hi): 22 significant bits for f16) and each
+// contraction is three MFMAs — a_hi.b_hi + a_lo.b_hi + a_hi.b_lo, f32 accumulation; the lo.lo term (2^-22 of the product) is
+// dropped — instead of one 16x slower f32-input instruction: the trick the error-compensated GEMMs of the mode already use.
+// tests/probes/probe_precision_design.py (CPU, the fp32 oracle with exactly this arithmetic injected): caption logits 1.0e-6 of the
+// logit scale from the fp32 reference at trained-like statistics, where 16-bit operands give 1.7e-4 and the budget of "1e-3
+// absolute" at max|logit| = 16 is 6.4e-5.  One workgroup = 4 waves x 32 virtual query rows of a unit, each wave over all keys
+// (S^T = K.Q^T, lane-local online softmax, O^T = V^T.P^T — the 16-bit kernels' transposed forms); K / V tiles of 32 keys are
+// split while they are staged (registers -> LDS as 16-bit hi and lo images, the next tile's global loads in flight under the
+// MFMAs): K in the GEMMs' XOR-swizzled 128-byte rows (ds_read_b128 fragments), V row-major in [d / 16][32 keys][16 d] blocks
+// that ds_read_b64_tr_b16 reads transposed (the streamed tower kernel's layout: no key permutation, no 2-byte scatter).
+// 24 MFMAs of v_mfma_f32_32x32x16 per 32 x 32 tile where the f32-input form issues 64 instructions of twice the latency.
+template <typename T16>
+__global__ __launch_bounds__(256, 2) void attn_split_kernel(const AttnF32P p) {
+  using x8 = typename Elt<T16>::x8;
+  using x4 = typename Elt<T16>::x4;
+  typedef short s16x8 __attribute__((ext_vector_type(8)));
+  constexpr int VSUB = 1152;              // bytes between the four [32 keys][16 d] blocks of a V image (1 KiB + 128: the two blocks
+                                          // a half-wave reads together sit 32 banks apart)
+  constexpr int KIMG = 4096, VIMG = 4 * VSUB;
+  __shared__ __attribute__((aligned(16))) char smem[2 * KIMG + 2 * VIMG];
+  char* const Kh = smem;
+  char* const Kl = smem + KIMG;
+  char* const Vh = smem + 2 * KIMG;
+  char* const Vl = Vh + VIMG;
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int hi = lane >> 5, l31 = lane & 31;
+  const int h = blockIdx.y;
+  int bk, first, count;
+  resolve_unit(p, blockIdx.z, bk, first, count);
+  const int rows = count * p.Nq;
+  const int base = blockIdx.x * 128;
+  if (base >= rows) return;
+  const RowInfo ri = row_info(p, base + wave * 32 + l31, first, rows);       // this lane's query row
+  const bool wave_live = base + wave * 32 < rows;                              // (uniform)
+  auto split8 = [](const f32x4& a, const f32x4& b, x8& vh, x8& vl) {
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      vh[e] = Elt<T16>::from_f32(a[e]);
+      vl[e] = Elt<T16>::from_f32(a[e] - (float)vh[e]);
+      vh[4 + e] = Elt<T16>::from_f32(b[e]);
+      vl[4 + e] = Elt<T16>::from_f32(b[e] - (float)vh[4 + e]);
+    }
+  };
+  // Q operand of k-step ks: d = ks * 16 + hi * 8 + 0..7 of this lane's row, scaled, hi and lo
+  x8 qh[4], ql[4];
+  {
+    const float* qrow = p.q + ((size_t)ri.qb * p.Nq + ri.t) * p.ldq + p.q_off + h * 64 + hi * 8;
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks) {
+      const f32x4 a = *(const f32x4*)(qrow + ks * 16) * p.scale;       // (row_info clamps invalid rows onto the last valid one)
+      const f32x4 b = *(const f32x4*)(qrow + ks * 16 + 4) * p.scale;
+      split8(a, b, qh[ks], ql[ks]);
+    }
+  }
+  const float* kg = p.k + (size_t)bk * p.kv_rows * p.ldk + p.k_off + h * 64;
+  const float* vg = p.v + (size_t)bk * p.kv_rows * p.ldv + p.v_off + h * 64;
+  // staging: thread -> (key = tid / 8, 16-byte f32 chunks c = tid % 8 and c + 8) of the tile, for K and for V
+  const int skey = tid >> 3, sc = tid & 7;
+  f32x4 kr[2], vr[2];
+  auto fetch = [&](int k0) {
+    const int key = k0 + skey;
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+      kr[j] = f32x4{0.f, 0.f, 0.f, 0.f};
+      vr[j] = f32x4{0.f, 0.f, 0.f, 0.f};
+      if (key < p.Nk) {
+        kr[j] = *(const f32x4*)(kg + (size_t)key * p.ldk + (sc + 8 * j) * 4);
+        vr[j] = *(const f32x4*)(vg + (size_t)key * p.ldv + (sc + 8 * j) * 4);
+      }
+    }
+  };
+  auto split4 = [](const f32x4& a, x4& vh, x4& vl) {
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      vh[e] = Elt<T16>::from_f32(a[e]);
+      vl[e] = Elt<T16>::from_f32(a[e] - (float)vh[e]);
+    }
+  };
+  const int sw = (l31 >> 1) & 7;
+  // transposed V reads: lane t of 16-lane group g supplies row (t >> 2), 8-byte chunk (t & 3) of its group's [4 keys][16 d] block
+  const int vlane = ((lane >> 4) & 1) * VSUB + (hi * 4 + ((lane & 15) >> 2)) * 32 + (lane & 3) * 8;
+  auto read_v = [&](const char* img, int dt, int hb) {
+    const char* a = img + vlane + hb * 512 + dt * (2 * VSUB);
+    const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(a));
+    const s16x4 hi4 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(a + 256));
+    const s16x8 both = __builtin_shufflevector(lo, hi4, 0, 1, 2, 3, 4, 5, 6, 7);
+    return __builtin_bit_cast(x8, both);
+  };
+  float m = -INFINITY, l = 0.f;
+  f32x16 O[2];
+#pragma unroll
+  for (int dt = 0; dt < 2; ++dt)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) O[dt][r] = 0.f;
+  fetch(0);
+  for (int k0 = 0; k0 < p.Nk; k0 += 32) {
+    __syncthreads();                       // every wave is done with the previous tile
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+      const int c = sc + 8 * j;            // 4 d values: d = c * 4 ..
+      x4 a, b;
+      split4(kr[j], a, b);
+      const int ko = skey * 128 + (((c >> 1) ^ ((skey >> 1) & 7)) << 4) + (c & 1) * 8;
+      *(x4*)(Kh + ko) = a;
+      *(x4*)(Kl + ko) = b;
+      split4(vr[j], a, b);
+      const int vo = (c >> 2) * VSUB + skey * 32 + (c & 3) * 8;
+      *(x4*)(Vh + vo) = a;
+      *(x4*)(Vl + vo) = b;
+    }
+    __syncthreads();
+    if (k0 + 32 < p.Nk) fetch(k0 + 32);    // (in flight under this tile's MFMAs)
+    if (!wave_live) continue;
+    // ---- S^T[key][row]: corrections first, the leading product last
+    f32x16 S;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) S[r] = 0.f;
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks) {
+      const int off = l31 * 128 + (((ks * 2 + hi) ^ sw) << 4);
+      const x8 kh = *(const x8*)(Kh + off);
+      const x8 kl = *(const x8*)(Kl + off);
+      S = Elt<T16>::mfma32(kl, qh[ks], S);
+      S = Elt<T16>::mfma32(kh, ql[ks], S);
+      S = Elt<T16>::mfma32(kh, qh[ks], S);
+    }
+    // ---- online softmax (exact running maximum): S[r] belongs to key k0 + (r & 3) + 8 * (r >> 2) + 4 * hi of this lane's row
+    float mt = -INFINITY;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int key = k0 + (r & 3) + 8 * (r >> 2) + 4 * hi;
+      if (key >= ri.klim) S[r] = -INFINITY;
+      mt = fmaxf(mt, S[r]);
+    }
+    mt = fmaxf(mt, __shfl_xor(mt, 32, 64));
+    const float mn = fmaxf(m, mt);
+    const float msafe = (mn == -INFINITY ? 0.f : mn) * kLog2e;
+    const float alpha = __builtin_amdgcn_exp2f(__builtin_fmaf(m, kLog2e, -msafe));     // (m = -inf -> 0)
+    float ps = 0.f;
+    x8 ph[2], pl[2];
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const float e = __builtin_amdgcn_exp2f(__builtin_fmaf(S[r], kLog2e, -msafe));   // (masked: 2^-inf = 0)
+      ps += e;
+      const T16 eh = Elt<T16>::from_f32(e);
+      ph[r >> 3][r & 7] = eh;
+      pl[r >> 3][r & 7] = Elt<T16>::from_f32(e - (float)eh);
+    }
+    ps += __shfl_xor(ps, 32, 64);
+    l = l * alpha + ps;
+    m = mn;
+#pragma unroll
+    for (int dt = 0; dt < 2; ++dt)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) O[dt][r] *= alpha;
+    // ---- O^T[d][row] += V^T[d][keys] . P^T[keys][row]
+#pragma unroll
+    for (int hb = 0; hb < 2; ++hb)
+#pragma unroll
+      for (int dt = 0; dt < 2; ++dt) {
+        const x8 vh = read_v(Vh, dt, hb);
+        const x8 vl = read_v(Vl, dt, hb);
+        O[dt] = Elt<T16>::mfma32(vl, ph[hb], O[dt]);
+        O[dt] = Elt<T16>::mfma32(vh, pl[hb], O[dt]);
+        O[dt] = Elt<T16>::mfma32(vh, ph[hb], O[dt]);
+      }
+  }
+  if (!wave_live || !ri.valid) return;
+  const float inv = l > 0.f ? 1.0f / l : 0.f;
+  // O[dt][r]: d = dt * 32 + (r & 3) + 8 * (r >> 2) + 4 * hi -> 4 consecutive d per register quad
+  const size_t row = (size_t)ri.qb * p.Nq + ri.t;
+#pragma unroll
+  for (int dt = 0; dt < 2; ++dt)
+#pragma unroll
+    for (int rq = 0; rq < 4; ++rq) {
+      const int d = dt * 32 + rq * 8 + 4 * hi;
+      const f32x4 v = {O[dt][rq * 4 + 0] * inv, O[dt][rq * 4 + 1] * inv, O[dt][rq * 4 + 2] * inv, O[dt][rq * 4 + 3] * inv};
+      if (p.out_mode == 0) {
+        *(f32x4*)((float*)p.out + row * p.ldo + h * 64 + d) = v;
+      } else {
+        const long long pln = p.ldo / 3;
+        T16* o = (T16*)p.out + row * p.ldo + h * 64 + d;
+        x4 vh, vl;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          vh[e] = Elt<T16>::from_f32(v[e]);
+          vl[e] = Elt<T16>::from_f32(v[e] - (float)vh[e]);
+        }
+        *(x4*)o = vh;
+        *(x4*)(o + pln) = vl;
+        *(x4*)(o + 2 * pln) = vh;
+      }
+    }
+}
+
 template <typename T16>
 __global__ __launch_bounds__(256) void attn_f32_arena_kernel(const AttnF32P p) {
   const int lane = threadIdx.x & 63;
@@ -1622,6 +1904,50 @@ extern "C" int vidil_attention_f32(const vidil_attn_f32_args* a, void* stream) {
     max_rows = a->kv_group * a->Nq;
   }
   VIDIL_REQUIRE(a->H <= 65535 && units <= 65535, "attention_f32: grid too large (H=%d units=%d)", a->H, units);
+  if (a->arith == 1 && a->kv16 != 0) {
+    // split-operand form against 16-bit K / V fragment tiles (the decode steps' cross-attention): the direct kernel's QS form
+    VIDIL_REQUIRE(max_rows <= 32 && a->kv_rows % 32 == 0 && a->kv_rows >= a->Nk && a->Nk <= 768,
+                  "attention_f32 (kv16): at most 32 query rows per unit (got %d), kv_rows=%d a multiple of 32 and >= Nk=%d <= 768", max_rows,
+                  a->kv_rows, a->Nk);
+    VIDIL_REQUIRE(a->q_off == 0 && !a->causal && a->kv_len == nullptr, "attention_f32 (kv16): no q_off / causal / kv_len in this form");
+    VIDIL_REQUIRE(a->out_mode == 2 ? a->ldo % 24 == 0 : false, "attention_f32 (kv16): out_mode 2 ([hi | lo | hi] rows, planes a multiple of 8) only");
+    const int nkt = (a->Nk + 31) / 32;
+    VIDIL_DISPATCH_DTYPE(a->dtype16, "attention_f32 (kv16)", {
+      AttnP<T> q{};
+      q.k = (const T*)(const void*)a->k; q.vt = (const T*)(const void*)a->v; q.out = (T*)a->out;
+      q.kv_index = a->kv_index; q.group_start = a->group_start;
+      q.Bq = a->Bq; q.H = a->H; q.Nq = a->Nq; q.Nk = a->Nk; q.Tq_cap = a->Nq; q.Tk_cap = a->kv_rows; q.NP = a->kv_rows;
+      q.kv_group = a->kv_group; q.ldo = (int)a->ldo; q.n_kv = units; q.out_mode = 2; q.tiled = 1; q.rb = 1;
+      q.q32 = a->q; q.ldq32 = a->ldq; q.q_scale = a->scale;
+      const dim3 g(1, a->H, units);
+      switch (nkt) {
+        case 1: hipLaunchKernelGGL((attn_direct_kernel<T, 1, true>), g, dim3(256), 0, s, q); break;
+        case 2: hipLaunchKernelGGL((attn_direct_kernel<T, 2, true>), g, dim3(256), 0, s, q); break;
+        case 3: hipLaunchKernelGGL((attn_direct_kernel<T, 3, true>), g, dim3(256), 0, s, q); break;
+        case 4: hipLaunchKernelGGL((attn_direct_kernel<T, 4, true>), g, dim3(256), 0, s, q); break;
+        case 5: hipLaunchKernelGGL((attn_direct_kernel<T, 5, true>), g, dim3(256), 0, s, q); break;
+        case 6: hipLaunchKernelGGL((attn_direct_kernel<T, 6, true>), g, dim3(256), 0, s, q); break;
+        case 7: hipLaunchKernelGGL((attn_direct_kernel<T, 7, true>), g, dim3(256), 0, s, q); break;
+        case 8: hipLaunchKernelGGL((attn_direct_kernel<T, 8, true>), g, dim3(256), 0, s, q); break;
+        default: hipLaunchKernelGGL((attn_direct_kernel<T, 24, true>), g, dim3(256), 0, s, q); break;
+      }
+      VIDIL_CHECK_LAUNCH("attention_f32 (kv16 direct)");
+      return VIDIL_OK;
+    });
+  }
+  VIDIL_REQUIRE(a->kv16 == 0, "attention_f32: kv16 needs arith == 1");
+  if (a->arith == 1) {
+    // split-operand form on f32 Q / K / V in place: any number of rows per unit (a unit of a few rows leaves three of the four
+    // waves without rows: they still stage)
+    VIDIL_REQUIRE((a->out_mode == 2 ? a->ldo % 12 == 0 : a->ldo % 4 == 0) && ((uintptr_t)a->out & 15) == 0,
+                  "attention_f32 (split): output rows must allow 8-byte (split3) / 16-byte (f32) stores");
+    const dim3 gridm((max_rows + 127) / 128, a->H, units);
+    if (bf) hipLaunchKernelGGL(attn_split_kernel<bf16>, gridm, dim3(256), 0, s, p);
+    else hipLaunchKernelGGL(attn_split_kernel<f16>, gridm, dim3(256), 0, s, p);
+    VIDIL_CHECK_LAUNCH("attention_f32 (split)");
+    return VIDIL_OK;
+  }
+  VIDIL_REQUIRE(a->arith == 0, "attention_f32: arith=%d (0: f32, 1: split-operand)", a->arith);
   // units of more than 8 query rows (the towers, the ITM encoder, prompt passes): the f32-MFMA kernel, 128 rows per workgroup;
   // a few rows per unit (the decode steps' cross-attention: 3 beams per image): the VALU kernel, which skips idle row groups
   static const bool allow_mfma = [] { const char* e = getenv("VIDIL_ATTN_F32_MFMA"); return !(e && e[0] == '0'); }();

@@ -260,8 +260,13 @@ def _f32_view(t, what):
 
 
 def attention_f32(q, k, v, out, *, Bq, H, Nq, Nk, kv_rows=None, kv_group=1, causal=False, causal_off=0, kv_len=None, kv_index=None,
-                  group_start=None, max_group=0, scale=0.125, split3=None, anc=None, arena_rows=0):
-    """softmax(q k^T * scale) v in plain f32 (the attention of the parity precision mode; vidil_attention_f32).
+                  group_start=None, max_group=0, scale=0.125, split3=None, anc=None, arena_rows=0, arith=0, kv16=False):
+    """softmax(q k^T * scale) v in f32 (the attention of the parity precision mode; vidil_attention_f32).
+
+    arith: 0 = plain f32 arithmetic; 1 = split-operand 16-bit MFMA (every operand as hi + lo, three products per contraction:
+    ~1e-6 of the logit scale from f32 arithmetic at a fifth of its cost; dense forms — the arena form always runs in f32).
+    kv16 (arith 1): ``k`` / ``v`` are 16-bit FRAGMENT TILES [n_kv, H, kv_rows, 64] (project_cross_kv(tiled=True)) instead of f32
+    rows — the decode steps' cross-attention, at most 32 query rows per unit; Q and the probabilities are split, K / V as stored.
 
     q, k, v: f32 matrices — typically COLUMN SLICES of the row-major output of a projection GEMM (``qkv32[:, :C]``, ``[:, C:2*C]``,
     ``[:, 2*C:]``): row stride and column offset are taken from the views, head h occupies columns h*64 .. h*64+63.
@@ -270,8 +275,15 @@ def attention_f32(q, k, v, out, *, Bq, H, Nq, Nk, kv_rows=None, kv_group=1, caus
     anc (+ arena_rows): the arena form — Nq == 1, key j of query row b is row j*arena_rows + anc[b][j] of k / v."""
     a = _lib.AttnF32Args()
     a.q, a.ldq = _f32_view(q, "attention_f32.q")
-    a.k, a.ldk = _f32_view(k, "attention_f32.k")
-    a.v, a.ldv = _f32_view(v, "attention_f32.v")
+    if kv16:
+        if k.dtype != v.dtype or k.dtype != out.dtype:
+            raise VidilHipError(f"attention_f32 (kv16): k / v / out must share one 16-bit dtype, got {k.dtype} / {v.dtype} / {out.dtype}")
+        a.k, a.v = _ptr(k, None, "attention_f32.k"), _ptr(v, None, "attention_f32.v")
+        _dt(k, "attention_f32.k")
+        a.ldk = a.ldv = 0
+    else:
+        a.k, a.ldk = _f32_view(k, "attention_f32.k")
+        a.v, a.ldv = _f32_view(v, "attention_f32.v")
     a.q_off = a.k_off = a.v_off = 0
     if split3 is None:
         split3 = out.dtype != torch.float32
@@ -292,6 +304,8 @@ def attention_f32(q, k, v, out, *, Bq, H, Nq, Nk, kv_rows=None, kv_group=1, caus
     a.anc_ld = 0 if anc is None else anc.stride(0)
     a.arena_rows = arena_rows
     a.scale = float(scale)
+    a.arith = 0 if anc is not None else int(arith)          # (the arena form has no split-operand kernel: f32 arithmetic)
+    a.kv16 = 1 if kv16 else 0
     check(_lib.load().vidil_attention_f32(C.byref(a), _stream()), "attention_f32")
     return out
 

@@ -22,7 +22,7 @@ import torch
 import torch.nn as nn
 
 from . import kernels as K
-from .packing import FP8, PackedCache, fold_layernorm, parity_attention_f32, require_cuda, v32, w3, w8, w16
+from .packing import FP8, PackedCache, fold_layernorm, parity_attention_arith, parity_attention_f32, parity_attention_kind, require_cuda, v32, w3, w8, w16
 
 LN_EPS_DEFAULT = 1e-12
 
@@ -215,7 +215,9 @@ class BertModel(PackedCache, nn.Module):
         return p
 
     def pack_flags(self):
-        return (self.parity,)
+        # (the attention kind of the parity mode decides the dtype of a session's KV arena and cross K|V: a change re-packs, and
+        #  with the new pack object every DecoderSession / captured step graph keyed on it is rebuilt — ADVICE r4)
+        return (self.parity, parity_attention_kind(self) if self.parity else None)
 
     def _folded(self, p):
         """Weights of the LN-folded text stack (built on first use, kept with the pack): per layer the cross query and
@@ -260,7 +262,9 @@ class BertModel(PackedCache, nn.Module):
                 raise K.VidilHipError(f"project_cross_kv (parity mode): image tokens must be [hi | lo | hi] rows of width "
                                       f"{3 * self.config.encoder_width}, got {tuple(enc16.shape)}")
 
-            if parity_attention_f32(self):
+            # (split-operand attention: consumers with at most 32 query rows per image — the caption decoder — keep the 16-bit
+            #  fragment tiles of the plain path, written by the K-tripled GEMM's heads epilogue: vidil_attention_f32 kv16)
+            if parity_attention_f32(self) and not (tiled and parity_attention_arith(self) == 1):
                 L, C = len(p["layers"]), self.config.hidden_size
                 dev = enc16.device
                 if out is not None and getattr(out, "f32", False) and (out.B, out.Te) == (B, Te) and out.k.device == dev:
@@ -432,11 +436,13 @@ class BertModel(PackedCache, nn.Module):
         Nk = t_off + T
         if arena is not None and T > 1 and t_off != 0:
             raise K.VidilHipError("run_layers: a multi-token block can only be appended to a beam arena at position 0")
-        f32_attn = parity_attention_f32(self)
+        f32_attn, arith = parity_attention_f32(self), parity_attention_arith(self)
         if f32_attn:
             # Q | K | V (and the cross query) stay f32 and row-major, the KV arena and the cross K | V are f32:
             # vidil_attention_f32 reads all of them in place.  (t_off > 0 happens in the arena form only.)
-            if (arena is not None and arena.k.dtype != torch.float32) or (cross is not None and not getattr(cross, "f32", False)):
+            # (split-operand kind: the cross K | V of a decoder session are 16-bit fragment tiles instead)
+            kv16 = cross is not None and arith == 1 and cross.tiled and not getattr(cross, "f32", False)
+            if (arena is not None and arena.k.dtype != torch.float32) or (cross is not None and not getattr(cross, "f32", False) and not kv16):
                 raise K.VidilHipError("run_layers (parity mode, f32 attention): the KV arena / cross K|V of this session were built for "
                                       "the 16-bit attention kernels — build the DecoderSession / CrossKV under the same $VIDIL_PARITY_ATTN")
             if t_off != 0 and not (arena is not None and T == 1):
@@ -453,7 +459,7 @@ class BertModel(PackedCache, nn.Module):
                                     arena_rows=arena.rows)
                 else:
                     K.attention_f32(qkv32[:, :C], qkv32[:, C:2 * C], qkv32[:, 2 * C:], o3, Bq=rows, H=H, Nq=T, Nk=T, causal=causal,
-                                    kv_len=kv_len)
+                                    kv_len=kv_len, arith=arith)
                     if arena is not None:   # the prompt's K / V in the arena: position t, slot r * arena_slot_stride
                         blk = qkv32.view(rows, T, 3 * C)
                         arena.k[i][:T, 0:rows * arena_slot_stride:arena_slot_stride] = blk[:, :, C:2 * C].permute(1, 0, 2)
@@ -477,9 +483,15 @@ class BertModel(PackedCache, nn.Module):
             K.layernorm(tmp, d["ao_g"], d["ao_bt"], eps, out16=h3, out32=h32, split3=True)
             if cross is not None and f32_attn:
                 K.gemm(h3, d["cq_w3"], d["cq_b"], out=q32)
-                kv = cross.k[i]                                         # f32 [B, Te, 2C]: keys | values
-                K.attention_f32(q32, kv[..., :C], kv[..., C:], o3, Bq=rows, H=H, Nq=T, Nk=cross.Te, kv_rows=cross.Te,
-                                kv_group=cross_group, kv_index=cross_index, group_start=cross_groups, max_group=cross_max_group)
+                if kv16:
+                    K.attention_f32(q32, cross.k[i], cross.vt[i], o3, Bq=rows, H=H, Nq=T, Nk=cross.Te, kv_rows=cross.Tk_cap,
+                                    kv_group=cross_group, kv_index=cross_index, group_start=cross_groups, max_group=cross_max_group,
+                                    arith=1, kv16=True)
+                else:
+                    kv = cross.k[i]                                     # f32 [B, Te, 2C]: keys | values
+                    K.attention_f32(q32, kv[..., :C], kv[..., C:], o3, Bq=rows, H=H, Nq=T, Nk=cross.Te, kv_rows=cross.Te,
+                                    kv_group=cross_group, kv_index=cross_index, group_start=cross_groups, max_group=cross_max_group,
+                                    arith=arith)
                 K.gemm(o3, d["co_w3"], d["co_b"], out=tmp, resid=h32)
                 K.layernorm(tmp, d["co_g"], d["co_bt"], eps, out16=h3, out32=h32, split3=True)
             elif cross is not None:

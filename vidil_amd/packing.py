@@ -74,7 +74,9 @@ def compute_dtype(module=None):
 # probabilities inside the attention kernels (their error averages over the keys).
 _parity_default = [os.environ.get("VIDIL_PARITY", "0") == "1"]
 _warned_bf16_parity = [False]
-_parity_attn_default = ["16" if os.environ.get("VIDIL_PARITY_ATTN", "f32") == "16" else "f32"]
+_PARITY_ATTN_KINDS = ("split", "f32", "16")
+_parity_attn_default = [os.environ.get("VIDIL_PARITY_ATTN", "split") if os.environ.get("VIDIL_PARITY_ATTN", "split") in _PARITY_ATTN_KINDS
+                        else "split"]
 
 
 def set_parity_mode(on, *modules):
@@ -96,13 +98,23 @@ def parity_mode(module=None) -> bool:
 
 
 def set_parity_attention(kind, *modules):
-    """Which attention the parity precision mode of ``modules`` (and their sub-modules) uses: "f32" — vidil_attention_f32,
-    plain f32 arithmetic on f32 Q / K / V: the mode's logits then sit ~1e-5 of the LOGIT SCALE from the fp32 reference (the
-    default; ~1/16 of the MFMA kernels' arithmetic rate) — or "16": the 16-bit MFMA attention kernels with [hi | lo | hi] outputs
-    (round 3's form: 2.4e-4 of the logit scale, because Q / K / V are rounded to 16 bits inside them; what the cheap parity MIX
-    of bench.py uses).  Without modules: the process-wide default ($VIDIL_PARITY_ATTN)."""
-    if kind not in ("f32", "16"):
-        raise ValueError("parity attention: 'f32' or '16'")
+    """Which attention the parity precision mode of ``modules`` (and their sub-modules) uses:
+      "split" (the default since round 5) — vidil_attention_f32 with arith = 1: f32 Q / K / V read in place, every operand of the
+        two contractions handed to the 16-bit MFMA as hi + lo (three products per contraction, f32 softmax) — the trick the
+        mode's GEMMs use; the decode steps' cross-attention keeps the 16-bit K / V fragment tiles of the plain path (bytes are what
+        bound it) and splits Q and the probabilities only.  Caption logits ~3e-5 of the LOGIT SCALE from the fp32 reference at
+        trained-like statistics (tests/test_trained_like_gpu.py), at a fifth of the f32 kernels' cost;
+      "f32" (round 4) — plain f32 arithmetic on f32 Q / K / V everywhere: ~1e-5 of the logit scale, ~1/16 of the MFMA kernels' rate;
+      "16" (round 3) — the 16-bit MFMA attention kernels with [hi | lo | hi] outputs: 2.4e-4 of the logit scale, because Q / K / V
+        are rounded to 16 bits inside them.
+    Without modules: the process-wide default ($VIDIL_PARITY_ATTN)."""
+    if kind is None:                      # drop the per-module choice again: the modules follow the process-wide default
+        for m in modules:
+            for sub in m.modules():
+                sub.__dict__.pop("_parity_attn", None)
+        return _parity_attn_default[0]
+    if kind not in _PARITY_ATTN_KINDS:
+        raise ValueError("parity attention: 'split', 'f32' or '16'")
     if not modules:
         _parity_attn_default[0] = kind
         return kind
@@ -112,10 +124,21 @@ def set_parity_attention(kind, *modules):
     return kind
 
 
-def parity_attention_f32(module=None) -> bool:
-    """True when the parity precision mode of ``module`` runs its attention in f32 (see set_parity_attention)."""
+def parity_attention_kind(module=None) -> str:
+    """"split", "f32" or "16" (see set_parity_attention)."""
     v = None if module is None else module.__dict__.get("_parity_attn")
-    return (_parity_attn_default[0] if v is None else v) == "f32"
+    return _parity_attn_default[0] if v is None else v
+
+
+def parity_attention_f32(module=None) -> bool:
+    """True when the parity precision mode of ``module`` keeps Q / K / V as f32 rows and runs vidil_attention_f32 on them (kinds
+    "split" and "f32"; see set_parity_attention)."""
+    return parity_attention_kind(module) != "16"
+
+
+def parity_attention_arith(module=None) -> int:
+    """vidil_attention_f32's ``arith`` for this module: 1 (split-operand MFMA) or 0 (f32 arithmetic)."""
+    return 1 if parity_attention_kind(module) == "split" else 0
 
 
 def w3(*weights, dtype=None):

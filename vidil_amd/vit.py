@@ -27,7 +27,7 @@ import torch
 import torch.nn as nn
 
 from . import kernels as K
-from .packing import FP8, PackedCache, fold_layernorm, require_cuda, v32, w3, w3_patch, w8, w16, w16_patch, parity_attention_f32
+from .packing import FP8, PackedCache, fold_layernorm, require_cuda, v32, w3, w3_patch, w8, w16, w16_patch, parity_attention_arith, parity_attention_f32, parity_attention_kind
 
 
 class PatchEmbed(nn.Module):
@@ -106,7 +106,7 @@ class VisionTransformer(PackedCache, nn.Module):
 
     # ------------------------------------------------------------------ packing
     def pack_flags(self):
-        return (self.fuse_layernorm, self.fp8, self.parity, self.parity_last_blocks)
+        return (self.fuse_layernorm, self.fp8, self.parity, self.parity_last_blocks, parity_attention_kind(self))
 
     @property
     def parity_last_blocks(self):
@@ -241,7 +241,7 @@ class VisionTransformer(PackedCache, nn.Module):
         o3 = torch.empty((M, 3 * D), dtype=cdt, device=dev)
         hid32 = torch.empty((M, Dh), dtype=torch.float32, device=dev)
         hid3 = torch.empty((M, 3 * Dh), dtype=cdt, device=dev)
-        f32_attn = parity_attention_f32(self)
+        f32_attn, arith = parity_attention_f32(self), parity_attention_arith(self)
         qkv32 = torch.empty((M, 3 * D), dtype=torch.float32, device=dev) if f32_attn else None
         plain = [b for b in p["blocks"] if "qkv_w3" not in b]
         if plain:       # mixed form: the leading blocks on plain 16-bit operands (unfused: LayerNorm kernel + plain GEMM)
@@ -261,7 +261,7 @@ class VisionTransformer(PackedCache, nn.Module):
             K.layernorm(x, b["n1g"], b["n1b"], self.ln_eps, out16=a3, split3=True)
             if f32_attn:    # Q | K | V stay f32 and row-major; the f32 attention reads them in place (no per-head scatter)
                 K.gemm(a3, b["qkv_w3"], b["qkv_b"], out=qkv32)
-                K.attention_f32(qkv32[:, :D], qkv32[:, D:2 * D], qkv32[:, 2 * D:], o3, Bq=B, H=H, Nq=T, Nk=T)
+                K.attention_f32(qkv32[:, :D], qkv32[:, D:2 * D], qkv32[:, 2 * D:], o3, Bq=B, H=H, Nq=T, Nk=T, arith=arith)
             else:
                 K.gemm(a3, b["qkv_w3"], b["qkv_b"], heads=heads)
                 K.attention(q, k, vt, o3, Bq=B, H=H, Nq=T, Nk=T, Tq_cap=T, Tk_cap=T, NP=NP, split3=True)
