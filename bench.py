@@ -16,11 +16,18 @@ Rank 0 prints ONE JSON line (see README / DESIGN.md §measurement).  Beside the 
   roofline            dominant GEMM instantiation of one instrumented step (HIP events) against the 2.5 PFLOP/s MFMA peak
   config.algorithmic_gflop_per_frame / whole_path_mfma_frac      SURVEY §8d's algorithmic count (ITM captions at 35 tokens)
   config.executed_gflop_per_frame / executed_mfma_frac           what the launches of the instrumented step really computed
+  secondary.streaming_input   the same step with FRESH frames every step, uploaded from pinned host memory on a copy stream under
+                      the previous step (double-buffered), inside the timed region
   secondary.f16       the same step on f16 operands (the type of the parity statement), a few steps
   secondary.fp8       the same step in the fp8 tower mode (config 5's operand type; a throughput mode with an accuracy contract)
   secondary.parity_mode_caption_path   caption path (ViT + beam decode) in the error-compensated "parity" precision mode
   secondary.parity_mode_full_step      the whole step (caption + filter + CLIP / scan) with all three models in that mode
-  secondary.parity_mix_full_step       ... in the cheapest mix that meets both stated tolerances (plain ViT, compensated decoder / CLIP)
+  secondary.parity_mix_full_step       ... in round 4's mix (plain ViT, compensated decoder / CLIP): inside 1e-3 at the random-init logit
+                      scale only (its error is proportional to the logit scale) — superseded by `parity_qualified`
+  parity_qualified    (top level, round 5) the configuration that delivers BOTH stated tolerances at a trained model's logit scale:
+                      captioner + CLIP error-compensated with the split-operand attention, filter plain f16 — frames/s, logit error on
+                      the benchmark's weights and on a synthetic trained-like state dict (max|logit| ~ 16), visual-token ranks vs the
+                      reference form
   parity              max |caption logit - fp32 CPU oracle| of a 2-frame prompt pass, for the timed dtype, plain f16 and the
                       parity mode, each with the tolerance the test suite asserts for it (computed in the cpu_baseline leg)
   one_off             work outside the metric that a run pays once: the CLIP text tower over the 42,759 ontology prompts
@@ -118,6 +125,20 @@ def build_models(device, size=224, clip_name="b32", vit="base", dtype="f16"):
     return cap, flt, clip, tok
 
 
+def build_trained_like_captioner(size=224, vit="base"):
+    """The captioner on the synthetic TRAINED-LIKE state dict of tests/test_trained_like_gpu.py (oracle/synth_weights.py — test
+    infrastructure, used here by the parity leg only: no checkpoint can be mounted on the bench box): seed-0 init, LayerNorm
+    gains with 10-50x outlier channels, residual rows ~1 sigma off zero, LM head scaled so that max|logit| ~ 16."""
+    from oracle.synth_weights import trained_like_
+    from vidil_amd.blip import BLIP_Decoder
+    from vidil_amd.tokenizer import SyntheticBertTokenizer
+
+    torch.manual_seed(0)
+    cap = BLIP_Decoder(image_size=size, vit=vit, tokenizer=SyntheticBertTokenizer()).eval()
+    trained_like_(cap, 300, head_scale=2.0, stream_shift=8.0)
+    return cap
+
+
 class GemmTimer:
     """Times every GEMM launch of one step with HIP events on the launch stream; kernels are named by the library
     itself (vidil_gemm_kernel_name: the dispatch is not restated here)."""
@@ -139,7 +160,7 @@ class GemmTimer:
             e0.record()
             r = timer._orig(a, w, bias, **kw)
             e1.record()
-            if "out" not in kw and not (kw.get("heads") or kw.get("patch") or kw.get("arena")):
+            if "out" not in kw and not (kw.get("heads") or kw.get("patch") or kw.get("arena") or kw.get("split3_out") is not None):
                 kw = dict(kw, out=r)
             timer.records.append((K.gemm_kernel_name(a, w, bias, **kw), 2.0 * M * N * Kd, e0, e1))
             timer.shapes.append((M, N, Kd))
@@ -216,13 +237,40 @@ def cpu_worker(args):
     prompt = cap.prompt_ids(1, "cpu")[0].long().numpy()
     x = clip_ref.preprocess_u8(synthetic_frames(1, args.frames, args.size, args.cpu_worker)[0])
     if args.cpu_worker == 0 and args.cpu_parity_file:
-        # parity sample for the bench line: fp32 prompt-pass caption logits of the first two frames of video 0 (the GPU
-        # side compares its own logits of the same frames with these: the oracle as the checker, in the CPU leg)
-        from oracle import med_ref, vit_ref
+        # parity samples for the bench line (the GPU side compares its own results on the same frames with these: the oracle
+        # as the checker, in the CPU leg):
+        #  lg_ref     fp32 prompt-pass caption logits of the first two frames of video 0, the benchmark's weights (seed 0)
+        #  tl_lg_ref  the same on the synthetic TRAINED-LIKE state dict (oracle/synth_weights.py: max|logit| ~ 16, LayerNorm
+        #             outlier gains, rows off zero) — the scale at which "within 1e-3" absolute is a hard statement
+        #  tok_idx / tok_gap   the reference FORM of the visual tokens of video 0's frames (run_visual_tokenization.py:276,298-308:
+        #             `image_embeds @ text_embeds.t()`, `np.argsort(score)[::-1][:5]`) on the oracle's CLIP embeddings: class
+        #             indices [F, 4, 5] and, per rank, the smaller of its two score gaps to the neighbouring ranks
+        from oracle import med_ref, synth_weights, tokens_ref, vit_ref
+        ref = {}
         with torch.no_grad():
             y_ref = vit_ref.vit_forward(sd_cap, x[:2], depth=depth, heads=heads)
             lg_ref, _ = med_ref.decoder_logits(sd_cap, cap.prompt_ids(2, "cpu").long(), y_ref)
-        np.save(args.cpu_parity_file, lg_ref.numpy())
+            ref["lg_ref"] = lg_ref.numpy()
+            cap_tl = build_trained_like_captioner(args.size, args.vit)
+            sd_tl = {k: v.detach().float() for k, v in cap_tl.state_dict().items()}
+            y_tl = vit_ref.vit_forward(sd_tl, x[:2], depth=depth, heads=heads)
+            tl_ref, _ = med_ref.decoder_logits(sd_tl, cap.prompt_ids(2, "cpu").long(), y_tl)
+            ref["tl_lg_ref"] = tl_ref.numpy()
+            del cap_tl, sd_tl
+            if args.clip == "b32":
+                emb = clip_ref.image_embeds(sd_clip, x)
+                idx = np.zeros((x.shape[0], 4, 5), np.int64)
+                gap = np.zeros((x.shape[0], 4, 5), np.float64)
+                for c, key in enumerate(tokens_ref.CATEGORIES):
+                    sc = (emb @ onto_embeds[key].t()).numpy()
+                    for f in range(sc.shape[0]):
+                        order = np.argsort(sc[f])[::-1][:6]
+                        sv = sc[f][order].astype(np.float64)
+                        idx[f, c] = order[:5]
+                        for j in range(5):
+                            gap[f, c, j] = min(sv[j - 1] - sv[j] if j else np.inf, sv[j] - sv[j + 1])
+                ref["tok_idx"], ref["tok_gap"] = idx, gap
+        np.savez(args.cpu_parity_file, **ref)
     open(os.path.join(args.cpu_sync_dir, f"ready{args.cpu_worker}"), "w").close()
     while not os.path.exists(os.path.join(args.cpu_sync_dir, "go")):
         time.sleep(0.01)
@@ -291,7 +339,7 @@ def time_steps(step, n):
     return (time.perf_counter() - t0) / n
 
 
-def secondary_measurements(args, cap, flt, clip, step, frames, dev, parity_file, log, engine=None):
+def secondary_measurements(args, cap, flt, clip, step, frames, dev, parity_file, log, engine=None, vtok=None, onto_texts=None):
     """After the timed region (rank 0, N = 1): the numbers the headline does not carry.  Everything here re-packs the
     models' weights for another operand type / precision mode, so it runs last."""
     from vidil_amd.blip import DecoderSession
@@ -313,10 +361,38 @@ def secondary_measurements(args, cap, flt, clip, step, frames, dev, parity_file,
         sess = DecoderSession(cap.text_decoder, y16, 2, 3, 20)
         return sess.prefill(prompt.contiguous().view(-1), P, shared=True).float().cpu().numpy()
 
-    ref = None
+    ref = tl_ref = tok_ref = None
     if parity_file and os.path.exists(parity_file):
-        ref = np.load(parity_file)
+        with np.load(parity_file) as z:
+            ref, tl_ref = z["lg_ref"], z["tl_lg_ref"]
+            tok_ref = (z["tok_idx"], z["tok_gap"]) if "tok_idx" in z.files else None
         os.remove(parity_file)
+
+    TOK_GAP = 5e-6      # a rank is "undecided" where the ORACLE's own adjacent scores are closer than this (two fp32 matmuls in
+    #                     different summation orders differ by ~1e-6; tests/test_parity_mode_gpu.py uses the same mask)
+
+    def topk_ranks():
+        """visual-token ranks of video 0's frames (device tower + scan, current precision configuration) against the reference
+        form on the oracle's embeddings, compared as class TEXTS (the real scene list repeats strings)."""
+        if tok_ref is None or vtok is None:
+            return None
+        from oracle.tokens_ref import CATEGORIES          # (the checker's category order, in the parity leg)
+        idx = vtok.frame_topk(frames[0])[0].cpu().numpy()
+        ridx, rgap = tok_ref
+        eq = und = 0
+        worst = 0.0
+        for f in range(idx.shape[0]):
+            for c, key in enumerate(CATEGORIES):
+                for j in range(idx.shape[2]):
+                    same = onto_texts[key][int(idx[f, c, j])] == onto_texts[key][int(ridx[f, c, j])]
+                    eq += same
+                    if not same:
+                        und += rgap[f, c, j] < TOK_GAP
+                        worst = max(worst, float(rgap[f, c, j]))
+        n = int(idx.shape[0] * idx.shape[1] * idx.shape[2])
+        return {"ranks": n, "equal": int(eq), "differ_where_the_oracle_gap_is_below_5e-6": int(und), "differ_elsewhere": int(n - eq - und),
+                "largest_oracle_gap_of_a_differing_rank": worst,
+                "reference": "run_visual_tokenization.py:276,298-308 on the fp32 oracle's CLIP embeddings (video 0)"}
     parity = {"sample": "prompt-pass caption logits (2 frames x 30,524 tokens) of video 0: device vs the fp32 CPU oracle of the cpu_baseline leg",
               "reference": "models/med.py:501-545,830-930 (BertLMHeadModel logits)"}
     tol = {"bf16": "8e-3 x max(1, max|logit|)  (tests/test_bf16_gpu.py)", "f16": "1e-3 x max(1, max|logit|)  (tests/test_models_gpu.py)",
@@ -329,7 +405,63 @@ def secondary_measurements(args, cap, flt, clip, step, frames, dev, parity_file,
         parity[label] = {"max_abs_logit_err": float(d.max()), "mean_abs_logit_err": float(d.mean()), "ref_absmax": float(np.abs(ref).max()),
                          "asserted_tol": asserted}
 
+    # ---- streaming input (run_video_CapFilt.py:128-137,165-170: the reference moves every frame to the device
+    # inside its loop): FRESH uint8 frames every step from pinned host memory, H2D on a copy stream into the other of two device
+    # buffers while the previous step computes — inside the timed region, in the timed dtype
+    try:
+        n_host = 3
+        host = [torch.from_numpy(synthetic_frames(Nv, F, args.size, 5000 + 1000 * i)).pin_memory() for i in range(n_host)]
+        dbuf = [torch.empty_like(frames), torch.empty_like(frames)]
+        copy_stream = torch.cuda.Stream()
+        main = torch.cuda.current_stream()
+        ready = [torch.cuda.Event(), torch.cuda.Event()]       # H2D of buffer b has landed
+        free = [torch.cuda.Event(), torch.cuda.Event()]        # the step that read buffer b has been queued to its end
+
+        def upload(i):
+            b = i & 1
+            with torch.cuda.stream(copy_stream):
+                copy_stream.wait_event(free[b])
+                dbuf[b].copy_(host[i % n_host], non_blocking=True)
+                ready[b].record(copy_stream)
+
+        def run_stream(n):
+            for b in (0, 1):
+                free[b].record(main)
+            upload(0)
+            for i in range(n):
+                main.wait_event(ready[i & 1])
+                if i + 1 < n:
+                    upload(i + 1)                       # (overlaps with this step's kernels; buffer (i + 1) & 1 was read by step i - 1)
+                step(dbuf[i & 1])
+                free[i & 1].record(main)
+            torch.cuda.synchronize()
+
+        run_stream(2)
+        n_st = max(3, min(args.steps, 5))
+        t0 = time.perf_counter()
+        run_stream(n_st)
+        dts = (time.perf_counter() - t0) / n_st
+        # the copy by itself, for the PCIe figure
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        dbuf[0].copy_(host[0], non_blocking=True)
+        torch.cuda.synchronize()
+        t_h2d = time.perf_counter() - t0
+        out["secondary"]["streaming_input"] = {
+            "value": round(Nv * F / dts, 2), "unit": "frames/s", "ms_per_step": round(dts * 1e3, 3), "steps": n_st,
+            "h2d_ms_per_step_alone": round(t_h2d * 1e3, 2), "h2d_GBps": round(frames.numel() / t_h2d / 1e9, 1),
+            "note": f"{n_host} distinct batches of {Nv} x {F} uint8 frames in pinned host memory, a different one every step, copied "
+                    "host -> device on a copy stream into the other of two device buffers while the previous step runs; the first "
+                    "upload of the run is inside the timed region too.  `value` keeps its frames resident (the contract's definition)"}
+        log(f"secondary streaming input: {Nv * F / dts:.0f} frames/s (H2D alone {t_h2d * 1e3:.1f} ms per step)")
+        del host, dbuf
+        torch.cuda.empty_cache()
+    except Exception as e:
+        out["secondary"]["streaming_input"] = {"value": None, "error": f"{type(e).__name__}: {e}"[:300]}
     record(f"timed_dtype_{args.dtype}", tol[args.dtype])
+    tr = topk_ranks()
+    if tr is not None:
+        parity["timed_dtype_topk_ranks_equal"] = tr
     # ---- the same step with the ITM short circuit (identical kept lists: max_filter is an any() over the frames)
     if engine is not None and not args.itm_short_circuit and engine.config.get("filter_mode", "max_filter") != "avg_filter":
         engine.config["itm_short_circuit"] = True
@@ -410,6 +542,48 @@ def secondary_measurements(args, cap, flt, clip, step, frames, dev, parity_file,
     except Exception as e:      # (a secondary number must not cost the headline line)
         out["secondary"]["parity_mode_full_step"] = {"value": None, "error": f"{type(e).__name__}: {e}"[:300]}
     set_parity_mode(False, cap, flt, clip)
+    # ---- the PARITY-QUALIFIED configuration (round 5): what it costs to deliver the two tolerances BASELINE states
+    # at a TRAINED model's logit scale — captioner (ViT + cross K|V + decoder + LM head) and CLIP error-compensated with the
+    # split-operand attention, the filter (no tolerance is stated for ITM logits) on plain f16 operands
+    try:
+        free_sessions()
+        set_parity_mode(True, cap, clip)
+        for _ in range(3):
+            step()
+        dtq = time_steps(step, max(2, min(args.steps, 3)))
+        pq = {"value": round(Nv * F / dtq, 2), "unit": "frames/s", "ms_per_step": round(dtq * 1e3, 3),
+              "slowdown_vs_plain_f16": round(dtq / dt16, 3) if args.dtype != "f16" else None,
+              "config": "same workload and step as `value`; f16 operands; captioner and CLIP in the parity precision mode (every GEMM on "
+                        "[hi | lo | hi] x [W_hi | W_hi | W_lo] operands, K tripled; split-operand 16-bit MFMA attention on f32 Q / K / V, "
+                        "the decode steps' cross-attention on 16-bit K / V tiles with Q and P split; f32 self-attention over the KV "
+                        "arena), filter (ViT + ITM) on plain f16 operands"}
+        if ref is not None:
+            d = np.abs(prompt_logits() - ref)
+            pq["max_abs_logit_err"] = float(d.max())
+            pq["logit_scale"] = float(np.abs(ref).max())
+        tr = topk_ranks()
+        if tr is not None:
+            pq["topk_ranks_equal"] = tr
+        if tl_ref is not None:
+            # ... and the same captioner code on the TRAINED-LIKE state dict (max|logit| ~ 16): the statement is absolute
+            cap_tl = build_trained_like_captioner(args.size, args.vit).to(dev)
+            set_compute_dtype("f16", cap_tl)
+            set_parity_mode(True, cap_tl)
+            _, y3 = cap_tl.visual_encoder.forward_u8(frames[0, :2].contiguous(), mean, std)
+            sess = DecoderSession(cap_tl.text_decoder, y3, 2, 3, 20, tiled_cross=True)      # (generate_ids' form: K / V tiles)
+            lg = sess.prefill(prompt.contiguous().view(-1), P, shared=True).float().cpu().numpy()
+            d = np.abs(lg - tl_ref)
+            pq["trained_like"] = {"max_abs_logit_err": float(d.max()), "logit_scale": float(np.abs(tl_ref).max()),
+                                  "asserted": "<= 1e-3 absolute on 8 teacher-forced passes at max|logit| 2 / 8 / 16 (tests/test_trained_like_gpu.py)",
+                                  "weights": "synthetic trained-like state dict (oracle/synth_weights.py): no checkpoint is mounted on the bench box; "
+                                             "tests/test_real_weights_gpu.py is skipped there for the same reason"}
+            del cap_tl, sess, y3
+            torch.cuda.empty_cache()
+        out["parity_qualified"] = pq
+        log(f"parity-qualified configuration: {Nv * F / dtq:.0f} frames/s")
+    except Exception as e:
+        out["parity_qualified"] = {"value": None, "error": f"{type(e).__name__}: {e}"[:300]}
+    set_parity_mode(False, cap, flt, clip)
     # ---- ... and in the CHEAPEST mix that still meets the two tolerances BASELINE states (tests/probes/probe_parity_mix.py;
     # tests/test_parity_mode_gpu.py asserts both): captioner = plain ViT + compensated cross K|V / decoder / LM head ("caption
     # logits within 1e-3" absolute: worst pass 7.6e-4), CLIP compensated ("top-k visual-token indices bit-exact" end to end),
@@ -426,8 +600,9 @@ def secondary_measurements(args, cap, flt, clip, step, frames, dev, parity_file,
             "value": round(Nv * F / dtm, 2), "unit": "frames/s", "ms_per_step": round(dtm * 1e3, 3),
             "slowdown_vs_plain_f16": round(dtm / dt16, 3) if args.dtype != "f16" else None,
             "note": "same workload and step as `value`; captioner: plain-f16 ViT + error-compensated cross K|V, decoder and LM head "
-                    "(caption logits within 1e-3 absolute on all 16 passes); CLIP tower error-compensated (visual-token ranks equal "
-                    "to the fp32 reference form end to end); filter on plain f16 operands"}
+                    "with the 16-bit attention kernels (caption logits within 1e-3 absolute on all 16 passes AT THE RANDOM-INIT LOGIT "
+                    "SCALE ONLY: the error of this mix is ~3e-4 of max|logit|, i.e. ~5e-3 at a trained model's 16 — `parity_qualified` "
+                    "is the configuration that holds there); CLIP tower error-compensated; filter on plain f16 operands"}
         log(f"secondary parity-mix full step: {Nv * F / dtm:.0f} frames/s")
     except Exception as e:
         out["secondary"]["parity_mix_full_step"] = {"value": None, "error": f"{type(e).__name__}: {e}"[:300]}
@@ -564,13 +739,14 @@ def main():
 
     pipe = FramePipeline(engine, vtok)
 
-    def step():
+    def step(fr=None):
+        fr = frames if fr is None else fr
         items = [dict(video_id=v, text=[]) for v in video_ids]
         if args.sequential:                      # the two scripts one after the other, as the reference runs them
-            engine.process(items, frames)
-            toks = vtok.process(video_ids, frames, [it["unfiltered_text"] for it in items])
+            engine.process(items, fr)
+            toks = vtok.process(video_ids, fr, [it["unfiltered_text"] for it in items])
             return items, toks
-        return pipe.process(items, frames)
+        return pipe.process(items, fr)
 
     def log(msg):
         if rank == 0:
@@ -680,14 +856,18 @@ def main():
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         log("cpu baseline...")
         import tempfile
-        parity_file = os.path.join(tempfile.gettempdir(), f"vidil_bench_parity_{os.getpid()}.npy")
+        parity_file = os.path.join(tempfile.gettempdir(), f"vidil_bench_parity_{os.getpid()}.npz")
         result["cpu_baseline"] = cpu_baseline(args, parity_file=parity_file)
     if rank == 0 and world == 1 and not args.no_secondary:
-        result.update(secondary_measurements(args, cap, flt, clip, step, frames, dev, parity_file, log, engine=engine))
+        result.update(secondary_measurements(args, cap, flt, clip, step, frames, dev, parity_file, log, engine=engine, vtok=vtok,
+                                             onto_texts=onto_texts))
     if rank == 0:
         result["statement"] = (f"value: {args.dtype} operands, plain precision mode — the throughput configuration (BASELINE configs[1]); the "
-                               "parity statement 'caption logits within 1e-3' holds as an absolute bound in the parity precision "
-                               "mode on f16 operands (tests/test_parity_mode_gpu.py), see `parity` and `secondary`")
+                               "parity statements ('caption logits within 1e-3' as an ABSOLUTE bound, also at a trained model's logit "
+                               "scale; visual-token ranks equal to the reference form) hold in the configuration timed as "
+                               "`parity_qualified` (tests/test_trained_like_gpu.py, tests/test_parity_mode_gpu.py); every logit figure is on "
+                               "random-init or synthetic trained-like weights — no checkpoint can be mounted on the bench / test boxes, "
+                               "tests/test_real_weights_gpu.py (3 tests) is skipped there")
         print(json.dumps(result), flush=True)
 
 

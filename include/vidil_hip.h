@@ -144,6 +144,11 @@ typedef struct vidil_gemm_args {
    * ln_fold stays 0 (A is not normalised here).  N % 64 == 0, N <= 1024. */
   const float* rln_gamma;
   const float* rln_beta;
+  /* EPI_F32 with out16 (ABI 10, round 5; no ln_stats_out / rln): non-zero = the 16-bit copy is written as ERROR-COMPENSATED
+   * operand rows [hi | lo | hi] (VIDIL_DT_SPLIT3's layout: three planes of ldo16 / 3 >= N columns; hi = T16(v), lo =
+   * T16(v - hi)) of v = act(acc + bias) + resid — what vidil_split3_f32 would make of the f32 output, from the same f32
+   * values — and `out` may then be NULL: the f32 rows are not written.  The parity precision mode's fc1 -> fc2 hand-over. */
+  int32_t out16_split3;
 } vidil_gemm_args;
 
 /* replaces: nn.Linear calls of models/vit.py:35-41,72,84; models/med.py:153-171,

@@ -547,3 +547,25 @@ def test_attention_f32_arena_form_follows_the_ancestry_table():
     s = (qd @ kk.view(R, n_keys, H, 64).permute(0, 2, 3, 1)) * 0.125
     ref = (torch.softmax(s, -1) @ vv.view(R, n_keys, H, 64).permute(0, 2, 1, 3)).reshape(R, C)
     assert (out.cpu().double() - ref).abs().max().item() < 3e-6
+
+
+# ------------------------------------------------------------------------------- out16_split3 (round 5)
+@pytest.mark.parametrize("M,N,K,act", [(300, 192, 384, 1), (4096, 3072, 2304, 1), (99000, 768, 1536, 0), (33000, 3072, 1536, 2), (10752, 3072, 2304, 1)])
+def test_gemm_f32_epilogue_writes_split3_operand_rows_itself(M, N, K, act):
+    """vidil_gemm_args.out16_split3: the f32 epilogue (bias + activation in f32) hands its result over as [hi | lo | hi] rows —
+    bit for bit what vidil_split3_f32 makes of the same GEMM's f32 output, on the 8-wave kernel (small grids) and the 4-wave one;
+    with `out` given as well the f32 rows are written too and equal the plain launch's."""
+    k = _k()
+    a = (_rand(M, K, seed=90) * 0.5).half().to(DEV)
+    w = (_rand(N, K, seed=91) * 0.05).half().to(DEV)
+    b = _rand(N, seed=92).to(DEV)
+    ref32 = k.gemm(a, w, b, out=torch.empty(M, N, dtype=torch.float32, device=DEV), act=act)
+    ref3 = k.split3(ref32, torch.empty(M, 3 * N, dtype=torch.float16, device=DEV))
+    got3 = torch.zeros(M, 3 * N, dtype=torch.float16, device=DEV)
+    k.gemm(a, w, b, split3_out=got3, act=act)
+    assert torch.equal(got3, ref3), (got3.float() - ref3.float()).abs().max().item()
+    got3b = torch.zeros(M, 3 * N, dtype=torch.float16, device=DEV)
+    out32 = torch.zeros(M, N, dtype=torch.float32, device=DEV)
+    k.gemm(a, w, b, split3_out=got3b, out=out32, act=act)
+    assert torch.equal(got3b, ref3) and torch.equal(out32, ref32)
+    print(f"split3_out {M}x{N}x{K} act {act}: {k.gemm_kernel_name(a, w, b, split3_out=got3, act=act)}")

@@ -173,12 +173,11 @@ def _run_layers(layers, x, B, T, H, eps, *, causal=False, kv_len=None, f32_attn=
     if "qkv_w3" in layers[0]:
         # Parity precision mode (round 4; as vit.VisionTransformer._run_blocks_parity): every GEMM on error-compensated
         # operands — LayerNorm and attention write [hi | lo | hi] rows (VIDIL_DT_SPLIT3), the quick-GELU output goes through
-        # f32 and vidil_split3_f32, weights are [W_hi | W_hi | W_lo], K tripled.  Q / K / V and the softmax probabilities
-        # are still rounded to 16 bits inside the attention kernels.
+        # the GEMM's own split3 epilogue, weights are [W_hi | W_hi | W_lo], K tripled.  Attention: vidil_attention_f32 on the f32
+        # Q | K | V rows (split-operand MFMA by default, or f32 arithmetic), or — kind "16" — the 16-bit kernels.
         Dh = layers[0]["fc1_w"].shape[0]
         a3 = torch.empty((M, 3 * D), dtype=cdt, device=dev)
         o3 = torch.empty((M, 3 * D), dtype=cdt, device=dev)
-        hid32 = torch.empty((M, Dh), dtype=torch.float32, device=dev)
         hid3 = torch.empty((M, 3 * Dh), dtype=cdt, device=dev)
         qkv32 = torch.empty((M, 3 * D), dtype=torch.float32, device=dev) if f32_attn else None
         for l in layers:
@@ -192,8 +191,7 @@ def _run_layers(layers, x, B, T, H, eps, *, causal=False, kv_len=None, f32_attn=
                 K.attention(q, k, vt, o3, Bq=B, H=H, Nq=T, Nk=T, Tq_cap=T, Tk_cap=T, NP=NP, causal=causal, kv_len=kv_len, split3=True)
             K.gemm(o3, l["o_w3"], l["o_b"], out=x, resid=x)
             K.layernorm(x, l["n2g"], l["n2b"], eps, out16=a3, split3=True)
-            K.gemm(a3, l["fc1_w3"], l["fc1_b"], out=hid32, act=K.ACT_QUICK_GELU)
-            K.split3(hid32, hid3)
+            K.gemm(a3, l["fc1_w3"], l["fc1_b"], split3_out=hid3, act=K.ACT_QUICK_GELU)
             K.gemm(hid3, l["fc2_w3"], l["fc2_b"], out=x, resid=x)
         return x
     stats = torch.empty((M, D // 64, 2), dtype=torch.float32, device=dev) if "fc1_f" in layers[0] else None

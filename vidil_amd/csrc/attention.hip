@@ -910,8 +910,8 @@ __global__ __launch_bounds__(512, 4) void attn_stream_kernel(const AttnP<T> p) {
 // four operands need more than 16 bits was measured on the CPU oracle (tests/probes/probe_precision_design.py, trained-like
 // statistics, of the logit scale): Q 1.7e-4, P 6.3e-5, V 2.1e-5, K 1.0e-5 — with Q and P split the 16-bit K / V leave 3.0e-5 where
 // the budget of "1e-3 absolute" at max|logit| = 16 is 6.4e-5, at the byte traffic of the plain kernel (f32 K / V: twice the bytes).
-template <typename T, int NKT, bool QS = false>
-__global__ __launch_bounds__(256) void attn_direct_kernel(const AttnP<T> p) {
+template <typename T, int NKT, bool QS = false, int VAR = 0>   // VAR (developer sweep of the QS form): 1 = three waves per SIMD, 2 = that with one key tile per wave and round
+__global__ __launch_bounds__(256, VAR ? 3 : 1) void attn_direct_kernel(const AttnP<T> p) {
   using f16 = T;
   using f16x8 = typename Elt<T>::x8;
   __shared__ float part_m[4][32];
@@ -969,7 +969,7 @@ __global__ __launch_bounds__(256) void attn_direct_kernel(const AttnP<T> p) {
     // This kernel streams each K / V^T byte exactly once and is HBM-bound, so every load of the wave's (up
     // to NI) key tiles is issued before the first MFMA: 16 x 16 B per lane in flight instead of 4.
     // Sequences longer than 8 key tiles (577 image tokens at 384^2) go through rounds of 2 tiles per wave.
-    constexpr int NI = NKT >= 8 ? 2 : (NKT + 3) / 4;
+    constexpr int NI = VAR == 2 ? 1 : (NKT >= 8 ? 2 : (NKT + 3) / 4);
     constexpr int ROUNDS = (NKT + 4 * NI - 1) / (4 * NI);
 #pragma unroll 1
     for (int round = 0; round < ROUNDS; ++round) {
@@ -1168,15 +1168,14 @@ int launch_lds(const AttnP<T>& p, int max_rows, hipStream_t s) {
   // + 2 KiB per wave for the output transposition (store_rows_lds) where a second workgroup still fits beside it
   constexpr bool ostage = 2 * (smem_kv + NW * 2048) <= 160 * 1024;
   constexpr int smem = smem_kv + (ostage ? NW * 2048 : 0);
-  static bool attr_set = false;
+  static unsigned long long attr_set = 0;   // (one bit per device: vidil_first_on_device)
   auto kern = attn_lds_kernel<T, NKT, NW>;
-  if (!attr_set) {
+  if (vidil_first_on_device(&attr_set)) {
     hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, smem);
     if (e != hipSuccess) {
       vidil_set_error("attention: hipFuncSetAttribute failed: %s", hipGetErrorString(e));
       return VIDIL_ELAUNCH;
     }
-    attr_set = true;
   }
   // rows a little over one round of NW blocks (the ITM cross-attention: 8 captions x 35 tokens = 280 rows per
   // image with NW = 8): a second round in the same workgroup instead of a second workgroup that would stage the
@@ -1206,18 +1205,17 @@ template <typename T, int NKT>
 int launch_stream(const AttnP<T>& p, hipStream_t s) {
   constexpr int smem = NKT * (4096 + 4 * 1152) + 8 * 2048;   // (attn_stream_kernel: TILE)
   static_assert(2 * smem <= 160 * 1024, "two workgroups per CU");
-  static bool attr_set = false;
+  static unsigned long long attr_set = 0;   // (one bit per device: vidil_first_on_device)
   const int n_cu = vidil_cu_count();
   auto kern16 = attn_stream_kernel<T, NKT, false>;
   auto kern8 = attn_stream_kernel<T, NKT, true>;
-  if (!attr_set) {
+  if (vidil_first_on_device(&attr_set)) {
     hipError_t e = hipFuncSetAttribute((const void*)kern16, hipFuncAttributeMaxDynamicSharedMemorySize, smem);
     if (e == hipSuccess) e = hipFuncSetAttribute((const void*)kern8, hipFuncAttributeMaxDynamicSharedMemorySize, smem);
     if (e != hipSuccess) {
       vidil_set_error("attention: stream kernel setup failed: %s", hipGetErrorString(e));
       return VIDIL_ELAUNCH;
     }
-    attr_set = true;
   }
   AttnP<T> q = p;
   q.ostage = 1;
@@ -1654,11 +1652,16 @@ __global__ __launch_bounds__(256) void attn_f32_mfma_kernel(const AttnF32P p) {
 // MFMAs): K in the GEMMs' XOR-swizzled 128-byte rows (ds_read_b128 fragments), V row-major in [d / 16][32 keys][16 d] blocks
 // that ds_read_b64_tr_b16 reads transposed (the streamed tower kernel's layout: no key permutation, no 2-byte scatter).
 // 24 MFMAs of v_mfma_f32_32x32x16 per 32 x 32 tile where the f32-input form issues 64 instructions of twice the latency.
-template <typename T16>
-__global__ __launch_bounds__(256, 2) void attn_split_kernel(const AttnF32P p) {
+template <typename T16, int NW>      // NW waves = NW x 32 virtual query rows of a unit per workgroup (8: a tower's 197 rows in ONE workgroup,
+#ifndef VIDIL_SPLIT_LB8
+#define VIDIL_SPLIT_LB8 4
+#endif
+__global__ __launch_bounds__(NW * 64, NW == 8 ? VIDIL_SPLIT_LB8 : 3) void attn_split_kernel(const AttnF32P p) {   // its K / V staged once)
   using x8 = typename Elt<T16>::x8;
   using x4 = typename Elt<T16>::x4;
   typedef short s16x8 __attribute__((ext_vector_type(8)));
+  constexpr int NT = NW * 64;
+  constexpr int NCH = 1024 / NT;          // 16-byte f32 chunks of the K tile (and of the V tile) per thread: 4 or 2... (32 keys x 16 chunks)
   constexpr int VSUB = 1152;              // bytes between the four [32 keys][16 d] blocks of a V image (1 KiB + 128: the two blocks
                                           // a half-wave reads together sit 32 banks apart)
   constexpr int KIMG = 4096, VIMG = 4 * VSUB;
@@ -1674,17 +1677,17 @@ __global__ __launch_bounds__(256, 2) void attn_split_kernel(const AttnF32P p) {
   int bk, first, count;
   resolve_unit(p, blockIdx.z, bk, first, count);
   const int rows = count * p.Nq;
-  const int base = blockIdx.x * 128;
+  const int base = blockIdx.x * (NW * 32);
   if (base >= rows) return;
   const RowInfo ri = row_info(p, base + wave * 32 + l31, first, rows);       // this lane's query row
   const bool wave_live = base + wave * 32 < rows;                              // (uniform)
-  auto split8 = [](const f32x4& a, const f32x4& b, x8& vh, x8& vl) {
+  // hi + lo of four f32: hi = the value with its low 13 mantissa bits cleared (exactly a 16-bit float for f16 operands inside
+  // f16's normal range; T16's own rounding otherwise), lo = T16(x - hi): x - hi is exact in f32, so hi + lo carries 21-22 bits
+  auto split4 = [](const f32x4& a, x4& vh, x4& vl) {
 #pragma unroll
     for (int e = 0; e < 4; ++e) {
       vh[e] = Elt<T16>::from_f32(a[e]);
       vl[e] = Elt<T16>::from_f32(a[e] - (float)vh[e]);
-      vh[4 + e] = Elt<T16>::from_f32(b[e]);
-      vl[4 + e] = Elt<T16>::from_f32(b[e] - (float)vh[4 + e]);
     }
   };
   // Q operand of k-step ks: d = ks * 16 + hi * 8 + 0..7 of this lane's row, scaled, hi and lo
@@ -1695,31 +1698,28 @@ __global__ __launch_bounds__(256, 2) void attn_split_kernel(const AttnF32P p) {
     for (int ks = 0; ks < 4; ++ks) {
       const f32x4 a = *(const f32x4*)(qrow + ks * 16) * p.scale;       // (row_info clamps invalid rows onto the last valid one)
       const f32x4 b = *(const f32x4*)(qrow + ks * 16 + 4) * p.scale;
-      split8(a, b, qh[ks], ql[ks]);
+      x4 ah, al, bh, bl;
+      split4(a, ah, al);
+      split4(b, bh, bl);
+      qh[ks] = __builtin_shufflevector(ah, bh, 0, 1, 2, 3, 4, 5, 6, 7);
+      ql[ks] = __builtin_shufflevector(al, bl, 0, 1, 2, 3, 4, 5, 6, 7);
     }
   }
   const float* kg = p.k + (size_t)bk * p.kv_rows * p.ldk + p.k_off + h * 64;
   const float* vg = p.v + (size_t)bk * p.kv_rows * p.ldv + p.v_off + h * 64;
-  // staging: thread -> (key = tid / 8, 16-byte f32 chunks c = tid % 8 and c + 8) of the tile, for K and for V
-  const int skey = tid >> 3, sc = tid & 7;
-  f32x4 kr[2], vr[2];
+  // staging: chunk q = tid + j * NT of the tile's 512 16-byte f32 chunks (key = q / 16, chunk c = q % 16), for K and for V
+  f32x4 kr[NCH / 2], vr[NCH / 2];
   auto fetch = [&](int k0) {
-    const int key = k0 + skey;
 #pragma unroll
-    for (int j = 0; j < 2; ++j) {
+    for (int j = 0; j < NCH / 2; ++j) {
+      const int q = tid + j * NT;
+      const int key = k0 + (q >> 4), c = q & 15;
       kr[j] = f32x4{0.f, 0.f, 0.f, 0.f};
       vr[j] = f32x4{0.f, 0.f, 0.f, 0.f};
       if (key < p.Nk) {
-        kr[j] = *(const f32x4*)(kg + (size_t)key * p.ldk + (sc + 8 * j) * 4);
-        vr[j] = *(const f32x4*)(vg + (size_t)key * p.ldv + (sc + 8 * j) * 4);
+        kr[j] = *(const f32x4*)(kg + (size_t)key * p.ldk + c * 4);
+        vr[j] = *(const f32x4*)(vg + (size_t)key * p.ldv + c * 4);
       }
-    }
-  };
-  auto split4 = [](const f32x4& a, x4& vh, x4& vl) {
-#pragma unroll
-    for (int e = 0; e < 4; ++e) {
-      vh[e] = Elt<T16>::from_f32(a[e]);
-      vl[e] = Elt<T16>::from_f32(a[e] - (float)vh[e]);
     }
   };
   const int sw = (l31 >> 1) & 7;
@@ -1732,6 +1732,13 @@ __global__ __launch_bounds__(256, 2) void attn_split_kernel(const AttnF32P p) {
     const s16x8 both = __builtin_shufflevector(lo, hi4, 0, 1, 2, 3, 4, 5, 6, 7);
     return __builtin_bit_cast(x8, both);
   };
+  // smallest key limit of the wave's rows: tiles that end below it need no mask
+  int kmin = ri.klim;
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) {
+    const int x = __shfl_xor(kmin, o, 64);
+    kmin = x < kmin ? x : kmin;
+  }
   float m = -INFINITY, l = 0.f;
   f32x16 O[2];
 #pragma unroll
@@ -1742,8 +1749,9 @@ __global__ __launch_bounds__(256, 2) void attn_split_kernel(const AttnF32P p) {
   for (int k0 = 0; k0 < p.Nk; k0 += 32) {
     __syncthreads();                       // every wave is done with the previous tile
 #pragma unroll
-    for (int j = 0; j < 2; ++j) {
-      const int c = sc + 8 * j;            // 4 d values: d = c * 4 ..
+    for (int j = 0; j < NCH / 2; ++j) {
+      const int q = tid + j * NT;
+      const int skey = q >> 4, c = q & 15;   // 4 d values: d = c * 4 ..
       x4 a, b;
       split4(kr[j], a, b);
       const int ko = skey * 128 + (((c >> 1) ^ ((skey >> 1) & 7)) << 4) + (c & 1) * 8;
@@ -1770,35 +1778,42 @@ __global__ __launch_bounds__(256, 2) void attn_split_kernel(const AttnF32P p) {
       S = Elt<T16>::mfma32(kh, ql[ks], S);
       S = Elt<T16>::mfma32(kh, qh[ks], S);
     }
-    // ---- online softmax (exact running maximum): S[r] belongs to key k0 + (r & 3) + 8 * (r >> 2) + 4 * hi of this lane's row
-    float mt = -INFINITY;
+    // ---- online softmax: S[r] belongs to key k0 + (r & 3) + 8 * (r >> 2) + 4 * hi of this lane's row.  The reference m moves
+    // only when a tile outgrows it by kLazy (a wave-uniform decision: softmax_tile above has the argument)
+    if (k0 + 32 > kmin) {                  // (uniform: a tile that reaches past some row's limit)
 #pragma unroll
-    for (int r = 0; r < 16; ++r) {
-      const int key = k0 + (r & 3) + 8 * (r >> 2) + 4 * hi;
-      if (key >= ri.klim) S[r] = -INFINITY;
-      mt = fmaxf(mt, S[r]);
+      for (int r = 0; r < 16; ++r) {
+        const int key = k0 + (r & 3) + 8 * (r >> 2) + 4 * hi;
+        if (key >= ri.klim) S[r] = -INFINITY;
+      }
     }
+    float mt = S[0];
+#pragma unroll
+    for (int r = 1; r < 16; ++r) mt = fmaxf(mt, S[r]);
     mt = fmaxf(mt, __shfl_xor(mt, 32, 64));
-    const float mn = fmaxf(m, mt);
-    const float msafe = (mn == -INFINITY ? 0.f : mn) * kLog2e;
-    const float alpha = __builtin_amdgcn_exp2f(__builtin_fmaf(m, kLog2e, -msafe));     // (m = -inf -> 0)
+    const bool grow = mt > m + kLazy;      // (m == -inf: true as soon as the row has seen one finite score)
+    if (__builtin_amdgcn_ballot_w64(grow) != 0) {
+      const float mn = grow ? mt : m;
+      const float alpha = __builtin_amdgcn_exp2f((m - (mn == -INFINITY ? 0.f : mn)) * kLog2e);   // keeps: 2^0; m == -inf: 0
+      l *= alpha;
+      m = mn;
+#pragma unroll
+      for (int dt = 0; dt < 2; ++dt)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) O[dt][r] *= alpha;
+    }
+    const float mc = (m == -INFINITY ? 0.f : m) * kLog2e;
     float ps = 0.f;
     x8 ph[2], pl[2];
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
-      const float e = __builtin_amdgcn_exp2f(__builtin_fmaf(S[r], kLog2e, -msafe));   // (masked: 2^-inf = 0)
+      const float e = __builtin_amdgcn_exp2f(__builtin_fmaf(S[r], kLog2e, -mc));   // (masked: 2^-inf = 0)
       ps += e;
       const T16 eh = Elt<T16>::from_f32(e);
       ph[r >> 3][r & 7] = eh;
       pl[r >> 3][r & 7] = Elt<T16>::from_f32(e - (float)eh);
     }
-    ps += __shfl_xor(ps, 32, 64);
-    l = l * alpha + ps;
-    m = mn;
-#pragma unroll
-    for (int dt = 0; dt < 2; ++dt)
-#pragma unroll
-      for (int r = 0; r < 16; ++r) O[dt][r] *= alpha;
+    l += ps;
     // ---- O^T[d][row] += V^T[d][keys] . P^T[keys][row]
 #pragma unroll
     for (int hb = 0; hb < 2; ++hb)
@@ -1812,6 +1827,7 @@ __global__ __launch_bounds__(256, 2) void attn_split_kernel(const AttnF32P p) {
       }
   }
   if (!wave_live || !ri.valid) return;
+  l += __shfl_xor(l, 32, 64);
   const float inv = l > 0.f ? 1.0f / l : 0.f;
   // O[dt][r]: d = dt * 32 + (r & 3) + 8 * (r >> 2) + 4 * hi -> 4 consecutive d per register quad
   const size_t row = (size_t)ri.qb * p.Nq + ri.t;
@@ -1827,11 +1843,7 @@ __global__ __launch_bounds__(256, 2) void attn_split_kernel(const AttnF32P p) {
         const long long pln = p.ldo / 3;
         T16* o = (T16*)p.out + row * p.ldo + h * 64 + d;
         x4 vh, vl;
-#pragma unroll
-        for (int e = 0; e < 4; ++e) {
-          vh[e] = Elt<T16>::from_f32(v[e]);
-          vl[e] = Elt<T16>::from_f32(v[e] - (float)vh[e]);
-        }
+        split4(v, vh, vl);
         *(x4*)o = vh;
         *(x4*)(o + pln) = vl;
         *(x4*)(o + 2 * pln) = vh;
@@ -1859,6 +1871,86 @@ __global__ __launch_bounds__(256) void attn_f32_arena_kernel(const AttnF32P p) {
   store_f32_row<T16>(p, (size_t)b, h, lane, acc / l);
 }
 
+// The arena form for up to 8 * MAXJ keys, in the shape of beam_attn_kernel (beam_attention.hip): one wave per (beam row, head);
+// lane (g = lane >> 3, c = lane & 7) owns the 8 d of chunk c of keys g, g + 8, ... — every K / V load 16 bytes wide and all of
+// them in flight together (their addresses depend on the ancestry row only), f32 scores / softmax / P.V on the VALU, the key
+// groups combined by a reduce-scatter (7 shuffles).  The one-key-at-a-time kernel above it replaces took 250 us per decode-step
+// launch at 10,752 beam rows (a wave reduction per key); the f32 arena holds twice the bytes of the 16-bit one, nothing more.
+template <typename T16, int MAXJ>
+__global__ __launch_bounds__(256) void attn_f32_arena_gather_kernel(const AttnF32P p) {
+  const int lane = threadIdx.x & 63;
+  const int unit = blockIdx.x * 4 + (threadIdx.x >> 6);       // (row, head)
+  if (unit >= p.Bq * p.H) return;
+  const int b = unit / p.H, h = unit - b * p.H;
+  const int g = lane >> 3, c = lane & 7;
+  const int32_t* __restrict__ anc = p.anc + (size_t)b * p.anc_ld;
+  const float* qp = p.q + (size_t)b * p.ldq + p.q_off + h * 64 + c * 8;
+  const f32x4 q0 = *(const f32x4*)qp * p.scale, q1 = *(const f32x4*)(qp + 4) * p.scale;
+  f32x4 k0[MAXJ], k1[MAXJ], v0[MAXJ], v1[MAXJ];
+  bool ok[MAXJ];
+#pragma unroll
+  for (int j = 0; j < MAXJ; ++j) {
+    const int t = g + 8 * j;
+    ok[j] = t < p.Nk;
+    const int tc = ok[j] ? t : p.Nk - 1;          // lanes past the end re-read the last key (masked below)
+    k0[j] = k1[j] = v0[j] = v1[j] = f32x4{0.f, 0.f, 0.f, 0.f};
+    if (8 * j < p.Nk) {                            // (wave-uniform)
+      const size_t row = (size_t)tc * p.arena_rows + anc[tc];
+      const float* kp = p.k + row * p.ldk + p.k_off + h * 64 + c * 8;
+      const float* vp = p.v + row * p.ldv + p.v_off + h * 64 + c * 8;
+      k0[j] = *(const f32x4*)kp; k1[j] = *(const f32x4*)(kp + 4);
+      v0[j] = *(const f32x4*)vp; v1[j] = *(const f32x4*)(vp + 4);
+    }
+  }
+  float s[MAXJ], m = -INFINITY;
+#pragma unroll
+  for (int j = 0; j < MAXJ; ++j) {
+    float d = 0.f;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) d = fmaf(q0[e], k0[j][e], d);
+#pragma unroll
+    for (int e = 0; e < 4; ++e) d = fmaf(q1[e], k1[j][e], d);
+    d += __shfl_xor(d, 1, 64);
+    d += __shfl_xor(d, 2, 64);
+    d += __shfl_xor(d, 4, 64);
+    s[j] = ok[j] ? d : -INFINITY;
+    m = fmaxf(m, s[j]);
+  }
+  m = fmaxf(m, __shfl_xor(m, 8, 64));
+  m = fmaxf(m, __shfl_xor(m, 16, 64));
+  m = fmaxf(m, __shfl_xor(m, 32, 64));     // Nk >= 1: finite
+  float o[8], l = 0.f;
+#pragma unroll
+  for (int e = 0; e < 8; ++e) o[e] = 0.f;
+#pragma unroll
+  for (int j = 0; j < MAXJ; ++j) {
+    const float pj = ok[j] ? expf(s[j] - m) : 0.f;
+    l += pj;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) { o[e] = fmaf(pj, v0[j][e], o[e]); o[4 + e] = fmaf(pj, v1[j][e], o[4 + e]); }
+  }
+  l += __shfl_xor(l, 8, 64);
+  l += __shfl_xor(l, 16, 64);
+  l += __shfl_xor(l, 32, 64);
+  // sum over the 8 key groups as a reduce-scatter; lane (g, c) ends with d = 8c + 4*g2 + 2*g1 + g0
+  const bool b2 = (g & 4) != 0, b1 = (g & 2) != 0, b0 = (g & 1) != 0;
+  float o4[4], o2[2];
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const float keep = b2 ? o[4 + i] : o[i], send = b2 ? o[i] : o[4 + i];
+    o4[i] = keep + __shfl_xor(send, 32, 64);
+  }
+#pragma unroll
+  for (int i = 0; i < 2; ++i) {
+    const float keep = b1 ? o4[2 + i] : o4[i], send = b1 ? o4[i] : o4[2 + i];
+    o2[i] = keep + __shfl_xor(send, 16, 64);
+  }
+  const float keep = b0 ? o2[1] : o2[0], send = b0 ? o2[0] : o2[1];
+  const float od = keep + __shfl_xor(send, 8, 64);
+  const int d = 8 * c + (b2 ? 4 : 0) + (b1 ? 2 : 0) + (b0 ? 1 : 0);
+  store_f32_row<T16>(p, (size_t)b, h, d, od / l);
+}
+
 }  // namespace
 
 extern "C" int vidil_attention_f32(const vidil_attn_f32_args* a, void* stream) {
@@ -1870,6 +1962,7 @@ extern "C" int vidil_attention_f32(const vidil_attn_f32_args* a, void* stream) {
   VIDIL_REQUIRE(a->out_mode == 0 || (a->out_mode == 2 && a->ldo % 3 == 0 && a->ldo / 3 >= (long long)a->H * 64 &&
                                      (a->dtype16 == VIDIL_DT_F16 || a->dtype16 == VIDIL_DT_BF16)),
                 "attention_f32: out_mode 0 (f32 rows) or 2 ([hi | lo | hi] 16-bit rows, ldo = 3 planes)");
+  VIDIL_REQUIRE(a->out_mode != 0 || a->ldo >= (long long)a->H * 64, "attention_f32: ldo=%lld < H*64 (f32 rows)", (long long)a->ldo);
   AttnF32P p;
   p.q = a->q; p.k = a->k; p.v = a->v; p.out = a->out;
   p.ldq = a->ldq; p.ldk = a->ldk; p.ldv = a->ldv; p.ldo = a->ldo;
@@ -1884,7 +1977,12 @@ extern "C" int vidil_attention_f32(const vidil_attn_f32_args* a, void* stream) {
   if (a->anc != nullptr) {
     VIDIL_REQUIRE(a->Nq == 1 && a->arena_rows > 0 && a->anc_ld >= a->Nk, "attention_f32: the arena form serves one query row per batch");
     const int units = a->Bq * a->H;
-    if (bf) hipLaunchKernelGGL(attn_f32_arena_kernel<bf16>, dim3((units + 3) / 4), dim3(256), 0, s, p);
+    const char* eg = vidil_dev_env("VIDIL_ATTN_F32_ARENA_GATHER");       // (developer: 0 = the one-key-at-a-time kernel)
+    const bool allow_gather = !(eg && eg[0] == '0');
+    if (allow_gather && a->Nk <= 32 && a->ldq % 4 == 0) {     // (the decode steps of a caption search: max_length <= 32)
+      if (bf) hipLaunchKernelGGL((attn_f32_arena_gather_kernel<bf16, 4>), dim3((units + 3) / 4), dim3(256), 0, s, p);
+      else hipLaunchKernelGGL((attn_f32_arena_gather_kernel<f16, 4>), dim3((units + 3) / 4), dim3(256), 0, s, p);
+    } else if (bf) hipLaunchKernelGGL(attn_f32_arena_kernel<bf16>, dim3((units + 3) / 4), dim3(256), 0, s, p);
     else hipLaunchKernelGGL(attn_f32_arena_kernel<f16>, dim3((units + 3) / 4), dim3(256), 0, s, p);
     VIDIL_CHECK_LAUNCH("attention_f32 (arena)");
     return VIDIL_OK;
@@ -1927,7 +2025,14 @@ extern "C" int vidil_attention_f32(const vidil_attn_f32_args* a, void* stream) {
         case 4: hipLaunchKernelGGL((attn_direct_kernel<T, 4, true>), g, dim3(256), 0, s, q); break;
         case 5: hipLaunchKernelGGL((attn_direct_kernel<T, 5, true>), g, dim3(256), 0, s, q); break;
         case 6: hipLaunchKernelGGL((attn_direct_kernel<T, 6, true>), g, dim3(256), 0, s, q); break;
-        case 7: hipLaunchKernelGGL((attn_direct_kernel<T, 7, true>), g, dim3(256), 0, s, q); break;
+        case 7: {
+          const char* ev = vidil_dev_env("VIDIL_ATTN_QS_VARIANT");
+          const int var = ev ? atoi(ev) : 2;      // (one key tile per wave and round, three waves per SIMD: 638 -> 555 us per 3,584-image launch)
+          if (var == 1) hipLaunchKernelGGL((attn_direct_kernel<T, 7, true, 1>), g, dim3(256), 0, s, q);
+          else if (var == 2) hipLaunchKernelGGL((attn_direct_kernel<T, 7, true, 2>), g, dim3(256), 0, s, q);
+          else hipLaunchKernelGGL((attn_direct_kernel<T, 7, true>), g, dim3(256), 0, s, q);
+          break;
+        }
         case 8: hipLaunchKernelGGL((attn_direct_kernel<T, 8, true>), g, dim3(256), 0, s, q); break;
         default: hipLaunchKernelGGL((attn_direct_kernel<T, 24, true>), g, dim3(256), 0, s, q); break;
       }
@@ -1941,9 +2046,19 @@ extern "C" int vidil_attention_f32(const vidil_attn_f32_args* a, void* stream) {
     // waves without rows: they still stage)
     VIDIL_REQUIRE((a->out_mode == 2 ? a->ldo % 12 == 0 : a->ldo % 4 == 0) && ((uintptr_t)a->out & 15) == 0,
                   "attention_f32 (split): output rows must allow 8-byte (split3) / 16-byte (f32) stores");
-    const dim3 gridm((max_rows + 127) / 128, a->H, units);
-    if (bf) hipLaunchKernelGGL(attn_split_kernel<bf16>, gridm, dim3(256), 0, s, p);
-    else hipLaunchKernelGGL(attn_split_kernel<f16>, gridm, dim3(256), 0, s, p);
+    // more than 128 rows per unit (a tower's 197): 8 waves per workgroup, so that one workgroup — one staging of the unit's K / V —
+    // serves up to 256 rows; 4 waves otherwise
+    const char* ew = vidil_dev_env("VIDIL_ATTN_SPLIT_NW");
+    const int nw = ew ? atoi(ew) : (max_rows > 128 ? 8 : 4);
+    if (nw == 8) {
+      const dim3 gridm((max_rows + 255) / 256, a->H, units);
+      if (bf) hipLaunchKernelGGL((attn_split_kernel<bf16, 8>), gridm, dim3(512), 0, s, p);
+      else hipLaunchKernelGGL((attn_split_kernel<f16, 8>), gridm, dim3(512), 0, s, p);
+    } else {
+      const dim3 gridm((max_rows + 127) / 128, a->H, units);
+      if (bf) hipLaunchKernelGGL((attn_split_kernel<bf16, 4>), gridm, dim3(256), 0, s, p);
+      else hipLaunchKernelGGL((attn_split_kernel<f16, 4>), gridm, dim3(256), 0, s, p);
+    }
     VIDIL_CHECK_LAUNCH("attention_f32 (split)");
     return VIDIL_OK;
   }

@@ -134,7 +134,10 @@ __global__ __launch_bounds__(256) void lsm_topk_kernel(const float* __restrict__
           for (int e = 0; e < 4; ++e)
             if (i + e != ban && x[e] >= thr) consider_raw(x[e], i + e);  // (the banned token counts in the softmax, never as a candidate)
         }
-        if ((it & 7) == 1) {
+        // (the refresh shuffles across the wave, so it runs only while EVERY lane is still inside the loop — on the
+        //  ragged last iteration of a vocabulary that is not a multiple of 1,024 some lanes have left, their registers are
+        //  undefined to a shuffle, and a bound derived from them could exceed real logits)
+        if ((it & 7) == 1 && __builtin_amdgcn_ballot_w64(true) == ~0ull) {
           float c = rs[0], t = -INFINITY;
 #pragma unroll
           for (int r = 0; r < K; ++r) {

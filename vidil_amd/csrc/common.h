@@ -22,6 +22,7 @@ typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
 // error plumbing ------------------------------------------------------------
 void vidil_set_error(const char* fmt, ...);
 int vidil_cu_count();                          // core.hip: compute units of the current device (cached; 256 when none answers)
+bool vidil_first_on_device(unsigned long long* mask);   // core.hip: true once per (flag word, current device) — per-device kernel setup
 const char* vidil_dev_env(const char* name);   // core.hip: developer overrides, read once per process (live under $VIDIL_DEV_ENV)
 
 // gemm256.hip: the 256x256 8-wave kernel for large problems (dispatched from vidil_gemm_f16)

@@ -20,13 +20,29 @@ void vidil_set_error(const char* fmt, ...) {
 // Compute units of the current device, read once (256 on MI355X; also the fallback when no device answers, e.g. the host-only
 // dispatch-name checks).  The tile-count thresholds of the GEMM dispatch are fractions of it: they were tuned as "workgroups
 // per CU", and the persistent grids are sized from the same number.
+// (per DEVICE, ADVICE r4: a process that drives more than one GPU — not how the path is deployed, one process per GPU, but not
+//  forbidden either — must not size the second device's grids from the first one's CU count)
 int vidil_cu_count() {
-  static const int n = [] {
-    int dev = 0, v = 0;
-    if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || v < 8) v = 256;
-    return v;
-  }();
-  return n;
+  static int cache[64] = {};
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return 256;
+  if (cache[dev] == 0) {
+    int v = 0;
+    if (hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || v < 8) v = 256;
+    cache[dev] = v;
+  }
+  return cache[dev];
+}
+
+// true exactly once per (flag word, current device): guards the per-device one-time setup of a kernel (the dynamic-LDS opt-in
+// of hipFuncSetAttribute applies to the device that is current when it is called)
+bool vidil_first_on_device(unsigned long long* mask) {
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return true;      // (unknown: do the setup again, it is idempotent)
+  const unsigned long long bit = 1ull << dev;
+  if (*mask & bit) return false;
+  *mask |= bit;
+  return true;
 }
 
 const char* vidil_dev_env(const char* name) {

@@ -299,15 +299,14 @@ __global__ __launch_bounds__(2 * waves_n(BM, BN) * 64) void gemm_kernel(const vi
 template <typename T, int BM, int BN, int ST, int EPI, int ACT>
 int launch(const vidil_gemm_args& a, hipStream_t s) {
   constexpr int smem = ST * (BM + BN) * BK * 2;
-  static bool attr_set = false;
+  static unsigned long long attr_set = 0;   // (one bit per device: vidil_first_on_device)
   auto kern = gemm_kernel<T, BM, BN, ST, EPI, ACT>;
-  if (!attr_set) {
+  if (vidil_first_on_device(&attr_set)) {
     hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, smem);
     if (e != hipSuccess) {
       vidil_set_error("gemm: hipFuncSetAttribute failed: %s", hipGetErrorString(e));
       return VIDIL_ELAUNCH;
     }
-    attr_set = true;
   }
   const int tiles = ((a.M + BM - 1) / BM) * ((a.N + BN - 1) / BN);
   hipLaunchKernelGGL(kern, dim3(tiles), dim3(2 * waves_n(BM, BN) * 64), smem, s, a);
@@ -400,6 +399,12 @@ int check_args(const vidil_gemm_args& a) {
     VIDIL_REQUIRE(a.epi == VIDIL_EPI_F32, "gemm/out16: only the f32 residual epilogue writes the 16-bit copy");
     VIDIL_REQUIRE(a.ldo16 >= a.N, "gemm/out16: ldo16=%d < N=%d", a.ldo16, a.N);
   }
+  if (a.out16_split3) {
+    VIDIL_REQUIRE(a.out16 && a.epi == VIDIL_EPI_F32 && !a.ln_stats_out && !a.rln_gamma && a.dtype != VIDIL_DT_FP8,
+                  "gemm/out16_split3: the plain f32 epilogue with out16 (16-bit operands, no ln_stats_out / rln)");
+    VIDIL_REQUIRE(a.ldo16 % 12 == 0 && a.ldo16 / 3 >= a.N && ((uintptr_t)a.out16 & 7) == 0,
+                  "gemm/out16_split3: ldo16=%d must be three planes of >= N=%d columns, each a multiple of 4", a.ldo16, a.N);
+  }
   if (a.ln_stats_out)
     VIDIL_REQUIRE(a.epi == VIDIL_EPI_F32 && a.act == VIDIL_ACT_NONE && a.N % 64 == 0 && a.dtype != VIDIL_DT_FP8,
                   "gemm/ln_stats_out: 16-bit operands, f32 residual epilogue without activation, N %% 64 == 0");
@@ -416,7 +421,7 @@ int check_args(const vidil_gemm_args& a) {
     case VIDIL_EPI_F16:
     case VIDIL_EPI_F32:
     case VIDIL_EPI_F8:
-      VIDIL_REQUIRE(a.out && a.ldo >= a.N, "gemm: bad out/ldo");
+      VIDIL_REQUIRE((a.out || (a.epi == VIDIL_EPI_F32 && a.out16_split3 && !a.resid)) && a.ldo >= a.N, "gemm: bad out/ldo");
       VIDIL_REQUIRE(a.act >= VIDIL_ACT_NONE && a.act <= VIDIL_ACT_QUICK_GELU, "gemm: unknown act %d", a.act);
       return VIDIL_OK;
     case VIDIL_EPI_HEADS: {

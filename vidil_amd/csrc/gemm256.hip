@@ -357,24 +357,17 @@ __global__ __launch_bounds__(512) void gemm256_kernel(const vidil_gemm_args p) {
 
 template <typename T, int EPI, int ACT, bool FOLD = false, typename TO = T, bool STATS = false, bool RLN = false>
 int launch256(const vidil_gemm_args& a, hipStream_t s) {
-  static bool attr_set = false;
+  static unsigned long long attr_set = 0;   // (one bit per device: vidil_first_on_device)
   auto kern = gemm256_kernel<T, TO, EPI, ACT, FOLD, STATS, RLN>;
   constexpr int lds = LDS_BYTES + ((FOLD || RLN) ? STATS_BYTES : 0);
-  if (!attr_set) {
+  if (vidil_first_on_device(&attr_set)) {
     hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
     if (e != hipSuccess) {
       vidil_set_error("gemm256: hipFuncSetAttribute failed: %s", hipGetErrorString(e));
       return VIDIL_ELAUNCH;
     }
-    attr_set = true;
   }
-  static int num_cu = 0;
-  if (num_cu == 0) {
-    int dev = 0, n = 0;
-    if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n < 8)
-      n = 256;
-    num_cu = n & ~7;
-  }
+  const int num_cu = vidil_cu_count() & ~7;     // (per device: core.hip)
   // persistent grid: one workgroup per CU (a multiple of 8 so every XCD gets the same number), never more than tiles
   int cus = num_cu;
   if (const char* e = vidil_dev_env("VIDIL_GEMM_CUS")) {      // developer: a stream confined to fewer CUs by a CU mask (tools/exp_cu_mask.py)
@@ -512,7 +505,8 @@ static bool prefer_4w(const vidil_gemm_args& a) {
       // round 4, same box, whole bench: the last-block fc2 (K = 3072) 1,040 -> 1,160 TFLOP/s on the 4-wave kernel, the LM head
       // (10,752 x 30,524, K = 768) 838 -> 708.  $VIDIL_GEMM4W_F32 = 0 / 1 forces one kernel (A/B switch).
       static const int f32_4w = [] { const char* e = getenv("VIDIL_GEMM4W_F32"); return e ? atoi(e) : VIDIL_GEMM4W_F32_DEFAULT; }();
-      return a.ln_stats_out != nullptr || (a.act == VIDIL_ACT_NONE && (f32_4w > 0 || (f32_4w < 0 && a.K >= 1536)));
+      // (round 5: with or without an activation — the parity mode's K-tripled fc1 + GELU, K = 2304, ran on the 8-wave kernel)
+      return a.ln_stats_out != nullptr || f32_4w > 0 || (f32_4w < 0 && a.K >= 1536);
     }
     default:
       return false;

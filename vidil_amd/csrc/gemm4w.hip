@@ -450,24 +450,17 @@ __global__ __launch_bounds__(256) void gemm4w_kernel(const vidil_gemm_args p) {
 
 template <typename T, int EPI, int ACT, bool FOLD = false, typename TO = T, bool STATS = false, bool RLN = false, int TM = 4>
 int launch4w(const vidil_gemm_args& a, hipStream_t s) {
-  static bool attr_set = false;
+  static unsigned long long attr_set = 0;   // (one bit per device: vidil_first_on_device)
   auto kern = gemm4w_kernel<T, TO, EPI, ACT, FOLD, STATS, RLN, TM>;
   constexpr int LDS_BYTES = kLds<TM>;
-  if (!attr_set) {
+  if (vidil_first_on_device(&attr_set)) {
     hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES);
     if (e != hipSuccess) {
       vidil_set_error("gemm4w: hipFuncSetAttribute failed: %s", hipGetErrorString(e));
       return VIDIL_ELAUNCH;
     }
-    attr_set = true;
   }
-  static int num_cu = 0;
-  if (num_cu == 0) {
-    int dev = 0, n = 0;
-    if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n < 8)
-      n = 256;
-    num_cu = n & ~7;
-  }
+  const int num_cu = vidil_cu_count() & ~7;     // (per device: core.hip)
   int cus = num_cu;
   if (const char* e = vidil_dev_env("VIDIL_GEMM_CUS")) {
     const int v = atoi(e) & ~7;

@@ -99,12 +99,12 @@ def _comm_device():
 def gather_json(obj):
     """Gather one JSON-serialisable object per rank (rank order); rank 0 gets the list, other ranks get None.
 
-    Two collectives and nothing else: an ``all_gather`` of the payload sizes (one int64 per rank), then ONE ``all_gather`` of
-    the UTF-8 bytes padded to the longest payload.  RCCL (backend 'nccl') moves device buffers over xGMI as a ring
-    all-gather, Gloo moves host buffers.  Round 4: this replaces a per-peer ``send`` / ``recv`` pair — the same code path
-    now runs for every world size including 1, so what an 8-GPU job executes is what the one-GPU box has already executed
-    (tests/test_dist_gpu.py); the price is that the padded payloads (a few KB per video: tens of MB for a full dataset)
-    land on every rank instead of rank 0 only."""
+    Two collectives and nothing else: an ``all_gather`` of the payload sizes (one int64 per rank), then ONE ``gather`` TO RANK 0
+    of the UTF-8 bytes padded to the longest payload (run_video_CapFilt.py:261-291 / run_visual_tokenization.py:447-463: only
+    rank 0 merges and writes).  RCCL (backend 'nccl') moves device buffers over xGMI, Gloo moves host buffers.  The same code
+    path runs for every world size including 1, so what an 8-GPU job executes is what the one-GPU box has already executed
+    (tests/test_dist_gpu.py).  Round 5: a true gather — round 4's second ``all_gather`` landed every rank's padded payload on
+    every rank; it remains as the fallback for a backend without ``gather`` ($VIDIL_GATHER=allgather forces it)."""
     if not is_dist_avail_and_initialized():
         return [obj]
     dev = _comm_device()
@@ -118,8 +118,17 @@ def gather_json(obj):
     mine = torch.zeros(cap, dtype=torch.uint8)
     mine[:len(raw)] = torch.frombuffer(bytearray(raw), dtype=torch.uint8)
     mine = mine.to(dev)
-    bufs = [torch.empty(cap, dtype=torch.uint8, device=dev) for _ in range(world)]
-    dist.all_gather(bufs, mine)
+    use_gather = os.environ.get("VIDIL_GATHER", "gather") != "allgather"
+    bufs = None
+    if use_gather:
+        try:
+            bufs = [torch.empty(cap, dtype=torch.uint8, device=dev) for _ in range(world)] if rank == 0 else None
+            dist.gather(mine, gather_list=bufs, dst=0)
+        except (RuntimeError, NotImplementedError):       # a backend without gather: every rank lands here alike
+            use_gather = False
+    if not use_gather:
+        bufs = [torch.empty(cap, dtype=torch.uint8, device=dev) for _ in range(world)]
+        dist.all_gather(bufs, mine)
     if rank != 0:
         return None
     return [json.loads(bufs[r][:sizes[r]].cpu().numpy().tobytes().decode("utf-8")) for r in range(world)]

@@ -82,6 +82,9 @@ def gemm(a, w, bias=None, **kw):
       * patch=dict(out=,pos=,tpi=): patch-embedding epilogue (row remap + pos embed).
       * arena=dict(q=,k=,v=,T=,H=,part0=,t_off=,arena_rows=,slot_stride=,Tcap=,q_scale=): Q rows + K/V rows
         appended to a beam-search KV arena [position][slot][H*64] (see vidil_beam_attention).
+      * split3_out=T16 [M,3N]: f32 epilogue (activation in f32) whose result is written as the error-compensated operand rows
+        [hi | lo | hi] of the next K-tripled GEMM (vidil_gemm_args.out16_split3) — the parity mode's fc1 -> fc2 hand-over
+        without the f32 round trip through ``split3``; ``out`` (f32), if given as well, also receives the f32 rows.
       * LayerNorm folded into a pre-LN block's GEMM pair (vidil_gemm_args.ln_fold): the residual GEMM passes
         ``out16=`` (T16 copy of the f32 stream it writes) and ``ln_stats_out=`` (per-row partial sums), the next
         GEMM passes that copy as ``a`` with ``ln=(colsum, eps, stats)`` and weights / bias folded by
@@ -102,7 +105,7 @@ def gemm_kernel_name(a, w, bias=None, **kw):
 
 def _gemm_build(a, w, bias=None, *, out=None, out_dtype=None, act=ACT_NONE, resid=None,
                 heads=None, patch=None, arena=None, M=None, lda=None, out16=None, ln_stats_out=None, ln=None, w_scale=None,
-                dtype16=None, rln=None):
+                dtype16=None, rln=None, split3_out=None):
     K_ = w.shape[1]
     if lda is None:
         M, Ka = a.shape
@@ -168,6 +171,22 @@ def _gemm_build(a, w, bias=None, *, out=None, out_dtype=None, act=ACT_NONE, resi
         g.ldo = ret.shape[-1]
         g.pos = _ptr(patch["pos"], torch.float32, "gemm.patch.pos")
         g.tpi = patch["tpi"]
+    elif split3_out is not None:
+        # f32 epilogue whose result leaves as [hi | lo | hi] operand rows of the next compensated GEMM (out16_split3); the f32
+        # rows themselves are written only when ``out`` (f32) is given too
+        if tuple(split3_out.shape) != (M, 3 * N) or split3_out.dtype != a.dtype or out16 is not None or resid is not None:
+            raise VidilHipError(f"gemm: split3_out must be {a.dtype} [{M}, {3 * N}] (no out16 / resid beside it), got "
+                                f"{split3_out.dtype} {tuple(split3_out.shape)}")
+        g.epi = EPI_F32
+        ret = split3_out
+        if out is not None:
+            g.out = _ptr(out, torch.float32, "gemm.out")
+            g.ldo = out.shape[-1]
+        else:
+            g.ldo = N
+        g.out16 = _ptr(split3_out, t16, "gemm.split3_out")
+        g.ldo16 = 3 * N
+        g.out16_split3 = 1
     else:
         if out is None:
             out = torch.empty((M, N), dtype=out_dtype or a.dtype, device=a.device)

@@ -431,7 +431,6 @@ class BertModel(PackedCache, nn.Module):
             ws["q"] = q
         o3 = torch.empty((M, 3 * C), dtype=cdt, device=dev)
         tmp = torch.empty((M, C), dtype=torch.float32, device=dev)
-        inter32 = torch.empty((M, cfg.intermediate_size), dtype=torch.float32, device=dev)
         inter3 = torch.empty((M, 3 * cfg.intermediate_size), dtype=cdt, device=dev)
         Nk = t_off + T
         if arena is not None and T > 1 and t_off != 0:
@@ -503,8 +502,7 @@ class BertModel(PackedCache, nn.Module):
                             group_start=cross_groups, max_group=cross_max_group, kv_tiled=cross.tiled, split3=True)
                 K.gemm(o3, d["co_w3"], d["co_b"], out=tmp, resid=h32)
                 K.layernorm(tmp, d["co_g"], d["co_bt"], eps, out16=h3, out32=h32, split3=True)
-            K.gemm(h3, d["i_w3"], d["i_b"], out=inter32, act=K.ACT_GELU_ERF)
-            K.split3(inter32, inter3)
+            K.gemm(h3, d["i_w3"], d["i_b"], split3_out=inter3, act=K.ACT_GELU_ERF)
             K.gemm(inter3, d["o_w3"], d["o_b"], out=tmp, resid=h32)
             K.layernorm(tmp, d["o_g"], d["o_bt"], eps, out16=h3, out32=h32, split3=True)
         return h32, h3

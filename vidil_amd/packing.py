@@ -70,8 +70,9 @@ def compute_dtype(module=None):
 # [W_hi | W_hi | W_lo], and ONE GEMM with K tripled accumulates x_hi·W_hi + x_lo·W_hi + x_hi·W_lo in f32, i.e. x·W to
 # ~2^-21 relative instead of the 2^-11 of plain f16 operands.  It is the mode in which BASELINE's "caption logits within
 # 1e-3" holds as an ABSOLUTE bound (tests/test_models_gpu.py) at ~3x the MFMA work; the throughput modes
-# (plain f16 / bf16 / fp8) stay the default.  What still rounds to 16 bits in parity mode: Q, K, V and the softmax
-# probabilities inside the attention kernels (their error averages over the keys).
+# (plain f16 / bf16 / fp8) stay the default.  Attention in the mode (set_parity_attention): since round 5 the split-operand form —
+# f32 Q / K / V from the projection GEMMs, every operand of Q.K^T and P.V as hi + lo on the 16-bit MFMA — by default; round 4's
+# plain f32 arithmetic and round 3's 16-bit kernels (Q, K, V and the probabilities rounded to 16 bits) remain selectable.
 _parity_default = [os.environ.get("VIDIL_PARITY", "0") == "1"]
 _warned_bf16_parity = [False]
 _PARITY_ATTN_KINDS = ("split", "f32", "16")

@@ -231,15 +231,15 @@ class VisionTransformer(PackedCache, nn.Module):
         """Parity precision mode: the same block sequence with every GEMM on error-compensated operands (K tripled):
         LayerNorm and attention write [hi | lo | hi] rows directly (VIDIL_DT_SPLIT3), the GELU output goes through f32
         and vidil_split3_f32.  Returns (y32, y3) with y3 = [M, 3D] split rows of the final LayerNorm (the cross K|V
-        projection's operand).  ~3x the MFMA work of the plain path; Q / K / V and the softmax probabilities are still
-        rounded to 16 bits inside the attention kernels."""
+        projection's operand).  ~3x the MFMA work of the plain path.  Attention (packing.set_parity_attention): "split" / "f32" —
+        Q | K | V stay f32 rows of the projection GEMM's output and vidil_attention_f32 reads them in place (split-operand MFMA
+        or f32 arithmetic); "16" — the per-head scatter and the 16-bit kernels, Q / K / V and the probabilities rounded to 16 bits."""
         D, H = self.embed_dim, self.num_heads
         dev, cdt = x.device, q.dtype
         M = B * T
         Dh = p["blocks"][0]["fc1_w"].shape[0]
         a3 = torch.empty((M, 3 * D), dtype=cdt, device=dev)
         o3 = torch.empty((M, 3 * D), dtype=cdt, device=dev)
-        hid32 = torch.empty((M, Dh), dtype=torch.float32, device=dev)
         hid3 = torch.empty((M, 3 * Dh), dtype=cdt, device=dev)
         f32_attn, arith = parity_attention_f32(self), parity_attention_arith(self)
         qkv32 = torch.empty((M, 3 * D), dtype=torch.float32, device=dev) if f32_attn else None
@@ -267,8 +267,8 @@ class VisionTransformer(PackedCache, nn.Module):
                 K.attention(q, k, vt, o3, Bq=B, H=H, Nq=T, Nk=T, Tq_cap=T, Tk_cap=T, NP=NP, split3=True)
             K.gemm(o3, b["proj_w3"], b["proj_b"], out=x, resid=x)
             K.layernorm(x, b["n2g"], b["n2b"], self.ln_eps, out16=a3, split3=True)
-            K.gemm(a3, b["fc1_w3"], b["fc1_b"], out=hid32, act=K.ACT_GELU_ERF)
-            K.split3(hid32, hid3)
+            # (fc1 + erf-GELU in f32, handed to fc2 as [hi | lo | hi] rows by the GEMM's own epilogue: no f32 round trip)
+            K.gemm(a3, b["fc1_w3"], b["fc1_b"], split3_out=hid3, act=K.ACT_GELU_ERF)
             K.gemm(hid3, b["fc2_w3"], b["fc2_b"], out=x, resid=x)
         y32 = torch.empty((M, D), dtype=torch.float32, device=dev)
         K.layernorm(x, p["norm_g"], p["norm_b"], self.ln_eps, out16=a3 if want16 else None, out32=y32, split3=True)
