@@ -395,7 +395,8 @@ def secondary_measurements(args, cap, flt, clip, step, frames, dev, parity_file,
                 "reference": "run_visual_tokenization.py:276,298-308 on the fp32 oracle's CLIP embeddings (video 0)"}
     parity = {"sample": "prompt-pass caption logits (2 frames x 30,524 tokens) of video 0: device vs the fp32 CPU oracle of the cpu_baseline leg",
               "reference": "models/med.py:501-545,830-930 (BertLMHeadModel logits)"}
-    tol = {"bf16": "8e-3 x max(1, max|logit|)  (tests/test_bf16_gpu.py)", "f16": "1e-3 x max(1, max|logit|)  (tests/test_models_gpu.py)",
+    tol = {"bf16": "1e-2 x max(1, max|logit|)  (tests/test_bf16_gpu.py; worst of 80 passes 7.7e-3: tests/probes/probe_plain_margin.py)",
+           "f16": "1.25e-3 x max(1, max|logit|)  (tests/test_models_gpu.py; worst of 80 passes 9.6e-4)",
            "fp8": "none (throughput mode; tests/test_fp8_gpu.py bounds captions / ITM decisions)"}
 
     def record(label, asserted):
@@ -545,9 +546,11 @@ def secondary_measurements(args, cap, flt, clip, step, frames, dev, parity_file,
     # ---- the PARITY-QUALIFIED configuration (round 5): what it costs to deliver the two tolerances BASELINE states
     # at a TRAINED model's logit scale — captioner (ViT + cross K|V + decoder + LM head) and CLIP error-compensated with the
     # split-operand attention, the filter (no tolerance is stated for ITM logits) on plain f16 operands
+    flt_dtype = args.dtype if args.dtype in ("f16", "bf16") else "f16"       # the filter as `value` runs it (no tolerance is stated for it)
     try:
         free_sessions()
         set_parity_mode(True, cap, clip)
+        set_compute_dtype(flt_dtype, flt)
         for _ in range(3):
             step()
         dtq = time_steps(step, max(2, min(args.steps, 3)))
@@ -556,7 +559,7 @@ def secondary_measurements(args, cap, flt, clip, step, frames, dev, parity_file,
               "config": "same workload and step as `value`; f16 operands; captioner and CLIP in the parity precision mode (every GEMM on "
                         "[hi | lo | hi] x [W_hi | W_hi | W_lo] operands, K tripled; split-operand 16-bit MFMA attention on f32 Q / K / V, "
                         "the decode steps' cross-attention on 16-bit K / V tiles with Q and P split; f32 self-attention over the KV "
-                        "arena), filter (ViT + ITM) on plain f16 operands"}
+                        f"arena), filter (ViT + ITM; BASELINE states no tolerance for ITM logits) on plain {flt_dtype} operands as in `value`"}
         if ref is not None:
             d = np.abs(prompt_logits() - ref)
             pq["max_abs_logit_err"] = float(d.max())
@@ -583,6 +586,7 @@ def secondary_measurements(args, cap, flt, clip, step, frames, dev, parity_file,
         log(f"parity-qualified configuration: {Nv * F / dtq:.0f} frames/s")
     except Exception as e:
         out["parity_qualified"] = {"value": None, "error": f"{type(e).__name__}: {e}"[:300]}
+    set_compute_dtype("f16", flt)
     set_parity_mode(False, cap, flt, clip)
     # ---- ... and in the CHEAPEST mix that still meets the two tolerances BASELINE states (tests/probes/probe_parity_mix.py;
     # tests/test_parity_mode_gpu.py asserts both): captioner = plain ViT + compensated cross K|V / decoder / LM head ("caption
@@ -716,12 +720,15 @@ def main():
     dev = torch.device("cuda", local)
 
     t_start = time.perf_counter()
+    flt_dtype = args.dtype
     if args.precision != "plain":
         args.dtype = "f16"                       # (the parity precision mode is an f16 statement: hi + lo = 22 significant bits)
     cap, flt, clip, tok = build_models(dev, args.size, args.clip, args.vit, args.dtype)
     if args.precision != "plain":
-        from vidil_amd.packing import set_parity_attention, set_parity_mode
+        from vidil_amd.packing import set_compute_dtype, set_parity_attention, set_parity_mode
         set_parity_mode(True, *((cap, clip) if args.precision == "qualified" else (cap, flt, clip)))
+        if args.precision == "qualified" and flt_dtype == "bf16":
+            set_compute_dtype("bf16", flt)       # (the filter stays on the timed dtype's plain operands)
         if args.parity_attn:
             set_parity_attention(args.parity_attn, cap, flt, clip)
     onto_embeds, onto_texts = synthetic_ontology(dim=clip.config.projection_dim)

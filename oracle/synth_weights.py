@@ -5,6 +5,7 @@ docker/download_blip_checkpoints.sh:3-7), and random-init weights lack what make
 trained model's scale: max|logit| of 10-25 (random init: ~2.5), LayerNorm gains with outlier channels, residual rows off zero.
 ``trained_like_`` gives a random-init model those statistics, seeded; the fp32 oracle and the device run the same state dict.
 Used by tests/ (tests/common.py re-exports it) and by bench.py's parity leg (the `parity_qualified` error at a trained scale)."""
+import numpy as np
 import torch
 
 
@@ -41,3 +42,25 @@ def trained_like_(module, seed, *, head_scale=7.0, outlier_gain=(10.0, 50.0), n_
             if sep_bias is not None and (name.endswith("cls.predictions.bias") or name.endswith("cls.predictions.decoder.bias")):
                 p[102] += sep_bias
     return done
+
+
+def portable_init_(module, seed):
+    """Overwrite every floating-point parameter of ``module`` from numpy's PCG64 stream — bit-identical on every host.
+    (torch's CPU normal sampler is vectorised differently on AVX2 and AVX-512 machines: `torch.manual_seed(0)` gives the build
+    container and the GPU box DIFFERENT random-init weights, so goldens tied to seeded torch init do not travel.)
+    Matrices / embeddings ~ N(0, 0.02) (the reference's init scale: models/vit.py:163-174, models/med.py:558-568), LayerNorm
+    gains 1 + N(0, 0.05), every other vector N(0, 0.05); parameters are visited in ``named_parameters`` order."""
+    rng = np.random.default_rng(seed)
+    ln_gains = {id(m.weight) for m in module.modules() if isinstance(m, torch.nn.LayerNorm)}
+    with torch.no_grad():
+        for name, p in module.named_parameters():
+            if not p.is_floating_point():
+                continue
+            if p.ndim >= 2:
+                v = rng.standard_normal(p.numel(), dtype=np.float32) * np.float32(0.02)
+            elif id(p) in ln_gains:
+                v = np.float32(1.0) + rng.standard_normal(p.numel(), dtype=np.float32) * np.float32(0.05)
+            else:
+                v = rng.standard_normal(p.numel(), dtype=np.float32) * np.float32(0.05)
+            p.copy_(torch.from_numpy(v.reshape(tuple(p.shape))))
+    return module

@@ -52,26 +52,6 @@ def synthetic_frames(n_videos, frames=8, size=224, first_video=0):
     return out
 
 
-from oracle.synth_weights import trained_like_  # noqa: E402,F401  (shared with bench.py's parity leg)
+from oracle.synth_weights import portable_init_, trained_like_  # noqa: E402,F401  (shared with bench.py's parity leg / smoke())
 
 
-def portable_init_(module, seed):
-    """Overwrite every floating-point parameter of ``module`` from numpy's PCG64 stream — bit-identical on every host.
-    (torch's CPU normal sampler is vectorised differently on AVX2 and AVX-512 machines: `torch.manual_seed(0)` gives the build
-    container and the GPU box DIFFERENT random-init weights, so goldens tied to seeded torch init do not travel.)
-    Matrices / embeddings ~ N(0, 0.02) (the reference's init scale: models/vit.py:163-174, models/med.py:558-568), LayerNorm
-    gains 1 + N(0, 0.05), every other vector N(0, 0.05); parameters are visited in ``named_parameters`` order."""
-    rng = np.random.default_rng(seed)
-    ln_gains = {id(m.weight) for m in module.modules() if isinstance(m, torch.nn.LayerNorm)}
-    with torch.no_grad():
-        for name, p in module.named_parameters():
-            if not p.is_floating_point():
-                continue
-            if p.ndim >= 2:
-                v = rng.standard_normal(p.numel(), dtype=np.float32) * np.float32(0.02)
-            elif id(p) in ln_gains:
-                v = np.float32(1.0) + rng.standard_normal(p.numel(), dtype=np.float32) * np.float32(0.05)
-            else:
-                v = rng.standard_normal(p.numel(), dtype=np.float32) * np.float32(0.05)
-            p.copy_(torch.from_numpy(v.reshape(tuple(p.shape))))
-    return module

@@ -221,7 +221,9 @@ def test_full_blip_caption_logits_and_beam_bf16_vs_fp32_oracle(bf16_models):
     dl = (lg.cpu() - ref0).abs()
     scale = max(1.0, ref0.abs().max().item())
     print(f"bf16 caption logits (prompt pass): max|d| {dl.max().item():.3e} mean {dl.mean().item():.3e} scale {scale:.2f}")
-    assert dl.max().item() <= 8e-3 * scale and dl.mean().item() <= 4e-3 * scale       # f16: 1e-3 / 5e-4 of the scale
+    # (round 5: bound set from tests/probes/probe_plain_margin.py bf16 — worst pass of 5 frame sets 6.9e-3 .. 7.7e-3 of the scale —
+    #  with 30 % headroom; rounds 2-4 asserted 8e-3: 4 % headroom on the worst set)
+    assert dl.max().item() <= 1e-2 * scale and dl.mean().item() <= 4e-3 * scale       # f16: 1.25e-3 / 5e-4 of the scale
     # free-running device beam search == the oracle's beam search driven by the DEVICE's bf16 logits (bit-identical ids)
     out_tok, _ = cap.generate_ids(y16, B, num_beams=nb, max_length=20, min_length=5)
     sess2 = DecoderSession(cap.text_decoder, y16, B, nb, 20)

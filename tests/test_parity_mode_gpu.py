@@ -116,7 +116,7 @@ def test_attention_split3_output_carries_the_f32_result(Bq, H, Nq, Nk, kv_group,
     # (what remains is the f16 rounding of the probabilities inside the kernel — common to both outputs; where it dominates,
     #  e.g. three query rows over 197 keys in the direct kernel: 2.7e-4 vs 2.3e-4, the two errors are the same size and which
     #  one is smaller is a coin toss, so the comparison carries that much slack)
-    assert e_split < 4e-4 and e_split <= e_hi + 1e-4, (e_split, e_hi)
+    assert e_split < 4e-4 and e_split <= e_hi + 5e-5, (e_split, e_hi)      # (slack cut to the measured coin-toss range, 4e-5)
 
 
 def test_beam_attention_split3_output():
@@ -245,12 +245,13 @@ def test_parity_mode_caption_logits_within_1e_3_absolute_on_every_forward_pass(p
     toks = out_tok.cpu().numpy()
     same = [bool(np.array_equal(toks[b][: len(seqs[b])], seqs[b])) for b in range(B)]
     # a search may legitimately take another branch where the ORACLE's own candidates are closer than the device's error
-    # (random-init weights: near-flat distributions, f32 ties do occur): decisive = every adjacent candidate gap > 1e-4
+    # (random-init weights: near-flat distributions, f32 ties do occur): decisive = every adjacent candidate gap > 2e-5, twice
+    # the mode's worst logit error on this sample (8e-6; ADVICE r4: the mask was 1e-4)
     gaps = np.stack([np.min(t["cand_scores"][:, :-1] - t["cand_scores"][:, 1:], axis=1) for t in otrace]).min(axis=0)
     print(f"parity mode free-running captions equal to the fp32 oracle: {sum(same)}/{B}; smallest candidate gap per image "
           f"{', '.join('%.1e' % g for g in gaps)}")
     for b in range(B):
-        assert same[b] or gaps[b] < 1e-4, (b, gaps[b])
+        assert same[b] or gaps[b] < 2e-5, (b, gaps[b])
     assert sum(same) >= B - 1
 
 
