@@ -50,6 +50,7 @@ sys.path.insert(0, ROOT)
 VG_SIZES = dict(objects=19958, attributes=15026, scenes=365, verbs=7410)
 MFMA_F16_PEAK_TFLOPS = 2500.0   # dense f16 / bf16, /opt/skills/guides/MI355X_MICROARCH.md
 MFMA_F8_PEAK_TFLOPS = 5000.0    # dense fp8 (v_mfma_scale_f32_32x32x64_f8f6f4), same guide
+HBM_PEAK_BYTES = 8.0e12         # HBM3E, same guide
 
 
 def mfma_peak_for(kernel_name):
@@ -146,6 +147,7 @@ class GemmTimer:
     def __init__(self):
         self.records = []
         self.shapes = []          # (M, N, K) of every record, for --gemm-shapes
+        self.out_bytes = []       # algorithmic epilogue bytes per output element of every record
 
     def install(self):
         from vidil_amd import kernels as K
@@ -164,6 +166,16 @@ class GemmTimer:
                 kw = dict(kw, out=r)
             timer.records.append((K.gemm_kernel_name(a, w, bias, **kw), 2.0 * M * N * Kd, e0, e1))
             timer.shapes.append((M, N, Kd))
+            # bytes the epilogue must move per output element (algorithmic): the f32 row written (+ read as the residual), the
+            # 16-bit copy / [hi | lo | hi] planes, or the 16-bit / fp8 output itself
+            o = kw.get("out")
+            if kw.get("split3_out") is not None:
+                ob = 6 + (4 if o is not None else 0)
+            elif o is not None and o.dtype == torch.float32 or kw.get("patch"):
+                ob = 4 + (4 if kw.get("resid") is not None or kw.get("patch") else 0) + (2 if kw.get("out16") is not None else 0)
+            else:
+                ob = r.element_size() if isinstance(r, torch.Tensor) else 2
+            timer.out_bytes.append(ob)
             return r
 
         K.gemm = timed
@@ -836,13 +848,43 @@ def main():
         n, flops, secs = agg[key]
         ach = flops / secs / 1e12
         # HBM bytes per launch of that kernel from the committed PMC passes of this same command
-        # (tools/profile_bench.sh -> profiles/pmc_traffic.json); null when no profile of this dtype has been taken.
-        traffic = None
+        # (tools/profile_bench.sh -> profiles/pmc_traffic.json, stamped with the commit it was taken at by tools/copy_profiles.sh);
+        # null when no profile of this dtype has been taken.  Counters cannot be collected inside this process (rocprofv3 wraps
+        # the command), so the figure is the profile's, not this run's: `traffic_source` says which.
+        traffic, traffic_source = None, None
         try:
             pmc = json.load(open(os.path.join(ROOT, "profiles", "pmc_traffic.json")))
             traffic = pmc["kernels"].get(key, {}).get("hbm_bytes_per_launch")
+            traffic_source = {"file": "profiles/pmc_traffic.json", "commit": pmc.get("commit"), "taken": pmc.get("taken"),
+                              "note": "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this command (average over the instantiation's launches)"}
         except (OSError, ValueError, KeyError):
             pass
+        # the dominant instantiation by SHAPE: one template instantiation serves launches on both
+        # sides of the ridge — the f32 + residual + row-partials kernel runs every fc2 (K = 3072: 341 flop per algorithmic
+        # byte, MFMA-bound) and every proj (N = K = 768: 128 flop / B against a ridge of 2.5 PF / 8 TB/s = 312: HBM-bound)
+        esz = 1 if "<fp8" in key else 2
+        groups = {}
+        for (name, fl, e0, e1), (M_, N_, K_), out_b in zip(timer.records, timer.shapes, timer.out_bytes):
+            if name != key:
+                continue
+            g_ = groups.setdefault((N_, K_), [0, 0.0, 0.0, 0.0])
+            g_[0] += 1
+            g_[1] += fl
+            g_[2] += e0.elapsed_time(e1) * 1e-3
+            # algorithmic bytes of one launch: A once, W once, and per output element what the epilogue must move
+            g_[3] += float(M_) * K_ * esz + float(N_) * K_ * esz + float(M_) * N_ * out_b
+        split = []
+        for (N_, K_), (cnt, fl, sec, byt) in sorted(groups.items(), key=lambda kv: -kv[1][2]):
+            intensity = fl / byt
+            hbm_bound = intensity < MFMA_F16_PEAK_TFLOPS * 1e12 / HBM_PEAK_BYTES
+            ent = {"N": N_, "K": K_, "launches": cnt, "ms": round(sec * 1e3, 3), "flop_per_algorithmic_byte": round(intensity, 1),
+                   "bound": "hbm" if hbm_bound else "mfma"}
+            if hbm_bound:
+                ent.update(achieved=round(byt / sec / 1e9, 1), peak=HBM_PEAK_BYTES / 1e9, unit="GB/s", frac=round(byt / sec / HBM_PEAK_BYTES, 4))
+            else:
+                ent.update(achieved=round(fl / sec / 1e12, 1), peak=mfma_peak_for(key), unit="TFLOP/s",
+                           frac=round(fl / sec / 1e12 / mfma_peak_for(key), 4))
+            split.append(ent)
         # executed work of that step: sum of 2 M N K over the GEMM launches + the attention kernels' 4 Nq Nk 64 per head +
         # the ontology scan — against the algorithmic count of SURVEY §8d, which charges every ITM caption at the
         # reference's 35 padded tokens while the product cuts captions to their length bucket
@@ -854,7 +896,8 @@ def main():
                                                         **{k: round(v / (Nv * F) / 1e9, 3) for k, v in timer.other_flops.items()}}
         peak = mfma_peak_for(key)
         result["roofline"] = {"bound": "mfma", "kernel": key, "achieved": round(ach, 1), "peak": peak,
-                              "unit": "TFLOP/s", "frac": round(ach / peak, 4), "traffic": traffic,
+                              "unit": "TFLOP/s", "frac": round(ach / peak, 4), "traffic": traffic, "traffic_source": traffic_source,
+                              "by_shape": split,
                               "algorithmic_flop_per_launch": round(flops / n),
                               "launches_per_step": n, "avg_launch_us": round(secs / n * 1e6, 2),
                               "all_gemm": {k: {"launches": v[0], "tflops": round(v[1] / v[2] / 1e12, 1),

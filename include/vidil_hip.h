@@ -149,6 +149,14 @@ typedef struct vidil_gemm_args {
    * T16(v - hi)) of v = act(acc + bias) + resid — what vidil_split3_f32 would make of the f32 output, from the same f32
    * values — and `out` may then be NULL: the f32 rows are not written.  The parity precision mode's fc1 -> fc2 hand-over. */
   int32_t out16_split3;
+  /* ERROR-COMPENSATED operands (ABI 10, round 5; the parity precision mode): non-zero = A rows are [x_hi | x_lo | x_hi]
+   * (three planes of Kl = K / 3 columns: what VIDIL_DT_SPLIT3 outputs look like) and W rows are [W_hi | W_hi | W_lo], so
+   * that the plain product over K = 3 Kl columns IS x_hi.W_hi + x_lo.W_hi + x_hi.W_lo (rounds 3-4 ran it as such).  With
+   * the flag set the library may compute the same three products INSIDE one K loop over Kl (x_hi / W_hi tiles fetched once
+   * instead of twice: 2/3 of the operand traffic per MFMA; f32 sums in a different order) — it does so for the f32, per-head
+   * (T >= 8) and patch epilogues at EVERY problem size and runs the plain K = 3 Kl product for the others, so a row's
+   * result never depends on the batch around it.  K % 96 == 0. */
+  int32_t split_k;
 } vidil_gemm_args;
 
 /* replaces: nn.Linear calls of models/vit.py:35-41,72,84; models/med.py:153-171,

@@ -570,3 +570,79 @@ def test_gemm_f32_epilogue_writes_split3_operand_rows_itself(M, N, K, act):
     k.gemm(a, w, b, split3_out=got3b, out=out32, act=act)
     assert torch.equal(got3b, ref3) and torch.equal(out32, ref32)
     print(f"split3_out {M}x{N}x{K} act {act}: {k.gemm_kernel_name(a, w, b, split3_out=got3, act=act)}")
+
+
+# ------------------------------------------------------------------------------- split_k: the in-loop compensated product (round 5)
+@pytest.mark.parametrize("M,N,K,act", [(197 * 3, 2304, 768, 0), (12, 30524, 768, 0), (197 * 130, 768, 3072, 0), (70000, 3072, 768, 1),
+                                       (45000, 1024, 640, 2), (300, 768, 192, 0)])
+def test_split_k_gemm_reproduces_the_fp32_product_at_every_size_with_the_same_bits(M, N, K, act):
+    """vidil_gemm_args.split_k: the three products x_hi.W_hi + x_hi.W_lo + x_lo.W_hi formed inside ONE K loop over Kl (gemm4w's C3
+    form: 128- or 256-row tiles by grid size) — as close to the fp64 product as the K-tripled launch, and BIT-IDENTICAL for a row
+    whether it is multiplied alone (a few rows: 128-row tiles) or inside the full problem (256-row tiles)."""
+    from vidil_amd.packing import w3
+
+    k = _k()
+    x = _rand(M, K, seed=40)
+    w = _rand(N, K, scale=0.03, seed=41)
+    bias = _rand(N, seed=42)
+    pre = x.double() @ w.double().t() + bias.double()
+    ref = pre if act == 0 else (torch.nn.functional.gelu(pre) if act == 1 else pre * torch.sigmoid(1.702 * pre))
+    a3 = k.split3(x.to(DEV), torch.empty(M, 3 * K, dtype=torch.float16, device=DEV))
+    w3d = w3(w, dtype=torch.float16).to(DEV)
+    name = k.gemm_kernel_name(a3, w3d, bias.to(DEV), out_dtype=torch.float32, act=act, split_k=True)
+    assert name.startswith("gemm4w_kernel") and name.endswith("true>"), name
+    got = k.gemm(a3, w3d, bias.to(DEV), out_dtype=torch.float32, act=act, split_k=True)
+    tripled = k.gemm(a3, w3d, bias.to(DEV), out_dtype=torch.float32, act=act)          # the K-tripled form of rounds 3-4
+    e, e3 = (got.cpu().double() - ref).abs().max().item(), (tripled.cpu().double() - ref).abs().max().item()
+    print(f"M={M} N={N} K={K} act={act}: {name}: max|d| vs fp64 {e:.2e} (K-tripled launch {e3:.2e})")
+    assert e < 1e-5 * max(1.0, ref.abs().max().item()) + 1e-5 and e < 3 * e3 + 1e-6
+    # a handful of rows alone: another tile height, another grid — the same bits
+    rows = torch.tensor([0, 1, M // 2, M - 1][: min(4, M)])
+    sub = k.gemm(a3[rows.to(DEV)].contiguous(), w3d, bias.to(DEV), out_dtype=torch.float32, act=act, split_k=True)
+    assert torch.equal(sub, got[rows.to(DEV)])
+    # the [hi | lo | hi] hand-over and the residual form on the same path
+    res = _rand(M, N, seed=43).to(DEV)
+    got_r = k.gemm(a3, w3d, bias.to(DEV), out=res.clone(), resid=res, act=act, split_k=True)
+    assert torch.equal(got_r, got + res)
+    if N % 8 == 0:
+        s3 = k.gemm(a3, w3d, bias.to(DEV), split3_out=torch.zeros(M, 3 * N, dtype=torch.float16, device=DEV), act=act, split_k=True)
+        assert torch.equal(s3, k.split3(got, torch.empty(M, 3 * N, dtype=torch.float16, device=DEV)))
+
+
+def test_split_k_gemm_per_head_scatter_and_patch_epilogues_equal_the_k_tripled_launch_to_rounding():
+    """EPI_HEADS (the cross K | V fragment tiles, T >= 8) and EPI_PATCH on the in-loop compensated product: 16-bit / f32 outputs
+    within one rounding of the K-tripled launch's (the f32 sums are taken in another order)."""
+    from vidil_amd.packing import w3
+
+    k = _k()
+    B, T, H, C = 40, 197, 12, 768
+    x = _rand(B * T, C, seed=50)
+    w = _rand(2 * C, C, scale=0.03, seed=51)
+    bias = _rand(2 * C, seed=52).to(DEV)
+    a3 = k.split3(x.to(DEV), torch.empty(B * T, 3 * C, dtype=torch.float16, device=DEV))
+    w3d = w3(w, dtype=torch.float16).to(DEV)
+    Tc = 224
+    outs = []
+    for sk in (True, False):
+        kk = torch.zeros(B, H, Tc, 64, dtype=torch.float16, device=DEV)
+        vv = torch.zeros(B, H, Tc, 64, dtype=torch.float16, device=DEV)
+        k.gemm(a3, w3d, bias, heads=dict(k=kk, vt=vv, T=T, H=H, part0=1, t_off=0, Tk_cap=Tc, tiled=True), split_k=sk)
+        outs.append((kk, vv))
+    for a_, b_ in zip(outs[0], outs[1]):
+        d = (a_.float() - b_.float()).abs()
+        # (one unit in the last place of the 16-bit value where the two f32 sums straddle a rounding boundary: ~0.1 % of the elements)
+        assert torch.allclose(a_.float(), b_.float(), rtol=1.1e-3, atol=1e-6) and (d > 0).float().mean().item() < 0.02, \
+            (d.max().item(), (d > 0).float().mean().item())
+    # patch embedding: [B*P, 3*768] split rows -> f32 stream rows (m + m / tpi + 1)
+    P = 196
+    xp = _rand(3 * P, 768, seed=53)
+    wp = _rand(C, 768, scale=0.03, seed=54)
+    pos = _rand(P + 1, C, seed=55).to(DEV)
+    ap = k.split3(xp.to(DEV), torch.empty(3 * P, 3 * 768, dtype=torch.float16, device=DEV))
+    wpd = w3(wp, dtype=torch.float16).to(DEV)
+    res = []
+    for sk in (True, False):
+        out = torch.zeros(3 * (P + 1), C, dtype=torch.float32, device=DEV)
+        k.gemm(ap, wpd, bias[:C].contiguous(), patch=dict(out=out, pos=pos, tpi=P), split_k=sk)
+        res.append(out)
+    assert (res[0] - res[1]).abs().max().item() < 2e-5

@@ -7,6 +7,14 @@ N=${2:-r4}
   echo "Bench line of the traced run (tracing costs a few %): \`$(cut -c1-260 $P/bench_traced.json)...\`"; echo
   cat $P/kernel_summary.md; echo; echo "## rocprofv3 --stats (t_kernel_stats.csv, top 25)"; echo; echo '```'; head -26 $P/trace/t_kernel_stats.csv | cut -c1-200; echo '```'; } > profiles/${N}_bench_kernel_trace.md
 { echo "# rocprofv3 --pmc passes (FETCH_SIZE / WRITE_SIZE / SQ_* in separate runs, each with --kernel-trace only) of the same bench command"; echo; cat $P/pmc_summary.md; } > profiles/${N}_bench_pmc.md
-cp $P/pmc_traffic.json profiles/pmc_traffic.json   # (what bench.py reads `roofline.traffic` from: the latest profile)
+# (what bench.py reads `roofline.traffic` from: the latest profile) — stamped with the commit / date it was taken at
+python3 - "$P/pmc_traffic.json" <<'PY'
+import json, subprocess, sys, time
+d = json.load(open(sys.argv[1]))
+d["commit"] = subprocess.run(["git", "rev-parse", "--short", "HEAD"], capture_output=True, text=True).stdout.strip()
+d["taken"] = time.strftime("%Y-%m-%d")
+json.dump(d, open(sys.argv[1], "w"), indent=1)
+PY
+cp $P/pmc_traffic.json profiles/pmc_traffic.json
 cp $P/pmc_traffic.json profiles/${N}_pmc_traffic.json
 cp $P/bench.json profiles/${N}_bench.json

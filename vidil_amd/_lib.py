@@ -39,7 +39,7 @@ class GemmArgs(C.Structure):
         ("pos", C.c_void_p), ("tpi", C.c_int32), ("kv_tiled", C.c_int32), ("dtype", C.c_int32),
         ("out16", C.c_void_p), ("ldo16", C.c_int32), ("ln_fold", C.c_int32), ("ln_colsum", C.c_void_p), ("ln_eps", C.c_float), ("ln_stats_out", C.c_void_p), ("ln_stats", C.c_void_p),
         ("w_scale", C.c_void_p), ("dtype16", C.c_int32), ("rln_gamma", C.c_void_p), ("rln_beta", C.c_void_p),
-        ("out16_split3", C.c_int32),
+        ("out16_split3", C.c_int32), ("split_k", C.c_int32),
     ]
 
 

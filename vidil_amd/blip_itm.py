@@ -111,7 +111,7 @@ class BLIP_ITM(PackedCache, nn.Module):
             cls32 = h32.view(P, ids.shape[1], C)[:, 0].contiguous()
             a3 = K.split3(cls32, torch.empty((P, 3 * C), dtype=p["itm_w"].dtype, device=dev))
             out = torch.empty((P, 2), dtype=torch.float32, device=dev)
-            K.gemm(a3, p["itm_w3"], p["itm_b"], out=out)
+            K.gemm(a3, p["itm_w3"], p["itm_b"], out=out, split_k=True)
             return out
         # only token 0 feeds the itm_head: the last layer runs on the [CLS] rows alone (BertModel.encode_cls)
         _, c16 = te.encode_cls(ids, lens, cross, cross_index=image_index, cross_groups=group_start,

@@ -183,16 +183,16 @@ def _run_layers(layers, x, B, T, H, eps, *, causal=False, kv_len=None, f32_attn=
         for l in layers:
             K.layernorm(x, l["n1g"], l["n1b"], eps, out16=a3, split3=True)
             if f32_attn:    # (Q | K | V stay f32 and row-major: vidil_attention_f32 reads them in place)
-                K.gemm(a3, l["qkv_w3"], l["qkv_b"], out=qkv32)
+                K.gemm(a3, l["qkv_w3"], l["qkv_b"], out=qkv32, split_k=True)
                 K.attention_f32(qkv32[:, :D], qkv32[:, D:2 * D], qkv32[:, 2 * D:], o3, Bq=B, H=H, Nq=T, Nk=T, causal=causal, kv_len=kv_len,
                                 arith=arith)
             else:
-                K.gemm(a3, l["qkv_w3"], l["qkv_b"], heads=heads)
+                K.gemm(a3, l["qkv_w3"], l["qkv_b"], heads=heads, split_k=True)
                 K.attention(q, k, vt, o3, Bq=B, H=H, Nq=T, Nk=T, Tq_cap=T, Tk_cap=T, NP=NP, causal=causal, kv_len=kv_len, split3=True)
-            K.gemm(o3, l["o_w3"], l["o_b"], out=x, resid=x)
+            K.gemm(o3, l["o_w3"], l["o_b"], out=x, resid=x, split_k=True)
             K.layernorm(x, l["n2g"], l["n2b"], eps, out16=a3, split3=True)
-            K.gemm(a3, l["fc1_w3"], l["fc1_b"], split3_out=hid3, act=K.ACT_QUICK_GELU)
-            K.gemm(hid3, l["fc2_w3"], l["fc2_b"], out=x, resid=x)
+            K.gemm(a3, l["fc1_w3"], l["fc1_b"], split3_out=hid3, act=K.ACT_QUICK_GELU, split_k=True)
+            K.gemm(hid3, l["fc2_w3"], l["fc2_b"], out=x, resid=x, split_k=True)
         return x
     stats = torch.empty((M, D // 64, 2), dtype=torch.float32, device=dev) if "fc1_f" in layers[0] else None
     if "qkv_w8" in layers[0] and T > 32:
@@ -333,7 +333,7 @@ class CLIPModel(PackedCache, nn.Module):
         cdt = patches16.dtype
         par = p["parity"]          # (then patches16 holds [hi | lo | hi] rows: see the callers)
         x = torch.empty((B * T, D), dtype=torch.float32, device=dev)
-        K.gemm(patches16, p["pe_w3"] if par else p["pe_w"], None, patch=dict(out=x, pos=p["pos"], tpi=P))
+        K.gemm(patches16, p["pe_w3"] if par else p["pe_w"], None, patch=dict(out=x, pos=p["pos"], tpi=P), split_k=par)
         K.set_cls_row(x, p["cls"], p["pos"], B, T, D)
         K.layernorm(x, p["pre_g"], p["pre_b"], vc.layer_norm_eps, out32=x)
         _run_layers(p["vlayers"], x, B, T, H, vc.layer_norm_eps, f32_attn=parity_attention_f32(self), arith=parity_attention_arith(self))
@@ -343,7 +343,7 @@ class CLIPModel(PackedCache, nn.Module):
                     out32=pooled32, split3=par)
         if pooled:
             return pooled32
-        emb = K.gemm(pooled16, p["vproj3"] if par else p["vproj"], None, out_dtype=torch.float32)
+        emb = K.gemm(pooled16, p["vproj3"] if par else p["vproj"], None, out_dtype=torch.float32, split_k=par)
         return K.l2_normalize_rows(emb)
 
     @torch.no_grad()
@@ -401,7 +401,7 @@ class CLIPModel(PackedCache, nn.Module):
         par = p["parity"]
         pooled16 = torch.empty((N, (3 if par else 1) * D), dtype=cdt, device=dev)
         K.layernorm(sel, p["fin_g"], p["fin_b"], tc.layer_norm_eps, out16=pooled16, split3=par)
-        emb = K.gemm(pooled16, p["tproj3"] if par else p["tproj"], None, out_dtype=torch.float32)
+        emb = K.gemm(pooled16, p["tproj3"] if par else p["tproj"], None, out_dtype=torch.float32, split_k=par)
         return K.l2_normalize_rows(emb)
 
     def forward(self, input_ids=None, pixel_values=None, attention_mask=None, **_):

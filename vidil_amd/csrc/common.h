@@ -31,6 +31,8 @@ int vidil_gemm256_launch(const vidil_gemm_args& a, hipStream_t s);
 const char* vidil_gemm256_variant(const vidil_gemm_args& a);   // "gemm256_kernel" or "gemm4w_kernel": which of the two runs it
 bool vidil_gemm4w128_wanted(const vidil_gemm_args& a);          // the 128 x 256-tile form of gemm4w (mid-size grids)
 int vidil_gemm4w128_launch(const vidil_gemm_args& a, hipStream_t s);
+bool vidil_gemm_c3_serves(const vidil_gemm_args& a);            // gemm.hip: a split_k launch that the in-loop compensated kernel takes (at every size)
+int vidil_gemm4w_c3_launch(const vidil_gemm_args& a, hipStream_t s);   // gemm4w.hip
 
 #define VIDIL_REQUIRE(cond, ...)                \
   do {                                          \

@@ -405,6 +405,9 @@ int check_args(const vidil_gemm_args& a) {
     VIDIL_REQUIRE(a.ldo16 % 12 == 0 && a.ldo16 / 3 >= a.N && ((uintptr_t)a.out16 & 7) == 0,
                   "gemm/out16_split3: ldo16=%d must be three planes of >= N=%d columns, each a multiple of 4", a.ldo16, a.N);
   }
+  if (a.split_k)
+    VIDIL_REQUIRE(a.K % 3 == 0 && (a.K / 3) % 32 == 0 && a.dtype != VIDIL_DT_FP8 && !a.ln_fold,
+                  "gemm/split_k: K=%d must be three planes of a multiple of 32 columns (16-bit operands, no ln_fold)", a.K);
   if (a.ln_stats_out)
     VIDIL_REQUIRE(a.epi == VIDIL_EPI_F32 && a.act == VIDIL_ACT_NONE && a.N % 64 == 0 && a.dtype != VIDIL_DT_FP8,
                   "gemm/ln_stats_out: 16-bit operands, f32 residual epilogue without activation, N %% 64 == 0");
@@ -492,10 +495,25 @@ int dispatch(const vidil_gemm_args& a, hipStream_t s) {
 
 }  // namespace
 
+// split_k (the parity precision mode's operands, see include/vidil_hip.h): which launches run the in-loop compensated product
+// (gemm4w's C3 form) — a property of the CALL (epilogue, alignment), never of its size, so that a row's result does not depend
+// on the batch around it; everything else runs the same operands as a plain GEMM with K = 3 Kl (the K-tripled form of rounds 3-4).
+bool vidil_gemm_c3_serves(const vidil_gemm_args& a) {
+  static const bool off = [] { const char* e = getenv("VIDIL_GEMM_C3"); return e && e[0] == '0'; }();    // (A/B switch)
+  if (!a.split_k || off) return false;
+  if (a.dtype == VIDIL_DT_FP8 || a.ln_fold || a.ln_stats_out || a.rln_gamma || a.K % 96 != 0) return false;
+  if (!(a.epi == VIDIL_EPI_F32 || a.epi == VIDIL_EPI_PATCH || (a.epi == VIDIL_EPI_HEADS && a.T >= 8))) return false;
+  return vidil_gemm256_eligible(a, true);
+}
+
 extern "C" int vidil_gemm(const vidil_gemm_args* args, void* stream) {
   VIDIL_REQUIRE(args != nullptr, "gemm: null args");
   const int rc = check_args(*args);
   if (rc != VIDIL_OK) return rc;
+  if (vidil_gemm_c3_serves(*args)) {
+    const int rc3 = vidil_gemm4w_c3_launch(*args, (hipStream_t)stream);
+    if (rc3 != -1000) return rc3;
+  }
   if (args->dtype == VIDIL_DT_FP8)
     return vidil_gemm256_launch(*args, (hipStream_t)stream);
   if (args->dtype == VIDIL_DT_BF16) return dispatch<bf16>(*args, (hipStream_t)stream);
@@ -508,6 +526,13 @@ extern "C" int vidil_gemm_kernel_name(const vidil_gemm_args* args, char* buf_hos
   if (rc != VIDIL_OK) return rc;
   const TileChoice c = choose_tile(*args);
   const char* t16 = (args->dtype == VIDIL_DT_FP8 ? args->dtype16 : args->dtype) == VIDIL_DT_BF16 ? "__bf16" : "_Float16";
+  if (vidil_gemm_c3_serves(*args)) {
+    const long t256 = (long)((args->M + 255) / 256) * ((args->N + 255) / 256);
+    const int tm = (t256 >= 5L * vidil_cu_count() / 8 || args->epi == VIDIL_EPI_PATCH) ? 4 : 2;
+    snprintf(buf_host, n, "gemm4w_kernel<%s, %s, %d, %d, false, false, false, %d, true>", t16, t16, args->epi,
+             args->epi == VIDIL_EPI_F32 ? args->act : 0, tm);
+    return VIDIL_OK;
+  }
   const char* t = args->dtype == VIDIL_DT_FP8 ? "fp8" : t16;                 // the spelling rocprofv3 demangles to
   const int act = (args->epi == VIDIL_EPI_F16 || args->epi == VIDIL_EPI_F32 || args->epi == VIDIL_EPI_F8) ? args->act : 0;
   const char* stats = (args->ln_stats_out && args->epi == VIDIL_EPI_F32) ? "true" : "false";

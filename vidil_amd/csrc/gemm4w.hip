@@ -68,9 +68,19 @@ __device__ __forceinline__ void glds16(const void* g, char* lds) {
                                    (__attribute__((address_space(3))) void*)lds, 16, 0, 0);
 }
 
-template <typename T, typename TO, int EPI, int ACT, bool FOLD, bool STATS, bool RLN, int TM = 4>
+// C3 (round 5): the ERROR-COMPENSATED product of the parity precision mode computed INSIDE the K loop.  A holds the rows
+// [x_hi | x_lo | x_hi] (three planes of Kl = K / 3 columns: VIDIL_DT_SPLIT3's layout) and W the rows [W_hi | W_hi | W_lo], exactly
+// as for the K-tripled plain launch — but instead of walking 3 Kl columns (every x_hi and every W_hi tile through LDS twice),
+// one iteration fetches 32 logical columns of x_hi, x_lo, W_hi and W_lo — a 128-byte LDS row is [hi 64 B | lo 64 B], so the
+// fragment loader's k-steps 0, 1 are the hi halves and 2, 3 the lo halves — and issues the three products from the same
+// registers: (a_hi, w_hi), (a_hi, w_lo), (a_lo, w_hi) = 24 * TM MFMAs per 64 KiB of LDS-DMA where the plain loop issues 16 * TM:
+// two thirds of the operand traffic (HBM, LDS-DMA and fragment reads alike) per MFMA.  The summation order differs from the
+// K-tripled launch's (hi.hi + hi.lo + lo.hi per 32 columns instead of three passes over K), so a problem must take ONE of the two
+// forms at every size: vidil_gemm routes split_k launches here whatever M is (TM = 2 for small grids: same k order, same bits).
+template <typename T, typename TO, int EPI, int ACT, bool FOLD, bool STATS, bool RLN, int TM = 4, bool C3 = false>
 __global__ __launch_bounds__(256) void gemm4w_kernel(const vidil_gemm_args p) {
   static_assert(TM == 4 || TM == 2, "256- or 128-row output tiles");
+  static_assert(!C3 || (sizeof(T) == 2 && !FOLD && !RLN && !STATS), "the in-loop compensated product: 16-bit operands, plain epilogues");
   constexpr int ESZ_OF_T = sizeof(T);
   static_assert(TM == 4 || !(FOLD || RLN), "the 128-row form is built without the row-statistics epilogues");
   constexpr int BUF = kBuf<TM>, RING_BYTES = kRing<TM>;
@@ -113,7 +123,8 @@ __global__ __launch_bounds__(256) void gemm4w_kernel(const vidil_gemm_args p) {
     remaining = (xcd < r ? q + 1 : q) - slot;
   }
   if (remaining <= 0) return;
-  const int nk = K / KT;
+  constexpr int KBYTES = C3 ? 64 : 128;          // bytes of a plane's row one K-tile covers
+  const int nk = C3 ? (K / 3) / 32 : K / KT;
 
   // ---- the DMA head: two K-tiles ahead of the MFMAs, walking this workgroup's tile sequence --------------------------
   // A thread's 16-B chunk of piece (half-tile hf, instruction i) is row hf*128 + i*32 + (tid >> 3) of the head tile, byte
@@ -122,11 +133,20 @@ __global__ __launch_bounds__(256) void gemm4w_kernel(const vidil_gemm_args p) {
   // UNIFORM 64-bit base (the address form `global_load_lds_dwordx4 v_off, s[base:base+1]`).  Sixteen precomputed offsets
   // (the gemm256 way) were the registers this kernel could not afford: they spilled, and a spill reload in front of a DMA
   // piece is an `s_waitcnt vmcnt(0)` — a full drain of the stream.
-  int h_r0, h_c16;
+  int h_r0, h_c16, h_c16w;
   {
     const int r0 = tid >> 3, sl = tid & 7;
     h_r0 = r0;
     h_c16 = (sl ^ ((r0 >> 1) & 7)) * 16;     // (rows 32 apart share the swizzle)
+    h_c16w = h_c16;
+    if constexpr (C3) {
+      // source slot s of the LDS row: s < 4 -> 16-byte piece s of the hi plane's 64 bytes, s >= 4 -> piece s - 4 of the lo
+      // plane's — plane 1 of an A row (Kl columns further), plane 2 of a W row (2 Kl columns further)
+      const int ssl = sl ^ ((r0 >> 1) & 7);
+      const int plane = (K / 3) * (int)sizeof(T);
+      h_c16 = (ssl & 3) * 16 + (ssl >> 2) * plane;
+      h_c16w = (ssl & 3) * 16 + (ssl >> 2) * 2 * plane;
+    }
   }
   const char* hbaseA = (const char*)p.A;    // first row of the head tile's A panel / W panel
   const char* hbaseW = (const char*)p.W;
@@ -162,10 +182,10 @@ __global__ __launch_bounds__(256) void gemm4w_kernel(const vidil_gemm_args p) {
 #endif
     if (sl < 2) {
       const int rr = row < h_limW ? row : h_limW;
-      glds16(hbaseW + (size_t)(h_kt * 128) + ((uint32_t)rr * pitchW + (uint32_t)h_c16), dst);   // (< 2^32: vidil_gemm256_eligible)
+      glds16(hbaseW + (size_t)(h_kt * KBYTES) + ((uint32_t)rr * pitchW + (uint32_t)(C3 ? h_c16w : h_c16)), dst);   // (< 2^32: vidil_gemm256_eligible)
     } else {
       const int rr = row < h_limA ? row : h_limA;
-      glds16(hbaseA + (size_t)(h_kt * 128) + ((uint32_t)rr * pitchA + (uint32_t)h_c16), dst);
+      glds16(hbaseA + (size_t)(h_kt * KBYTES) + ((uint32_t)rr * pitchA + (uint32_t)h_c16), dst);
     }
   };
   auto head_advance = [&]() {
@@ -204,6 +224,20 @@ __global__ __launch_bounds__(256) void gemm4w_kernel(const vidil_gemm_args p) {
   constexpr int T_A = TM == 2 ? NFR + 1 : (ESZ == 2 ? VIDIL_4W_TA : 10);   // barrier A goes after this MFMA (developer sweep: -DVIDIL_4W_TA=17..29)
   constexpr int T_B = T_A + NPIECE * STEP;          // barrier B goes after this MFMA
   static_assert(T_B < NM - 2 && NFR <= T_A, "schedule");
+  // ---- C3 schedule: six (A k-step, W k-step) products per K-tile; fragments sets S0 = k-steps 0, 1 (hi), S1 = 2, 3 (lo)
+  //   pairs 0, 1: (0,0) (1,1)  hi.hi   | reads: fw[1] of THIS tile (deferred, see below), then S1 of this tile
+  //   pairs 2, 3: (0,2) (1,3)  hi.lo   | barrier A, the DMA pieces of tile g+2, barrier B
+  //   pairs 4, 5: (2,0) (3,1)  lo.hi   | S0 of tile g+1: the A fragments once pair 3 has issued (fa[0], fa[1] are dead),
+  //                                    |   fw[0] once pair 4 has issued; fw[1] feeds pair 5 to the end of the iteration, so the next
+  //                                    |   tile's fw[1] is read in the first slots of the next iteration (first needed by its pair 1)
+  constexpr int NM3 = 6 * NKS;
+  constexpr int C3_RS1 = 4;                                   // first slot of the S1 reads (after the deferred fw[1])
+  constexpr int C3_TA = C3_RS1 + NFR + 1;                     // barrier A: every read of this tile has been issued
+  constexpr int C3_STEP = TM == 4 ? 3 : 1;
+  constexpr int C3_TB = C3_TA + NPIECE * C3_STEP;             // barrier B after this MFMA
+  constexpr int C3_NA = (C3_TB + 2 > 4 * NKS ? C3_TB + 2 : 4 * NKS);      // first slot of the next tile's A fragments
+  constexpr int C3_NW = (C3_NA + 2 * TM > 5 * NKS ? C3_NA + 2 * TM : 5 * NKS);   // first slot of the next tile's fw[0]
+  static_assert(!C3 || (C3_NW + 4 <= NM3 && C3_TA + 1 <= 2 * NKS + NKS), "C3 schedule");
   auto read_frag = [&](const char* buf, int ks, int r) {     // r: 0-3 = W column tiles, 4-7 = A row tiles
 #if defined(VIDIL_4W_ABLATE) && (VIDIL_4W_ABLATE & 8)
     if (p.M > 0) return;     // developer ablation: no fragment reads
@@ -343,7 +377,63 @@ __global__ __launch_bounds__(256) void gemm4w_kernel(const vidil_gemm_args p) {
       });
       cb ^= 1;
     };
-    if (nk == 1) {
+    auto iteration_c3 = [&](auto first_tag, auto last_tag) {
+      constexpr bool FIRST = decltype(first_tag)::value;
+      constexpr bool LAST = decltype(last_tag)::value;
+      const char* const buf = smem + cb * BUF;
+      const char* const nbuf = smem + (cb ^ 1) * BUF;
+      static_for<NM3>([&](auto n_tag) {
+        constexpr int n = decltype(n_tag)::value;
+        constexpr int pr = n / NKS, i = (n >> 2) % TM, j = n & 3;
+        constexpr int ka = pr == 0 ? 0 : pr == 1 ? 1 : pr == 2 ? 0 : pr == 3 ? 1 : pr == 4 ? 2 : 3;
+        constexpr int kw = pr == 0 ? 0 : pr == 1 ? 1 : pr == 2 ? 2 : pr == 3 ? 3 : pr == 4 ? 0 : 1;
+        if constexpr (FIRST && pr == 0) {
+          f32x16 zero = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+          ACC(i, j) = Mma<T>::mma(fw[kw][j], fa[ka][i], zero);
+        } else {
+          ACC(i, j) = Mma<T>::mma(fw[kw][j], fa[ka][i], ACC(i, j));
+        }
+        if constexpr (!FIRST && n < 4) read_frag(buf, 1, n);                                  // fw[1] of this tile (deferred)
+        if constexpr (n >= C3_RS1 && n < C3_RS1 + NFR) read_frag(buf, KH + (n - C3_RS1) / NFK, (n - C3_RS1) % NFK);   // S1
+        if constexpr (n == C3_TA) {
+          __builtin_amdgcn_s_waitcnt(0xC07F);                                    // lgkmcnt(0)
+          __builtin_amdgcn_s_barrier();
+        }
+        if constexpr (n > C3_TA && n <= C3_TB && (n - C3_TA - 1) % C3_STEP == 0) {
+          constexpr int pc = (n - C3_TA - 1) / C3_STEP;
+          issue_piece(pc);
+          if constexpr (pc == NPIECE - 1) head_advance();
+        }
+        if constexpr (BIAS_LDS && LAST && n == 0) {
+          if (p.bias != nullptr) {     // (uniform) the epilogue's bias vector for this wave's 128 columns by one LDS-DMA instruction
+            int lane_s;
+            asm volatile("v_mbcnt_lo_u32_b32 %0, -1, 0\n\tv_mbcnt_hi_u32_b32 %0, -1, %0" : "=v"(lane_s));
+            int col = n0 + wc2 * 128 + (lane_s & 31) * 4;
+            col = col + 4 <= N ? col : N - 4;
+            glds16(p.bias + col, smem + RING_BYTES + wave * 8192 + 4096);
+          }
+        }
+        if constexpr (n == C3_TB + 1) {
+          asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NPIECE) : "memory");
+          __builtin_amdgcn_s_barrier();
+        }
+        if constexpr (!LAST) {                                                   // S0 of the next K-tile, except fw[1]
+          if constexpr (n >= C3_NA && n < C3_NA + 2 * TM) read_frag(nbuf, (n - C3_NA) / TM, 4 + (n - C3_NA) % TM);   // fa[0][*], fa[1][*]
+          if constexpr (n >= C3_NW && n < C3_NW + 4) read_frag(nbuf, 0, n - C3_NW);                                  // fw[0][*]
+        }
+        __builtin_amdgcn_sched_barrier(0);
+      });
+      cb ^= 1;
+    };
+    if constexpr (C3) {
+      if (nk == 1) {
+        iteration_c3(std::true_type{}, std::true_type{});
+      } else {
+        iteration_c3(std::true_type{}, std::false_type{});
+        for (int u = 2; u < nk; ++u) iteration_c3(std::false_type{}, std::false_type{});
+        iteration_c3(std::false_type{}, std::true_type{});
+      }
+    } else if (nk == 1) {
       iteration(std::true_type{}, std::true_type{});
     } else {
       iteration(std::true_type{}, std::false_type{});
@@ -448,10 +538,10 @@ __global__ __launch_bounds__(256) void gemm4w_kernel(const vidil_gemm_args p) {
 #undef ACC
 }
 
-template <typename T, int EPI, int ACT, bool FOLD = false, typename TO = T, bool STATS = false, bool RLN = false, int TM = 4>
+template <typename T, int EPI, int ACT, bool FOLD = false, typename TO = T, bool STATS = false, bool RLN = false, int TM = 4, bool C3 = false>
 int launch4w(const vidil_gemm_args& a, hipStream_t s) {
   static unsigned long long attr_set = 0;   // (one bit per device: vidil_first_on_device)
-  auto kern = gemm4w_kernel<T, TO, EPI, ACT, FOLD, STATS, RLN, TM>;
+  auto kern = gemm4w_kernel<T, TO, EPI, ACT, FOLD, STATS, RLN, TM, C3>;
   constexpr int LDS_BYTES = kLds<TM>;
   if (vidil_first_on_device(&attr_set)) {
     hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES);
@@ -563,6 +653,37 @@ static int launch4w_fp8(const vidil_gemm_args& a, hipStream_t s) {
     default:
       return -1000;
   }
+#endif
+}
+
+// split_k launches (the parity precision mode's GEMMs): the in-loop compensated product, at EVERY size — 256-row tiles once they
+// fill the chip, 128-row tiles below (same k order per output element: same bits), so that a row's result never depends on the
+// batch around it.  Epilogues the mode uses: f32 (+ activation, residual, the [hi | lo | hi] hand-over), the per-head scatter
+// (cross K | V tiles; Q / K / V of the "16" attention kind), the patch embedding.
+template <typename T, int TM>
+static int launch4w_c3_tm(const vidil_gemm_args& a, hipStream_t s) {
+  switch (a.epi) {
+    case VIDIL_EPI_F32:
+      if (a.act == VIDIL_ACT_NONE) return launch4w<T, VIDIL_EPI_F32, VIDIL_ACT_NONE, false, T, false, false, TM, true>(a, s);
+      if (a.act == VIDIL_ACT_GELU_ERF) return launch4w<T, VIDIL_EPI_F32, VIDIL_ACT_GELU_ERF, false, T, false, false, TM, true>(a, s);
+      return launch4w<T, VIDIL_EPI_F32, VIDIL_ACT_QUICK_GELU, false, T, false, false, TM, true>(a, s);
+    case VIDIL_EPI_HEADS:
+      return launch4w<T, VIDIL_EPI_HEADS, VIDIL_ACT_NONE, false, T, false, false, TM, true>(a, s);
+    case VIDIL_EPI_PATCH:
+      if constexpr (TM == 4) return launch4w<T, VIDIL_EPI_PATCH, VIDIL_ACT_NONE, false, T, false, false, 4, true>(a, s);
+      return -1000;
+    default:
+      return -1000;
+  }
+}
+int vidil_gemm4w_c3_launch(const vidil_gemm_args& a, hipStream_t s) {
+#ifdef VIDIL_4W_DEV_ONE
+  return -1000;
+#else
+  const long t256 = (long)((a.M + 255) / 256) * ((a.N + 255) / 256);
+  const bool big = t256 >= 5L * vidil_cu_count() / 8 || a.epi == VIDIL_EPI_PATCH;      // (the patch epilogue is built for 256-row tiles only)
+  if (a.dtype == VIDIL_DT_BF16) return big ? launch4w_c3_tm<bf16, 4>(a, s) : launch4w_c3_tm<bf16, 2>(a, s);
+  return big ? launch4w_c3_tm<f16, 4>(a, s) : launch4w_c3_tm<f16, 2>(a, s);
 #endif
 }
 

@@ -85,6 +85,8 @@ def gemm(a, w, bias=None, **kw):
       * split3_out=T16 [M,3N]: f32 epilogue (activation in f32) whose result is written as the error-compensated operand rows
         [hi | lo | hi] of the next K-tripled GEMM (vidil_gemm_args.out16_split3) — the parity mode's fc1 -> fc2 hand-over
         without the f32 round trip through ``split3``; ``out`` (f32), if given as well, also receives the f32 rows.
+      * split_k=True: ``a`` holds [x_hi | x_lo | x_hi] rows and ``w`` [W_hi | W_hi | W_lo] (packing.w3): the error-compensated
+        product of the parity precision mode; the library may form the three products inside one K loop (vidil_gemm_args.split_k).
       * LayerNorm folded into a pre-LN block's GEMM pair (vidil_gemm_args.ln_fold): the residual GEMM passes
         ``out16=`` (T16 copy of the f32 stream it writes) and ``ln_stats_out=`` (per-row partial sums), the next
         GEMM passes that copy as ``a`` with ``ln=(colsum, eps, stats)`` and weights / bias folded by
@@ -105,7 +107,7 @@ def gemm_kernel_name(a, w, bias=None, **kw):
 
 def _gemm_build(a, w, bias=None, *, out=None, out_dtype=None, act=ACT_NONE, resid=None,
                 heads=None, patch=None, arena=None, M=None, lda=None, out16=None, ln_stats_out=None, ln=None, w_scale=None,
-                dtype16=None, rln=None, split3_out=None):
+                dtype16=None, rln=None, split3_out=None, split_k=False):
     K_ = w.shape[1]
     if lda is None:
         M, Ka = a.shape
@@ -135,6 +137,7 @@ def _gemm_build(a, w, bias=None, *, out=None, out_dtype=None, act=ACT_NONE, resi
         g.dtype16 = _dt(t16, "gemm.dtype16")
         g.w_scale = _ptr(w_scale, torch.float32, "gemm.w_scale")
     g.bias = _ptr(bias, torch.float32, "gemm.bias")
+    g.split_k = 1 if split_k else 0        # A = [x_hi | x_lo | x_hi] rows, W = [W_hi | W_hi | W_lo] (the parity mode's operands)
     g.M, g.N, g.K = M, N, K
     g.lda = 0 if lda is None else lda
     g.act = act

@@ -273,11 +273,11 @@ class BertModel(PackedCache, nn.Module):
                     kv32 = torch.empty((L, B, Te, 2 * C), dtype=torch.float32, device=dev)
                     ph = torch.zeros((L, B, 1), dtype=torch.float32, device=dev)
                 for i, d in enumerate(p["layers"]):
-                    K.gemm(enc16, d["ckv_w3"], d["ckv_b"], out=kv32[i].view(B * Te, 2 * C))
+                    K.gemm(enc16, d["ckv_w3"], d["ckv_b"], out=kv32[i].view(B * Te, 2 * C), split_k=True)
                 return CrossKV(kv32, ph, B, Te, 0, f32=True)
 
             def kv_gemm(d, **heads):
-                K.gemm(enc16, d["ckv_w3"], d["ckv_b"], heads=heads)
+                K.gemm(enc16, d["ckv_w3"], d["ckv_b"], heads=heads, split_k=True)
         elif self.fp8 and "ckv_w8" in p["layers"][0] and enc16.shape[1] % 128 == 0:
             # fp8 tower mode (BASELINE config 5): e4m3 image tokens x e4m3 K|V weights, K / V written in the 16-bit type
             # (clamped first: torch's e4m3 cast does not saturate — 470 becomes NaN — while every device-side conversion does)
@@ -450,7 +450,7 @@ class BertModel(PackedCache, nn.Module):
             q32 = torch.empty((M, C), dtype=torch.float32, device=dev) if cross is not None else None
         for i, d in enumerate(p["layers"]):
             if f32_attn:
-                K.gemm(h3, d["qkv_w3"], d["qkv_b"], out=qkv32)
+                K.gemm(h3, d["qkv_w3"], d["qkv_b"], out=qkv32, split_k=True)
                 if arena is not None and T == 1:
                     arena.k[i][t_off].copy_(qkv32[:, C:2 * C])          # position t_off, slot = producing beam row
                     arena.v[i][t_off].copy_(qkv32[:, 2 * C:])
@@ -464,24 +464,24 @@ class BertModel(PackedCache, nn.Module):
                         arena.k[i][:T, 0:rows * arena_slot_stride:arena_slot_stride] = blk[:, :, C:2 * C].permute(1, 0, 2)
                         arena.v[i][:T, 0:rows * arena_slot_stride:arena_slot_stride] = blk[:, :, 2 * C:].permute(1, 0, 2)
             elif arena is not None and T == 1:
-                K.gemm(h3, d["qkv_w3"], d["qkv_b"],
+                K.gemm(h3, d["qkv_w3"], d["qkv_b"], split_k=True,
                        arena=dict(q=q, k=arena.k[i], v=arena.v[i], T=1, H=H, part0=0, t_off=t_off, Tcap=arena.Tcap,
                                   arena_rows=arena.rows, slot_stride=1, q_scale=0.125))
                 K.beam_attention(q, arena.k[i], arena.v[i], arena.anc, o3, rows=rows, H=H, n_keys=Nk, split3=True)
             else:
-                K.gemm(h3, d["qkv_w3"], d["qkv_b"],
+                K.gemm(h3, d["qkv_w3"], d["qkv_b"], split_k=True,
                        heads=dict(q=q, k=self_k[i], vt=self_vt[i], T=T, H=H, part0=0, t_off=t_off, Tq_cap=T,
                                   Tk_cap=Tk_cap, NP=NPs, q_scale=0.125))
                 K.attention(q, self_k[i], self_vt[i], o3, Bq=rows, H=H, Nq=T, Nk=Nk, Tq_cap=T, Tk_cap=Tk_cap, NP=NPs,
                             causal=causal, causal_off=t_off, kv_len=kv_len, split3=True)
                 if arena is not None:
-                    K.gemm(h3, d["qkv_w3"][C:], d["qkv_b"][C:],
+                    K.gemm(h3, d["qkv_w3"][C:], d["qkv_b"][C:], split_k=True,
                            arena=dict(k=arena.k[i], v=arena.v[i], T=T, H=H, part0=1, t_off=0, Tcap=arena.Tcap,
                                       arena_rows=arena.rows, slot_stride=arena_slot_stride))
-            K.gemm(o3, d["ao_w3"], d["ao_b"], out=tmp, resid=h32)
+            K.gemm(o3, d["ao_w3"], d["ao_b"], out=tmp, resid=h32, split_k=True)
             K.layernorm(tmp, d["ao_g"], d["ao_bt"], eps, out16=h3, out32=h32, split3=True)
             if cross is not None and f32_attn:
-                K.gemm(h3, d["cq_w3"], d["cq_b"], out=q32)
+                K.gemm(h3, d["cq_w3"], d["cq_b"], out=q32, split_k=True)
                 if kv16:
                     K.attention_f32(q32, cross.k[i], cross.vt[i], o3, Bq=rows, H=H, Nq=T, Nk=cross.Te, kv_rows=cross.Tk_cap,
                                     kv_group=cross_group, kv_index=cross_index, group_start=cross_groups, max_group=cross_max_group,
@@ -491,19 +491,19 @@ class BertModel(PackedCache, nn.Module):
                     K.attention_f32(q32, kv[..., :C], kv[..., C:], o3, Bq=rows, H=H, Nq=T, Nk=cross.Te, kv_rows=cross.Te,
                                     kv_group=cross_group, kv_index=cross_index, group_start=cross_groups, max_group=cross_max_group,
                                     arith=arith)
-                K.gemm(o3, d["co_w3"], d["co_b"], out=tmp, resid=h32)
+                K.gemm(o3, d["co_w3"], d["co_b"], out=tmp, resid=h32, split_k=True)
                 K.layernorm(tmp, d["co_g"], d["co_bt"], eps, out16=h3, out32=h32, split3=True)
             elif cross is not None:
-                K.gemm(h3, d["cq_w3"], d["cq_b"], heads=dict(q=q, T=T, H=H, part0=0, Tq_cap=T, q_scale=0.125))
+                K.gemm(h3, d["cq_w3"], d["cq_b"], heads=dict(q=q, T=T, H=H, part0=0, Tq_cap=T, q_scale=0.125), split_k=True)
                 # (project_cross_kv(last_layer_vt=True) keeps the LAST layer's values in a V^T buffer of their own)
                 last = i == len(p["layers"]) - 1 and cross.last_vt is not None
                 K.attention(q, cross.k[i], cross.last_vt if last else cross.vt[i], o3, Bq=rows, H=H, Nq=T, Nk=cross.Te, Tq_cap=T,
                             Tk_cap=cross.Tk_cap, NP=cross.last_NP if last else cross.NP, kv_group=cross_group, kv_index=cross_index,
                             group_start=cross_groups, max_group=cross_max_group, kv_tiled=cross.tiled, split3=True)
-                K.gemm(o3, d["co_w3"], d["co_b"], out=tmp, resid=h32)
+                K.gemm(o3, d["co_w3"], d["co_b"], out=tmp, resid=h32, split_k=True)
                 K.layernorm(tmp, d["co_g"], d["co_bt"], eps, out16=h3, out32=h32, split3=True)
-            K.gemm(h3, d["i_w3"], d["i_b"], split3_out=inter3, act=K.ACT_GELU_ERF)
-            K.gemm(inter3, d["o_w3"], d["o_b"], out=tmp, resid=h32)
+            K.gemm(h3, d["i_w3"], d["i_b"], split3_out=inter3, act=K.ACT_GELU_ERF, split_k=True)
+            K.gemm(inter3, d["o_w3"], d["o_b"], out=tmp, resid=h32, split_k=True)
             K.layernorm(tmp, d["o_g"], d["o_bt"], eps, out16=h3, out32=h32, split3=True)
         return h32, h3
 
@@ -781,13 +781,13 @@ class BertLMHeadModel(PackedCache, nn.Module):
             last32 = h32.view(rows, T, C)[:, T - 1].contiguous()
             a3 = K.split3(last32, torch.empty((rows, 3 * C), dtype=cdt, device=dev))
             t32 = torch.empty((rows, C), dtype=torch.float32, device=dev)
-            K.gemm(a3, p["t_w3"], p["t_b"], out=t32, act=K.ACT_GELU_ERF)
+            K.gemm(a3, p["t_w3"], p["t_b"], out=t32, act=K.ACT_GELU_ERF, split_k=True)
             tn32 = torch.empty((rows, C), dtype=torch.float32, device=dev)
             K.layernorm(t32, p["t_g"], p["t_bt"], cfg.layer_norm_eps, out32=tn32)
             K.split3(tn32, a3)
             if out is None:
                 out = torch.empty((rows, cfg.vocab_size), dtype=torch.float32, device=dev)
-            K.gemm(a3, p["dec_w3"], p["dec_b"], out=out)
+            K.gemm(a3, p["dec_w3"], p["dec_b"], out=out, split_k=True)
             return out
         last = h16.view(-1)[(T - 1) * C:]  # row r of the strided view = token T-1 of sequence r
         t32 = torch.empty((rows, C), dtype=torch.float32, device=dev)

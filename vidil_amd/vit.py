@@ -172,7 +172,7 @@ class VisionTransformer(PackedCache, nn.Module):
         T = P + 1
         x = torch.empty((B * T, D), dtype=torch.float32, device=patches16.device)
         # (parity mode: patches16 holds [hi | lo | hi] rows, see forward_u8)
-        K.gemm(patches16, p["pe_w3"] if p["parity"] else p["pe_w"], p["pe_b"], patch=dict(out=x, pos=p["pos"], tpi=P))
+        K.gemm(patches16, p["pe_w3"] if p["parity"] else p["pe_w"], p["pe_b"], patch=dict(out=x, pos=p["pos"], tpi=P), split_k=p["parity"])
         K.set_cls_row(x, p["cls"], p["pos"], B, T, D)
         return x
 
@@ -260,16 +260,16 @@ class VisionTransformer(PackedCache, nn.Module):
                 continue
             K.layernorm(x, b["n1g"], b["n1b"], self.ln_eps, out16=a3, split3=True)
             if f32_attn:    # Q | K | V stay f32 and row-major; the f32 attention reads them in place (no per-head scatter)
-                K.gemm(a3, b["qkv_w3"], b["qkv_b"], out=qkv32)
+                K.gemm(a3, b["qkv_w3"], b["qkv_b"], out=qkv32, split_k=True)
                 K.attention_f32(qkv32[:, :D], qkv32[:, D:2 * D], qkv32[:, 2 * D:], o3, Bq=B, H=H, Nq=T, Nk=T, arith=arith)
             else:
-                K.gemm(a3, b["qkv_w3"], b["qkv_b"], heads=heads)
+                K.gemm(a3, b["qkv_w3"], b["qkv_b"], heads=heads, split_k=True)
                 K.attention(q, k, vt, o3, Bq=B, H=H, Nq=T, Nk=T, Tq_cap=T, Tk_cap=T, NP=NP, split3=True)
-            K.gemm(o3, b["proj_w3"], b["proj_b"], out=x, resid=x)
+            K.gemm(o3, b["proj_w3"], b["proj_b"], out=x, resid=x, split_k=True)
             K.layernorm(x, b["n2g"], b["n2b"], self.ln_eps, out16=a3, split3=True)
             # (fc1 + erf-GELU in f32, handed to fc2 as [hi | lo | hi] rows by the GEMM's own epilogue: no f32 round trip)
-            K.gemm(a3, b["fc1_w3"], b["fc1_b"], split3_out=hid3, act=K.ACT_GELU_ERF)
-            K.gemm(hid3, b["fc2_w3"], b["fc2_b"], out=x, resid=x)
+            K.gemm(a3, b["fc1_w3"], b["fc1_b"], split3_out=hid3, act=K.ACT_GELU_ERF, split_k=True)
+            K.gemm(hid3, b["fc2_w3"], b["fc2_b"], out=x, resid=x, split_k=True)
         y32 = torch.empty((M, D), dtype=torch.float32, device=dev)
         K.layernorm(x, p["norm_g"], p["norm_b"], self.ln_eps, out16=a3 if want16 else None, out32=y32, split3=True)
         return y32, (a3 if want16 else None)
