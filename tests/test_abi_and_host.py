@@ -111,12 +111,12 @@ def test_argument_validation_without_a_gpu():
     import os
     if not any(k in os.environ for k in ("VIDIL_GEMM4W", "VIDIL_GEMM4W128", "VIDIL_GEMM256", "VIDIL_GEMM4W_MIN_TILES", "VIDIL_GEMM4W_F32")):
         g.K = 3072            # ... unless the reduction is long (round 4: the towers' last fc2, the parity mode's K-tripled GEMMs)
-        assert lib.vidil_gemm_kernel_name(ctypes.byref(g), buf, 128) == 0 and buf.value == b"gemm4w_kernel<__bf16, __bf16, 1, 0, false, false, false, 4>"
+        assert lib.vidil_gemm_kernel_name(ctypes.byref(g), buf, 128) == 0 and buf.value == b"gemm4w_kernel<__bf16, __bf16, 1, 0, false, false, false, 4, false>"
         g.K = 768
         g.epi = 0
-        assert lib.vidil_gemm_kernel_name(ctypes.byref(g), buf, 128) == 0 and buf.value == b"gemm4w_kernel<__bf16, __bf16, 0, 0, false, false, false, 4>"
+        assert lib.vidil_gemm_kernel_name(ctypes.byref(g), buf, 128) == 0 and buf.value == b"gemm4w_kernel<__bf16, __bf16, 0, 0, false, false, false, 4, false>"
         g.M, g.epi = 10752, 1
-        assert lib.vidil_gemm_kernel_name(ctypes.byref(g), buf, 128) == 0 and buf.value == b"gemm4w_kernel<__bf16, __bf16, 1, 0, false, false, false, 2>"
+        assert lib.vidil_gemm_kernel_name(ctypes.byref(g), buf, 128) == 0 and buf.value == b"gemm4w_kernel<__bf16, __bf16, 1, 0, false, false, false, 2, false>"
         g.epi = 1
     g.M, g.dtype = 3072, 0
     assert lib.vidil_gemm_kernel_name(ctypes.byref(g), buf, 128) == 0 and buf.value.startswith(b"gemm_kernel<_Float16, ")

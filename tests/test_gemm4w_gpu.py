@@ -269,10 +269,10 @@ def test_gemm4w_128_row_tile_form_equals_the_other_kernels(monkeypatch, dtype, M
         return outs
 
     monkeypatch.setenv("VIDIL_GEMM4W128", "0")
-    assert "gemm4w_kernel" not in k.gemm_kernel_name(a, w, bias, out=x0, resid=x0) or not k.gemm_kernel_name(a, w, bias, out=x0, resid=x0).endswith(", 2>")
+    assert "gemm4w_kernel" not in k.gemm_kernel_name(a, w, bias, out=x0, resid=x0) or not k.gemm_kernel_name(a, w, bias, out=x0, resid=x0).endswith(", 2, false>")
     ref = run_all()
     monkeypatch.setenv("VIDIL_GEMM4W128", "1")
-    assert k.gemm_kernel_name(a, w, bias, out=x0, resid=x0).startswith("gemm4w_kernel") and k.gemm_kernel_name(a, w, bias, out=x0, resid=x0).endswith(", 2>")
+    assert k.gemm_kernel_name(a, w, bias, out=x0, resid=x0).startswith("gemm4w_kernel") and k.gemm_kernel_name(a, w, bias, out=x0, resid=x0).endswith(", 2, false>")
     got = run_all()
     for r, g in zip(ref, got):
         assert torch.equal(r, g)

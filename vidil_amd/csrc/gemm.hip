@@ -538,8 +538,8 @@ extern "C" int vidil_gemm_kernel_name(const vidil_gemm_args* args, char* buf_hos
   const char* stats = (args->ln_stats_out && args->epi == VIDIL_EPI_F32) ? "true" : "false";
   if (c.big) {
     const char* kn = c.big == 2 ? "gemm4w_kernel" : vidil_gemm256_variant(*args);
-    if (kn[4] == '4') snprintf(buf_host, n, "%s<%s, %s, %d, %d, %s, %s, %s, %d>", kn, t, t16, args->epi, act, args->ln_fold ? "true" : "false",
-                               stats, args->rln_gamma ? "true" : "false", c.big == 2 ? 2 : 4);      // (gemm4w: + its row-tile count)
+    if (kn[4] == '4') snprintf(buf_host, n, "%s<%s, %s, %d, %d, %s, %s, %s, %d, false>", kn, t, t16, args->epi, act, args->ln_fold ? "true" : "false",
+                               stats, args->rln_gamma ? "true" : "false", c.big == 2 ? 2 : 4);      // (gemm4w: + its row-tile count and the C3 flag)
     else snprintf(buf_host, n, "%s<%s, %s, %d, %d, %s, %s, %s>", kn, t, t16, args->epi, act, args->ln_fold ? "true" : "false", stats,
                   args->rln_gamma ? "true" : "false");
   }
