@@ -119,3 +119,30 @@ def test_blip_retrieval_features_rerank_and_tokenizer_vs_oracle(tmp_path):
     assert set(out["v0"]["frame_tokens"][0].keys()) == set(CATEGORIES) and len(out["v0"]["frame_tokens"]) == NF
     for key in CATEGORIES:                                       # emitted tokens are the unprompted class strings
         assert all(t in texts[key] for fr in out["v0"]["frame_tokens"] for t in fr[key])
+
+
+def test_blip_itm_forward_with_the_itc_head_vs_oracle(tmp_path):
+    """BLIP_ITM.forward(image, caption, match_head='itc') (models/blip_itm.py:60-67; round 5: it used to raise on BLIP_ITM and exist
+    on BLIP_Retrieval only): normalize(vision_proj(image [CLS])) @ normalize(text_proj(text [CLS], mode='text'))^T."""
+    from oracle import clip_ref, retrieval_ref
+    from vidil_amd.blip_itm import BLIP_ITM
+
+    m = _small_retrieval(str(tmp_path))
+    perturb_(m, 701)
+    sd = {k: v.clone() for k, v in m.state_dict().items()}
+    m = m.to(DEV)
+    NF = 4
+    u8 = synthetic_frames(1, NF, size=64, first_video=62)[0]
+    x = clip_ref.preprocess_u8(u8)
+    caps = [f"w{1200 + 7 * j} w{2100 + j} w{3300 + 3 * j}" for j in range(NF)]
+    sim = BLIP_ITM.forward(m, x.to(DEV), caps, match_head="itc")          # (the base class's own 'itc' branch)
+    assert tuple(sim.shape) == (NF, NF)
+    assert torch.equal(sim, m.forward(x.to(DEV), caps, match_head="itc"))
+    ids, lens = m.tokenize(caps)
+    mask = (torch.arange(35)[None] < lens[:, None]).long()
+    with torch.no_grad():
+        _, img_ref = retrieval_ref.image_features(sd, x, depth=2, heads=4)
+        txt_ref = retrieval_ref.text_features(sd, ids.long(), mask, layers=2, H=4)
+    assert (sim.cpu() - img_ref @ txt_ref.t()).abs().max().item() < 3e-3
+    with pytest.raises(ValueError):
+        BLIP_ITM.forward(m, x.to(DEV), caps, match_head="nope")

@@ -32,7 +32,7 @@ class BLIP_ITM(PackedCache, nn.Module):
         cfg.encoder_width = vision_width
         self.text_encoder = BertModel(config=cfg, add_pooling_layer=False)
         text_width = cfg.hidden_size
-        self.vision_proj = nn.Linear(vision_width, embed_dim)   # 'itc' head: kept for checkpoint keys only
+        self.vision_proj = nn.Linear(vision_width, embed_dim)   # 'itc' head (forward(match_head='itc'))
         self.text_proj = nn.Linear(text_width, embed_dim)
         self.itm_head = nn.Linear(text_width, 2)
 
@@ -40,10 +40,36 @@ class BLIP_ITM(PackedCache, nn.Module):
         p = dict(itm_w=w16(self.itm_head.weight, dtype=self.cdt), itm_b=v32(self.itm_head.bias), parity=self.parity)
         if p["parity"]:          # parity precision mode: [W_hi | W_hi | W_lo] against the [hi | lo | hi] rows of the [CLS] states
             p["itm_w3"] = w3(self.itm_head.weight, dtype=self.cdt)
+        # the 'itc' head's two projections (models/blip_itm.py:60-67; plain operands)
+        p.update(vp_w=w16(self.vision_proj.weight, dtype=self.cdt), vp_b=v32(self.vision_proj.bias),
+                 tp_w=w16(self.text_proj.weight, dtype=self.cdt), tp_b=v32(self.text_proj.bias))
         return p
 
     def parameters_for_fingerprint(self):
-        return [self.itm_head.weight, self.itm_head.bias]
+        return [self.itm_head.weight, self.itm_head.bias, self.vision_proj.weight, self.vision_proj.bias,
+                self.text_proj.weight, self.text_proj.bias]
+
+    def _project_cls(self, h16, rows, T, w, b):
+        """normalize(Linear(token 0 of each of ``rows`` sequences of length T)) -> f32 [rows, embed_dim]."""
+        C = h16.shape[-1]
+        out = torch.empty((rows, w.shape[0]), dtype=torch.float32, device=h16.device)
+        K.gemm(h16.view(-1), w, b, out=out, M=rows, lda=T * C)
+        return K.l2_normalize_rows(out)
+
+    @torch.no_grad()
+    def itc_similarity(self, y16, n_images, captions, device):
+        """models/blip_itm.py:60-67 (match_head='itc'): normalize(vision_proj(image [CLS])) @ normalize(text_proj(text [CLS]))^T
+        with the text encoder in mode='text' (no cross-attention) -> f32 [n_images, len(captions)], exact-f32 scores."""
+        if self.parity:
+            raise NotImplementedError("match_head='itc' has no parity-precision form (it is not on the CapFilt path)")
+        p = self.packed()
+        img = self._project_cls(y16, n_images, y16.shape[0] // n_images, p["vp_w"], p["vp_b"])
+        ids, lens = self.tokenize(list(captions))
+        t_eff = max(1, min(ITM_MAX_LENGTH, int(lens.max().item())))
+        d_ids = ids[:, :t_eff].to(device).contiguous()
+        _, h16 = self.text_encoder.encode(d_ids, lens.to(device).contiguous(), None)
+        txt = self._project_cls(h16, d_ids.shape[0], t_eff, p["tp_w"], p["tp_b"])
+        return K.scan_scores(img, txt)
 
     # ------------------------------------------------------------------ tokenisation
     def tokenize(self, captions):
@@ -123,11 +149,13 @@ class BLIP_ITM(PackedCache, nn.Module):
     @torch.no_grad()
     def forward(self, image, caption, match_head="itm"):
         """Reference call shape (models/blip_itm.py:41-58): F images, F captions -> [F,2]."""
-        if match_head != "itm":
-            raise NotImplementedError("match_head='itc' is not on the hot path")
+        if match_head not in ("itm", "itc"):
+            raise ValueError(f"unknown match_head {match_head!r}")
         require_cuda(image, "BLIP_ITM.forward")
         F = image.shape[0]
         _, y16 = self.visual_encoder.forward_both(image)
+        if match_head == "itc":          # [F, F] similarities (models/blip_itm.py:60-67)
+            return self.itc_similarity(y16, F, caption, image.device)
         ids, lens = self.tokenize(list(caption))
         return self.itm_pairs(y16, F, ids, lens, torch.arange(F, dtype=torch.int32))
 

@@ -39,22 +39,9 @@ class BLIP_Retrieval(BLIP_ITM):
     def _pack(self):
         if self.__dict__.get("_parity"):     # (explicitly switched on for THIS model)
             raise NotImplementedError("the parity precision mode is built for BLIP_Decoder, BLIP_ITM and CLIPModel, not for the retrieval heads")
-        p = super()._pack()
-        p.update(vp_w=w16(self.vision_proj.weight, dtype=self.cdt), vp_b=v32(self.vision_proj.bias),
-                 tp_w=w16(self.text_proj.weight, dtype=self.cdt), tp_b=v32(self.text_proj.bias))
-        return p
+        return super()._pack()          # (BLIP_ITM packs the two ITC projections: vp_w / vp_b / tp_w / tp_b)
 
-    def parameters_for_fingerprint(self):
-        return super().parameters_for_fingerprint() + [self.vision_proj.weight, self.vision_proj.bias,
-                                                       self.text_proj.weight, self.text_proj.bias]
-
-    # ------------------------------------------------------------------ features
-    def _project_cls(self, h16, rows, T, w, b):
-        """normalize(Linear(token 0 of each of ``rows`` sequences of length T)) -> f32 [rows, embed_dim]."""
-        C = h16.shape[-1]
-        out = torch.empty((rows, w.shape[0]), dtype=torch.float32, device=h16.device)
-        K.gemm(h16.view(-1), w, b, out=out, M=rows, lda=T * C)
-        return K.l2_normalize_rows(out)
+    # ------------------------------------------------------------------ features (_project_cls: BLIP_ITM)
 
     @torch.no_grad()
     def image_features_u8(self, frames_u8):
