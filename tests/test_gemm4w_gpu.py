@@ -309,7 +309,9 @@ def test_arena_epilogue_on_the_256_row_kernels(monkeypatch, dtype, T, stride):
         ka = torch.zeros(Tcap, rows, D, dtype=dtype, device=DEV)
         va = torch.zeros(Tcap, rows, D, dtype=dtype, device=DEV)
         ar = dict(q=q, k=ka, v=va, T=T, H=H, part0=0, t_off=t_off, arena_rows=rows, slot_stride=stride, Tcap=Tcap, q_scale=qs)
-        names.add(k.gemm_kernel_name(a, w, bias, arena=ar).split("<")[0] + k.gemm_kernel_name(a, w, bias, arena=ar)[-4:])
+        nm = k.gemm_kernel_name(a, w, bias, arena=ar)
+        # (kernel + its row-tile count: gemm4w's template arguments end "..., <TM>, <C3>>", gemm256's have neither)
+        names.add(nm.split("<")[0] + (nm.split(",")[-2].strip() if nm.startswith("gemm4w") else ""))
         k.gemm(a, w, bias, arena=ar)
         assert torch.equal(q, want_q)
         got_k = ka[t_off:t_off + T, ::stride].permute(1, 0, 2).reshape(M, D)

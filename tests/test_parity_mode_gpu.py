@@ -629,10 +629,12 @@ def test_split_k_gemm_per_head_scatter_and_patch_epilogues_equal_the_k_tripled_l
         k.gemm(a3, w3d, bias, heads=dict(k=kk, vt=vv, T=T, H=H, part0=1, t_off=0, Tk_cap=Tc, tiled=True), split_k=sk)
         outs.append((kk, vv))
     for a_, b_ in zip(outs[0], outs[1]):
-        d = (a_.float() - b_.float()).abs()
-        # (one unit in the last place of the 16-bit value where the two f32 sums straddle a rounding boundary: ~0.1 % of the elements)
-        assert torch.allclose(a_.float(), b_.float(), rtol=1.1e-3, atol=1e-6) and (d > 0).float().mean().item() < 0.02, \
-            (d.max().item(), (d > 0).float().mean().item())
+        # one unit in the last place of the 16-bit value where the two f32 sums straddle a rounding boundary (~0.1 % of the
+        # elements): compared as bit patterns — same sign, ordinals at most 1 apart
+        ia, ib = a_.view(torch.int16).int(), b_.view(torch.int16).int()
+        ulps = torch.where((ia < 0) == (ib < 0), (ia - ib).abs(), torch.full_like(ia, 99))
+        frac = (ulps > 0).float().mean().item()
+        assert ulps.max().item() <= 1 and frac < 0.02, (ulps.max().item(), frac)
     # patch embedding: [B*P, 3*768] split rows -> f32 stream rows (m + m / tpi + 1)
     P = 196
     xp = _rand(3 * P, 768, seed=53)
