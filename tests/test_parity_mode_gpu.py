@@ -632,9 +632,13 @@ def test_split_k_gemm_per_head_scatter_and_patch_epilogues_equal_the_k_tripled_l
         # one unit in the last place of the 16-bit value where the two f32 sums straddle a rounding boundary (~0.1 % of the
         # elements): compared as bit patterns — same sign, ordinals at most 1 apart
         ia, ib = a_.view(torch.int16).int(), b_.view(torch.int16).int()
-        ulps = torch.where((ia < 0) == (ib < 0), (ia - ib).abs(), torch.full_like(ia, 99))
+        oa, ob = torch.where(ia >= 0, ia, -(ia & 0x7FFF)), torch.where(ib >= 0, ib, -(ib & 0x7FFF))      # monotonic ordinals (+-0 -> 0)
+        ulps = (oa - ob).abs()
+        # (small values: the two f32 sums differ by ~1e-6 ABSOLUTE — sums of O(1) terms in another order — which is many ulps of a
+        #  16-bit value near zero; one ulp OR that absolute difference)
+        ok = (ulps <= 1) | ((a_.float() - b_.float()).abs() <= 4e-6)
         frac = (ulps > 0).float().mean().item()
-        assert ulps.max().item() <= 1 and frac < 0.02, (ulps.max().item(), frac)
+        assert bool(ok.all()) and frac < 0.02, ((a_.float() - b_.float()).abs()[~ok].max().item() if not bool(ok.all()) else 0.0, frac)
     # patch embedding: [B*P, 3*768] split rows -> f32 stream rows (m + m / tpi + 1)
     P = 196
     xp = _rand(3 * P, 768, seed=53)
