@@ -106,6 +106,9 @@ CONFIGS = [
     ("cross: P f16 only", dict(cross=dict(p="f16"))),
     ("cross: K V hi8, Q P split; rest split", dict(vit=ALL("split"), dself=ALL("split"), cross=dict(q="split", k="hi8", v="hi8", p="split"))),
     ("cross: K hi8, V f16, Q P split; rest split", dict(vit=ALL("split"), dself=ALL("split"), cross=dict(q="split", k="hi8", v="f16", p="split"))),
+    ("decoder self: K V f16, Q P split", dict(dself=dict(q="split", k="f16", v="f16", p="split"))),
+    ("decoder self: V f16 only", dict(dself=dict(v="f16"))),
+    ("decoder self: K f16 only", dict(dself=dict(k="f16"))),
     ("ViT: K V f16 only", dict(vit=dict(k="f16", v="f16"))),
     ("ViT: Q f16 only", dict(vit=dict(q="f16"))),
     ("ViT: P f16 only", dict(vit=dict(p="f16"))),

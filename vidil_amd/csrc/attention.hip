@@ -910,7 +910,7 @@ __global__ __launch_bounds__(512, 4) void attn_stream_kernel(const AttnP<T> p) {
 // four operands need more than 16 bits was measured on the CPU oracle (tests/probes/probe_precision_design.py, trained-like
 // statistics, of the logit scale): Q 1.7e-4, P 6.3e-5, V 2.1e-5, K 1.0e-5 — with Q and P split the 16-bit K / V leave 3.0e-5 where
 // the budget of "1e-3 absolute" at max|logit| = 16 is 6.4e-5, at the byte traffic of the plain kernel (f32 K / V: twice the bytes).
-template <typename T, int NKT, bool QS = false, int VAR = 0>   // VAR (developer sweep of the QS form): 1 = three waves per SIMD, 2 = that with one key tile per wave and round
+template <typename T, int NKT, bool QS = false, int VAR = 0>   // VAR 2 (the QS form at 197 keys): three waves per SIMD, one key tile per wave and round
 __global__ __launch_bounds__(256, VAR ? 3 : 1) void attn_direct_kernel(const AttnP<T> p) {
   using f16 = T;
   using f16x8 = typename Elt<T>::x8;
@@ -2028,8 +2028,8 @@ extern "C" int vidil_attention_f32(const vidil_attn_f32_args* a, void* stream) {
         case 7: {
           const char* ev = vidil_dev_env("VIDIL_ATTN_QS_VARIANT");
           const int var = ev ? atoi(ev) : 2;      // (one key tile per wave and round, three waves per SIMD: 638 -> 555 us per 3,584-image launch)
-          if (var == 1) hipLaunchKernelGGL((attn_direct_kernel<T, 7, true, 1>), g, dim3(256), 0, s, q);
-          else if (var == 2) hipLaunchKernelGGL((attn_direct_kernel<T, 7, true, 2>), g, dim3(256), 0, s, q);
+          // (variant 1 — two key tiles per wave at three waves per SIMD — spills 27 registers: 602 us; not built any more)
+          if (var == 2) hipLaunchKernelGGL((attn_direct_kernel<T, 7, true, 2>), g, dim3(256), 0, s, q);
           else hipLaunchKernelGGL((attn_direct_kernel<T, 7, true>), g, dim3(256), 0, s, q);
           break;
         }
