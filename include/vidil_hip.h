@@ -147,7 +147,9 @@ typedef struct vidil_gemm_args {
   /* EPI_F32 with out16 (ABI 10, round 5; no ln_stats_out / rln): non-zero = the 16-bit copy is written as ERROR-COMPENSATED
    * operand rows [hi | lo | hi] (VIDIL_DT_SPLIT3's layout: three planes of ldo16 / 3 >= N columns; hi = T16(v), lo =
    * T16(v - hi)) of v = act(acc + bias) + resid — what vidil_split3_f32 would make of the f32 output, from the same f32
-   * values — and `out` may then be NULL: the f32 rows are not written.  The parity precision mode's fc1 -> fc2 hand-over. */
+   * values — and `out` may then be NULL: the f32 rows are not written.  The parity precision mode's fc1 -> fc2 hand-over.
+   * 2 = write planes hi | lo only (plane 2, a copy of plane 0, is left untouched): for a consumer that is a split_k launch in
+   * the K-loop form (vidil_gemm_split_k_in_loop() != 0 and an f32 / per-head (T >= 8) / patch epilogue), which reads planes 0 / 1. */
   int32_t out16_split3;
   /* ERROR-COMPENSATED operands (ABI 10, round 5; the parity precision mode): non-zero = A rows are [x_hi | x_lo | x_hi]
    * (three planes of Kl = K / 3 columns: what VIDIL_DT_SPLIT3 outputs look like) and W rows are [W_hi | W_hi | W_lo], so
@@ -163,6 +165,9 @@ typedef struct vidil_gemm_args {
  * 236,301,314,512,534; timm PatchEmbed conv (models/vit.py:144-145,182) as an
  * im2col-free GEMM; HF CLIP q/k/v/out/fc1/fc2/projection Linears. */
 int vidil_gemm(const vidil_gemm_args* args, void* stream);
+/* 1 when split_k launches with an eligible epilogue take the K-loop form in this process (0: $VIDIL_GEMM_C3=0 — every split_k
+ * launch is the plain K = 3 Kl product and reads all three planes of its A rows). */
+int vidil_gemm_split_k_in_loop(void);
 /* Name of the kernel instantiation vidil_gemm would launch for `args` (the spelling rocprofv3 prints, e.g.
  * "gemm256_kernel<f16, 1, 0>"), written NUL-terminated into buf[0..n).  For profilers / bench.py. */
 int vidil_gemm_kernel_name(const vidil_gemm_args* args, char* buf_host, int32_t n);

@@ -569,6 +569,11 @@ def test_gemm_f32_epilogue_writes_split3_operand_rows_itself(M, N, K, act):
     out32 = torch.zeros(M, N, dtype=torch.float32, device=DEV)
     k.gemm(a, w, b, split3_out=got3b, out=out32, act=act)
     assert torch.equal(got3b, ref3) and torch.equal(out32, ref32)
+    # split3_planes=2 (the consumer is a split_k launch in the K-loop form, which reads planes hi | lo only): the third plane is
+    # left untouched
+    got2 = torch.full((M, 3 * N), 7.0, dtype=torch.float16, device=DEV)
+    k.gemm(a, w, b, split3_out=got2, act=act, split3_planes=2)
+    assert torch.equal(got2[:, :2 * N], ref3[:, :2 * N]) and bool((got2[:, 2 * N:] == 7.0).all())
     print(f"split3_out {M}x{N}x{K} act {act}: {k.gemm_kernel_name(a, w, b, split3_out=got3, act=act)}")
 
 

@@ -81,6 +81,7 @@ SIGNATURES = {
     "vidil_num_entry_points": (_i32, []),
     "vidil_gemm": (_i32, [C.POINTER(GemmArgs), _p]),
     "vidil_gemm_kernel_name": (_i32, [C.POINTER(GemmArgs), C.c_char_p, _i32]),
+    "vidil_gemm_split_k_in_loop": (_i32, []),
     "vidil_layernorm": (_i32, [_p, _i64, _p, _p, _f32, _i32, _i32, _p, _i32, _p, _p]),
     "vidil_split3_f32": (_i32, [_p, _p, _i32, _i32, _i32, _p]),
     "vidil_attention": (_i32, [_p, _p, _p, _p, _p, _p, _p] + [_i32] * 16 + [_p]),

@@ -179,6 +179,9 @@ def _run_layers(layers, x, B, T, H, eps, *, causal=False, kv_len=None, f32_attn=
         a3 = torch.empty((M, 3 * D), dtype=cdt, device=dev)
         o3 = torch.empty((M, 3 * D), dtype=cdt, device=dev)
         hid3 = torch.empty((M, 3 * Dh), dtype=cdt, device=dev)
+        # (fc2 consumes these rows as a split_k launch with the f32 epilogue: in the K-loop form it reads planes hi | lo only, so fc1
+        #  need not write the third)
+        planes = 2 if K.split_k_in_loop() else 3
         qkv32 = torch.empty((M, 3 * D), dtype=torch.float32, device=dev) if f32_attn else None
         for l in layers:
             K.layernorm(x, l["n1g"], l["n1b"], eps, out16=a3, split3=True)
@@ -191,7 +194,7 @@ def _run_layers(layers, x, B, T, H, eps, *, causal=False, kv_len=None, f32_attn=
                 K.attention(q, k, vt, o3, Bq=B, H=H, Nq=T, Nk=T, Tq_cap=T, Tk_cap=T, NP=NP, causal=causal, kv_len=kv_len, split3=True)
             K.gemm(o3, l["o_w3"], l["o_b"], out=x, resid=x, split_k=True)
             K.layernorm(x, l["n2g"], l["n2b"], eps, out16=a3, split3=True)
-            K.gemm(a3, l["fc1_w3"], l["fc1_b"], split3_out=hid3, act=K.ACT_QUICK_GELU, split_k=True)
+            K.gemm(a3, l["fc1_w3"], l["fc1_b"], split3_out=hid3, act=K.ACT_QUICK_GELU, split_k=True, split3_planes=planes)
             K.gemm(hid3, l["fc2_w3"], l["fc2_b"], out=x, resid=x, split_k=True)
         return x
     stats = torch.empty((M, D // 64, 2), dtype=torch.float32, device=dev) if "fc1_f" in layers[0] else None

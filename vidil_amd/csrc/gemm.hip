@@ -400,6 +400,7 @@ int check_args(const vidil_gemm_args& a) {
     VIDIL_REQUIRE(a.ldo16 >= a.N, "gemm/out16: ldo16=%d < N=%d", a.ldo16, a.N);
   }
   if (a.out16_split3) {
+    VIDIL_REQUIRE(a.out16_split3 == 1 || a.out16_split3 == 2, "gemm/out16_split3: 1 (three planes) or 2 (hi | lo only), got %d", a.out16_split3);
     VIDIL_REQUIRE(a.out16 && a.epi == VIDIL_EPI_F32 && !a.ln_stats_out && !a.rln_gamma && a.dtype != VIDIL_DT_FP8,
                   "gemm/out16_split3: the plain f32 epilogue with out16 (16-bit operands, no ln_stats_out / rln)");
     VIDIL_REQUIRE(a.ldo16 % 12 == 0 && a.ldo16 / 3 >= a.N && ((uintptr_t)a.out16 & 7) == 0,
@@ -498,9 +499,14 @@ int dispatch(const vidil_gemm_args& a, hipStream_t s) {
 // split_k (the parity precision mode's operands, see include/vidil_hip.h): which launches run the in-loop compensated product
 // (gemm4w's C3 form) — a property of the CALL (epilogue, alignment), never of its size, so that a row's result does not depend
 // on the batch around it; everything else runs the same operands as a plain GEMM with K = 3 Kl (the K-tripled form of rounds 3-4).
-bool vidil_gemm_c3_serves(const vidil_gemm_args& a) {
+static bool c3_switched_off() {
   static const bool off = [] { const char* e = getenv("VIDIL_GEMM_C3"); return e && e[0] == '0'; }();    // (A/B switch)
-  if (!a.split_k || off) return false;
+  return off;
+}
+extern "C" int vidil_gemm_split_k_in_loop(void) { return c3_switched_off() ? 0 : 1; }
+
+bool vidil_gemm_c3_serves(const vidil_gemm_args& a) {
+  if (!a.split_k || c3_switched_off()) return false;
   if (a.dtype == VIDIL_DT_FP8 || a.ln_fold || a.ln_stats_out || a.rln_gamma || a.K % 96 != 0) return false;
   if (!(a.epi == VIDIL_EPI_F32 || a.epi == VIDIL_EPI_PATCH || (a.epi == VIDIL_EPI_HEADS && a.T >= 8))) return false;
   return vidil_gemm256_eligible(a, true);

@@ -112,6 +112,26 @@ __global__ __launch_bounds__(256) void gemm4w_kernel(const vidil_gemm_args p) {
   const int lda = p.lda > 0 ? p.lda : K;
   const int tiles_n = (N + 255) >> 8;
   const int tiles_m = (M + (1 << MSH) - 1) >> MSH;
+  // developer experiment: a COLUMN-BLOCKED tile walk — blocks of `cblk` column tiles, all row panels
+  // inside a block — so that the W rows an XCD works on at any one time stay inside its 4-MiB L2 (launch4w copies
+  // $VIDIL_4W_COLBLOCK into the patch epilogue's `tpi` field for the other epilogues; 0 = the row-major walk)
+  // (compiled in only with -DVIDIL_4W_COLBLOCK_EXP: the extra uniform state costs the hot instantiations 7-10 more spilled
+  //  registers, which is not a price the shipped kernels pay for a developer knob)
+#ifdef VIDIL_4W_COLBLOCK_EXP
+  const int cblk = EPI == VIDIL_EPI_PATCH ? 0 : p.tpi;
+#endif
+  auto tile_of = [&](int lt, int& tm, int& tn) {
+#ifdef VIDIL_4W_COLBLOCK_EXP
+    if (cblk > 0) {
+      const int per = tiles_m * cblk, cbk = lt / per, r = lt - cbk * per;
+      tm = r / cblk;
+      tn = cbk * cblk + (r - tm * cblk);
+      return;
+    }
+#endif
+    tm = lt / tiles_n;
+    tn = lt - tm * tiles_n;
+  };
   // persistent workgroups, XCD-contiguous tile ranges: as gemm256.hip
   int logical, remaining;
   const int tile_step = gridDim.x >= 8 ? (gridDim.x >> 3) : 1;
@@ -157,8 +177,8 @@ __global__ __launch_bounds__(256) void gemm4w_kernel(const vidil_gemm_args p) {
   //                        iteration issues its 16 pieces unconditionally and the counted waits stay uniform
   const uint32_t pitchA = (uint32_t)lda * ESZ, pitchW = (uint32_t)K * ESZ;
   auto head_setup = [&](int lt) {
-    const int tile_m = lt / tiles_n;
-    const int tile_n = lt - tile_m * tiles_n;
+    int tile_m, tile_n;
+    tile_of(lt, tile_m, tile_n);
     const int hm0 = tile_m << MSH, hn0 = tile_n << 8;
     hbaseA = (const char*)p.A + (size_t)hm0 * pitchA;
     hbaseW = (const char*)p.W + (size_t)hn0 * pitchW;
@@ -258,8 +278,8 @@ __global__ __launch_bounds__(256) void gemm4w_kernel(const vidil_gemm_args p) {
   int cb = 0;   // ring buffer of the tile the MFMAs are on
 
   for (;;) {   // ======================================================================== one output tile
-    const int tile_m = logical / tiles_n;
-    const int tile_n = logical - tile_m * tiles_n;
+    int tile_m, tile_n;
+    tile_of(logical, tile_m, tile_n);
     const int m0 = tile_m << MSH, n0 = tile_n << 8;
     // S0 of the tile's first K-tile (landed and visible since barrier B of the previous iteration / the start of the
     // stream).  Not fetched ahead across the epilogue: 64 live registers there cost more than this exposed LDS latency.
@@ -560,7 +580,19 @@ int launch4w(const vidil_gemm_args& a, hipStream_t s) {
   // (fewer tiles than CUs: one workgroup per tile — the count rounded UP to the XCD multiple, the spare workgroups find
   //  their XCD's range empty and leave; rounded down, a few workgroups would run two tiles and double the launch's time)
   const int tiles = ntiles >= cus ? cus : (ntiles >= 8 ? ((ntiles + 7) & ~7) : ntiles);
+#ifdef VIDIL_4W_COLBLOCK_EXP
+  vidil_gemm_args a2 = a;
+  if constexpr (EPI != VIDIL_EPI_PATCH) {
+    a2.tpi = 0;
+    if (const char* e = vidil_dev_env("VIDIL_4W_COLBLOCK")) {       // developer: column-blocked tile walk (see the kernel)
+      const int cb = atoi(e), tn = (a.N + 255) / 256;
+      if (cb > 0 && cb < tn && tn % cb == 0) a2.tpi = cb;
+    }
+  }
+  hipLaunchKernelGGL(kern, dim3(tiles), dim3(256), LDS_BYTES, s, a2);
+#else
   hipLaunchKernelGGL(kern, dim3(tiles), dim3(256), LDS_BYTES, s, a);
+#endif
   VIDIL_CHECK_LAUNCH("gemm4w");
   return VIDIL_OK;
 }

@@ -97,6 +97,13 @@ def gemm(a, w, bias=None, **kw):
     return ret
 
 
+def split_k_in_loop() -> bool:
+    """True when the library forms the parity mode's compensated products inside one K loop (vidil_gemm_split_k_in_loop): such a
+    consumer reads planes hi | lo of its [hi | lo | hi] operand rows only, so a producer may leave the third plane unwritten
+    (``gemm(..., split3_out=, split3_planes=2)``)."""
+    return bool(_lib.load().vidil_gemm_split_k_in_loop())
+
+
 def gemm_kernel_name(a, w, bias=None, **kw):
     """The kernel instantiation ``gemm`` would launch for these arguments, as rocprofv3 spells it."""
     g, _ = _gemm_build(a, w, bias, **kw)
@@ -107,7 +114,7 @@ def gemm_kernel_name(a, w, bias=None, **kw):
 
 def _gemm_build(a, w, bias=None, *, out=None, out_dtype=None, act=ACT_NONE, resid=None,
                 heads=None, patch=None, arena=None, M=None, lda=None, out16=None, ln_stats_out=None, ln=None, w_scale=None,
-                dtype16=None, rln=None, split3_out=None, split_k=False):
+                dtype16=None, rln=None, split3_out=None, split_k=False, split3_planes=3):
     K_ = w.shape[1]
     if lda is None:
         M, Ka = a.shape
@@ -189,7 +196,7 @@ def _gemm_build(a, w, bias=None, *, out=None, out_dtype=None, act=ACT_NONE, resi
             g.ldo = N
         g.out16 = _ptr(split3_out, t16, "gemm.split3_out")
         g.ldo16 = 3 * N
-        g.out16_split3 = 1
+        g.out16_split3 = 2 if split3_planes == 2 else 1      # (2: the consumer is a split_k launch in the K-loop form)
     else:
         if out is None:
             out = torch.empty((M, N), dtype=out_dtype or a.dtype, device=a.device)

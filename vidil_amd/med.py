@@ -432,6 +432,9 @@ class BertModel(PackedCache, nn.Module):
         o3 = torch.empty((M, 3 * C), dtype=cdt, device=dev)
         tmp = torch.empty((M, C), dtype=torch.float32, device=dev)
         inter3 = torch.empty((M, 3 * cfg.intermediate_size), dtype=cdt, device=dev)
+        # (fc2 consumes these rows as a split_k launch with the f32 epilogue: in the K-loop form it reads planes hi | lo only, so fc1
+        #  need not write the third)
+        planes = 2 if K.split_k_in_loop() else 3
         Nk = t_off + T
         if arena is not None and T > 1 and t_off != 0:
             raise K.VidilHipError("run_layers: a multi-token block can only be appended to a beam arena at position 0")
@@ -502,7 +505,7 @@ class BertModel(PackedCache, nn.Module):
                             group_start=cross_groups, max_group=cross_max_group, kv_tiled=cross.tiled, split3=True)
                 K.gemm(o3, d["co_w3"], d["co_b"], out=tmp, resid=h32, split_k=True)
                 K.layernorm(tmp, d["co_g"], d["co_bt"], eps, out16=h3, out32=h32, split3=True)
-            K.gemm(h3, d["i_w3"], d["i_b"], split3_out=inter3, act=K.ACT_GELU_ERF, split_k=True)
+            K.gemm(h3, d["i_w3"], d["i_b"], split3_out=inter3, act=K.ACT_GELU_ERF, split_k=True, split3_planes=planes)
             K.gemm(inter3, d["o_w3"], d["o_b"], out=tmp, resid=h32, split_k=True)
             K.layernorm(tmp, d["o_g"], d["o_bt"], eps, out16=h3, out32=h32, split3=True)
         return h32, h3

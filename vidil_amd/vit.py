@@ -241,6 +241,9 @@ class VisionTransformer(PackedCache, nn.Module):
         a3 = torch.empty((M, 3 * D), dtype=cdt, device=dev)
         o3 = torch.empty((M, 3 * D), dtype=cdt, device=dev)
         hid3 = torch.empty((M, 3 * Dh), dtype=cdt, device=dev)
+        # (fc2 consumes these rows as a split_k launch with the f32 epilogue: in the K-loop form it reads planes hi | lo only, so fc1
+        #  need not write the third)
+        planes = 2 if K.split_k_in_loop() else 3
         f32_attn, arith = parity_attention_f32(self), parity_attention_arith(self)
         qkv32 = torch.empty((M, 3 * D), dtype=torch.float32, device=dev) if f32_attn else None
         plain = [b for b in p["blocks"] if "qkv_w3" not in b]
@@ -268,7 +271,7 @@ class VisionTransformer(PackedCache, nn.Module):
             K.gemm(o3, b["proj_w3"], b["proj_b"], out=x, resid=x, split_k=True)
             K.layernorm(x, b["n2g"], b["n2b"], self.ln_eps, out16=a3, split3=True)
             # (fc1 + erf-GELU in f32, handed to fc2 as [hi | lo | hi] rows by the GEMM's own epilogue: no f32 round trip)
-            K.gemm(a3, b["fc1_w3"], b["fc1_b"], split3_out=hid3, act=K.ACT_GELU_ERF, split_k=True)
+            K.gemm(a3, b["fc1_w3"], b["fc1_b"], split3_out=hid3, act=K.ACT_GELU_ERF, split_k=True, split3_planes=planes)
             K.gemm(hid3, b["fc2_w3"], b["fc2_b"], out=x, resid=x, split_k=True)
         y32 = torch.empty((M, D), dtype=torch.float32, device=dev)
         K.layernorm(x, p["norm_g"], p["norm_b"], self.ln_eps, out16=a3 if want16 else None, out32=y32, split3=True)
