@@ -41,6 +41,10 @@ extern "C" {
  * a weight [W_hi | W_hi | W_lo] one K-tripled GEMM then yields x·W to ~2^-21 relative instead of ~2^-11 (the "parity"
  * precision mode of vidil_amd: caption logits within 1e-3 of the fp32 reference). */
 #define VIDIL_DT_SPLIT3 0x100
+/* with VIDIL_DT_SPLIT3 (vidil_layernorm; vidil_attention_f32's out_mode 3): rows laid out as three planes, but only planes
+ * hi | lo are written — for a consumer that is a split_k GEMM in the K-loop form (vidil_gemm_split_k_in_loop), which reads
+ * planes 0 / 1 of its A rows only (ABI 10, round 5) */
+#define VIDIL_DT_SPLIT2 0x200
 
 #define VIDIL_OK 0
 #define VIDIL_EINVAL (-1)   /* bad argument (shape, alignment, null pointer)  */
@@ -250,6 +254,7 @@ int vidil_attention(const void* q, const void* k, const void* vt, void* out,
 /*   j*arena_rows + anc[b*anc_ld + j] of k / v (the beam search's append-only  */
 /*   KV arena in f32, vidil_beam_ancestry's table); Nk keys.                   */
 /*  out row (b*Nq + t), column h*64 + d, row stride ldo: out_mode 0 = f32;     */
+/*   out_mode 3 = as 2 with planes hi | lo only (VIDIL_DT_SPLIT2);             */
 /*   out_mode 2 = dtype16 rows as three planes [hi | lo | hi] of ldo/3 columns */
 /*   (what VIDIL_DT_SPLIT3 outputs look like: the next compensated GEMM's A).  */
 /*  arith (ABI 10, round 5): 0 = plain f32 arithmetic (above); 1 = SPLIT-     */

@@ -19,6 +19,7 @@ LIB_PATH = os.environ.get("VIDIL_HIP_LIB") or os.path.join(_HERE, "csrc", "libvi
 EPI_F16, EPI_F32, EPI_HEADS, EPI_PATCH, EPI_ARENA, EPI_F8 = 0, 1, 2, 3, 4, 5
 DT_F16, DT_BF16, DT_FP8 = 0, 1, 2
 DT_SPLIT3 = 0x100     # output flag: rows written as error-compensated operands [hi | lo | hi] (include/vidil_hip.h)
+DT_SPLIT2 = 0x200      # with DT_SPLIT3: planes hi | lo written only (include/vidil_hip.h VIDIL_DT_SPLIT2)
 ACT_NONE, ACT_GELU_ERF, ACT_QUICK_GELU = 0, 1, 2
 
 

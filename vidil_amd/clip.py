@@ -182,18 +182,22 @@ def _run_layers(layers, x, B, T, H, eps, *, causal=False, kv_len=None, f32_attn=
         # (fc2 consumes these rows as a split_k launch with the f32 epilogue: in the K-loop form it reads planes hi | lo only, so fc1
         #  need not write the third)
         planes = 2 if K.split_k_in_loop() else 3
+        import os
+        if planes == 2 and os.environ.get("VIDIL_POISON_SPLIT3") == "1":       # (developer: NaNs in the unwritten third planes —
+            for _b in (a3, o3, hid3,):                               #  any consumer that reads one shows up at once)
+                _b[:, 2 * (_b.shape[1] // 3):] = float("nan")
         qkv32 = torch.empty((M, 3 * D), dtype=torch.float32, device=dev) if f32_attn else None
         for l in layers:
-            K.layernorm(x, l["n1g"], l["n1b"], eps, out16=a3, split3=True)
+            K.layernorm(x, l["n1g"], l["n1b"], eps, out16=a3, split3=True, planes=planes)
             if f32_attn:    # (Q | K | V stay f32 and row-major: vidil_attention_f32 reads them in place)
                 K.gemm(a3, l["qkv_w3"], l["qkv_b"], out=qkv32, split_k=True)
                 K.attention_f32(qkv32[:, :D], qkv32[:, D:2 * D], qkv32[:, 2 * D:], o3, Bq=B, H=H, Nq=T, Nk=T, causal=causal, kv_len=kv_len,
-                                arith=arith)
+                                arith=arith, planes=planes)
             else:
                 K.gemm(a3, l["qkv_w3"], l["qkv_b"], heads=heads, split_k=True)
                 K.attention(q, k, vt, o3, Bq=B, H=H, Nq=T, Nk=T, Tq_cap=T, Tk_cap=T, NP=NP, causal=causal, kv_len=kv_len, split3=True)
             K.gemm(o3, l["o_w3"], l["o_b"], out=x, resid=x, split_k=True)
-            K.layernorm(x, l["n2g"], l["n2b"], eps, out16=a3, split3=True)
+            K.layernorm(x, l["n2g"], l["n2b"], eps, out16=a3, split3=True, planes=planes)
             K.gemm(a3, l["fc1_w3"], l["fc1_b"], split3_out=hid3, act=K.ACT_QUICK_GELU, split_k=True, split3_planes=planes)
             K.gemm(hid3, l["fc2_w3"], l["fc2_b"], out=x, resid=x, split_k=True)
         return x

@@ -1091,11 +1091,11 @@ __global__ __launch_bounds__(256, VAR ? 3 : 1) void attn_direct_kernel(const Att
         l8[e] = Elt<T>::from_f32(x - (float)h16);
       }
       f16* const og = p.out + ((size_t)qb * p.Nq + t) * p.ldo + h * 64 + db * 8;
-      if (p.out_mode == 2) {       // [hi | lo | hi] planes (VIDIL_DT_SPLIT3)
+      if (p.out_mode >= 2) {       // [hi | lo | hi] planes (VIDIL_DT_SPLIT3; 3: hi | lo only)
         const int pl = p.ldo / 3;
         *(f16x8*)og = h8;
         *(f16x8*)(og + pl) = l8;
-        *(f16x8*)(og + 2 * pl) = h8;
+        if (p.out_mode == 2) *(f16x8*)(og + 2 * pl) = h8;
       } else {
         *(f16x8*)og = o8;
       }
@@ -1374,7 +1374,7 @@ __device__ __forceinline__ void store_f32_row(const AttnF32P& p, size_t row, int
     const T16 lo = Elt<T16>::from_f32(v - (float)hi);
     o[0] = hi;
     o[pl] = lo;
-    o[2 * pl] = hi;
+    if (p.out_mode != 3) o[2 * pl] = hi;
   }
 }
 
@@ -1634,7 +1634,7 @@ __global__ __launch_bounds__(256) void attn_f32_mfma_kernel(const AttnF32P p) {
         }
         *(x4*)o = vh;
         *(x4*)(o + pl) = vl;
-        *(x4*)(o + 2 * pl) = vh;
+        if (p.out_mode != 3) *(x4*)(o + 2 * pl) = vh;
       }
     }
 }
@@ -1846,7 +1846,7 @@ __global__ __launch_bounds__(NW * 64, NW == 8 ? VIDIL_SPLIT_LB8 : 3) void attn_s
         split4(v, vh, vl);
         *(x4*)o = vh;
         *(x4*)(o + pln) = vl;
-        *(x4*)(o + 2 * pln) = vh;
+        if (p.out_mode != 3) *(x4*)(o + 2 * pln) = vh;
       }
     }
 }
@@ -1959,9 +1959,9 @@ extern "C" int vidil_attention_f32(const vidil_attn_f32_args* a, void* stream) {
   VIDIL_REQUIRE(a->ldq % 4 == 0 && a->ldk % 4 == 0 && a->ldv % 4 == 0 && a->q_off % 4 == 0 && a->k_off % 4 == 0 && a->v_off % 4 == 0 &&
                     ((uintptr_t)a->q & 15) == 0 && ((uintptr_t)a->k & 15) == 0 && ((uintptr_t)a->v & 15) == 0,
                 "attention_f32: rows and head offsets must be 16-byte aligned");
-  VIDIL_REQUIRE(a->out_mode == 0 || (a->out_mode == 2 && a->ldo % 3 == 0 && a->ldo / 3 >= (long long)a->H * 64 &&
+  VIDIL_REQUIRE(a->out_mode == 0 || ((a->out_mode == 2 || a->out_mode == 3) && a->ldo % 3 == 0 && a->ldo / 3 >= (long long)a->H * 64 &&
                                      (a->dtype16 == VIDIL_DT_F16 || a->dtype16 == VIDIL_DT_BF16)),
-                "attention_f32: out_mode 0 (f32 rows) or 2 ([hi | lo | hi] 16-bit rows, ldo = 3 planes)");
+                "attention_f32: out_mode 0 (f32 rows), 2 ([hi | lo | hi] 16-bit rows, ldo = 3 planes) or 3 (those planes, hi | lo written)");
   VIDIL_REQUIRE(a->out_mode != 0 || a->ldo >= (long long)a->H * 64, "attention_f32: ldo=%lld < H*64 (f32 rows)", (long long)a->ldo);
   AttnF32P p;
   p.q = a->q; p.k = a->k; p.v = a->v; p.out = a->out;
@@ -2008,14 +2008,14 @@ extern "C" int vidil_attention_f32(const vidil_attn_f32_args* a, void* stream) {
                   "attention_f32 (kv16): at most 32 query rows per unit (got %d), kv_rows=%d a multiple of 32 and >= Nk=%d <= 768", max_rows,
                   a->kv_rows, a->Nk);
     VIDIL_REQUIRE(a->q_off == 0 && !a->causal && a->kv_len == nullptr, "attention_f32 (kv16): no q_off / causal / kv_len in this form");
-    VIDIL_REQUIRE(a->out_mode == 2 ? a->ldo % 24 == 0 : false, "attention_f32 (kv16): out_mode 2 ([hi | lo | hi] rows, planes a multiple of 8) only");
+    VIDIL_REQUIRE(a->out_mode >= 2 ? a->ldo % 24 == 0 : false, "attention_f32 (kv16): out_mode 2 / 3 ([hi | lo | hi] rows, planes a multiple of 8) only");
     const int nkt = (a->Nk + 31) / 32;
     VIDIL_DISPATCH_DTYPE(a->dtype16, "attention_f32 (kv16)", {
       AttnP<T> q{};
       q.k = (const T*)(const void*)a->k; q.vt = (const T*)(const void*)a->v; q.out = (T*)a->out;
       q.kv_index = a->kv_index; q.group_start = a->group_start;
       q.Bq = a->Bq; q.H = a->H; q.Nq = a->Nq; q.Nk = a->Nk; q.Tq_cap = a->Nq; q.Tk_cap = a->kv_rows; q.NP = a->kv_rows;
-      q.kv_group = a->kv_group; q.ldo = (int)a->ldo; q.n_kv = units; q.out_mode = 2; q.tiled = 1; q.rb = 1;
+      q.kv_group = a->kv_group; q.ldo = (int)a->ldo; q.n_kv = units; q.out_mode = a->out_mode; q.tiled = 1; q.rb = 1;
       q.q32 = a->q; q.ldq32 = a->ldq; q.q_scale = a->scale;
       const dim3 g(1, a->H, units);
       switch (nkt) {
@@ -2044,7 +2044,7 @@ extern "C" int vidil_attention_f32(const vidil_attn_f32_args* a, void* stream) {
   if (a->arith == 1) {
     // split-operand form on f32 Q / K / V in place: any number of rows per unit (a unit of a few rows leaves three of the four
     // waves without rows: they still stage)
-    VIDIL_REQUIRE((a->out_mode == 2 ? a->ldo % 12 == 0 : a->ldo % 4 == 0) && ((uintptr_t)a->out & 15) == 0,
+    VIDIL_REQUIRE((a->out_mode >= 2 ? a->ldo % 12 == 0 : a->ldo % 4 == 0) && ((uintptr_t)a->out & 15) == 0,
                   "attention_f32 (split): output rows must allow 8-byte (split3) / 16-byte (f32) stores");
     // more than 128 rows per unit (a tower's 197): 8 waves per workgroup, so that one workgroup — one staging of the unit's K / V —
     // serves up to 256 rows; 4 waves otherwise
@@ -2066,7 +2066,7 @@ extern "C" int vidil_attention_f32(const vidil_attn_f32_args* a, void* stream) {
   // units of more than 8 query rows (the towers, the ITM encoder, prompt passes): the f32-MFMA kernel, 128 rows per workgroup;
   // a few rows per unit (the decode steps' cross-attention: 3 beams per image): the VALU kernel, which skips idle row groups
   static const bool allow_mfma = [] { const char* e = getenv("VIDIL_ATTN_F32_MFMA"); return !(e && e[0] == '0'); }();
-  if (allow_mfma && max_rows > 8 && (a->out_mode == 2 ? a->ldo % 12 == 0 : a->ldo % 4 == 0) && ((uintptr_t)a->out & 15) == 0) {   // (16-B / 8-B row stores)
+  if (allow_mfma && max_rows > 8 && (a->out_mode >= 2 ? a->ldo % 12 == 0 : a->ldo % 4 == 0) && ((uintptr_t)a->out & 15) == 0) {   // (16-B / 8-B row stores)
     const dim3 gridm((max_rows + 127) / 128, a->H, units);
     if (bf) hipLaunchKernelGGL(attn_f32_mfma_kernel<bf16>, gridm, dim3(256), 0, s, p);
     else hipLaunchKernelGGL(attn_f32_mfma_kernel<f16>, gridm, dim3(256), 0, s, p);

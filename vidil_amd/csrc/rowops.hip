@@ -62,7 +62,7 @@ __global__ __launch_bounds__(256) void layernorm_kernel(const float* __restrict_
         T* o = out16 + (size_t)row * 3 * D + c;
         *(x4*)o = h4;
         *(x4*)(o + D) = l4;
-        *(x4*)(o + 2 * D) = h4;
+        if (split3 != 2) *(x4*)(o + 2 * D) = h4;        // (2 = VIDIL_DT_SPLIT2: planes hi | lo only)
       } else {
         __builtin_nontemporal_store(x4{(T)y[0], (T)y[1], (T)y[2], (T)y[3]}, (x4*)(out16 + (size_t)row * D + c));
       }
@@ -272,8 +272,9 @@ extern "C" int vidil_layernorm(const float* x, int64_t x_stride, const float* ga
   VIDIL_REQUIRE(x_stride % 4 == 0, "layernorm: x_stride must be a multiple of 4");
   if (out16 && dtype16 == VIDIL_DT_FP8)
     return layernorm_launch<fp8>(x, x_stride, gamma, beta, eps, M, D, (fp8*)out16, out_f32, (hipStream_t)stream);
-  const int split3 = out16 && (dtype16 & VIDIL_DT_SPLIT3) ? 1 : 0;      // out16 rows are [hi | lo | hi], 3D wide
-  VIDIL_DISPATCH_DTYPE(out16 ? (dtype16 & ~VIDIL_DT_SPLIT3) : VIDIL_DT_F16, "layernorm",
+  const int split3 = out16 && (dtype16 & VIDIL_DT_SPLIT3) ? ((dtype16 & VIDIL_DT_SPLIT2) ? 2 : 1) : 0;      // out16 rows are [hi | lo | hi], 3D wide
+  VIDIL_REQUIRE(!(dtype16 & VIDIL_DT_SPLIT2) || (dtype16 & VIDIL_DT_SPLIT3), "layernorm: VIDIL_DT_SPLIT2 qualifies VIDIL_DT_SPLIT3");
+  VIDIL_DISPATCH_DTYPE(out16 ? (dtype16 & ~(VIDIL_DT_SPLIT3 | VIDIL_DT_SPLIT2)) : VIDIL_DT_F16, "layernorm",
                        return layernorm_launch<T>(x, x_stride, gamma, beta, eps, M, D, (T*)out16, out_f32, (hipStream_t)stream, split3));
 }
 

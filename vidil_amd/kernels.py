@@ -11,7 +11,7 @@ import ctypes as C
 import torch
 
 from . import _lib
-from ._lib import (ACT_GELU_ERF, ACT_NONE, ACT_QUICK_GELU, DT_BF16, DT_F16, DT_FP8, DT_SPLIT3, EPI_ARENA, EPI_F8, EPI_F16, EPI_F32,
+from ._lib import (ACT_GELU_ERF, ACT_NONE, ACT_QUICK_GELU, DT_BF16, DT_F16, DT_FP8, DT_SPLIT2, DT_SPLIT3, EPI_ARENA, EPI_F8, EPI_F16, EPI_F32,
                    EPI_HEADS, EPI_PATCH, BeamState, GemmArgs, VidilHipError, check)
 
 __all__ = [
@@ -229,16 +229,17 @@ def _gemm_build(a, w, bias=None, *, out=None, out_dtype=None, act=ACT_NONE, resi
 
 
 # ---------------------------------------------------------------------- row kernels
-def layernorm(x, gamma, beta, eps, *, M=None, D=None, x_stride=None, out16=None, out32=None, split3=False):
+def layernorm(x, gamma, beta, eps, *, M=None, D=None, x_stride=None, out16=None, out32=None, split3=False, planes=3):
     """LayerNorm rows of f32 ``x``.  Rows are ``x_stride`` elements apart (default dense).
-    split3: ``out16`` is [M, 3D] and receives the error-compensated operand rows [hi | lo | hi] (VIDIL_DT_SPLIT3)."""
+    split3: ``out16`` is [M, 3D] and receives the error-compensated operand rows [hi | lo | hi] (VIDIL_DT_SPLIT3); planes=2
+    (VIDIL_DT_SPLIT2): only hi | lo are written — for consumers that are split_k GEMMs in the K-loop form (split_k_in_loop())."""
     lib = _lib.load()
     D = D if D is not None else x.shape[-1]
     M = M if M is not None else x.numel() // D
     x_stride = x_stride if x_stride is not None else D
     dt16 = DT_F16
     if out16 is not None:
-        dt16 = _dt(out16, "ln.out16", fp8_ok=not split3) | (DT_SPLIT3 if split3 else 0)
+        dt16 = _dt(out16, "ln.out16", fp8_ok=not split3) | (DT_SPLIT3 if split3 else 0) | (DT_SPLIT2 if split3 and planes == 2 else 0)
         if split3 and out16.shape[-1] != 3 * D:
             raise VidilHipError(f"layernorm: split3 out16 must be [M, {3 * D}], got {tuple(out16.shape)}")
     check(lib.vidil_layernorm(_ptr(x, torch.float32, "ln.x"), x_stride, _ptr(gamma, torch.float32, "ln.gamma"),
@@ -289,7 +290,7 @@ def _f32_view(t, what):
 
 
 def attention_f32(q, k, v, out, *, Bq, H, Nq, Nk, kv_rows=None, kv_group=1, causal=False, causal_off=0, kv_len=None, kv_index=None,
-                  group_start=None, max_group=0, scale=0.125, split3=None, anc=None, arena_rows=0, arith=0, kv16=False):
+                  group_start=None, max_group=0, scale=0.125, split3=None, anc=None, arena_rows=0, arith=0, kv16=False, planes=3):
     """softmax(q k^T * scale) v in f32 (the attention of the parity precision mode; vidil_attention_f32).
 
     arith: 0 = plain f32 arithmetic; 1 = split-operand 16-bit MFMA (every operand as hi + lo, three products per contraction:
@@ -318,7 +319,7 @@ def attention_f32(q, k, v, out, *, Bq, H, Nq, Nk, kv_rows=None, kv_group=1, caus
         split3 = out.dtype != torch.float32
     a.out = _ptr(out, None, "attention_f32.out")
     a.ldo = out.stride(-2) if out.dim() >= 2 else out.shape[-1]
-    a.out_mode = 2 if split3 else 0
+    a.out_mode = (3 if planes == 2 else 2) if split3 else 0       # (3: [hi | lo | hi] rows with planes hi | lo written only)
     a.dtype16 = _dt(out, "attention_f32.out") if split3 else DT_F16
     a.Bq, a.H, a.Nq, a.Nk = Bq, H, Nq, Nk
     a.kv_rows = Nk if kv_rows is None else kv_rows

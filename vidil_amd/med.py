@@ -433,8 +433,17 @@ class BertModel(PackedCache, nn.Module):
         tmp = torch.empty((M, C), dtype=torch.float32, device=dev)
         inter3 = torch.empty((M, 3 * cfg.intermediate_size), dtype=cdt, device=dev)
         # (fc2 consumes these rows as a split_k launch with the f32 epilogue: in the K-loop form it reads planes hi | lo only, so fc1
-        #  need not write the third)
+        #  need not write the third; with the f32-row attention kinds the same holds for EVERY consumer of h3 / o3 — Q|K|V, the
+        #  cross query, both output projections, fc1 — while kind "16" feeds h3 to arena / short-sequence scatter epilogues,
+        #  which run the plain K = 3 Kl product and read all three planes)
         planes = 2 if K.split_k_in_loop() else 3
+        planes_h = planes if parity_attention_f32(self) else 3
+        if planes == 2 and os.environ.get("VIDIL_POISON_SPLIT3") == "1":       # (developer: NaNs in the unwritten third planes —
+            for _b in (inter3,):                               #  any consumer that reads one shows up at once)
+                _b[:, 2 * (_b.shape[1] // 3):] = float("nan")
+        if planes_h == 2 and os.environ.get("VIDIL_POISON_SPLIT3") == "1":       # (developer: NaNs in the unwritten third planes —
+            for _b in (o3, h3,):                               #  any consumer that reads one shows up at once)
+                _b[:, 2 * (_b.shape[1] // 3):] = float("nan")
         Nk = t_off + T
         if arena is not None and T > 1 and t_off != 0:
             raise K.VidilHipError("run_layers: a multi-token block can only be appended to a beam arena at position 0")
@@ -458,10 +467,10 @@ class BertModel(PackedCache, nn.Module):
                     arena.k[i][t_off].copy_(qkv32[:, C:2 * C])          # position t_off, slot = producing beam row
                     arena.v[i][t_off].copy_(qkv32[:, 2 * C:])
                     K.attention_f32(qkv32[:, :C], arena.k[i], arena.v[i], o3, Bq=rows, H=H, Nq=1, Nk=Nk, anc=arena.anc,
-                                    arena_rows=arena.rows)
+                                    arena_rows=arena.rows, planes=planes_h)
                 else:
                     K.attention_f32(qkv32[:, :C], qkv32[:, C:2 * C], qkv32[:, 2 * C:], o3, Bq=rows, H=H, Nq=T, Nk=T, causal=causal,
-                                    kv_len=kv_len, arith=arith)
+                                    kv_len=kv_len, arith=arith, planes=planes_h)
                     if arena is not None:   # the prompt's K / V in the arena: position t, slot r * arena_slot_stride
                         blk = qkv32.view(rows, T, 3 * C)
                         arena.k[i][:T, 0:rows * arena_slot_stride:arena_slot_stride] = blk[:, :, C:2 * C].permute(1, 0, 2)
@@ -482,20 +491,20 @@ class BertModel(PackedCache, nn.Module):
                            arena=dict(k=arena.k[i], v=arena.v[i], T=T, H=H, part0=1, t_off=0, Tcap=arena.Tcap,
                                       arena_rows=arena.rows, slot_stride=arena_slot_stride))
             K.gemm(o3, d["ao_w3"], d["ao_b"], out=tmp, resid=h32, split_k=True)
-            K.layernorm(tmp, d["ao_g"], d["ao_bt"], eps, out16=h3, out32=h32, split3=True)
+            K.layernorm(tmp, d["ao_g"], d["ao_bt"], eps, out16=h3, out32=h32, split3=True, planes=planes_h)
             if cross is not None and f32_attn:
                 K.gemm(h3, d["cq_w3"], d["cq_b"], out=q32, split_k=True)
                 if kv16:
                     K.attention_f32(q32, cross.k[i], cross.vt[i], o3, Bq=rows, H=H, Nq=T, Nk=cross.Te, kv_rows=cross.Tk_cap,
                                     kv_group=cross_group, kv_index=cross_index, group_start=cross_groups, max_group=cross_max_group,
-                                    arith=1, kv16=True)
+                                    arith=1, kv16=True, planes=planes_h)
                 else:
                     kv = cross.k[i]                                     # f32 [B, Te, 2C]: keys | values
                     K.attention_f32(q32, kv[..., :C], kv[..., C:], o3, Bq=rows, H=H, Nq=T, Nk=cross.Te, kv_rows=cross.Te,
                                     kv_group=cross_group, kv_index=cross_index, group_start=cross_groups, max_group=cross_max_group,
-                                    arith=arith)
+                                    arith=arith, planes=planes_h)
                 K.gemm(o3, d["co_w3"], d["co_b"], out=tmp, resid=h32, split_k=True)
-                K.layernorm(tmp, d["co_g"], d["co_bt"], eps, out16=h3, out32=h32, split3=True)
+                K.layernorm(tmp, d["co_g"], d["co_bt"], eps, out16=h3, out32=h32, split3=True, planes=planes_h)
             elif cross is not None:
                 K.gemm(h3, d["cq_w3"], d["cq_b"], heads=dict(q=q, T=T, H=H, part0=0, Tq_cap=T, q_scale=0.125), split_k=True)
                 # (project_cross_kv(last_layer_vt=True) keeps the LAST layer's values in a V^T buffer of their own)
@@ -504,10 +513,10 @@ class BertModel(PackedCache, nn.Module):
                             Tk_cap=cross.Tk_cap, NP=cross.last_NP if last else cross.NP, kv_group=cross_group, kv_index=cross_index,
                             group_start=cross_groups, max_group=cross_max_group, kv_tiled=cross.tiled, split3=True)
                 K.gemm(o3, d["co_w3"], d["co_b"], out=tmp, resid=h32, split_k=True)
-                K.layernorm(tmp, d["co_g"], d["co_bt"], eps, out16=h3, out32=h32, split3=True)
+                K.layernorm(tmp, d["co_g"], d["co_bt"], eps, out16=h3, out32=h32, split3=True, planes=planes_h)
             K.gemm(h3, d["i_w3"], d["i_b"], split3_out=inter3, act=K.ACT_GELU_ERF, split_k=True, split3_planes=planes)
             K.gemm(inter3, d["o_w3"], d["o_b"], out=tmp, resid=h32, split_k=True)
-            K.layernorm(tmp, d["o_g"], d["o_bt"], eps, out16=h3, out32=h32, split3=True)
+            K.layernorm(tmp, d["o_g"], d["o_bt"], eps, out16=h3, out32=h32, split3=True, planes=planes_h)
         return h32, h3
 
     def _text_fold_ok(self, cdt):

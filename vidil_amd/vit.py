@@ -244,6 +244,10 @@ class VisionTransformer(PackedCache, nn.Module):
         # (fc2 consumes these rows as a split_k launch with the f32 epilogue: in the K-loop form it reads planes hi | lo only, so fc1
         #  need not write the third)
         planes = 2 if K.split_k_in_loop() else 3
+        import os
+        if planes == 2 and os.environ.get("VIDIL_POISON_SPLIT3") == "1":       # (developer: NaNs in the unwritten third planes —
+            for _b in (a3, o3, hid3,):                               #  any consumer that reads one shows up at once)
+                _b[:, 2 * (_b.shape[1] // 3):] = float("nan")
         f32_attn, arith = parity_attention_f32(self), parity_attention_arith(self)
         qkv32 = torch.empty((M, 3 * D), dtype=torch.float32, device=dev) if f32_attn else None
         plain = [b for b in p["blocks"] if "qkv_w3" not in b]
@@ -261,20 +265,20 @@ class VisionTransformer(PackedCache, nn.Module):
                 K.gemm(xn, b["fc1_w"], b["fc1_b"], out=hid, act=K.ACT_GELU_ERF)
                 K.gemm(hid, b["fc2_w"], b["fc2_b"], out=x, resid=x)
                 continue
-            K.layernorm(x, b["n1g"], b["n1b"], self.ln_eps, out16=a3, split3=True)
+            K.layernorm(x, b["n1g"], b["n1b"], self.ln_eps, out16=a3, split3=True, planes=planes)
             if f32_attn:    # Q | K | V stay f32 and row-major; the f32 attention reads them in place (no per-head scatter)
                 K.gemm(a3, b["qkv_w3"], b["qkv_b"], out=qkv32, split_k=True)
-                K.attention_f32(qkv32[:, :D], qkv32[:, D:2 * D], qkv32[:, 2 * D:], o3, Bq=B, H=H, Nq=T, Nk=T, arith=arith)
+                K.attention_f32(qkv32[:, :D], qkv32[:, D:2 * D], qkv32[:, 2 * D:], o3, Bq=B, H=H, Nq=T, Nk=T, arith=arith, planes=planes)
             else:
                 K.gemm(a3, b["qkv_w3"], b["qkv_b"], heads=heads, split_k=True)
                 K.attention(q, k, vt, o3, Bq=B, H=H, Nq=T, Nk=T, Tq_cap=T, Tk_cap=T, NP=NP, split3=True)
             K.gemm(o3, b["proj_w3"], b["proj_b"], out=x, resid=x, split_k=True)
-            K.layernorm(x, b["n2g"], b["n2b"], self.ln_eps, out16=a3, split3=True)
+            K.layernorm(x, b["n2g"], b["n2b"], self.ln_eps, out16=a3, split3=True, planes=planes)
             # (fc1 + erf-GELU in f32, handed to fc2 as [hi | lo | hi] rows by the GEMM's own epilogue: no f32 round trip)
             K.gemm(a3, b["fc1_w3"], b["fc1_b"], split3_out=hid3, act=K.ACT_GELU_ERF, split_k=True, split3_planes=planes)
             K.gemm(hid3, b["fc2_w3"], b["fc2_b"], out=x, resid=x, split_k=True)
         y32 = torch.empty((M, D), dtype=torch.float32, device=dev)
-        K.layernorm(x, p["norm_g"], p["norm_b"], self.ln_eps, out16=a3 if want16 else None, out32=y32, split3=True)
+        K.layernorm(x, p["norm_g"], p["norm_b"], self.ln_eps, out16=a3 if want16 else None, out32=y32, split3=True, planes=planes)
         return y32, (a3 if want16 else None)
 
     def _run_blocks_fp8(self, p, x, B, T, q, k, vt, heads, NP, want16):
