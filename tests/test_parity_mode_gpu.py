@@ -687,3 +687,57 @@ def test_two_plane_split_rows_of_layernorm_and_attention_f32_leave_the_third_pla
         k.attention_f32(q, kk, v, a3, Bq=Bq, H=H, Nq=Nq, Nk=Nk, kv_group=kvg, arith=arith)
         k.attention_f32(q, kk, v, a2, Bq=Bq, H=H, Nq=Nq, Nk=Nk, kv_group=kvg, arith=arith, planes=2)
         assert torch.equal(a2[:, :2 * C], a3[:, :2 * C]) and bool((a2[:, 2 * C:] == 7.0).all()), (Bq, Nq, Nk)
+
+
+def test_parity_qualified_results_do_not_depend_on_batch_composition():
+    """The property behind 1/2/4/8-GPU equality, in the PARITY-QUALIFIED configuration (captioner + CLIP compensated, filter plain):
+    a video processed alone (a few hundred GEMM rows: 128-row tiles of the K-loop kernel, 4-wave attention workgroups) gives the
+    bits it gives inside a batch of 36 videos (256-row tiles) — ViT output and CLIP embeddings compared bit for bit, captions, kept
+    lists and visual tokens as strings."""
+    from vidil_amd.blip import BLIP_Decoder
+    from vidil_amd.blip_itm import BLIP_ITM
+    from vidil_amd.capfilt import CapFiltEngine
+    from vidil_amd.clip import CLIPModel
+    from vidil_amd.packing import set_compute_dtype, set_parity_mode
+    from vidil_amd.tokenizer import SyntheticBertTokenizer
+    from vidil_amd.visual_tokenization import CATEGORIES, VisualTokenizer
+    from oracle import clip_ref
+
+    torch.manual_seed(0)
+    tok = SyntheticBertTokenizer()
+    cap = BLIP_Decoder(image_size=224, vit="base", tokenizer=tok).eval()
+    itm = BLIP_ITM(image_size=224, vit="base", tokenizer=tok).eval()
+    clip = CLIPModel().eval()
+    for i, m in enumerate((cap, itm, clip)):
+        perturb_(m, 100 + i)
+    cap, itm, clip = cap.to(DEV), itm.to(DEV), clip.to(DEV)
+    set_compute_dtype("f16", cap, clip)
+    set_compute_dtype("bf16", itm)
+    set_parity_mode(True, cap, clip)
+    Nv, F = 36, 8
+    u8 = torch.from_numpy(synthetic_frames(Nv, F, first_video=300)).to(DEV)
+    cfg = dict(caption=True, filter=True, filter_generated_only=True, keep_original_caption=False, threshold=0.4,
+               filter_mode="max_filter", generation_mode="beam", image_size=224, vit="base", topk_visualize=5)
+    eng = CapFiltEngine(cfg, DEV, captioner=cap, filterer=itm)
+    g = torch.Generator().manual_seed(5)
+    emb, texts = {}, {}
+    for key, n in zip(CATEGORIES, (500, 300, 60, 200)):
+        e = torch.randn(n, 512, generator=g)
+        emb[key], texts[key] = e / e.norm(dim=-1, keepdim=True), [f"{key}_{i}" for i in range(n)]
+    vt = VisualTokenizer(cfg, clip, texts, emb, DEV)
+
+    def run(lo, hi):
+        items = [dict(video_id=f"video{v}", text=[]) for v in range(lo, hi)]
+        eng.process(items, u8[lo:hi])
+        t = vt.process([it["video_id"] for it in items], u8[lo:hi], [[] for _ in items])
+        y32, _ = cap.visual_encoder.forward_u8(u8[lo:hi].reshape(-1, 224, 224, 3), clip_ref.CLIP_MEAN, clip_ref.CLIP_STD)
+        ce = clip.encode_image_u8(u8[lo:hi].reshape(-1, 224, 224, 3))
+        return items, t, y32.clone(), ce.clone()
+
+    all_items, all_t, all_y, all_c = run(0, Nv)
+    for v in (0, 17, 35):
+        it, t, y, c = run(v, v + 1)
+        assert torch.equal(y, all_y[v * F:(v + 1) * F]), "ViT output bits depend on the batch"
+        assert torch.equal(c, all_c[v * F:(v + 1) * F]), "CLIP embedding bits depend on the batch"
+        assert it[0]["unfiltered_text"] == all_items[v]["unfiltered_text"] and it[0]["text"] == all_items[v]["text"]
+        assert t[f"video{v}"] == all_t[f"video{v}"]
