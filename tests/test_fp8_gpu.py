@@ -230,3 +230,47 @@ def test_fp8_tower_accuracy_contract_over_32_videos():
 FP8_ITM_DP_MEAN, FP8_ITM_DP_MAX = 0.015, 0.04
 FP8_TOP5_OVERLAP = 0.88
 FP8_MIN_SAME_CAPTIONS = 0.15
+
+
+@pytest.mark.parametrize("sep_bias", [None, 8.0])     # None: every search runs to the length limit (16 decode steps); 8: staggered endings
+def test_fp8_tower_captions_on_trained_like_weights(sep_bias):
+    """the fp8 contract MEASURED where it matters — on the synthetic trained-like captioner (oracle/synth_weights.py:
+    LayerNorm outlier gains, rows off zero, LM head scaled to max|logit| ~ 16, a [SEP] bias that ends searches at different lengths):
+    peaked token distributions instead of the near-flat ones of random init, where a 3-mantissa-bit perturbation flips most beams.
+    Free-running beam captions of the fp8 tower mode against the f16 path on the same weights and frames."""
+    import json
+    import os
+
+    from common import ROOT, trained_like_
+    from vidil_amd.blip import BLIP_Decoder
+    from vidil_amd.packing import set_compute_dtype
+    from oracle import clip_ref
+    from vidil_amd.tokenizer import SyntheticBertTokenizer
+
+    torch.manual_seed(0)
+    cap = BLIP_Decoder(image_size=224, vit="base", tokenizer=SyntheticBertTokenizer()).eval()
+    trained_like_(cap, 300, head_scale=2.0, stream_shift=8.0, sep_bias=sep_bias)
+    cap = cap.to(DEV)
+    NV, F = 16, 8
+    u8 = torch.from_numpy(synthetic_frames(NV, F, first_video=70)).to(DEV).reshape(NV * F, 224, 224, 3)
+    toks = {}
+    for mode in ("f16", "fp8"):
+        set_compute_dtype(mode, cap)
+        _, y16 = cap.visual_encoder.forward_u8(u8, clip_ref.CLIP_MEAN, clip_ref.CLIP_STD)
+        out_tok, out_len = cap.generate_ids(y16, NV * F, num_beams=3, max_length=20, min_length=5)
+        toks[mode] = [tuple(r[:n]) for r, n in zip(out_tok.cpu().tolist(), out_len.cpu().tolist())]
+    same = sum(a == b for a, b in zip(toks["f16"], toks["fp8"]))
+    lens = sorted({len(t) for t in toks["f16"]})
+    # token-level agreement of the captions that differ (how far the two searches run together)
+    common = [next((i for i, (x, y) in enumerate(zip(a, b)) if x != y), min(len(a), len(b))) for a, b in zip(toks["f16"], toks["fp8"])]
+    rec = dict(sep_bias=sep_bias, frames=NV * F, identical_captions=same, caption_lengths_f16=lens, mean_common_prefix=sum(common) / len(common))
+    os.makedirs(os.path.join(ROOT, "gpurun_out"), exist_ok=True)
+    with open(os.path.join(ROOT, "gpurun_out", f"fp8_contract_trained_like_{sep_bias}.json"), "w") as fh:
+        json.dump(rec, fh, indent=1)
+    print(f"fp8 tower vs f16 on trained-like weights (sep_bias {sep_bias}): {same}/{NV * F} identical free-running captions (f16 caption lengths {lens}; "
+          f"mean common prefix {rec['mean_common_prefix']:.1f} tokens)")
+    assert same >= FP8_MIN_SAME_CAPTIONS_TRAINED_LIKE * NV * F
+
+
+FP8_MIN_SAME_CAPTIONS_TRAINED_LIKE = 0.40    # measured (round 5): 65 / 128 and 66 / 128 identical 20-token searches (51 %), the differing ones
+#                                              run together for 14 of their 20 tokens on average; random-init weights: 29 %
