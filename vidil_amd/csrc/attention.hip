@@ -2046,10 +2046,11 @@ extern "C" int vidil_attention_f32(const vidil_attn_f32_args* a, void* stream) {
     // waves without rows: they still stage)
     VIDIL_REQUIRE((a->out_mode >= 2 ? a->ldo % 12 == 0 : a->ldo % 4 == 0) && ((uintptr_t)a->out & 15) == 0,
                   "attention_f32 (split): output rows must allow 8-byte (split3) / 16-byte (f32) stores");
-    // more than 128 rows per unit (a tower's 197): 8 waves per workgroup, so that one workgroup — one staging of the unit's K / V —
-    // serves up to 256 rows; 4 waves otherwise
+    // 4 waves (128 rows) per workgroup. The 8-wave form (one staging of a unit's K / V serves up to 256 rows: $VIDIL_ATTN_SPLIT_NW=8)
+    // measured 2 - 12 % slower on a tower's 197 rows at 512 ... 3584 images and 0.8 % slower end to end (round 5):
+    // 59 of its 256 rows are padding, and the staging it saves was not what bounds the kernel
     const char* ew = vidil_dev_env("VIDIL_ATTN_SPLIT_NW");
-    const int nw = ew ? atoi(ew) : (max_rows > 128 ? 8 : 4);
+    const int nw = ew ? atoi(ew) : 4;
     if (nw == 8) {
       const dim3 gridm((max_rows + 255) / 256, a->H, units);
       if (bf) hipLaunchKernelGGL((attn_split_kernel<bf16, 8>), gridm, dim3(512), 0, s, p);
