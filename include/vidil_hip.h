@@ -373,6 +373,20 @@ int vidil_logsoftmax_topk(const float* logits, const float* beam_scores,
                           int32_t V, int32_t ban_token, float* out_scores,
                           int32_t* out_index, void* stream);
 
+/* The same step under `generate(..., repetition_penalty = p != 1.0)` (reference:  */
+/* models/blip.py:127,161 hands its argument to HF generate; the captioning call   */
+/* site run_video_CapFilt.py:101 leaves it at 1.0): HF's                           */
+/* RepetitionPenaltyLogitsProcessor runs first in the processor list and, in beam  */
+/* search, on the log-probabilities — for every token t among the first cur_len    */
+/* ids of the row's sequence seqs[(b*nb+beam)*ld_seqs ..] (prompt included):       */
+/*   lp[t] = lp[t] < 0 ? lp[t] * penalty : lp[t] / penalty   (f32, once per token) */
+/* before the ban (MinLength) and the beam score are applied.  cur_len <= 64.      */
+int vidil_logsoftmax_topk_penalty(const float* logits, const float* beam_scores,
+                                  int32_t B, int32_t nb, int32_t beams_in_logits,
+                                  int32_t V, int32_t ban_token, const int32_t* seqs,
+                                  int32_t cur_len, int32_t ld_seqs, float penalty,
+                                  float* out_scores, int32_t* out_index, void* stream);
+
 typedef struct vidil_beam_state {
   int32_t* seqs;        /* [B*nb, max_len] token ids (current beams)          */
   int32_t* seqs_next;   /* [B*nb, max_len] scratch, swapped by the caller     */

@@ -76,13 +76,18 @@ def log_softmax_rows(logits):
 
 
 def beam_search(step_fn, prompt_ids, *, num_beams=3, max_length=20, min_length=5, eos_token_id=102,
-                pad_token_id=0, trace=None, rule="4.15"):
+                pad_token_id=0, trace=None, rule="4.15", repetition_penalty=1.0):
     """Run beam search.
 
     step_fn(input_ids[np.int64, rows x cur_len], beam_idx or None) -> logits[rows, V] (f32) for
     the LAST position.  ``beam_idx`` (np.int64[rows]) is the row gather applied to
     the sequences since the previous call (the caller reorders its KV cache with
     it, models/med.py:951-955); None on the first call.
+
+    repetition_penalty: ``models/blip.py:161`` hands its own argument (default 1.0, what ``run_video_CapFilt.py:101``
+    leaves it at) to ``generate``; a value != 1.0 installs a RepetitionPenaltyLogitsProcessor FIRST in the processor list
+    (before MinLength), and beam search runs the list on the LOG-PROBABILITIES: every token already in a row's
+    ``input_ids`` (prompt included) gets ``s * penalty if s < 0 else s / penalty`` (f32).
 
     rule: "4.15" (the version the reference names — the product's behaviour) or "5.15" (the installed
     version, executable here: tests/test_beam_hf.py); the differences are the three ``# RULE`` sites.
@@ -108,6 +113,12 @@ def beam_search(step_fn, prompt_ids, *, num_beams=3, max_length=20, min_length=5
         logits = np.asarray(step_fn(input_ids, beam_idx), dtype=np.float32)
         V = logits.shape[-1]
         scores = log_softmax_rows(logits)
+        if repetition_penalty != 1.0:                          # RepetitionPenaltyLogitsProcessor (gather / where / scatter_)
+            pen = np.float32(repetition_penalty)
+            for r in range(scores.shape[0]):
+                toks = np.unique(input_ids[r])
+                sc = scores[r, toks]
+                scores[r, toks] = np.where(sc < 0, sc * pen, sc / pen).astype(np.float32)
         if cur_len < min_length:                               # MinLengthLogitsProcessor
             scores[:, eos_token_id] = -np.inf
         scores = scores + beam_scores[:, None]

@@ -42,7 +42,8 @@ def table_logits_fn(V, seed, eos, eos_boost=0.3, eos_from=0, ban=(0,), scale=2.0
     return fn
 
 
-def hf_generate(logits_fn, prompt_ids, V, *, num_beams, max_length, min_length, eos_token_id, pad_token_id):
+def hf_generate(logits_fn, prompt_ids, V, *, num_beams, max_length, min_length, eos_token_id, pad_token_id,
+                repetition_penalty=1.0):
     """Returns (list of np.int64 sequences with trailing pads stripped, list of float scores) from the installed
     transformers' beam search (length_penalty 1.0, early_stopping False, no sampling, no cache)."""
     from transformers import GenerationMixin, PretrainedConfig, PreTrainedModel
@@ -73,7 +74,7 @@ def hf_generate(logits_fn, prompt_ids, V, *, num_beams, max_length, min_length, 
     m = _LM(_Cfg(vocab_size=V))
     out = m.generate(torch.as_tensor(np.asarray(prompt_ids), dtype=torch.long), num_beams=num_beams, max_length=max_length,
                      min_length=min_length, eos_token_id=eos_token_id, pad_token_id=pad_token_id, do_sample=False,
-                     use_cache=False, length_penalty=1.0, early_stopping=False, repetition_penalty=1.0,
+                     use_cache=False, length_penalty=1.0, early_stopping=False, repetition_penalty=float(repetition_penalty),
                      return_dict_in_generate=True, output_scores=True)
     seqs = []
     for row in out.sequences.numpy():

@@ -14,11 +14,12 @@ V, EOS, PAD = 13, 2, 7      # (a zero pad id makes 5.15 fill its output with EOS
 PROMPT = [5, 1, 3, 1]
 
 
-def _run(rule, fn, B, nb, max_len, min_len):
+def _run(rule, fn, B, nb, max_len, min_len, penalty=1.0):
     prompts = np.array([PROMPT] * B, dtype=np.int64)
     prompts[:, 1] = np.array([1, 4, 6])[np.arange(B) % 3]   # distinct contexts per image
     return prompts, beam_ref.beam_search(lambda ids, bi: fn(ids), prompts, num_beams=nb, max_length=max_len,
-                                         min_length=min_len, eos_token_id=EOS, pad_token_id=PAD, rule=rule)
+                                         min_length=min_len, eos_token_id=EOS, pad_token_id=PAD, rule=rule,
+                                         repetition_penalty=penalty)
 
 
 CONFIGS = [(3, 12, 6, 0.3), (3, 20, 5, 0.15), (2, 9, 5, 0.5), (4, 10, 7, 0.3), (6, 8, 5, 0.3), (3, 7, 5, 0.6),
@@ -41,6 +42,25 @@ def test_rule_5_15_equals_installed_transformers(nb, max_len, min_len, eos_boost
     assert n_cases == 36
     if eos_boost >= 0.3:
         assert n_eos_ended > 0         # the EOS paths (ban, rank rule, banking, early stop) were exercised
+
+
+@pytest.mark.parametrize("penalty", [1.3, 2.0, 0.7])
+@pytest.mark.parametrize("nb,max_len,min_len,eos_boost", [(3, 12, 6, 0.3), (3, 20, 5, 0.15), (2, 9, 5, 0.5)])
+def test_repetition_penalty_equals_installed_transformers(nb, max_len, min_len, eos_boost, penalty):
+    """``generate(..., repetition_penalty=p)`` with beam search (models/blip.py:154-161 passes its argument through): the
+    processor acts on the log-probabilities of every token already in the row, prompt included, before MinLength."""
+    changed = 0
+    for seed in range(8):
+        fn = hf_beam.table_logits_fn(V, 900 + seed, EOS, eos_boost=eos_boost, ban=(PAD,))
+        prompts, (seqs, scores) = _run("5.15", fn, 3, nb, max_len, min_len, penalty)
+        _, (plain, _) = _run("5.15", fn, 3, nb, max_len, min_len)
+        hseqs, hscores = hf_beam.hf_generate(fn, prompts, V, num_beams=nb, max_length=max_len, min_length=min_len,
+                                             eos_token_id=EOS, pad_token_id=PAD, repetition_penalty=penalty)
+        for b in range(3):
+            assert seqs[b].tolist() == hseqs[b].tolist(), (seed, b, seqs[b], hseqs[b])
+            assert scores[b] == pytest.approx(hscores[b], rel=1e-5, abs=1e-6)
+            changed += int(seqs[b].tolist() != plain[b].tolist())
+    assert changed > 0                 # the penalty moved some searches (a vocabulary of 13 repeats tokens all the time)
 
 
 @pytest.mark.parametrize("nb,max_len,min_len", [(3, 20, 5), (3, 12, 6), (2, 9, 5), (4, 10, 7)])

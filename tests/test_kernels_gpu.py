@@ -709,6 +709,49 @@ def test_logsoftmax_topk_on_structured_rows():
     assert i2[0].cpu().tolist() == [0, 1, 2, 3, 4, 5]            # beams 0 and 1 tie everywhere: lowest flat indices first
 
 
+@pytest.mark.parametrize("nb,V,ban,penalty,nbl", [(3, 30524, 102, 1.3, 3), (3, 30524, -1, 0.6, 3), (3, 30524, 102, 2.0, 1),
+                                                  (1, 777, -1, 1.1, 1), (4, 5000, 3, 1.5, 4)])
+def test_logsoftmax_topk_repetition_penalty(nb, V, ban, penalty, nbl):
+    """`vidil_logsoftmax_topk_penalty`: HF's RepetitionPenaltyLogitsProcessor on the log-probabilities of the tokens a row already
+    holds (models/blip.py:161 `repetition_penalty=`; oracle/beam_ref.py).  The history is planted on each row's best logits (a
+    penalty > 1 has to push them out of the candidates), on repeated tokens (penalised once), on the banned token, and — for
+    a penalty < 1 — on mid-ranked logits that it has to pull IN."""
+    k = _k()
+    B, L, cur = 5, 20, 9
+    logits = _rand(B * nbl, V, scale=2.0, seed=70)
+    g = torch.Generator().manual_seed(71)
+    seqs = torch.zeros(B * nb, L, dtype=torch.int32)
+    for b in range(B):
+        for j in range(nbl):
+            row = logits[b * nbl + j]
+            order = torch.argsort(row, descending=True)
+            top = order[torch.randperm(12, generator=g)[:4]]                 # four of the row's twelve best logits
+            mid = order[50 + torch.randperm(100, generator=g)[:2]]
+            h = torch.cat([top, mid, top[:1], torch.tensor([max(ban, 0)]), torch.randint(0, V, (1,), generator=g)])
+            seqs[b * nb + j, :cur] = h.to(torch.int32)
+    bs = torch.tensor([0.0, -1e9, -1e9, -1e9][:nb] * B)
+    if nbl == nb:
+        bs[nb:] = -_rand(B * nb - nb, seed=72).abs() * 3
+    lp = torch.log_softmax(logits, -1)
+    for b in range(B):
+        for j in range(nbl):
+            r = b * nbl + j
+            toks = seqs[b * nb + j, :cur].long()
+            sc = lp[r, toks]
+            lp[r, toks] = torch.where(sc < 0, sc * penalty, sc / penalty)      # gather / where / scatter_: HF's three lines
+    if ban >= 0:
+        lp[:, ban] = float("-inf")
+    beam_of_row = bs.view(B, nb)[:, :nbl].reshape(-1)
+    rs, ri = torch.topk((lp + beam_of_row[:, None]).view(B, -1), 2 * nb, dim=1, largest=True, sorted=True)
+    s, i = k.logsoftmax_topk(logits.to(DEV), bs.to(DEV), B, nb, ban, beams_in_logits=nbl, seqs=seqs.to(DEV), cur_len=cur,
+                             penalty=penalty)
+    assert torch.equal(i.cpu().long(), ri)
+    assert torch.allclose(s.cpu(), rs, rtol=1e-5, atol=1e-5)
+    # and it differs from the plain selection (the planted history matters)
+    s0, i0 = k.logsoftmax_topk(logits.to(DEV), bs.to(DEV), B, nb, ban, beams_in_logits=nbl)
+    assert not torch.equal(i0.cpu(), i.cpu())
+
+
 def test_gemm_arena_epilogue():
     """EPI_ARENA: Q rows + K/V rows appended at [position][slot][H*64]; decode step (T=1) and prompt block (T=P)."""
     k = _k()

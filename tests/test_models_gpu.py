@@ -780,6 +780,105 @@ def test_device_beam_search_equals_installed_transformers_when_nothing_ends_earl
         assert score[b].item() * max_len == pytest.approx(hscores[b] * (max_len - 4), rel=1e-4)
 
 
+@pytest.mark.parametrize("penalty", [1.3, 0.7])
+def test_device_beam_search_with_repetition_penalty_matches_oracle_and_transformers(penalty):
+    """``generate(..., repetition_penalty=p)`` with beam search (models/blip.py:127,161): the device's candidate selection with the
+    penalty against oracle/beam_ref.py (4.15 rule, [SEP] in reach) — ids bit-exact — and, with [SEP] out of reach, against the
+    installed transformers' own generate(repetition_penalty=p).  The table LM makes repeats attractive (the tokens a row already
+    holds get a boost), so the penalty decides candidates at every step."""
+    from oracle import beam_ref, hf_beam
+
+    K = _K()
+    B, nb, V, EOS, PAD = 3, 3, 30524, 102, 0
+    prompt = np.array([[30522, 1037, 3861, 1997]] * B, dtype=np.int64)
+    prompt[:, 1] += np.arange(B)
+
+    def make_fn(seed, eos_boost):
+        base = hf_beam.table_logits_fn(V, seed, EOS, eos_boost=eos_boost, ban=(PAD,), scale=3.0)
+
+        def fn(ids):
+            out = base(ids).copy()
+            for r in range(ids.shape[0]):
+                out[r, ids[r]] += 9.0                       # what the row already holds is what the LM likes best
+            return out
+        return fn
+
+    def device(fn, max_len, min_len, pen):
+        bufs = K.BeamBuffers(B, nb, max_len, DEV)
+        bufs.reset(torch.from_numpy(prompt).to(torch.int32).to(DEV))
+        cur_len = 4
+        while True:
+            ids = bufs.seqs[:, :cur_len].cpu().numpy().astype(np.int64)
+            cs, ci = K.logsoftmax_topk(torch.from_numpy(fn(ids)).to(DEV), bufs.beam_scores, B, nb, EOS if cur_len < min_len else -1,
+                                       seqs=bufs.seqs if pen != 1.0 else None, cur_len=cur_len, penalty=pen)
+            K.beam_update(bufs, cs, ci, V, cur_len, EOS, PAD)
+            cur_len += 1
+            if cur_len >= max_len or int(bufs.n_done.item()) == B:
+                break
+        tok, ln, score = K.beam_finalize(bufs, cur_len, EOS, PAD)
+        return tok.cpu().numpy(), score.cpu().numpy()
+
+    # (1) the product's rule, [SEP] competitive
+    fn = make_fn(31, 0.5)
+    seqs, scores = beam_ref.beam_search(lambda ids, bi: fn(ids), prompt, num_beams=nb, max_length=12, min_length=5,
+                                        eos_token_id=EOS, pad_token_id=PAD, repetition_penalty=penalty)
+    plain, _ = beam_ref.beam_search(lambda ids, bi: fn(ids), prompt, num_beams=nb, max_length=12, min_length=5,
+                                    eos_token_id=EOS, pad_token_id=PAD)
+    assert any(a.tolist() != c.tolist() for a, c in zip(seqs, plain))      # the penalty changed the captions
+    tok, score = device(fn, 12, 5, penalty)
+    for b in range(B):
+        assert tok[b][: len(seqs[b])].tolist() == seqs[b].tolist(), (b, tok[b], seqs[b])
+        assert score[b] == pytest.approx(scores[b], rel=1e-5)
+    # (2) executable third-party code, [SEP] out of reach (where the 4.15 and the installed rule rank identically)
+    fn = make_fn(32, 0.0)
+    hseqs, hscores = hf_beam.hf_generate(fn, prompt, V, num_beams=nb, max_length=10, min_length=5, eos_token_id=EOS,
+                                         pad_token_id=PAD, repetition_penalty=penalty)
+    tok, score = device(fn, 10, 5, penalty)
+    for b in range(B):
+        assert tok[b][:10].tolist() == hseqs[b][:10].tolist(), (b, tok[b], hseqs[b])
+        assert score[b] * 10 == pytest.approx(hscores[b] * 6, rel=1e-4)
+
+
+def test_generate_with_repetition_penalty_runs_the_penalised_search(full_models):
+    """BLIP_Decoder.generate_ids(repetition_penalty=p) through the production decode loop (eager, captured graphs, replay): equal
+    to oracle/beam_ref.py's penalised search driven by the DEVICE's logits, different from the unpenalised captions, and the
+    session cache keeps the two apart (the step graphs bake the penalty in)."""
+    from oracle import beam_ref, clip_ref
+    from vidil_amd.blip import DecoderSession
+
+    cap = full_models["cap"]
+    B, nb, pen = 4, 3, 1.6
+    u8 = synthetic_frames(1, B, first_video=33)[0]
+    _, y16 = cap.visual_encoder.forward_u8(torch.from_numpy(u8).to(DEV), clip_ref.CLIP_MEAN, clip_ref.CLIP_STD)
+    prompt = cap.prompt_ids(B, "cpu").long().numpy()
+    sess = DecoderSession(cap.text_decoder, y16, B, nb, 20)
+
+    def dev_step(ids, beam_idx):
+        if beam_idx is None:
+            lg = sess.prefill(torch.from_numpy(ids).to(torch.int32).reshape(-1).to(DEV), ids.shape[1])
+        else:
+            lg = sess.step(torch.from_numpy(ids[:, -1].copy()).to(torch.int32).to(DEV),
+                           torch.from_numpy(beam_idx).to(torch.int32).to(DEV), ids.shape[1] - 1)
+        return lg.cpu().numpy()
+
+    want, _ = beam_ref.beam_search(dev_step, prompt, num_beams=nb, max_length=20, min_length=5, eos_token_id=102, pad_token_id=0,
+                                   repetition_penalty=pen)
+    cap.__dict__.pop("_decode_state", None)
+    try:
+        plain = cap.generate_ids(y16, B, num_beams=nb, max_length=20, min_length=5)[0].cpu().numpy()
+        for rep in range(3):                       # eager, capture, replay
+            toks = cap.generate_ids(y16, B, num_beams=nb, max_length=20, min_length=5, repetition_penalty=pen)[0].cpu().numpy()
+            for b in range(B):
+                assert np.array_equal(toks[b][: len(want[b])], want[b]), (rep, b, toks[b], want[b])
+        assert not np.array_equal(toks, plain)
+        again = cap.generate_ids(y16, B, num_beams=nb, max_length=20, min_length=5)[0].cpu().numpy()
+        assert np.array_equal(again, plain)
+        with pytest.raises(ValueError):
+            cap.generate_ids(y16, B, num_beams=nb, max_length=20, min_length=5, repetition_penalty=0.0)
+    finally:
+        cap.__dict__.pop("_decode_state", None)
+
+
 # =============================================================== end to end vs the oracle pipeline
 def _ontology(dim=512, seed=3, sizes=None):
     g = torch.Generator().manual_seed(seed)

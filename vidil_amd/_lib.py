@@ -95,6 +95,7 @@ SIGNATURES = {
     "vidil_gather_rows_f32": (_i32, [_p, _p, _p, _i32, _i32, _p]),
     "vidil_l2_normalize_rows": (_i32, [_p, _i32, _i32, _p]),
     "vidil_logsoftmax_topk": (_i32, [_p, _p, _i32, _i32, _i32, _i32, _i32, _p, _p, _p]),
+    "vidil_logsoftmax_topk_penalty": (_i32, [_p, _p, _i32, _i32, _i32, _i32, _i32, _p, _i32, _i32, C.c_float, _p, _p, _p]),
     "vidil_beam_update": (_i32, [C.POINTER(BeamState), _p, _p] + [_i32] * 7 + [_p]),
     "vidil_beam_finalize": (_i32, [C.POINTER(BeamState)] + [_i32] * 6 + [_p, _p, _p, _p]),
     "vidil_beam_ancestry": (_i32, [_p, _p, _p, _i32, _i32, _i32, _p]),
@@ -113,7 +114,7 @@ class VidilHipError(RuntimeError):
     pass
 
 
-ABI_VERSION = 10     # include/vidil_hip.h as this binding mirrors it (struct layouts, argument lists)
+ABI_VERSION = 11     # include/vidil_hip.h as this binding mirrors it (struct layouts, argument lists)
 
 
 def load():

@@ -205,7 +205,7 @@ class BLIP_Decoder(nn.Module):
     # ------------------------------------------------------------------ beam decode
     @torch.no_grad()
     def generate_ids(self, enc16, B, *, num_beams=3, max_length=30, min_length=10, trace: DecodeTrace = None,
-                     check_done_every=2, streams=1, compact_min=256):
+                     check_done_every=2, streams=1, compact_min=256, repetition_penalty=1.0):
         """enc16: f16 [B*Te, width] image tokens of B images.  Returns (tokens i32 [B,max_length], lens i32 [B]):
         best hypothesis incl. the prompt, then [SEP] if it fits, then [PAD].
 
@@ -214,10 +214,16 @@ class BLIP_Decoder(nn.Module):
         round robin).  Measured at 3,072 images: 2 parts +0.2 %, 3 parts -1.4 %, 4 parts -3.8 % of the whole step — the
         ~160 launches of a decode step are short but each already covers the chip (decode time scales ~1/CUs under a
         CU mask, tools/exp_cu_mask.py), so the default stays 1; kept for small batches per part of a larger job.
-        A search is per image, so the tokens do not depend on the split."""
+        A search is per image, so the tokens do not depend on the split.
+
+        ``repetition_penalty`` != 1.0 (models/blip.py:127,161; the captioning call site leaves it at 1.0): the candidate
+        selection of every step penalises the log-probabilities of the tokens a beam already holds, prompt included
+        (``vidil_logsoftmax_topk_penalty``; oracle/beam_ref.py ``repetition_penalty``)."""
         require_cuda(enc16, "BLIP_Decoder.generate")
+        if not repetition_penalty > 0:
+            raise ValueError(f"repetition_penalty must be a strictly positive float, got {repetition_penalty}")   # (HF's message)
         kw = dict(num_beams=num_beams, max_length=max_length, min_length=min_length, check_done_every=check_done_every,
-                  compact_min=compact_min)
+                  compact_min=compact_min, repetition_penalty=float(repetition_penalty))
         if streams <= 1 or trace is not None or B < 2 * streams:
             g = self._beam_search(enc16, B, trace=trace, slot=0, **kw)
             while True:
@@ -258,7 +264,7 @@ class BLIP_Decoder(nn.Module):
         return torch.cat([r[0] for r in results]), torch.cat([r[1] for r in results])
 
     def _beam_search(self, enc16, B, *, num_beams, max_length, min_length, trace=None, check_done_every=2, slot=0,
-                     compact_min=256):
+                     compact_min=256, repetition_penalty=1.0):
         """Generator: queues the prompt pass and one decode step per ``next()`` on the current stream, returns
         (tokens, lens) through StopIteration."""
         dec, bert = self.text_decoder, self.text_decoder.bert
@@ -274,7 +280,8 @@ class BLIP_Decoder(nn.Module):
         # — be captured once into HIP graphs (one per step index: the position is baked into the launches) and replayed.
         prompt = self.prompt_ids(B, dev)
         P = prompt.shape[1]
-        key = (B, nb, max_length, min_length, str(dev), enc16.shape[0] // B, P, slot)
+        rp = float(repetition_penalty)             # (part of the session keys: the step graphs bake it into their launches)
+        key = (B, nb, max_length, min_length, str(dev), enc16.shape[0] // B, P, rp, slot)
         cache = self.__dict__.setdefault("_decode_state", {})
         st = cache.get(key)
         packs = (dec.packed(), bert.packed())     # captured graphs hold the addresses of these packed weights
@@ -308,7 +315,8 @@ class BLIP_Decoder(nn.Module):
 
         def first_unit(logits):
             bufs = cur["bufs"]
-            cs, ci = K.logsoftmax_topk(logits, bufs.beam_scores, B, nb, eos if P < min_length else -1, beams_in_logits=1)
+            cs, ci = K.logsoftmax_topk(logits, bufs.beam_scores, B, nb, eos if P < min_length else -1, beams_in_logits=1,
+                                       seqs=bufs.seqs if rp != 1.0 else None, cur_len=P, penalty=rp)
             if trace is not None:
                 trace.logits.append(logits.clone()); trace.cand_scores.append(cs.clone()); trace.cand_index.append(ci.clone())
             K.beam_update(bufs, cs, ci, V, P, eos, pad)
@@ -317,7 +325,8 @@ class BLIP_Decoder(nn.Module):
             """Decode step at length c: forward of the token appended last, candidate selection, beam update."""
             sess, bufs = cur["sess"], cur["bufs"]
             logits = sess.step(bufs.next_tok, bufs.beam_idx, c - 1)
-            cs, ci = K.logsoftmax_topk(logits, bufs.beam_scores, cur["B"], nb, eos if c < min_length else -1)
+            cs, ci = K.logsoftmax_topk(logits, bufs.beam_scores, cur["B"], nb, eos if c < min_length else -1,
+                                       seqs=bufs.seqs if rp != 1.0 else None, cur_len=c, penalty=rp)
             if trace is not None:
                 trace.logits.append(logits.clone()); trace.cand_scores.append(cs.clone()); trace.cand_index.append(ci.clone())
             K.beam_update(bufs, cs, ci, V, c, eos, pad)
@@ -348,7 +357,7 @@ class BLIP_Decoder(nn.Module):
                 return False
             Bp = fit[-1]
             images = torch.cat([active, active[-1:].expand(Bp - A)])           # padding: copies of the last one, marked done
-            key2 = (Bp, nb, max_length, min_length, str(dev), enc16.shape[0] // B, P, ("compact", slot))
+            key2 = (Bp, nb, max_length, min_length, str(dev), enc16.shape[0] // B, P, rp, ("compact", slot))
             st2 = cache.get(key2)
             if st2 is not None and not (st2["packs"][0] is packs[0] and st2["packs"][1] is packs[1]):
                 st2 = None
@@ -432,7 +441,8 @@ class BLIP_Decoder(nn.Module):
                         s_["graphs_ok"] = False
                         s_["graphs"].clear()
                     inner = self._beam_search(enc16, B, num_beams=num_beams, max_length=max_length, min_length=min_length,
-                                              trace=trace, check_done_every=check_done_every, slot=slot, compact_min=compact_min)
+                                              trace=trace, check_done_every=check_done_every, slot=slot, compact_min=compact_min,
+                                              repetition_penalty=rp)
                     return (yield from inner)
             else:
                 unit(cur_len)
@@ -499,11 +509,9 @@ class BLIP_Decoder(nn.Module):
             _, y16 = self.visual_encoder.forward_both(image)
             return self.decode_captions(self.sample_ids(y16, image.shape[0], top_p=top_p, max_length=max_length,
                                                         min_length=min_length))
-        if repetition_penalty != 1.0:
-            raise NotImplementedError("repetition_penalty != 1.0 with beam search is not on the hot path")
         _, y16 = self.visual_encoder.forward_both(image)
         out_tok, _ = self.generate_ids(y16, image.shape[0], num_beams=num_beams, max_length=max_length,
-                                       min_length=min_length)
+                                       min_length=min_length, repetition_penalty=repetition_penalty)
         return self.decode_captions(out_tok)
 
     def forward(self, image, caption):

@@ -52,12 +52,21 @@ __device__ float block_reduce_sum(float v, float* red) {
   return (red[0] + red[1]) + (red[2] + red[3]);
 }
 
-template <int NB>
+// RP: the repetition penalty of `generate(..., repetition_penalty != 1.0)` with beam search (reference: models/blip.py:161
+// passes it to HF generate, whose RepetitionPenaltyLogitsProcessor runs FIRST in the processor list and, in beam search, on the
+// LOG-PROBABILITIES: every token already in a row's sequence — prompt included — gets `s < 0 ? s * penalty : s / penalty`; oracle:
+// oracle/beam_ref.py, pinned against the installed transformers by tests/test_beam_hf.py).  The row's history tokens are kept
+// out of the raw-logit candidates (a penalty < 1 RAISES their score, so "best logits = best scores" does not hold for them)
+// and are scored one per thread once the row's log-sum-exp is known.
+template <int NB, bool RP>
 __global__ __launch_bounds__(256) void lsm_topk_kernel(const float* __restrict__ logits,
                                                        const float* __restrict__ beam_scores, int NBL, int V,
-                                                       int ban, float* __restrict__ out_s, int* __restrict__ out_i) {
+                                                       int ban, float* __restrict__ out_s, int* __restrict__ out_i,
+                                                       const int32_t* __restrict__ hist, int hist_len, int ld_hist,
+                                                       float penalty) {
   constexpr int K = 2 * NB;
   __shared__ float red[4];
+  __shared__ int hs_tok[MAXLEN];
   __shared__ float ls[256 * K];
   __shared__ int li[256 * K];
   __shared__ Cand wbest[4];
@@ -91,6 +100,16 @@ __global__ __launch_bounds__(256) void lsm_topk_kernel(const float* __restrict__
   constexpr float L2E = 1.4426950408889634f;
   for (int beam = 0; beam < NBL; ++beam) {
     const float* row = logits + ((size_t)b * NBL + beam) * V;
+    if (RP) {
+      __syncthreads();                                   // (the previous row's readers are done)
+      if (tid < hist_len) hs_tok[tid] = hist[((size_t)b * NB + beam) * ld_hist + tid];
+      __syncthreads();
+    }
+    auto in_hist = [&](int t) {
+      bool f = false;
+      for (int h = 0; h < hist_len; ++h) f |= hs_tok[h] == t;
+      return f;
+    };
     float m = -INFINITY, sum = 0.f;
     float rs[K];
     int ri[K];
@@ -132,7 +151,7 @@ __global__ __launch_bounds__(256) void lsm_topk_kernel(const float* __restrict__
         if (__builtin_amdgcn_ballot_w64(mx >= thr) != 0) {
 #pragma unroll
           for (int e = 0; e < 4; ++e)
-            if (i + e != ban && x[e] >= thr) consider_raw(x[e], i + e);  // (the banned token counts in the softmax, never as a candidate)
+            if (i + e != ban && x[e] >= thr && !(RP && in_hist(i + e))) consider_raw(x[e], i + e);  // (the banned token counts in the softmax, never as a candidate)
         }
         // (the refresh shuffles across the wave, so it runs only while EVERY lane is still inside the loop — on the
         //  ragged last iteration of a vocabulary that is not a multiple of 1,024 some lanes have left, their registers are
@@ -158,7 +177,7 @@ __global__ __launch_bounds__(256) void lsm_topk_kernel(const float* __restrict__
           m = x;
         }
         sum += __builtin_amdgcn_exp2f((x - m) * L2E);
-        if (i != ban) consider_raw(x, i);
+        if (i != ban && !(RP && in_hist(i))) consider_raw(x, i);
       }
     }
     const float M = block_reduce_max(m, red);
@@ -169,6 +188,15 @@ __global__ __launch_bounds__(256) void lsm_topk_kernel(const float* __restrict__
 #pragma unroll
     for (int j = 0; j < K; ++j)
       if (ri[j] != 0x7fffffff) consider((rs[j] - M) - lse + bs, beam * V + ri[j]);
+    if (RP && tid < hist_len) {
+      const int t = hs_tok[tid];
+      bool first = t >= 0 && t < V && t != ban;          // (scatter_ of equal values: a repeated token is penalised once)
+      for (int h = 0; h < tid; ++h) first &= hs_tok[h] != t;
+      if (first) {
+        const float lp = (row[t] - M) - lse;
+        consider((lp < 0.f ? lp * penalty : lp / penalty) + bs, beam * V + t);
+      }
+    }
   }
 #pragma unroll
   for (int j = 0; j < K; ++j) { ls[tid * K + j] = ts[j]; li[tid * K + j] = ti[j]; }
@@ -293,26 +321,49 @@ __global__ void beam_finalize_kernel(const vidil_beam_state st, int B, int nb, i
 
 }  // namespace
 
+static int launch_lsm_topk(const float* logits, const float* beam_scores, int32_t B, int32_t nb, int32_t nbl, int32_t V,
+                           int32_t ban_token, float* out_scores, int32_t* out_index, const int32_t* hist, int32_t hist_len,
+                           int32_t ld_hist, float penalty, void* stream, const char* who) {
+  VIDIL_REQUIRE(nbl >= 1 && nbl <= nb, "%s: beams_in_logits=%d must be in [1, num_beams=%d]", who, nbl, nb);
+  VIDIL_REQUIRE(logits && beam_scores && out_scores && out_index, "%s: null pointer", who);
+  VIDIL_REQUIRE(B > 0 && V > 0, "%s: bad shape", who);
+  VIDIL_REQUIRE((long)nb * V < 0x7fffffffL, "%s: nb*V overflows int32", who);
+  hipStream_t s = (hipStream_t)stream;
+#define VIDIL_LSM(NB_)                                                                                                          \
+  case NB_:                                                                                                                     \
+    if (hist) hipLaunchKernelGGL((lsm_topk_kernel<NB_, true>), dim3(B), dim3(256), 0, s, logits, beam_scores, nbl, V, ban_token, \
+                                 out_scores, out_index, hist, hist_len, ld_hist, penalty);                                      \
+    else hipLaunchKernelGGL((lsm_topk_kernel<NB_, false>), dim3(B), dim3(256), 0, s, logits, beam_scores, nbl, V, ban_token,     \
+                            out_scores, out_index, nullptr, 0, 0, 1.f);                                                         \
+    break;
+  switch (nb) {
+    VIDIL_LSM(1) VIDIL_LSM(2) VIDIL_LSM(3) VIDIL_LSM(4)
+    default:
+      vidil_set_error("%s: num_beams=%d not supported (1..4)", who, nb);
+      return VIDIL_EUNSUP;
+  }
+#undef VIDIL_LSM
+  VIDIL_CHECK_LAUNCH(who);
+  return VIDIL_OK;
+}
+
 extern "C" int vidil_logsoftmax_topk(const float* logits, const float* beam_scores, int32_t B, int32_t nb,
                                      int32_t beams_in_logits, int32_t V, int32_t ban_token, float* out_scores,
                                      int32_t* out_index, void* stream) {
-  const int nbl = beams_in_logits;
-  VIDIL_REQUIRE(nbl >= 1 && nbl <= nb, "logsoftmax_topk: beams_in_logits=%d must be in [1, num_beams=%d]", nbl, nb);
-  VIDIL_REQUIRE(logits && beam_scores && out_scores && out_index, "logsoftmax_topk: null pointer");
-  VIDIL_REQUIRE(B > 0 && V > 0, "logsoftmax_topk: bad shape");
-  VIDIL_REQUIRE((long)nb * V < 0x7fffffffL, "logsoftmax_topk: nb*V overflows int32");
-  hipStream_t s = (hipStream_t)stream;
-  switch (nb) {
-    case 1: hipLaunchKernelGGL(lsm_topk_kernel<1>, dim3(B), dim3(256), 0, s, logits, beam_scores, nbl, V, ban_token, out_scores, out_index); break;
-    case 2: hipLaunchKernelGGL(lsm_topk_kernel<2>, dim3(B), dim3(256), 0, s, logits, beam_scores, nbl, V, ban_token, out_scores, out_index); break;
-    case 3: hipLaunchKernelGGL(lsm_topk_kernel<3>, dim3(B), dim3(256), 0, s, logits, beam_scores, nbl, V, ban_token, out_scores, out_index); break;
-    case 4: hipLaunchKernelGGL(lsm_topk_kernel<4>, dim3(B), dim3(256), 0, s, logits, beam_scores, nbl, V, ban_token, out_scores, out_index); break;
-    default:
-      vidil_set_error("logsoftmax_topk: num_beams=%d not supported (1..4)", nb);
-      return VIDIL_EUNSUP;
-  }
-  VIDIL_CHECK_LAUNCH("logsoftmax_topk");
-  return VIDIL_OK;
+  return launch_lsm_topk(logits, beam_scores, B, nb, beams_in_logits, V, ban_token, out_scores, out_index, nullptr, 0, 0, 1.f,
+                         stream, "logsoftmax_topk");
+}
+
+extern "C" int vidil_logsoftmax_topk_penalty(const float* logits, const float* beam_scores, int32_t B, int32_t nb,
+                                             int32_t beams_in_logits, int32_t V, int32_t ban_token, const int32_t* seqs,
+                                             int32_t cur_len, int32_t ld_seqs, float penalty, float* out_scores,
+                                             int32_t* out_index, void* stream) {
+  VIDIL_REQUIRE(seqs != nullptr, "logsoftmax_topk_penalty: null sequences");
+  VIDIL_REQUIRE(cur_len >= 1 && cur_len <= MAXLEN && ld_seqs >= cur_len,
+                "logsoftmax_topk_penalty: cur_len=%d must be in [1, %d] and <= ld_seqs=%d", cur_len, MAXLEN, ld_seqs);
+  VIDIL_REQUIRE(penalty > 0.f, "logsoftmax_topk_penalty: penalty must be a strictly positive float");
+  return launch_lsm_topk(logits, beam_scores, B, nb, beams_in_logits, V, ban_token, out_scores, out_index, seqs, cur_len,
+                         ld_seqs, penalty, stream, "logsoftmax_topk_penalty");
 }
 
 static int check_state(const vidil_beam_state* st, int nb, int max_len, const char* who) {

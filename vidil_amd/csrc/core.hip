@@ -65,6 +65,6 @@ const char* vidil_dev_env(const char* name) {
 }
 
 extern "C" const char* vidil_last_error(void) { return g_err; }
-extern "C" int vidil_abi_version(void) { return 10; }
+extern "C" int vidil_abi_version(void) { return 11; }
 // keep in sync with include/vidil_hip.h (tests/test_abi.py parses the header)
-extern "C" int vidil_num_entry_points(void) { return 27; }
+extern "C" int vidil_num_entry_points(void) { return 28; }

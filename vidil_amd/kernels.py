@@ -416,16 +416,28 @@ def l2_normalize_rows(x):
 
 
 # ------------------------------------------------------------------------ beam search
-def logsoftmax_topk(logits, beam_scores, B, nb, ban_token=-1, out_scores=None, out_index=None, beams_in_logits=None):
+def logsoftmax_topk(logits, beam_scores, B, nb, ban_token=-1, out_scores=None, out_index=None, beams_in_logits=None,
+                    seqs=None, cur_len=0, penalty=1.0):
+    """``seqs`` (i32 [B*nb, max_len], the beams' token ids) with ``cur_len`` and ``penalty``: the repetition penalty of
+    ``generate(..., repetition_penalty=penalty)`` on the log-probabilities of the tokens each row already holds."""
     V = logits.shape[-1]
     dev = logits.device
     if out_scores is None:
         out_scores = torch.empty((B, 2 * nb), dtype=torch.float32, device=dev)
     if out_index is None:
         out_index = torch.empty((B, 2 * nb), dtype=torch.int32, device=dev)
+    nbl = nb if beams_in_logits is None else beams_in_logits
+    if seqs is not None:
+        if seqs.dim() != 2 or seqs.shape[0] != B * nb or seqs.stride(1) != 1:
+            raise ValueError(f"logsoftmax_topk: seqs must be [B*nb={B * nb}, max_len] with unit column stride, got {tuple(seqs.shape)}")
+        check(_lib.load().vidil_logsoftmax_topk_penalty(_ptr(logits, torch.float32, "topk.logits"),
+                                                        _ptr(beam_scores, torch.float32, "topk.beam_scores"), B, nb, nbl, V,
+                                                        ban_token, _ptr(seqs, torch.int32, "topk.seqs"), cur_len, seqs.stride(0),
+                                                        float(penalty), _ptr(out_scores, torch.float32),
+                                                        _ptr(out_index, torch.int32), _stream()), "logsoftmax_topk_penalty")
+        return out_scores, out_index
     check(_lib.load().vidil_logsoftmax_topk(_ptr(logits, torch.float32, "topk.logits"),
-                                            _ptr(beam_scores, torch.float32, "topk.beam_scores"), B, nb,
-                                            nb if beams_in_logits is None else beams_in_logits, V,
+                                            _ptr(beam_scores, torch.float32, "topk.beam_scores"), B, nb, nbl, V,
                                             ban_token, _ptr(out_scores, torch.float32), _ptr(out_index, torch.int32),
                                             _stream()), "logsoftmax_topk")
     return out_scores, out_index
