@@ -259,7 +259,7 @@ __device__ __forceinline__ void store_rows(const AttnP<T>& p, const RowInfo& ri,
   using f16 = T;
   if (!ri.valid) return;
   const int hi = (threadIdx.x & 63) >> 5;
-  if (p.out_mode == 2) {   // wave-uniform: hi = T(o), lo = T(o - hi), planes [hi | lo | hi]
+  if (p.out_mode >= 2) {   // wave-uniform: hi = T(o), lo = T(o - hi), planes [hi | lo | hi] (3: hi | lo only)
     const int pl = p.ldo / 3;
     f16* og = p.out + ((size_t)ri.qb * p.Nq + ri.t) * p.ldo + h * 64 + 4 * hi;
 #pragma unroll
@@ -275,7 +275,7 @@ __device__ __forceinline__ void store_rows(const AttnP<T>& p, const RowInfo& ri,
         }
         *(f16x4*)(og + dt * 32 + rq * 8) = vh;
         *(f16x4*)(og + pl + dt * 32 + rq * 8) = vl;
-        *(f16x4*)(og + 2 * pl + dt * 32 + rq * 8) = vh;
+        if (p.out_mode == 2) *(f16x4*)(og + 2 * pl + dt * 32 + rq * 8) = vh;
       }
     return;
   }
@@ -1103,6 +1103,155 @@ __global__ __launch_bounds__(256, VAR ? 3 : 1) void attn_direct_kernel(const Att
   }
 }
 
+// ------------------------------------------------------------------ direct kernel, ONE WAVE per (kv batch, head)
+// rows <= 32, K / V in fragment tiles or in rows (any number of key tiles).  The four-wave kernel above splits a unit's key tiles over its
+// waves, issues every load, computes, and merges the partials through LDS: nothing of a workgroup is in flight while it computes
+// and merges, and the overlap has to come from the other workgroups of the CU — measured (round 5, 3,584 images x 12 heads x 197
+// keys, developer ablation): the loads alone 355 us (6.1 TB/s), with the merge 371, with the arithmetic 455 (plain) / 551 (split
+// Q and P).  Here a wave owns a whole unit: it walks the unit's key tiles with the online softmax, tile kt + D requested before
+// tile kt is computed (a register ring of D + 1 fragment sets), so every resident wave has D tiles (8 KiB each) in flight at any
+// time; no LDS, no barrier, no merge — the 32 rows leave straight from the accumulators.  QS: the split form (f32 queries and the
+// probabilities as hi + lo, as above).  The summation order differs from the four-wave kernel's (one running (m, l, O) instead of
+// four merged ones), so a shape takes ONE of the two at every batch size and in either K / V layout: every launch of <= 32 rows and
+// more than one key tile comes here (a session's tiled and row-major forms give the same bits, as they did on the four-wave kernel).
+template <typename T, bool QS, int D, bool TILED>
+__global__ __launch_bounds__(256, (QS || !TILED) ? 2 : 3) void attn_direct1_kernel(const AttnP<T> p) {
+  using f16 = T;
+  using f16x8 = typename Elt<T>::x8;
+  constexpr int NBUF = D + 1;
+  const int lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int hi = lane >> 5, l31 = lane & 31;
+  const int unit = blockIdx.x * 4 + wave;            // (adjacent waves: adjacent heads of one kv batch — adjacent K / V blocks)
+  if (unit >= p.H * p.n_kv) return;
+  const int z = unit / p.H, h = unit - z * p.H;
+  int bk, first, count;
+  resolve_unit(p, z, bk, first, count);
+  const int rows = count * p.Nq;
+  if (rows <= 0) return;  // a kv batch nobody attends to
+  const int nk = p.Nk;
+  const RowInfo ri = row_info(p, l31, first, rows);
+  const f16* kg = p.k + ((size_t)bk * p.H + h) * p.Tk_cap * 64;
+  const f16* vg = p.vt + ((size_t)bk * p.H + h) * 64 * (size_t)(TILED ? p.Tk_cap : p.NP);
+  const int ntiles = (nk + 31) >> 5;
+
+  f16x8 kf[NBUF][4], vf[NBUF][2][2];
+  auto load = [&](f16x8 (&kfb)[4], f16x8 (&vfb)[2][2], int kt) {
+    // (rows / key groups past the last key are not fetched: they stay zero and are masked in the tile)
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks) kfb[ks] = zero8<T>();
+#pragma unroll
+    for (int dt = 0; dt < 2; ++dt)
+#pragma unroll
+      for (int hb = 0; hb < 2; ++hb) vfb[dt][hb] = zero8<T>();
+    if constexpr (TILED) {
+      // fragment tiles: each instruction of the wave reads one contiguous KiB
+      const f16* kt_base = kg + (size_t)kt * 2048 + (hi * 32 + l31) * 8;
+      if (kt * 32 + l31 < nk) {
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks) kfb[ks] = *(const f16x8*)(kt_base + ks * 512);
+      }
+      const f16* vt_base = vg + (size_t)kt * 2048 + (hi * 32 + l31) * 8;
+#pragma unroll
+      for (int hb = 0; hb < 2; ++hb) {
+        if ((kt * 2 + hb) * 16 + 4 * hi < nk) {
+#pragma unroll
+          for (int dt = 0; dt < 2; ++dt) vfb[dt][hb] = *(const f16x8*)(vt_base + (hb * 2 + dt) * 512);
+        }
+      }
+    } else {
+      // K rows [Tk_cap][64], V^T rows [64][NP] in vt_pos order: the same fragments, 32-byte pieces of 32 rows
+      int krow = kt * 32 + l31;
+      krow = krow < nk ? krow : nk - 1;  // clamped rows are masked in the tile
+      const f16* kr = kg + (size_t)krow * 64 + hi * 8;
+#pragma unroll
+      for (int ks = 0; ks < 4; ++ks) kfb[ks] = *(const f16x8*)(kr + ks * 16);
+#pragma unroll
+      for (int hb = 0; hb < 2; ++hb) {
+        const int blk0 = (kt * 2 + hb) * 16;
+        if (blk0 < nk) {
+#pragma unroll
+          for (int dt = 0; dt < 2; ++dt) vfb[dt][hb] = *(const f16x8*)(vg + (size_t)(dt * 32 + l31) * p.NP + blk0 + 8 * hi);
+        }
+      }
+    }
+  };
+#pragma unroll
+  for (int j = 0; j < D; ++j)
+    if (j < ntiles) load(kf[j], vf[j], j);
+
+  f16x8 qf[4], ql[QS ? 4 : 1];
+  if constexpr (QS) {
+    const float* qg = p.q32 + ((size_t)ri.qb * p.Nq + ri.t) * p.ldq32 + h * 64 + hi * 8;
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks) {
+      const f32x4 a = *(const f32x4*)(qg + ks * 16) * p.q_scale, b = *(const f32x4*)(qg + ks * 16 + 4) * p.q_scale;
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        qf[ks][e] = Elt<T>::from_f32(a[e]);
+        ql[ks][e] = Elt<T>::from_f32(a[e] - (float)qf[ks][e]);
+        qf[ks][4 + e] = Elt<T>::from_f32(b[e]);
+        ql[ks][4 + e] = Elt<T>::from_f32(b[e] - (float)qf[ks][4 + e]);
+      }
+    }
+  } else {
+    const f16* qg = p.q + (((size_t)ri.qb * p.H + h) * p.Tq_cap + ri.t) * 64 + hi * 8;
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks) qf[ks] = *(const f16x8*)(qg + ks * 16);
+  }
+  int kmin = ri.klim;
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) {
+    const int x = __shfl_xor(kmin, o, 64);
+    kmin = x < kmin ? x : kmin;
+  }
+  float m = -INFINITY, l = 0.f;
+  f32x16 O[2];
+#pragma unroll
+  for (int dt = 0; dt < 2; ++dt)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) O[dt][r] = 0.f;
+
+  auto compute = [&](const f16x8 (&kfb)[4], const f16x8 (&vfb)[2][2], int kt) {
+    f32x16 S;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) S[r] = 0.f;
+    if constexpr (QS) {
+#pragma unroll
+      for (int ks = 0; ks < 4; ++ks) S = Elt<T>::mfma32(kfb[ks], ql[ks], S);
+    }
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks) S = Elt<T>::mfma32(kfb[ks], qf[ks], S);
+    const bool tail = (kt * 32 + 32) > nk;  // tile reaches past the last key: V^T needs zeroing too
+    const bool need_mask = (kt * 32 + 32) > kmin;
+    auto vfrag = [&](int dt, int hb) {
+      const int blk0 = (kt * 2 + hb) * 16;
+      f16x8 v = vfb[dt][hb];
+      if (tail) {
+#pragma unroll
+        for (int e = 0; e < 8; ++e)
+          if (blk0 + 4 * hi + (e & 3) + 8 * (e >> 2) >= nk) v[e] = (f16)0.f;
+      }
+      return v;
+    };
+    if constexpr (QS) softmax_pv_tile_psplit<T>(S, kt * 32, ri.klim, need_mask, m, l, O, vfrag);
+    else softmax_pv_tile<T, true, false>(S, kt * 32, ri.klim, need_mask, m, l, O, vfrag);
+  };
+#pragma unroll 1
+  for (int kt0 = 0; kt0 < ntiles; kt0 += NBUF) {
+#pragma unroll
+    for (int j = 0; j < NBUF; ++j) {
+      const int kt = kt0 + j;
+      if (kt < ntiles) {                             // (wave-uniform)
+        if (kt + D < ntiles) load(kf[(j + D) % NBUF], vf[(j + D) % NBUF], kt + D);
+        compute(kf[j], vf[j], kt);
+      }
+    }
+  }
+  l += __shfl_xor(l, 32, 64);
+  store_rows(p, ri, h, O, l > 0.f ? 1.0f / l : 0.f);
+}
+
 // ------------------------------------------------------------------ one wave, one key tile
 // rows <= 32 and Nk <= 32 (decoder self-attention over the cached tokens): a single wave per (unit, head),
 // operands straight from memory, no LDS and no barrier.
@@ -1229,6 +1378,32 @@ int launch_stream(const AttnP<T>& p, hipStream_t s) {
   return VIDIL_OK;
 }
 
+// the one-wave-per-unit direct kernel; $VIDIL_ATTN_DIRECT1=0 keeps the four-wave kernel (developer A / B)
+template <typename T>
+bool direct1_enabled(const AttnP<T>& p) {
+  const char* e = vidil_dev_env("VIDIL_ATTN_DIRECT1");
+  return e == nullptr || e[0] != '0';
+}
+template <typename T, bool QS>
+int launch_direct1(const AttnP<T>& p, hipStream_t s) {
+  const int units = p.H * p.n_kv;
+  const dim3 grid((units + 3) / 4);
+  // prefetch depth (round 5, 3,584 images x 12 heads x 197 keys): plain 370 us at depth 1 (depth 2 spills: 588), split 402 at depth 1,
+  // 413 at 2 ($VIDIL_ATTN_DIRECT1_DEPTH=2, split form only); the four-wave kernel 461 / 544
+  if constexpr (QS) {
+    const char* e = vidil_dev_env("VIDIL_ATTN_DIRECT1_DEPTH");
+    if (e != nullptr && atoi(e) == 2 && p.tiled) {
+      hipLaunchKernelGGL((attn_direct1_kernel<T, true, 2, true>), grid, dim3(256), 0, s, p);
+      VIDIL_CHECK_LAUNCH("attention/direct1");
+      return VIDIL_OK;
+    }
+  }
+  if (p.tiled) hipLaunchKernelGGL((attn_direct1_kernel<T, QS, 1, true>), grid, dim3(256), 0, s, p);
+  else hipLaunchKernelGGL((attn_direct1_kernel<T, QS, 1, false>), grid, dim3(256), 0, s, p);
+  VIDIL_CHECK_LAUNCH("attention/direct1");
+  return VIDIL_OK;
+}
+
 template <typename T, int NKT>
 int launch_any(const AttnP<T>& p, int max_rows, hipStream_t s) {
   if constexpr (NKT == 7)
@@ -1239,6 +1414,7 @@ int launch_any(const AttnP<T>& p, int max_rows, hipStream_t s) {
     return VIDIL_OK;
   }
   if (max_rows <= 32) {
+    if (direct1_enabled(p)) return launch_direct1<T, false>(p, s);
     hipLaunchKernelGGL((attn_direct_kernel<T, NKT>), dim3(1, p.H, p.n_kv), dim3(256), 0, s, p);
     VIDIL_CHECK_LAUNCH("attention/direct");
     return VIDIL_OK;
@@ -1265,6 +1441,7 @@ int attention_dispatch(const AttnP<T>& p, int nkt, int max_rows, int Nk, hipStre
   // kernel, 224-key chunks re-staged through LDS in the staged kernel
   if (nkt <= 24) {
     if (max_rows <= 32) {
+      if (direct1_enabled(p)) return launch_direct1<T, false>(p, s);
       hipLaunchKernelGGL((attn_direct_kernel<T, 24>), dim3(1, p.H, p.n_kv), dim3(256), 0, s, p);
       VIDIL_CHECK_LAUNCH("attention/direct");
       return VIDIL_OK;
@@ -2018,6 +2195,7 @@ extern "C" int vidil_attention_f32(const vidil_attn_f32_args* a, void* stream) {
       q.kv_group = a->kv_group; q.ldo = (int)a->ldo; q.n_kv = units; q.out_mode = a->out_mode; q.tiled = 1; q.rb = 1;
       q.q32 = a->q; q.ldq32 = a->ldq; q.q_scale = a->scale;
       const dim3 g(1, a->H, units);
+      if (direct1_enabled(q)) return launch_direct1<T, true>(q, s);
       switch (nkt) {
         case 1: hipLaunchKernelGGL((attn_direct_kernel<T, 1, true>), g, dim3(256), 0, s, q); break;
         case 2: hipLaunchKernelGGL((attn_direct_kernel<T, 2, true>), g, dim3(256), 0, s, q); break;
