@@ -7,7 +7,7 @@
 // table `group_start`) are flattened into "virtual rows" v = (qb - first)*Nq + t,
 // so an image's K/V are fetched once for every caption / beam that attends to it.
 //
-// Two kernels, both built on v_mfma_f32_32x32x16_f16 with the scores computed
+// The kernels are built on v_mfma_f32_32x32x16_f16 with the scores computed
 // TRANSPOSED (S^T = K·Q^T) so a lane owns one query row and the online softmax
 // is lane-local (one cross-half shuffle per key tile), and with the output
 // accumulated TRANSPOSED too (O^T = V^T·P^T) so the running rescale and the
@@ -17,11 +17,17 @@
 //                      ([64][keys], stride keys+8) staged once in LDS (strides
 //                      chosen so the ds_read_b128 fragment reads are conflict
 //                      free); each wave owns 32 virtual rows, 4 or 8 waves.
-//   attn_direct_kernel rows <= 32 (decode steps, prefill): every K/V element is
+//   attn_direct1_kernel rows <= 32 (decode steps, prefill): every K/V element is
 //                      used by one wave only, so fragments are loaded straight
-//                      from HBM/L2 into MFMA operands (no LDS round trip); the 4
-//                      waves split the key tiles (flash-decoding) and merge their
-//                      (m, l, O) partials through 17 KB of LDS.
+//                      from HBM/L2 into MFMA operands (no LDS round trip); ONE wave
+//                      owns a (batch, head) unit and walks its key tiles, the next
+//                      tile requested before the current one is computed.
+//   attn_direct_kernel the same with the 4 waves of a workgroup splitting a unit's
+//                      key tiles (flash-decoding) and merging (m, l, O) through LDS:
+//                      the form before the end of round 5, kept behind
+//                      $VIDIL_ATTN_DIRECT1=0 for A / B measurements.
+// (plus the streamed tower kernel, the one-tile wave kernel and, further down, the
+//  f32 / split-operand kernels of the parity precision mode: each has its own header)
 //
 // The key order inside a 16-key MFMA step is the order the S^T accumulator
 // layout leaves the P values in ({0-3,8-11} / {4-7,12-15} per half-wave).  V^T
