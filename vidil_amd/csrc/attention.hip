@@ -1392,6 +1392,7 @@ bool direct1_enabled(const AttnP<T>& p) {
 }
 template <typename T, bool QS>
 int launch_direct1(const AttnP<T>& p, hipStream_t s) {
+  VIDIL_REQUIRE((long long)p.H * p.n_kv < 0x7fffffffLL, "attention: H=%d x %d kv batches overflow the unit index", p.H, p.n_kv);
   const int units = p.H * p.n_kv;
   const dim3 grid((units + 3) / 4);
   // prefetch depth (round 5, 3,584 images x 12 heads x 197 keys): plain 370 us at depth 1 (depth 2 spills: 588), split 402 at depth 1,
