@@ -161,7 +161,11 @@ typedef struct vidil_gemm_args {
    * the flag set the library may compute the same three products INSIDE one K loop over Kl (x_hi / W_hi tiles fetched once
    * instead of twice: 2/3 of the operand traffic per MFMA; f32 sums in a different order) — it does so for the f32, per-head
    * (T >= 8) and patch epilogues at EVERY problem size and runs the plain K = 3 Kl product for the others, so a row's
-   * result never depends on the batch around it.  K % 96 == 0. */
+   * result never depends on the batch around it.  K % 96 == 0.
+   * 2 (ABI 12, round 6) = as 1, and the caller states that ONLY planes 0 / 1 of the A rows were written (a producer run with
+   * VIDIL_DT_SPLIT2 / out16_split3 = 2 / attention out_mode 3): the launch must take the K-loop form; when this call's
+   * epilogue, alignment or shape does not qualify for it the library returns VIDIL_EINVAL instead of running the plain
+   * K = 3 Kl product over an unwritten plane. */
   int32_t split_k;
 } vidil_gemm_args;
 
@@ -172,6 +176,11 @@ int vidil_gemm(const vidil_gemm_args* args, void* stream);
 /* 1 when split_k launches with an eligible epilogue take the K-loop form in this process (0: $VIDIL_GEMM_C3=0 — every split_k
  * launch is the plain K = 3 Kl product and reads all three planes of its A rows). */
 int vidil_gemm_split_k_in_loop(void);
+/* (ABI 12) Per CALL: 1 when vidil_gemm would run `args` (split_k != 0) in the K-loop form — planes 0 / 1 of the A rows are
+ * all it reads, so their producer may be run with VIDIL_DT_SPLIT2 / out16_split3 = 2 / out_mode 3 —, 0 when it would run the plain
+ * K = 3 Kl product over all three planes (split_k == 2 is then refused by vidil_gemm), < 0 for invalid arguments.  Launches
+ * nothing.  Hosts size their producers' `planes` with it instead of assuming vidil_gemm_split_k_in_loop() covers every call. */
+int vidil_gemm_split_k_serves(const vidil_gemm_args* args);
 /* Name of the kernel instantiation vidil_gemm would launch for `args` (the spelling rocprofv3 prints, e.g.
  * "gemm256_kernel<f16, 1, 0>"), written NUL-terminated into buf[0..n).  For profilers / bench.py. */
 int vidil_gemm_kernel_name(const vidil_gemm_args* args, char* buf_host, int32_t n);

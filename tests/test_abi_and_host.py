@@ -29,8 +29,8 @@ def test_library_exports_every_declared_symbol():
     for n in names:
         assert hasattr(lib, n), f"{n} declared in include/vidil_hip.h but not exported"
     assert set(names) == set(_lib.SIGNATURES), set(names) ^ set(_lib.SIGNATURES)
-    assert lib.vidil_num_entry_points() == len(names) == 28
-    assert lib.vidil_abi_version() == 11 == _lib.ABI_VERSION
+    assert lib.vidil_num_entry_points() == len(names) == 29
+    assert lib.vidil_abi_version() == 12 == _lib.ABI_VERSION
 
 
 def test_gemm_args_struct_matches_header_field_order():

@@ -27,6 +27,14 @@ toks = {{v: dict(frame_tokens=[dict(objects=["o"])], caption=[], aggregated_toke
 vt.write_outputs({out!r}, toks)
 t = vdist.max_over_ranks(float(rank + 1))
 assert t == float(world), t
+assert vdist.ranks_seen() == world, vdist.ranks_seen()          # one identity per rank (CPU ranks: host + pid)
+# the collective of gather_json is chosen before it is issued: both forms deliver the same list to rank 0, None elsewhere
+assert vdist._gather_supported()
+a = vdist.gather_json(dict(rank=rank))
+os.environ["VIDIL_GATHER"] = "allgather"
+assert not vdist._gather_supported()
+b = vdist.gather_json(dict(rank=rank))
+assert a == b == ([dict(rank=r) for r in range(world)] if rank == 0 else None), (a, b)
 vdist.barrier()
 """
 
@@ -72,3 +80,16 @@ def test_two_rank_gather_equals_single_process(tmp_path):
     d = json.load(open(os.path.join(out2, "video_text_CapFilt.json")))
     assert list(d.keys()) == [f"video{i}" for i in range(11) if i % 4 != 3]      # filtered-out videos drop, order kept
     assert list(json.load(open(os.path.join(out2, "video_text_Cap.json"))).keys()) == [f"video{i}" for i in range(11)]
+
+
+def test_gather_collective_is_decided_before_it_is_issued():
+    """no try/except around the collective — the source of gather_json holds no exception handler, and an error
+    inside the collective propagates (here: a process group whose gather raises)."""
+    import ast
+    import inspect
+
+    from vidil_amd import dist as vdist
+
+    tree = ast.parse(inspect.getsource(vdist.gather_json))
+    assert not [n for n in ast.walk(tree) if isinstance(n, ast.Try)]
+    assert vdist.ranks_seen() == 1 and vdist.gather_json({"a": 1}) == [{"a": 1}]      # no process group: identity

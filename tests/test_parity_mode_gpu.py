@@ -741,3 +741,70 @@ def test_parity_qualified_results_do_not_depend_on_batch_composition():
         assert torch.equal(c, all_c[v * F:(v + 1) * F]), "CLIP embedding bits depend on the batch"
         assert it[0]["unfiltered_text"] == all_items[v]["unfiltered_text"] and it[0]["text"] == all_items[v]["text"]
         assert t[f"video{v}"] == all_t[f"video{v}"]
+
+
+def test_split_k_two_plane_operands_are_refused_where_the_plain_product_would_read_the_third_plane():
+    """producers leave plane 2 of their [hi | lo | hi] rows unwritten only where the CONSUMER call takes the
+    K-loop form — asked per call (vidil_gemm_split_k_serves) — and a consumer told its A rows hold two planes (split_k = 2) fails
+    with EINVAL instead of running the plain K = 3 Kl product over the unwritten plane.  The per-head epilogue with fewer than 8
+    tokens per sequence is such a call (tiny image configs: Te < 8)."""
+    from vidil_amd import kernels as K
+    from vidil_amd.packing import w3
+
+    torch.manual_seed(3)
+    C, H, T, B = 128, 2, 5, 6
+    M = B * T
+    x = torch.randn(M, C, device=DEV)
+    w = torch.randn(2 * C, C) * 0.05
+    a3 = K.split3(x, torch.empty((M, 3 * C), dtype=torch.float16, device=DEV))
+    w3_ = w3(w, dtype=torch.float16).to(DEV)
+    bias = torch.zeros(2 * C, device=DEV)
+    k = torch.zeros((B, H, T, 64), dtype=torch.float16, device=DEV)
+    v = torch.zeros((B, H, T, 64), dtype=torch.float16, device=DEV)
+    heads = dict(k=k, vt=v, T=T, H=H, part0=1, t_off=0, Tk_cap=T, NP=0)
+    out32 = torch.empty((M, 2 * C), dtype=torch.float32, device=DEV)
+    assert K.split_k_in_loop()
+    assert K.split_k_serves(a3, w3_, bias, out=out32)                  # f32 epilogue: the K-loop form at every size
+    assert not K.split_k_serves(a3, w3_, bias, heads=heads)            # 5 tokens per sequence: the plain K = 3 Kl product
+    # three valid planes: served by the plain product, same values as the f32 epilogue's
+    K.gemm(a3, w3_, bias, heads=heads, split_k=True)
+    K.gemm(a3, w3_, bias, out=out32, split_k=True, a_planes=2)
+    torch.cuda.synchronize()
+    ref = out32.view(B, T, 2, H, 64)
+    assert torch.allclose(k.float(), ref[:, :, 0].permute(0, 2, 1, 3), atol=2e-3, rtol=2e-3)
+    # two planes only (NaN in the third, as a two-plane producer may leave it): refused, loudly
+    a2 = a3.clone()
+    a2[:, 2 * C:] = float("nan")
+    with pytest.raises(K.VidilHipError, match="split_k=2"):
+        K.gemm(a2, w3_, bias, heads=heads, split_k=True, a_planes=2)
+    K.gemm(a2, w3_, bias, out=out32, split_k=True, a_planes=2)         # ... and the K-loop form never reads it
+    torch.cuda.synchronize()
+    assert torch.isfinite(out32).all()
+
+
+def test_tiny_image_parity_captioner_has_no_unwritten_plane_on_its_path(monkeypatch):
+    """The concrete case of ADVICE r5: a 32 x 32 image config has Te = 5 image tokens, so the cross K | V projection's per-head
+    epilogue runs the plain product over ALL planes of the ViT's output rows — which the final LayerNorm therefore writes in full.
+    With $VIDIL_POISON_SPLIT3 (NaNs in every plane a producer is allowed to skip) the logits stay finite and equal the unpoisoned run."""
+    from vidil_amd.blip import BLIP_Decoder, DecoderSession
+    from vidil_amd.packing import set_compute_dtype, set_parity_mode
+    from vidil_amd.tokenizer import SyntheticBertTokenizer
+
+    torch.manual_seed(0)
+    cap = BLIP_Decoder(image_size=32, vit="base", tokenizer=SyntheticBertTokenizer()).eval().to(DEV)
+    set_compute_dtype("f16", cap)
+    set_parity_mode(True, cap)
+    img = torch.randn(3, 3, 32, 32, device=DEV)
+    prompt = cap.prompt_ids(3, DEV)
+    P = prompt.shape[1]
+
+    def logits():
+        _, y3 = cap.visual_encoder.forward_both(img)
+        sess = DecoderSession(cap.text_decoder, y3, 3, 3, 12, tiled_cross=True)
+        return sess.prefill(prompt.contiguous().view(-1), P, shared=True).float().cpu()
+
+    a = logits()
+    monkeypatch.setenv("VIDIL_POISON_SPLIT3", "1")
+    b = logits()
+    assert torch.isfinite(a).all() and torch.isfinite(b).all()
+    assert torch.equal(a, b)

@@ -83,6 +83,7 @@ SIGNATURES = {
     "vidil_gemm": (_i32, [C.POINTER(GemmArgs), _p]),
     "vidil_gemm_kernel_name": (_i32, [C.POINTER(GemmArgs), C.c_char_p, _i32]),
     "vidil_gemm_split_k_in_loop": (_i32, []),
+    "vidil_gemm_split_k_serves": (_i32, [C.POINTER(GemmArgs)]),
     "vidil_layernorm": (_i32, [_p, _i64, _p, _p, _f32, _i32, _i32, _p, _i32, _p, _p]),
     "vidil_split3_f32": (_i32, [_p, _p, _i32, _i32, _i32, _p]),
     "vidil_attention": (_i32, [_p, _p, _p, _p, _p, _p, _p] + [_i32] * 16 + [_p]),
@@ -114,7 +115,7 @@ class VidilHipError(RuntimeError):
     pass
 
 
-ABI_VERSION = 11     # include/vidil_hip.h as this binding mirrors it (struct layouts, argument lists)
+ABI_VERSION = 12     # include/vidil_hip.h as this binding mirrors it (struct layouts, argument lists)
 
 
 def load():

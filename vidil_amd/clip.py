@@ -179,27 +179,33 @@ def _run_layers(layers, x, B, T, H, eps, *, causal=False, kv_len=None, f32_attn=
         a3 = torch.empty((M, 3 * D), dtype=cdt, device=dev)
         o3 = torch.empty((M, 3 * D), dtype=cdt, device=dev)
         hid3 = torch.empty((M, 3 * Dh), dtype=cdt, device=dev)
-        # (fc2 consumes these rows as a split_k launch with the f32 epilogue: in the K-loop form it reads planes hi | lo only, so fc1
-        #  need not write the third)
-        planes = 2 if K.split_k_in_loop() else 3
+        # (planes hi | lo only where EVERY consumer of the rows takes the K-loop form — asked per call, vit.py has the reasoning;
+        #  the consumers state a_planes so that a launch that would read an unwritten plane fails instead)
+        qkv32 = torch.empty((M, 3 * D), dtype=torch.float32, device=dev) if f32_attn else None
+        planes, l0 = 3, layers[0]
+        if K.split_k_in_loop():
+            qkv_kw = dict(out=qkv32) if f32_attn else dict(heads=heads)
+            if (K.split_k_serves(a3, l0["qkv_w3"], l0["qkv_b"], **qkv_kw) and K.split_k_serves(o3, l0["o_w3"], l0["o_b"], out=x, resid=x)
+                    and K.split_k_serves(a3, l0["fc1_w3"], l0["fc1_b"], split3_out=hid3, act=K.ACT_QUICK_GELU)
+                    and K.split_k_serves(hid3, l0["fc2_w3"], l0["fc2_b"], out=x, resid=x)):
+                planes = 2
         import os
         if planes == 2 and os.environ.get("VIDIL_POISON_SPLIT3") == "1":       # (developer: NaNs in the unwritten third planes —
             for _b in (a3, o3, hid3,):                               #  any consumer that reads one shows up at once)
                 _b[:, 2 * (_b.shape[1] // 3):] = float("nan")
-        qkv32 = torch.empty((M, 3 * D), dtype=torch.float32, device=dev) if f32_attn else None
         for l in layers:
             K.layernorm(x, l["n1g"], l["n1b"], eps, out16=a3, split3=True, planes=planes)
             if f32_attn:    # (Q | K | V stay f32 and row-major: vidil_attention_f32 reads them in place)
-                K.gemm(a3, l["qkv_w3"], l["qkv_b"], out=qkv32, split_k=True)
+                K.gemm(a3, l["qkv_w3"], l["qkv_b"], out=qkv32, split_k=True, a_planes=planes)
                 K.attention_f32(qkv32[:, :D], qkv32[:, D:2 * D], qkv32[:, 2 * D:], o3, Bq=B, H=H, Nq=T, Nk=T, causal=causal, kv_len=kv_len,
                                 arith=arith, planes=planes)
             else:
-                K.gemm(a3, l["qkv_w3"], l["qkv_b"], heads=heads, split_k=True)
+                K.gemm(a3, l["qkv_w3"], l["qkv_b"], heads=heads, split_k=True, a_planes=planes)
                 K.attention(q, k, vt, o3, Bq=B, H=H, Nq=T, Nk=T, Tq_cap=T, Tk_cap=T, NP=NP, causal=causal, kv_len=kv_len, split3=True)
-            K.gemm(o3, l["o_w3"], l["o_b"], out=x, resid=x, split_k=True)
+            K.gemm(o3, l["o_w3"], l["o_b"], out=x, resid=x, split_k=True, a_planes=planes if f32_attn else 3)
             K.layernorm(x, l["n2g"], l["n2b"], eps, out16=a3, split3=True, planes=planes)
-            K.gemm(a3, l["fc1_w3"], l["fc1_b"], split3_out=hid3, act=K.ACT_QUICK_GELU, split_k=True, split3_planes=planes)
-            K.gemm(hid3, l["fc2_w3"], l["fc2_b"], out=x, resid=x, split_k=True)
+            K.gemm(a3, l["fc1_w3"], l["fc1_b"], split3_out=hid3, act=K.ACT_QUICK_GELU, split_k=True, split3_planes=planes, a_planes=planes)
+            K.gemm(hid3, l["fc2_w3"], l["fc2_b"], out=x, resid=x, split_k=True, a_planes=planes)
         return x
     stats = torch.empty((M, D // 64, 2), dtype=torch.float32, device=dev) if "fc1_f" in layers[0] else None
     if "qkv_w8" in layers[0] and T > 32:

@@ -1323,15 +1323,9 @@ int launch_lds(const AttnP<T>& p, int max_rows, hipStream_t s) {
   // + 2 KiB per wave for the output transposition (store_rows_lds) where a second workgroup still fits beside it
   constexpr bool ostage = 2 * (smem_kv + NW * 2048) <= 160 * 1024;
   constexpr int smem = smem_kv + (ostage ? NW * 2048 : 0);
-  static unsigned long long attr_set = 0;   // (one bit per device: vidil_first_on_device)
+  static std::atomic<unsigned long long> attr_set{0};   // (one bit per device that has the opt-in: vidil_lds_opt_in)
   auto kern = attn_lds_kernel<T, NKT, NW>;
-  if (vidil_first_on_device(&attr_set)) {
-    hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, smem);
-    if (e != hipSuccess) {
-      vidil_set_error("attention: hipFuncSetAttribute failed: %s", hipGetErrorString(e));
-      return VIDIL_ELAUNCH;
-    }
-  }
+  if (const int rc_ = vidil_lds_opt_in(attr_set, (const void*)kern, smem, "attention")) return rc_;
   // rows a little over one round of NW blocks (the ITM cross-attention: 8 captions x 35 tokens = 280 rows per
   // image with NW = 8): a second round in the same workgroup instead of a second workgroup that would stage the
   // unit's K/V again for a handful of rows
@@ -1360,18 +1354,12 @@ template <typename T, int NKT>
 int launch_stream(const AttnP<T>& p, hipStream_t s) {
   constexpr int smem = NKT * (4096 + 4 * 1152) + 8 * 2048;   // (attn_stream_kernel: TILE)
   static_assert(2 * smem <= 160 * 1024, "two workgroups per CU");
-  static unsigned long long attr_set = 0;   // (one bit per device: vidil_first_on_device)
+  static std::atomic<unsigned long long> attr_set16{0}, attr_set8{0};   // (one bit per device that has the opt-in: vidil_lds_opt_in)
   const int n_cu = vidil_cu_count();
   auto kern16 = attn_stream_kernel<T, NKT, false>;
   auto kern8 = attn_stream_kernel<T, NKT, true>;
-  if (vidil_first_on_device(&attr_set)) {
-    hipError_t e = hipFuncSetAttribute((const void*)kern16, hipFuncAttributeMaxDynamicSharedMemorySize, smem);
-    if (e == hipSuccess) e = hipFuncSetAttribute((const void*)kern8, hipFuncAttributeMaxDynamicSharedMemorySize, smem);
-    if (e != hipSuccess) {
-      vidil_set_error("attention: stream kernel setup failed: %s", hipGetErrorString(e));
-      return VIDIL_ELAUNCH;
-    }
-  }
+  if (const int rc_ = vidil_lds_opt_in(attr_set16, (const void*)kern16, smem, "attention (stream kernel)")) return rc_;
+  if (const int rc_ = vidil_lds_opt_in(attr_set8, (const void*)kern8, smem, "attention (stream kernel)")) return rc_;
   AttnP<T> q = p;
   q.ostage = 1;
   // two resident workgroups per CU, every one walking the same number of units (+-1)

@@ -1,6 +1,7 @@
 // Shared device/host helpers for libvidil_hip.so (gfx950 only).
 #pragma once
 #include <hip/hip_runtime.h>
+#include <atomic>
 #include <stdint.h>
 #include <stdio.h>
 #include "../../include/vidil_hip.h"
@@ -22,7 +23,7 @@ typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
 // error plumbing ------------------------------------------------------------
 void vidil_set_error(const char* fmt, ...);
 int vidil_cu_count();                          // core.hip: compute units of the current device (cached; 256 when none answers)
-bool vidil_first_on_device(unsigned long long* mask);   // core.hip: true once per (flag word, current device) — per-device kernel setup
+int vidil_lds_opt_in(std::atomic<unsigned long long>& mask, const void* kern, int bytes, const char* who);   // core.hip: per-device dynamic-LDS opt-in, bit set after success
 const char* vidil_dev_env(const char* name);   // core.hip: developer overrides, read once per process (live under $VIDIL_DEV_ENV)
 
 // gemm256.hip: the 256x256 8-wave kernel for large problems (dispatched from vidil_gemm_f16)

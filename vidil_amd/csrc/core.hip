@@ -23,26 +23,33 @@ void vidil_set_error(const char* fmt, ...) {
 // (per DEVICE, ADVICE r4: a process that drives more than one GPU — not how the path is deployed, one process per GPU, but not
 //  forbidden either — must not size the second device's grids from the first one's CU count)
 int vidil_cu_count() {
-  static int cache[64] = {};
+  static std::atomic<int> cache[64] = {};
   int dev = 0;
   if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return 256;
-  if (cache[dev] == 0) {
-    int v = 0;
+  int v = cache[dev].load(std::memory_order_relaxed);
+  if (v == 0) {
     if (hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || v < 8) v = 256;
-    cache[dev] = v;
+    cache[dev].store(v, std::memory_order_relaxed);        // (racing threads store the same value)
   }
-  return cache[dev];
+  return v;
 }
 
-// true exactly once per (flag word, current device): guards the per-device one-time setup of a kernel (the dynamic-LDS opt-in
-// of hipFuncSetAttribute applies to the device that is current when it is called)
-bool vidil_first_on_device(unsigned long long* mask) {
+// per-device one-time dynamic-LDS opt-in of a kernel (hipFuncSetAttribute applies to the device that is current when it is
+// called).  `mask` holds one bit per device that HAS the attribute: the bit is set only after the call succeeded, so a failed
+// opt-in is reported by this launch and retried by the next one, and it is an atomic word — two host threads driving
+// different devices may both run the (idempotent) setup, neither loses the other's bit.
+int vidil_lds_opt_in(std::atomic<unsigned long long>& mask, const void* kern, int bytes, const char* who) {
   int dev = 0;
-  if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return true;      // (unknown: do the setup again, it is idempotent)
-  const unsigned long long bit = 1ull << dev;
-  if (*mask & bit) return false;
-  *mask |= bit;
-  return true;
+  const bool known = hipGetDevice(&dev) == hipSuccess && dev >= 0 && dev < 64;      // (unknown device: set it every time)
+  const unsigned long long bit = known ? 1ull << dev : 0ull;
+  if (known && (mask.load(std::memory_order_acquire) & bit)) return VIDIL_OK;
+  const hipError_t e = hipFuncSetAttribute(kern, hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
+  if (e != hipSuccess) {
+    vidil_set_error("%s: hipFuncSetAttribute(%d B of dynamic LDS) failed: %s", who, bytes, hipGetErrorString(e));
+    return VIDIL_ELAUNCH;
+  }
+  mask.fetch_or(bit, std::memory_order_release);
+  return VIDIL_OK;
 }
 
 const char* vidil_dev_env(const char* name) {
@@ -65,6 +72,6 @@ const char* vidil_dev_env(const char* name) {
 }
 
 extern "C" const char* vidil_last_error(void) { return g_err; }
-extern "C" int vidil_abi_version(void) { return 11; }
+extern "C" int vidil_abi_version(void) { return 12; }
 // keep in sync with include/vidil_hip.h (tests/test_abi.py parses the header)
-extern "C" int vidil_num_entry_points(void) { return 28; }
+extern "C" int vidil_num_entry_points(void) { return 29; }

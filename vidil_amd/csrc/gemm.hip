@@ -299,15 +299,9 @@ __global__ __launch_bounds__(2 * waves_n(BM, BN) * 64) void gemm_kernel(const vi
 template <typename T, int BM, int BN, int ST, int EPI, int ACT>
 int launch(const vidil_gemm_args& a, hipStream_t s) {
   constexpr int smem = ST * (BM + BN) * BK * 2;
-  static unsigned long long attr_set = 0;   // (one bit per device: vidil_first_on_device)
+  static std::atomic<unsigned long long> attr_set{0};   // (one bit per device that has the opt-in: vidil_lds_opt_in)
   auto kern = gemm_kernel<T, BM, BN, ST, EPI, ACT>;
-  if (vidil_first_on_device(&attr_set)) {
-    hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, smem);
-    if (e != hipSuccess) {
-      vidil_set_error("gemm: hipFuncSetAttribute failed: %s", hipGetErrorString(e));
-      return VIDIL_ELAUNCH;
-    }
-  }
+  if (const int rc_ = vidil_lds_opt_in(attr_set, (const void*)kern, smem, "gemm")) return rc_;
   const int tiles = ((a.M + BM - 1) / BM) * ((a.N + BN - 1) / BN);
   hipLaunchKernelGGL(kern, dim3(tiles), dim3(2 * waves_n(BM, BN) * 64), smem, s, a);
   VIDIL_CHECK_LAUNCH("gemm");
@@ -406,6 +400,7 @@ int check_args(const vidil_gemm_args& a) {
     VIDIL_REQUIRE(a.ldo16 % 12 == 0 && a.ldo16 / 3 >= a.N && ((uintptr_t)a.out16 & 7) == 0,
                   "gemm/out16_split3: ldo16=%d must be three planes of >= N=%d columns, each a multiple of 4", a.ldo16, a.N);
   }
+  VIDIL_REQUIRE(a.split_k >= 0 && a.split_k <= 2, "gemm/split_k: 0, 1 (three planes) or 2 (planes hi | lo only), got %d", a.split_k);
   if (a.split_k)
     VIDIL_REQUIRE(a.K % 3 == 0 && (a.K / 3) % 32 == 0 && a.dtype != VIDIL_DT_FP8 && !a.ln_fold,
                   "gemm/split_k: K=%d must be three planes of a multiple of 32 columns (16-bit operands, no ln_fold)", a.K);
@@ -512,6 +507,15 @@ bool vidil_gemm_c3_serves(const vidil_gemm_args& a) {
   return vidil_gemm256_eligible(a, true);
 }
 
+extern "C" int vidil_gemm_split_k_serves(const vidil_gemm_args* args) {
+  VIDIL_REQUIRE(args != nullptr, "gemm_split_k_serves: null args");
+  vidil_gemm_args a = *args;
+  if (a.split_k == 2) a.split_k = 1;          // (the question is about the call, not about what the caller already assumed)
+  const int rc = check_args(a);
+  if (rc != VIDIL_OK) return rc;
+  return vidil_gemm_c3_serves(a) ? 1 : 0;
+}
+
 extern "C" int vidil_gemm(const vidil_gemm_args* args, void* stream) {
   VIDIL_REQUIRE(args != nullptr, "gemm: null args");
   const int rc = check_args(*args);
@@ -519,6 +523,13 @@ extern "C" int vidil_gemm(const vidil_gemm_args* args, void* stream) {
   if (vidil_gemm_c3_serves(*args)) {
     const int rc3 = vidil_gemm4w_c3_launch(*args, (hipStream_t)stream);
     if (rc3 != -1000) return rc3;
+  }
+  if (args->split_k == 2) {
+    // the caller wrote planes hi | lo of the A rows only: the plain K = 3 Kl product below would read plane 2
+    vidil_set_error("gemm/split_k=2: this call does not qualify for the K-loop compensated product (epi=%d T=%d K=%d, alignment, or "
+                    "$VIDIL_GEMM_C3=0) and its A rows hold planes hi | lo only — produce three planes and pass split_k=1", args->epi,
+                    args->T, args->K);
+    return VIDIL_EINVAL;
   }
   if (args->dtype == VIDIL_DT_FP8)
     return vidil_gemm256_launch(*args, (hipStream_t)stream);

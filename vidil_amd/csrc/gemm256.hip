@@ -357,16 +357,10 @@ __global__ __launch_bounds__(512) void gemm256_kernel(const vidil_gemm_args p) {
 
 template <typename T, int EPI, int ACT, bool FOLD = false, typename TO = T, bool STATS = false, bool RLN = false>
 int launch256(const vidil_gemm_args& a, hipStream_t s) {
-  static unsigned long long attr_set = 0;   // (one bit per device: vidil_first_on_device)
+  static std::atomic<unsigned long long> attr_set{0};   // (one bit per device that has the opt-in: vidil_lds_opt_in)
   auto kern = gemm256_kernel<T, TO, EPI, ACT, FOLD, STATS, RLN>;
   constexpr int lds = LDS_BYTES + ((FOLD || RLN) ? STATS_BYTES : 0);
-  if (vidil_first_on_device(&attr_set)) {
-    hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
-    if (e != hipSuccess) {
-      vidil_set_error("gemm256: hipFuncSetAttribute failed: %s", hipGetErrorString(e));
-      return VIDIL_ELAUNCH;
-    }
-  }
+  if (const int rc_ = vidil_lds_opt_in(attr_set, (const void*)kern, lds, "gemm256")) return rc_;
   const int num_cu = vidil_cu_count() & ~7;     // (per device: core.hip)
   // persistent grid: one workgroup per CU (a multiple of 8 so every XCD gets the same number), never more than tiles
   int cus = num_cu;

@@ -560,16 +560,10 @@ __global__ __launch_bounds__(256) void gemm4w_kernel(const vidil_gemm_args p) {
 
 template <typename T, int EPI, int ACT, bool FOLD = false, typename TO = T, bool STATS = false, bool RLN = false, int TM = 4, bool C3 = false>
 int launch4w(const vidil_gemm_args& a, hipStream_t s) {
-  static unsigned long long attr_set = 0;   // (one bit per device: vidil_first_on_device)
+  static std::atomic<unsigned long long> attr_set{0};   // (one bit per device that has the opt-in: vidil_lds_opt_in)
   auto kern = gemm4w_kernel<T, TO, EPI, ACT, FOLD, STATS, RLN, TM, C3>;
   constexpr int LDS_BYTES = kLds<TM>;
-  if (vidil_first_on_device(&attr_set)) {
-    hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES);
-    if (e != hipSuccess) {
-      vidil_set_error("gemm4w: hipFuncSetAttribute failed: %s", hipGetErrorString(e));
-      return VIDIL_ELAUNCH;
-    }
-  }
+  if (const int rc_ = vidil_lds_opt_in(attr_set, (const void*)kern, LDS_BYTES, "gemm4w")) return rc_;
   const int num_cu = vidil_cu_count() & ~7;     // (per device: core.hip)
   int cus = num_cu;
   if (const char* e = vidil_dev_env("VIDIL_GEMM_CUS")) {

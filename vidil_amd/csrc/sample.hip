@@ -173,14 +173,8 @@ extern "C" int vidil_sample_top_k_top_p(const float* logits, int32_t* seqs, int3
     vidil_set_error("sample: vocabulary of %d tokens does not fit the LDS row buffer (<= 38400)", V);
     return VIDIL_EUNSUP;
   }
-  static unsigned long long attr_set = 0;   // (one bit per device: vidil_first_on_device)
-  if (vidil_first_on_device(&attr_set)) {
-    hipError_t e = hipFuncSetAttribute((const void*)sample_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024);
-    if (e != hipSuccess) {
-      vidil_set_error("sample: hipFuncSetAttribute failed: %s", hipGetErrorString(e));
-      return VIDIL_ELAUNCH;
-    }
-  }
+  static std::atomic<unsigned long long> attr_set{0};   // (one bit per device that has the opt-in: vidil_lds_opt_in)
+  if (const int rc_ = vidil_lds_opt_in(attr_set, (const void*)sample_kernel, 150 * 1024, "sample")) return rc_;
   const SampleP p{logits, seqs, done, n_done, next_tok, B, V, max_len, cur_len, min_length, eos_id, pad_id, top_k, top_p,
                   rep_penalty, (uint32_t)(seed & 0xffffffffu), (uint32_t)(seed >> 32), (uint32_t)step, (uint32_t)row_offset};
   hipLaunchKernelGGL(sample_kernel, dim3(B), dim3(256), lds, (hipStream_t)stream, p);

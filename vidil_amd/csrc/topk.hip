@@ -52,13 +52,8 @@ extern "C" int vidil_topk_rows(const float* x, int64_t row_stride, int32_t R, in
     vidil_set_error("topk_rows: rows of %d values do not fit the LDS row buffer (<= 38400)", N);
     return VIDIL_EUNSUP;
   }
-  static unsigned long long attr_set = 0;   // (one bit per device: vidil_first_on_device)
-  if (vidil_first_on_device(&attr_set)) {
-    if (hipFuncSetAttribute((const void*)topk_rows_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024) != hipSuccess) {
-      vidil_set_error("topk_rows: hipFuncSetAttribute failed");
-      return VIDIL_ELAUNCH;
-    }
-  }
+  static std::atomic<unsigned long long> attr_set{0};   // (one bit per device that has the opt-in: vidil_lds_opt_in)
+  if (const int rc_ = vidil_lds_opt_in(attr_set, (const void*)topk_rows_kernel, 150 * 1024, "topk_rows")) return rc_;
   hipLaunchKernelGGL(topk_rows_kernel, dim3(R), dim3(256), lds, (hipStream_t)stream, x, row_stride, N, k, out_v, out_i);
   VIDIL_CHECK_LAUNCH("topk_rows");
   return VIDIL_OK;

@@ -96,6 +96,46 @@ def _comm_device():
     return torch.device("cpu")
 
 
+#: backends whose ProcessGroup implements ``gather`` (torch 2.x: ProcessGroupNCCL — RCCL on ROCm — and ProcessGroupGloo both do;
+#: ucc / mpi builds are not exercised here and take the all_gather form)
+_GATHER_BACKENDS = ("nccl", "gloo")
+
+
+def _gather_supported():
+    """Same answer on every rank by construction: the environment switch and the backend's name, nothing measured."""
+    if os.environ.get("VIDIL_GATHER", "gather") == "allgather":
+        return False
+    return str(dist.get_backend()).lower() in _GATHER_BACKENDS
+
+
+def ranks_seen():
+    """How many DISTINCT devices the job's ranks sit on: an ``all_gather`` of a 16-byte device identity (the GPU's UUID; host
+    name hash + pid for a CPU rank), counted on every rank.  An N-GPU run proves "one rank per GPU, N different GPUs" in its
+    own output with it (bench.py: ``config.ranks_seen``)."""
+    import hashlib
+    import socket
+
+    ident = torch.zeros(16, dtype=torch.uint8)
+    if torch.cuda.is_available() and _comm_device().type == "cuda":
+        idx = torch.cuda.current_device()
+        props = torch.cuda.get_device_properties(idx)
+        uuid = getattr(props, "uuid", None)
+        if uuid is not None and hasattr(uuid, "bytes"):
+            raw = bytes(uuid.bytes)[:16]
+        else:   # (no UUID from this torch build: host + PCI bus id / ordinal still keeps the GPUs of a job apart)
+            raw = hashlib.sha1(f"{socket.gethostname()}:{getattr(props, 'pci_bus_id', idx)}:{idx}".encode()).digest()[:16]
+    else:
+        raw = hashlib.sha1(f"{socket.gethostname()}:{os.getpid()}".encode()).digest()[:16]
+    ident[:len(raw)] = torch.frombuffer(bytearray(raw), dtype=torch.uint8)
+    if not is_dist_avail_and_initialized():
+        return 1
+    dev = _comm_device()
+    mine = ident.to(dev)
+    every = [torch.zeros(16, dtype=torch.uint8, device=dev) for _ in range(dist.get_world_size())]
+    dist.all_gather(every, mine)
+    return len({bytes(t.cpu().numpy().tobytes()) for t in every})
+
+
 def gather_json(obj):
     """Gather one JSON-serialisable object per rank (rank order); rank 0 gets the list, other ranks get None.
 
@@ -103,8 +143,8 @@ def gather_json(obj):
     of the UTF-8 bytes padded to the longest payload (run_video_CapFilt.py:261-291 / run_visual_tokenization.py:447-463: only
     rank 0 merges and writes).  RCCL (backend 'nccl') moves device buffers over xGMI, Gloo moves host buffers.  The same code
     path runs for every world size including 1, so what an 8-GPU job executes is what the one-GPU box has already executed
-    (tests/test_dist_gpu.py).  Round 5: a true gather — round 4's second ``all_gather`` landed every rank's padded payload on
-    every rank; it remains as the fallback for a backend without ``gather`` ($VIDIL_GATHER=allgather forces it)."""
+    (tests/test_dist_gpu.py).  A true gather since round 5; ``all_gather`` of the payloads remains for a backend known not to
+    implement ``gather`` and behind $VIDIL_GATHER=allgather (``_gather_supported``: decided before the collective)."""
     if not is_dist_avail_and_initialized():
         return [obj]
     dev = _comm_device()
@@ -118,15 +158,14 @@ def gather_json(obj):
     mine = torch.zeros(cap, dtype=torch.uint8)
     mine[:len(raw)] = torch.frombuffer(bytearray(raw), dtype=torch.uint8)
     mine = mine.to(dev)
-    use_gather = os.environ.get("VIDIL_GATHER", "gather") != "allgather"
-    bufs = None
+    # the collective is chosen BEFORE any is issued, from facts every rank shares (the env switch and the backend's name):
+    # nothing is decided by catching an exception around a collective — an error raised on some ranks only (an OOM on rank 0)
+    # would otherwise send those to another collective than the rest of the job sits in.  Real errors propagate.
+    use_gather = _gather_supported()
     if use_gather:
-        try:
-            bufs = [torch.empty(cap, dtype=torch.uint8, device=dev) for _ in range(world)] if rank == 0 else None
-            dist.gather(mine, gather_list=bufs, dst=0)
-        except (RuntimeError, NotImplementedError):       # a backend without gather: every rank lands here alike
-            use_gather = False
-    if not use_gather:
+        bufs = [torch.empty(cap, dtype=torch.uint8, device=dev) for _ in range(world)] if rank == 0 else None
+        dist.gather(mine, gather_list=bufs, dst=0)
+    else:
         bufs = [torch.empty(cap, dtype=torch.uint8, device=dev) for _ in range(world)]
         dist.all_gather(bufs, mine)
     if rank != 0:

@@ -87,6 +87,8 @@ def gemm(a, w, bias=None, **kw):
         without the f32 round trip through ``split3``; ``out`` (f32), if given as well, also receives the f32 rows.
       * split_k=True: ``a`` holds [x_hi | x_lo | x_hi] rows and ``w`` [W_hi | W_hi | W_lo] (packing.w3): the error-compensated
         product of the parity precision mode; the library may form the three products inside one K loop (vidil_gemm_args.split_k).
+        ``a_planes=2``: only planes hi | lo of ``a`` were written (a ``planes=2`` / ``split3_planes=2`` producer) — the call fails
+        with EINVAL instead of silently reading the third plane when it does not qualify for the K-loop form.
       * LayerNorm folded into a pre-LN block's GEMM pair (vidil_gemm_args.ln_fold): the residual GEMM passes
         ``out16=`` (T16 copy of the f32 stream it writes) and ``ln_stats_out=`` (per-row partial sums), the next
         GEMM passes that copy as ``a`` with ``ln=(colsum, eps, stats)`` and weights / bias folded by
@@ -104,6 +106,20 @@ def split_k_in_loop() -> bool:
     return bool(_lib.load().vidil_gemm_split_k_in_loop())
 
 
+def split_k_serves(a, w, bias=None, **kw) -> bool:
+    """Per CALL (vidil_gemm_split_k_serves): True when ``gemm(a, w, bias, split_k=True, **kw)`` would take the K-loop form and
+    read planes hi | lo of ``a`` only.  A producer may leave the third plane of its rows unwritten only if this holds for EVERY
+    consumer of those rows (process-wide ``split_k_in_loop()`` is necessary, not sufficient: the per-head epilogue with fewer
+    than 8 tokens per sequence, or an unaligned vector, takes the plain K = 3 Kl product).  Launches nothing."""
+    kw = dict(kw, split_k=True)
+    kw.pop("a_planes", None)
+    g, _ = _gemm_build(a, w, bias, **kw)
+    rc = _lib.load().vidil_gemm_split_k_serves(C.byref(g))
+    if rc < 0:
+        check(rc, "gemm_split_k_serves")
+    return rc == 1
+
+
 def gemm_kernel_name(a, w, bias=None, **kw):
     """The kernel instantiation ``gemm`` would launch for these arguments, as rocprofv3 spells it."""
     g, _ = _gemm_build(a, w, bias, **kw)
@@ -114,7 +130,7 @@ def gemm_kernel_name(a, w, bias=None, **kw):
 
 def _gemm_build(a, w, bias=None, *, out=None, out_dtype=None, act=ACT_NONE, resid=None,
                 heads=None, patch=None, arena=None, M=None, lda=None, out16=None, ln_stats_out=None, ln=None, w_scale=None,
-                dtype16=None, rln=None, split3_out=None, split_k=False, split3_planes=3):
+                dtype16=None, rln=None, split3_out=None, split_k=False, split3_planes=3, a_planes=3):
     K_ = w.shape[1]
     if lda is None:
         M, Ka = a.shape
@@ -144,7 +160,11 @@ def _gemm_build(a, w, bias=None, *, out=None, out_dtype=None, act=ACT_NONE, resi
         g.dtype16 = _dt(t16, "gemm.dtype16")
         g.w_scale = _ptr(w_scale, torch.float32, "gemm.w_scale")
     g.bias = _ptr(bias, torch.float32, "gemm.bias")
-    g.split_k = 1 if split_k else 0        # A = [x_hi | x_lo | x_hi] rows, W = [W_hi | W_hi | W_lo] (the parity mode's operands)
+    # A = [x_hi | x_lo | x_hi] rows, W = [W_hi | W_hi | W_lo] (the parity mode's operands); a_planes=2: the producer of ``a`` wrote
+    # planes hi | lo only — the library then refuses (EINVAL) any launch that would read the third instead of the K-loop form
+    if a_planes not in (2, 3) or (a_planes == 2 and not split_k):
+        raise VidilHipError(f"gemm: a_planes={a_planes} (2 needs split_k=True)")
+    g.split_k = (2 if a_planes == 2 else 1) if split_k else 0
     g.M, g.N, g.K = M, N, K
     g.lda = 0 if lda is None else lda
     g.act = act

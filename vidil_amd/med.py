@@ -432,12 +432,26 @@ class BertModel(PackedCache, nn.Module):
         o3 = torch.empty((M, 3 * C), dtype=cdt, device=dev)
         tmp = torch.empty((M, C), dtype=torch.float32, device=dev)
         inter3 = torch.empty((M, 3 * cfg.intermediate_size), dtype=cdt, device=dev)
-        # (fc2 consumes these rows as a split_k launch with the f32 epilogue: in the K-loop form it reads planes hi | lo only, so fc1
-        #  need not write the third; with the f32-row attention kinds the same holds for EVERY consumer of h3 / o3 — Q|K|V, the
-        #  cross query, both output projections, fc1 — while kind "16" feeds h3 to arena / short-sequence scatter epilogues,
-        #  which run the plain K = 3 Kl product and read all three planes)
-        planes = 2 if K.split_k_in_loop() else 3
-        planes_h = planes if parity_attention_f32(self) else 3
+        # Which producers may leave the third plane of their [hi | lo | hi] rows unwritten: only those whose EVERY
+        # consumer takes the K-loop form of the compensated product, asked per CALL (K.split_k_serves: the process-wide switch
+        # is necessary, not sufficient).  inter3 feeds fc2 (f32 epilogue); with the f32-row attention kinds h3 / o3 feed Q|K|V,
+        # the cross query, both output projections and fc1, all with the f32 epilogue; kind "16" feeds h3 to arena / short-sequence
+        # scatter epilogues, which run the plain K = 3 Kl product over all three planes.  The consumers state a_planes, so a
+        # launch that would read an unwritten plane fails (EINVAL) instead of computing on it.
+        f32_attn, arith = parity_attention_f32(self), parity_attention_arith(self)
+        qkv32 = torch.empty((M, 3 * C), dtype=torch.float32, device=dev) if f32_attn else None
+        q32 = torch.empty((M, C), dtype=torch.float32, device=dev) if f32_attn and cross is not None else None
+        d0 = p["layers"][0]
+        planes = planes_h = 3
+        if K.split_k_in_loop():
+            if K.split_k_serves(inter3, d0["o_w3"], d0["o_b"], out=tmp, resid=h32):
+                planes = 2
+            if f32_attn and planes == 2 and all((
+                    K.split_k_serves(h3, d0["qkv_w3"], d0["qkv_b"], out=qkv32),
+                    K.split_k_serves(o3, d0["ao_w3"], d0["ao_b"], out=tmp, resid=h32),
+                    K.split_k_serves(h3, d0["i_w3"], d0["i_b"], split3_out=inter3, act=K.ACT_GELU_ERF),
+                    cross is None or K.split_k_serves(h3, d0["cq_w3"], d0["cq_b"], out=q32))):
+                planes_h = 2
         if planes == 2 and os.environ.get("VIDIL_POISON_SPLIT3") == "1":       # (developer: NaNs in the unwritten third planes —
             for _b in (inter3,):                               #  any consumer that reads one shows up at once)
                 _b[:, 2 * (_b.shape[1] // 3):] = float("nan")
@@ -447,7 +461,6 @@ class BertModel(PackedCache, nn.Module):
         Nk = t_off + T
         if arena is not None and T > 1 and t_off != 0:
             raise K.VidilHipError("run_layers: a multi-token block can only be appended to a beam arena at position 0")
-        f32_attn, arith = parity_attention_f32(self), parity_attention_arith(self)
         if f32_attn:
             # Q | K | V (and the cross query) stay f32 and row-major, the KV arena and the cross K | V are f32:
             # vidil_attention_f32 reads all of them in place.  (t_off > 0 happens in the arena form only.)
@@ -458,11 +471,14 @@ class BertModel(PackedCache, nn.Module):
                                       "the 16-bit attention kernels — build the DecoderSession / CrossKV under the same $VIDIL_PARITY_ATTN")
             if t_off != 0 and not (arena is not None and T == 1):
                 raise K.VidilHipError("run_layers (parity mode, f32 attention): cached self-attention keys are served by the arena form only")
-            qkv32 = torch.empty((M, 3 * C), dtype=torch.float32, device=dev)
-            q32 = torch.empty((M, C), dtype=torch.float32, device=dev) if cross is not None else None
+            if kv16 and T * max(1, cross_group) > 32 and cross_groups is None and cross_index is None:
+                # (the kv16 form serves at most 32 query rows per image — a DecoderSession's decode steps and shared
+                #  prompt pass; a longer prompt x group must be built with the f32-row cross K|V instead)
+                raise K.VidilHipError(f"run_layers (parity mode, split attention): {T} tokens x {cross_group} sequences per image exceed the 32 "
+                                      "query rows per image the 16-bit cross K/V tiles serve — build the session with tiled_cross=False")
         for i, d in enumerate(p["layers"]):
             if f32_attn:
-                K.gemm(h3, d["qkv_w3"], d["qkv_b"], out=qkv32, split_k=True)
+                K.gemm(h3, d["qkv_w3"], d["qkv_b"], out=qkv32, split_k=True, a_planes=planes_h)
                 if arena is not None and T == 1:
                     arena.k[i][t_off].copy_(qkv32[:, C:2 * C])          # position t_off, slot = producing beam row
                     arena.v[i][t_off].copy_(qkv32[:, 2 * C:])
@@ -490,10 +506,10 @@ class BertModel(PackedCache, nn.Module):
                     K.gemm(h3, d["qkv_w3"][C:], d["qkv_b"][C:], split_k=True,
                            arena=dict(k=arena.k[i], v=arena.v[i], T=T, H=H, part0=1, t_off=0, Tcap=arena.Tcap,
                                       arena_rows=arena.rows, slot_stride=arena_slot_stride))
-            K.gemm(o3, d["ao_w3"], d["ao_b"], out=tmp, resid=h32, split_k=True)
+            K.gemm(o3, d["ao_w3"], d["ao_b"], out=tmp, resid=h32, split_k=True, a_planes=planes_h)
             K.layernorm(tmp, d["ao_g"], d["ao_bt"], eps, out16=h3, out32=h32, split3=True, planes=planes_h)
             if cross is not None and f32_attn:
-                K.gemm(h3, d["cq_w3"], d["cq_b"], out=q32, split_k=True)
+                K.gemm(h3, d["cq_w3"], d["cq_b"], out=q32, split_k=True, a_planes=planes_h)
                 if kv16:
                     K.attention_f32(q32, cross.k[i], cross.vt[i], o3, Bq=rows, H=H, Nq=T, Nk=cross.Te, kv_rows=cross.Tk_cap,
                                     kv_group=cross_group, kv_index=cross_index, group_start=cross_groups, max_group=cross_max_group,
@@ -503,7 +519,7 @@ class BertModel(PackedCache, nn.Module):
                     K.attention_f32(q32, kv[..., :C], kv[..., C:], o3, Bq=rows, H=H, Nq=T, Nk=cross.Te, kv_rows=cross.Te,
                                     kv_group=cross_group, kv_index=cross_index, group_start=cross_groups, max_group=cross_max_group,
                                     arith=arith, planes=planes_h)
-                K.gemm(o3, d["co_w3"], d["co_b"], out=tmp, resid=h32, split_k=True)
+                K.gemm(o3, d["co_w3"], d["co_b"], out=tmp, resid=h32, split_k=True, a_planes=planes_h)
                 K.layernorm(tmp, d["co_g"], d["co_bt"], eps, out16=h3, out32=h32, split3=True, planes=planes_h)
             elif cross is not None:
                 K.gemm(h3, d["cq_w3"], d["cq_b"], heads=dict(q=q, T=T, H=H, part0=0, Tq_cap=T, q_scale=0.125), split_k=True)
@@ -514,8 +530,8 @@ class BertModel(PackedCache, nn.Module):
                             group_start=cross_groups, max_group=cross_max_group, kv_tiled=cross.tiled, split3=True)
                 K.gemm(o3, d["co_w3"], d["co_b"], out=tmp, resid=h32, split_k=True)
                 K.layernorm(tmp, d["co_g"], d["co_bt"], eps, out16=h3, out32=h32, split3=True, planes=planes_h)
-            K.gemm(h3, d["i_w3"], d["i_b"], split3_out=inter3, act=K.ACT_GELU_ERF, split_k=True, split3_planes=planes)
-            K.gemm(inter3, d["o_w3"], d["o_b"], out=tmp, resid=h32, split_k=True)
+            K.gemm(h3, d["i_w3"], d["i_b"], split3_out=inter3, act=K.ACT_GELU_ERF, split_k=True, split3_planes=planes, a_planes=planes_h)
+            K.gemm(inter3, d["o_w3"], d["o_b"], out=tmp, resid=h32, split_k=True, a_planes=planes)
             K.layernorm(tmp, d["o_g"], d["o_bt"], eps, out16=h3, out32=h32, split3=True, planes=planes_h)
         return h32, h3
 

@@ -241,15 +241,24 @@ class VisionTransformer(PackedCache, nn.Module):
         a3 = torch.empty((M, 3 * D), dtype=cdt, device=dev)
         o3 = torch.empty((M, 3 * D), dtype=cdt, device=dev)
         hid3 = torch.empty((M, 3 * Dh), dtype=cdt, device=dev)
-        # (fc2 consumes these rows as a split_k launch with the f32 epilogue: in the K-loop form it reads planes hi | lo only, so fc1
-        #  need not write the third)
-        planes = 2 if K.split_k_in_loop() else 3
+        # (a consumer that takes the K-loop form of the compensated product reads planes hi | lo of its operand rows only, so their
+        #  producer need not write the third — decided per CALL from the blocks' actual consumers (the process-wide
+        #  switch alone is not enough, e.g. the per-head epilogue with fewer than 8 tokens runs the plain K = 3 Kl product); the
+        #  consumers then state a_planes, so a launch that would read an unwritten plane fails instead of computing on it)
+        f32_attn, arith = parity_attention_f32(self), parity_attention_arith(self)
+        qkv32 = torch.empty((M, 3 * D), dtype=torch.float32, device=dev) if f32_attn else None
+        b3 = next((b for b in p["blocks"] if "qkv_w3" in b), None)
+        planes = 3
+        if b3 is not None and K.split_k_in_loop():
+            qkv_kw = dict(out=qkv32) if f32_attn else dict(heads=heads)
+            if (K.split_k_serves(a3, b3["qkv_w3"], b3["qkv_b"], **qkv_kw) and K.split_k_serves(o3, b3["proj_w3"], b3["proj_b"], out=x, resid=x)
+                    and K.split_k_serves(a3, b3["fc1_w3"], b3["fc1_b"], split3_out=hid3, act=K.ACT_GELU_ERF)
+                    and K.split_k_serves(hid3, b3["fc2_w3"], b3["fc2_b"], out=x, resid=x)):
+                planes = 2
         import os
         if planes == 2 and os.environ.get("VIDIL_POISON_SPLIT3") == "1":       # (developer: NaNs in the unwritten third planes —
             for _b in (a3, o3, hid3,):                               #  any consumer that reads one shows up at once)
                 _b[:, 2 * (_b.shape[1] // 3):] = float("nan")
-        f32_attn, arith = parity_attention_f32(self), parity_attention_arith(self)
-        qkv32 = torch.empty((M, 3 * D), dtype=torch.float32, device=dev) if f32_attn else None
         plain = [b for b in p["blocks"] if "qkv_w3" not in b]
         if plain:       # mixed form: the leading blocks on plain 16-bit operands (unfused: LayerNorm kernel + plain GEMM)
             xn = torch.empty((M, D), dtype=cdt, device=dev)
@@ -267,18 +276,20 @@ class VisionTransformer(PackedCache, nn.Module):
                 continue
             K.layernorm(x, b["n1g"], b["n1b"], self.ln_eps, out16=a3, split3=True, planes=planes)
             if f32_attn:    # Q | K | V stay f32 and row-major; the f32 attention reads them in place (no per-head scatter)
-                K.gemm(a3, b["qkv_w3"], b["qkv_b"], out=qkv32, split_k=True)
+                K.gemm(a3, b["qkv_w3"], b["qkv_b"], out=qkv32, split_k=True, a_planes=planes)
                 K.attention_f32(qkv32[:, :D], qkv32[:, D:2 * D], qkv32[:, 2 * D:], o3, Bq=B, H=H, Nq=T, Nk=T, arith=arith, planes=planes)
             else:
-                K.gemm(a3, b["qkv_w3"], b["qkv_b"], heads=heads, split_k=True)
-                K.attention(q, k, vt, o3, Bq=B, H=H, Nq=T, Nk=T, Tq_cap=T, Tk_cap=T, NP=NP, split3=True)
-            K.gemm(o3, b["proj_w3"], b["proj_b"], out=x, resid=x, split_k=True)
+                K.gemm(a3, b["qkv_w3"], b["qkv_b"], heads=heads, split_k=True, a_planes=planes)
+                K.attention(q, k, vt, o3, Bq=B, H=H, Nq=T, Nk=T, Tq_cap=T, Tk_cap=T, NP=NP, split3=True)      # (writes all three planes)
+            K.gemm(o3, b["proj_w3"], b["proj_b"], out=x, resid=x, split_k=True, a_planes=planes if f32_attn else 3)
             K.layernorm(x, b["n2g"], b["n2b"], self.ln_eps, out16=a3, split3=True, planes=planes)
             # (fc1 + erf-GELU in f32, handed to fc2 as [hi | lo | hi] rows by the GEMM's own epilogue: no f32 round trip)
-            K.gemm(a3, b["fc1_w3"], b["fc1_b"], split3_out=hid3, act=K.ACT_GELU_ERF, split_k=True, split3_planes=planes)
-            K.gemm(hid3, b["fc2_w3"], b["fc2_b"], out=x, resid=x, split_k=True)
+            K.gemm(a3, b["fc1_w3"], b["fc1_b"], split3_out=hid3, act=K.ACT_GELU_ERF, split_k=True, split3_planes=planes, a_planes=planes)
+            K.gemm(hid3, b["fc2_w3"], b["fc2_b"], out=x, resid=x, split_k=True, a_planes=planes)
         y32 = torch.empty((M, D), dtype=torch.float32, device=dev)
-        K.layernorm(x, p["norm_g"], p["norm_b"], self.ln_eps, out16=a3 if want16 else None, out32=y32, split3=True, planes=planes)
+        # (the image tokens leave this module: their consumer — BertModel.project_cross_kv, any epilogue, any token count — is not
+        #  known here, so all three planes are written: one launch per forward)
+        K.layernorm(x, p["norm_g"], p["norm_b"], self.ln_eps, out16=a3 if want16 else None, out32=y32, split3=True, planes=3)
         return y32, (a3 if want16 else None)
 
     def _run_blocks_fp8(self, p, x, B, T, q, k, vt, heads, NP, want16):
