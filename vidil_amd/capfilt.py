@@ -126,7 +126,9 @@ class CapFiltEngine:
     config keys (configs/pipeline_config/*.yaml of the reference): caption, filter,
     filter_generated_only, keep_original_caption, threshold, filter_mode, generation_mode,
     do_sentence_tokenization, image_size, vit, caption_model_ckpt, filterer_model_ckpt.
-    Own keys: decode_streams (parts of the batch whose beam searches run side by side on their own streams; default 1:
+    Own keys: tower_chunk_videos (round 6: the ViTs, the CLIP tower and the ITM run over at most this many videos at a time while
+    ONE beam search runs over every image of the batch — the decode steps' GEMMs have 3 rows per image, so a search over the
+    images of several tower chunks runs them at 4x the rows per launch; 0 / absent = no chunking); decode_streams (parts of the batch whose beam searches run side by side on their own streams; default 1:
     measured +0.2 % with 2, -4 % with 4 at 3,072 frames — a decode step already occupies the chip); itm_short_circuit (default False = score every (frame, caption) pair like the reference; True = the
     any()-short-circuit of ``_filter_enqueue``, same kept lists with a fraction of the ITM work).
     """
@@ -176,9 +178,15 @@ class CapFiltEngine:
         cfg = self.config
         Nv, F = frames_u8.shape[0], frames_u8.shape[1]
         st = dict(items=items, Nv=Nv, F=F, tok=None, fy16=None, itm=None)
+        st["spans"] = spans = self.tower_spans(Nv)
         st["flat"] = flat = blip_frames(frames_u8.reshape(Nv * F, *frames_u8.shape[2:]), cfg.get("image_size", 224))
         if cfg["caption"]:
-            _, y16 = self.captioner.visual_encoder.forward_u8(flat, CLIP_MEAN, CLIP_STD)
+            # the caption ViT over one tower chunk at a time (its activations are sized by the chunk), every chunk's image tokens
+            # into ONE beam search: a search is per image and every decode kernel's arithmetic is independent of the rows around
+            # a row, so the captions are those of per-chunk searches (tests/test_models_gpu.py) at a multiple of the rows per launch
+            ys = [self.captioner.visual_encoder.forward_u8(flat[a * F:b * F], CLIP_MEAN, CLIP_STD)[1] for a, b in spans]
+            y16 = ys[0] if len(ys) == 1 else torch.cat(ys)
+            del ys
             if cfg.get("generation_mode", "beam") == "beam":
                 out_tok, _ = self.captioner.generate_ids(y16, Nv * F, num_beams=3, max_length=20, min_length=5,
                                                          streams=cfg.get("decode_streams", 1))
@@ -188,12 +196,20 @@ class CapFiltEngine:
             st["tok"] = self._to_host("tok", out_tok)
         return st
 
+    def tower_spans(self, Nv):
+        """[start, end) video ranges the towers and the ITM run over (config ``tower_chunk_videos``; one span when unset)."""
+        c = int(self.config.get("tower_chunk_videos") or 0)
+        if c <= 0 or Nv <= c:
+            return [(0, Nv)]
+        return [(a, min(a + c, Nv)) for a in range(0, Nv, c)]
+
     @torch.no_grad()
     def encode_filter_frames(self, st):
         """Phase 2 (no host wait): the filter's ViT needs the frames only, so it is queued before the host blocks on the
         caption ids and runs while the captions are decoded to strings, de-duplicated and tokenised again."""
         if self.config["filter"]:
-            _, st["fy16"] = self.filterer.visual_encoder.forward_u8(st["flat"], CLIP_MEAN, CLIP_STD)
+            F = st["F"]
+            st["fy16"] = [self.filterer.visual_encoder.forward_u8(st["flat"][a * F:b * F], CLIP_MEAN, CLIP_STD)[1] for a, b in st["spans"]]
 
     @torch.no_grad()
     def captions_ready(self, st):
@@ -231,7 +247,17 @@ class CapFiltEngine:
                 to_filter.append(None)
         st["generated"], st["to_filter"] = generated, to_filter
         if cfg["filter"]:
-            st["itm"] = self._filter_enqueue(st["fy16"], Nv, F, to_filter, st.get("home"))
+            # the ITM pairs of one tower chunk at a time (a video's pairs only meet that video's frames): the per-image cross K/V of
+            # the filter are sized by the chunk and released behind the chunk's last launch
+            home = st.get("home")
+            st["itm"] = []
+            for (a, b), fy in zip(st["spans"], st["fy16"]):
+                pend = self._filter_enqueue(fy, b - a, F, to_filter[a:b], None if home is None else home[a:b],
+                                            tag=f"{a}:" if len(st["spans"]) > 1 else "")
+                if pend is not None and not pend["short"] and len(st["spans"]) > 1:
+                    pend["cross"] = pend["y16"] = None         # (every launch that reads them is queued: stream-ordered reuse)
+                st["itm"].append(pend)
+            st["fy16"] = None
 
     @torch.no_grad()
     def finish(self, st):
@@ -239,13 +265,15 @@ class CapFiltEngine:
         cfg, items, Nv, F = self.config, st["items"], st["Nv"], st["F"]
         n_pairs = 0
         if cfg["filter"]:
-            kept = self._filter_finish(st["itm"], Nv, F, st["to_filter"])
+            kept = []
+            for (a, b), pend in zip(st["spans"], st["itm"]):
+                kept.extend(self._filter_finish(pend, b - a, F, st["to_filter"][a:b]))
+                n_pairs += pend["n_pairs"] if pend is not None else 0
             for v, item in enumerate(items):
                 if cfg["filter_generated_only"]:
                     item["text"] = list(item.get("text", [])) + kept[v]
                 else:
                     item["text"] = kept[v]
-            n_pairs = st["itm"]["n_pairs"] if st["itm"] is not None else 0
         self.last_stats = dict(videos=Nv, frames=Nv * F, unique_captions=sum(len(g) for g in st["generated"]),
                                itm_pairs=n_pairs)
         return items
@@ -331,7 +359,7 @@ class CapFiltEngine:
             logits = flt.itm_pairs(pend["y16"], pend["n_images"], ids, lens, group_start=group_start,
                                    max_group=int(counts.max()), pair_text=torch.from_numpy(pair_l), cross=pend["cross"])
         prob = torch.nn.functional.softmax(logits, dim=1)[:, 1].contiguous()
-        pend["calls"].append((self._to_host(f"itm{len(pend['calls'])}", prob), pair_c, pair_f))
+        pend["calls"].append((self._to_host(f"itm{pend.get('tag', '')}{len(pend['calls'])}", prob), pair_c, pair_f))
         pend["n_pairs"] += len(pair_c)
 
     def _collect(self, pend):
@@ -341,7 +369,7 @@ class CapFiltEngine:
             pend["prob"][pair_c, pair_f] = prob.numpy()
         pend["calls"] = []
 
-    def _filter_enqueue(self, y16, Nv, F, caps_per_video, home=None):
+    def _filter_enqueue(self, y16, Nv, F, caps_per_video, home=None, tag=""):
         """Queue the filter's text side.  Default: every (frame, caption) pair, as the reference evaluates them, in
         length buckets.  ``itm_short_circuit`` (config, max_filter only): the rule ``max over frames > threshold`` is an
         any(); a generated caption is first scored against the frame it was generated from (``home``), and only the
@@ -355,7 +383,7 @@ class CapFiltEngine:
         ids, lens = flt.tokenize(all_caps)
         lens_np = lens.numpy().astype(np.int64)
         n_caps = np.fromiter((len(c) for c in caps_per_video), dtype=np.int64, count=Nv)
-        pend = dict(ids=ids, lens=lens, y16=y16, F=F, n_images=Nv * F, n_pairs=0, calls=[],
+        pend = dict(ids=ids, lens=lens, y16=y16, F=F, n_images=Nv * F, n_pairs=0, calls=[], tag=tag,
                     cap_video=np.repeat(np.arange(Nv, dtype=np.int64), n_caps),
                     prob=np.full((len(all_caps), F), np.nan, dtype=np.float32), short=False)
         every = np.arange(len(all_caps), dtype=np.int64)

@@ -171,6 +171,11 @@ class BertModel(PackedCache, nn.Module):
     """ITM text encoder / decoder trunk.  ``forward`` is not the generic HF signature: the hot
     path calls ``encode`` (ITM) or is driven by ``BertLMHeadModel``."""
 
+    #: images per cross-attention / cross K|V projection launch of a decode batch (a search over more images — the images of
+    #: several tower chunks — issues these launches per block of this many images: byte-floor kernels whose launch already fills
+    #: the chip, kept at the sizes every per-unit offset of theirs has been exercised at)
+    MAX_IMAGES_PER_LAUNCH = 4096
+
     def __init__(self, config, add_pooling_layer=False):
         super().__init__()
         if add_pooling_layer:
@@ -276,18 +281,18 @@ class BertModel(PackedCache, nn.Module):
                     K.gemm(enc16, d["ckv_w3"], d["ckv_b"], out=kv32[i].view(B * Te, 2 * C), split_k=True)
                 return CrossKV(kv32, ph, B, Te, 0, f32=True)
 
-            def kv_gemm(d, **heads):
-                K.gemm(enc16, d["ckv_w3"], d["ckv_b"], heads=heads, split_k=True)
+            def kv_gemm(d, r0=0, r1=None, **heads):
+                K.gemm(enc16[r0:r1], d["ckv_w3"], d["ckv_b"], heads=heads, split_k=True)
         elif self.fp8 and "ckv_w8" in p["layers"][0] and enc16.shape[1] % 128 == 0:
             # fp8 tower mode (BASELINE config 5): e4m3 image tokens x e4m3 K|V weights, K / V written in the 16-bit type
             # (clamped first: torch's e4m3 cast does not saturate — 470 becomes NaN — while every device-side conversion does)
             enc8 = enc16.clamp(-448.0, 448.0).to(FP8)
 
-            def kv_gemm(d, **heads):
-                K.gemm(enc8, d["ckv_w8"], d["ckv_b"], w_scale=d["ckv_s"], dtype16=cdt, heads=heads)
+            def kv_gemm(d, r0=0, r1=None, **heads):
+                K.gemm(enc8[r0:r1], d["ckv_w8"], d["ckv_b"], w_scale=d["ckv_s"], dtype16=cdt, heads=heads)
         else:
-            def kv_gemm(d, **heads):
-                K.gemm(enc16, d["ckv_w"], d["ckv_b"], heads=heads)
+            def kv_gemm(d, r0=0, r1=None, **heads):
+                K.gemm(enc16[r0:r1], d["ckv_w"], d["ckv_b"], heads=heads)
         if tiled:
             Tc = (Te + 31) // 32 * 32
             L = len(p["layers"])
@@ -297,8 +302,12 @@ class BertModel(PackedCache, nn.Module):
             else:
                 k = torch.empty((L, B, H, Tc, 64), dtype=cdt, device=dev)
                 v = torch.empty((L, B, H, Tc, 64), dtype=cdt, device=dev)
+            # (the images of several tower chunks — a decode batch, round 6 — are projected MAX_IMAGES_PER_LAUNCH at a time: the
+            #  launch sizes the tower-sized path has always run, whatever the search holds)
             for i, d in enumerate(p["layers"]):
-                kv_gemm(d, k=k[i], vt=v[i], T=Te, H=H, part0=1, t_off=0, Tk_cap=Tc, tiled=True)
+                for b0 in range(0, B, self.MAX_IMAGES_PER_LAUNCH):
+                    b1 = min(B, b0 + self.MAX_IMAGES_PER_LAUNCH)
+                    kv_gemm(d, b0 * Te, b1 * Te, k=k[i][b0:b1], vt=v[i][b0:b1], T=Te, H=H, part0=1, t_off=0, Tk_cap=Tc, tiled=True)
             return CrossKV(k, v, B, Te, Tc, tiled=True, Tk_cap=Tc)
         NPt = (Te + 15) // 16 * 16
         NP = 0 if v_rowmajor else NPt
@@ -403,15 +412,26 @@ class BertModel(PackedCache, nn.Module):
                 # every query batch that shares an image (the beams of a caption search, the captions of a
                 # frame) is served by one fetch of that image's K/V: see vidil_attention's grouping forms
                 K.gemm(h16, d["cq_w"], d["cq_b"], heads=dict(q=q, T=T, H=H, part0=0, Tq_cap=T, q_scale=0.125))
-                K.attention(q, cross.k[i], cross.vt[i], o, Bq=rows, H=H, Nq=T, Nk=cross.Te, Tq_cap=T,
-                            Tk_cap=cross.Tk_cap, NP=cross.NP, kv_group=cross_group, kv_index=cross_index,
-                            group_start=cross_groups, max_group=cross_max_group, kv_tiled=cross.tiled)
+                for b0, b1 in self._cross_blocks(cross, cross_index, cross_groups):
+                    r0, r1 = b0 * cross_group, min(rows, b1 * cross_group)
+                    K.attention(q[r0:r1], cross.k[i][b0:b1], cross.vt[i][b0:b1], o[r0 * T:r1 * T], Bq=r1 - r0, H=H, Nq=T, Nk=cross.Te,
+                                Tq_cap=T, Tk_cap=cross.Tk_cap, NP=cross.NP, kv_group=cross_group, kv_index=cross_index,
+                                group_start=cross_groups, max_group=cross_max_group, kv_tiled=cross.tiled)
                 K.gemm(o, d["co_w"], d["co_b"], out=tmp, resid=h32)
                 K.layernorm(tmp, d["co_g"], d["co_bt"], eps, out16=h16, out32=h32)
             K.gemm(h16, d["i_w"], d["i_b"], out=inter, act=K.ACT_GELU_ERF)
             K.gemm(inter, d["o_w"], d["o_b"], out=tmp, resid=h32)
             K.layernorm(tmp, d["o_g"], d["o_bt"], eps, out16=h16, out32=h32)
         return h32, h16
+
+    def _cross_blocks(self, cross, cross_index, cross_groups):
+        """Image ranges [b0, b1) of the cross-attention launches of one layer: the whole batch, or — uniform grouping (a beam
+        search: image b serves query batches b * group .. b * group + group - 1) over more than MAX_IMAGES_PER_LAUNCH images —
+        blocks of that many images, each a launch over contiguous slices of Q, K, V and the output rows."""
+        B, n = cross.B, self.MAX_IMAGES_PER_LAUNCH
+        if cross_index is not None or cross_groups is not None or B <= n:
+            return [(0, B)]
+        return [(b0, min(B, b0 + n)) for b0 in range(0, B, n)]
 
     def _run_layers_parity(self, p, h32, h3, *, rows, T, self_k, self_vt, t_off, Tk_cap, NPs, causal, kv_len, cross, cross_index,
                            cross_group, cross_groups, cross_max_group, ws, arena, arena_slot_stride):
@@ -511,9 +531,11 @@ class BertModel(PackedCache, nn.Module):
             if cross is not None and f32_attn:
                 K.gemm(h3, d["cq_w3"], d["cq_b"], out=q32, split_k=True, a_planes=planes_h)
                 if kv16:
-                    K.attention_f32(q32, cross.k[i], cross.vt[i], o3, Bq=rows, H=H, Nq=T, Nk=cross.Te, kv_rows=cross.Tk_cap,
-                                    kv_group=cross_group, kv_index=cross_index, group_start=cross_groups, max_group=cross_max_group,
-                                    arith=1, kv16=True, planes=planes_h)
+                    for b0, b1 in self._cross_blocks(cross, cross_index, cross_groups):
+                        r0, r1 = b0 * cross_group * T, min(rows, b1 * cross_group) * T
+                        K.attention_f32(q32[r0:r1], cross.k[i][b0:b1], cross.vt[i][b0:b1], o3[r0:r1], Bq=(r1 - r0) // T, H=H, Nq=T, Nk=cross.Te,
+                                        kv_rows=cross.Tk_cap, kv_group=cross_group, kv_index=cross_index, group_start=cross_groups,
+                                        max_group=cross_max_group, arith=1, kv16=True, planes=planes_h)
                 else:
                     kv = cross.k[i]                                     # f32 [B, Te, 2C]: keys | values
                     K.attention_f32(q32, kv[..., :C], kv[..., C:], o3, Bq=rows, H=H, Nq=T, Nk=cross.Te, kv_rows=cross.Te,

@@ -185,7 +185,14 @@ class VisualTokenizer:
         """GPU half of ``process`` without any host wait: queues the tower + ontology scan and a copy of the top-k
         indices into pinned host memory; returns (host tensor, event behind the copy) for ``assemble``."""
         Nv, F = frames_u8.shape[0], frames_u8.shape[1]
-        idx, _ = self.frame_topk(frames_u8.reshape(Nv * F, *frames_u8.shape[2:]))
+        flat = frames_u8.reshape(Nv * F, *frames_u8.shape[2:])
+        # (a batch of several tower chunks — config ``tower_chunk_videos``, see CapFiltEngine — goes through the tower and the scan
+        #  one chunk at a time: activations sized by the chunk; a frame's tokens do not depend on the frames around it)
+        c = int(self.config.get("tower_chunk_videos") or 0) * F
+        if c > 0 and flat.shape[0] > c:
+            idx = torch.cat([self.frame_topk(flat[a:a + c])[0] for a in range(0, flat.shape[0], c)])
+        else:
+            idx, _ = self.frame_topk(flat)
         if self._pinned is None or self._pinned.shape != idx.shape:
             self._pinned = torch.empty(idx.shape, dtype=idx.dtype, pin_memory=True)
         self._pinned.copy_(idx, non_blocking=True)
