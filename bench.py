@@ -850,7 +850,8 @@ def main():
     torch.cuda.synchronize()
     dt = vdist.max_over_ranks(time.perf_counter() - t0)
     stats = dict(engine.last_stats)
-    log(f"timed region done: {dt:.3f}s for {args.steps} steps")
+    peak_gib = torch.cuda.max_memory_allocated() / 2**30
+    log(f"timed region done: {dt:.3f}s for {args.steps} steps (peak device memory {peak_gib:.0f} GiB of 288 GB HBM3E)")
 
     result = None
     if rank == 0:
@@ -871,7 +872,7 @@ def main():
                                    f"(beam 3, 16 decode steps) + CapFilt ITM + CLIP {'ViT-B/32' if args.clip == 'b32' else 'ViT-L/14'} visual tokens vs 42,759-class "
                                    f"vg-sized ontology; random-init weights (seed 0)",
                        "videos_per_step_per_gpu": Nv, "frames_per_video": F, "tower_chunk_videos": args.tower_chunk_videos or Nv,
-                       "decode_batch_images": Nv * F,
+                       "decode_batch_images": Nv * F, "peak_device_memory_gib": round(peak_gib, 1),
                        "unique_captions_per_video": round(c_mean, 2), "itm_pairs_per_step": stats["itm_pairs"],
                        "itm_schedule": ("short circuit: own frame first, other frames only for captions that failed there"
                                         if args.itm_short_circuit else "every (frame, caption) pair, as the reference"),

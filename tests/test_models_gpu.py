@@ -1056,6 +1056,42 @@ def test_interleaved_pipeline_gives_the_results_of_the_two_engines_called_in_tur
         assert all(len(it["unfiltered_text"]) >= 1 for it in b)
 
 
+def test_tower_chunks_with_one_beam_search_give_the_unchunked_results(full_models, monkeypatch):
+    """Round 6: `tower_chunk_videos` runs the ViTs, the CLIP tower and the ITM over a few videos at a time and ONE beam
+    search over every image of the batch; the cross K/V projection and the decode steps' cross-attention of such a search are launched
+    per block of BertModel.MAX_IMAGES_PER_LAUNCH images.  A search is per image and a pair's ITM score / a frame's tokens do not
+    depend on the batch around them: items and visual tokens must be those of the unchunked engine, to the last character — with
+    ragged chunks (5 videos in chunks of 2), with several image blocks per launch sequence, and through the short circuit."""
+    from vidil_amd.capfilt import CapFiltEngine
+    from vidil_amd.med import BertModel
+    from vidil_amd.pipeline import FramePipeline
+    from vidil_amd.visual_tokenization import VisualTokenizer
+
+    fm = full_models
+    Nv, F = 5, 8
+    u8 = torch.from_numpy(synthetic_frames(Nv, F, first_video=41)).to(DEV)
+    emb, texts = _ontology()
+    res = {}
+    for chunk, blk, short in ((0, None, False), (2, None, False), (2, 12, False), (3, 7, True), (0, None, True)):
+        if blk is not None:
+            monkeypatch.setattr(BertModel, "MAX_IMAGES_PER_LAUNCH", blk)      # 40 images -> 4 / 6 launches per layer
+        cfg = dict(caption=True, filter=True, filter_generated_only=True, keep_original_caption=False, threshold=0.5,
+                   filter_mode="max_filter", generation_mode="beam", image_size=224, vit="base", topk_visualize=5,
+                   do_sentence_tokenization=False, tower_chunk_videos=chunk, itm_short_circuit=short)
+        eng = CapFiltEngine(cfg, DEV, captioner=fm["cap"], filterer=fm["itm"])
+        vt = VisualTokenizer(cfg, fm["clip"], texts, emb, DEV)
+        assert eng.tower_spans(Nv) == ([(0, Nv)] if chunk == 0 else [(a, min(a + chunk, Nv)) for a in range(0, Nv, chunk)])
+        fm["cap"].__dict__.pop("_decode_state", None)                         # (sessions are keyed by shape, not by block size)
+        items = [dict(video_id=f"video{v}", text=[]) for v in range(Nv)]
+        res[(chunk, blk, short)] = FramePipeline(eng, vt).process(items, u8) + (eng.last_stats["itm_pairs"],)
+        monkeypatch.undo()
+    base = res[(0, None, False)]
+    assert res[(2, None, False)] == base and res[(2, 12, False)] == base
+    assert res[(3, 7, True)][:2] == res[(0, None, True)][:2] == base[:2]        # (the short circuit scores fewer pairs, keeps the same)
+    assert all(len(it["unfiltered_text"]) >= 1 for it in base[0])
+    fm["cap"].__dict__.pop("_decode_state", None)
+
+
 def test_itm_short_circuit_keeps_exactly_the_captions_the_exhaustive_schedule_keeps(full_models):
     """max_filter is an any() over the frames: scoring a caption on its own frame first and on the other frames only
     if it failed there must give the same kept lists for every threshold, with fewer pairs scored whenever some
