@@ -120,7 +120,7 @@ typedef struct vidil_gemm_args {
    * producer (EPI_F32, the residual GEMM that writes the stream x): out16 != NULL additionally stores
    *   T16(x) [M, ldo16] — the RAW stream in the operand type — and, per row and per 64 output columns, the
    *   partial (sum, sum of squares) of the f32 values into ln_stats_out f32 [M][N/64][2] (N % 64 == 0);
-   * consumer (EPI_F16 / EPI_HEADS with ln_fold != 0; needs K == the LayerNorm width D): A is that raw T16(x),
+   * consumer (EPI_F16 / EPI_HEADS / EPI_ARENA (round 6) with ln_fold != 0; needs K == the LayerNorm width D): A is that raw T16(x),
    *   W is W' = T16(gamma (.) W) (gamma scales the K axis), bias is b' = b + W·beta, ln_colsum[n] = sum_k W'[n][k],
    *   ln_stats = the producer's partials [M][K/64][2]; the kernel combines them into mean_m, rstd_m and applies
    *   y[m][n] = rstd_m * (acc[m][n] - mean_m * ln_colsum[n]) + b'[n]  in its epilogue (then act / the

@@ -423,6 +423,80 @@ def test_itm_with_layernorms_folded_into_the_text_stack_vs_oracle_and_vs_the_unf
     assert 0 < d < 2e-3                      # different rounding point, same function (0 would mean the path did not switch)
 
 
+def test_decoder_with_layernorms_folded_into_its_gemms_vs_the_unfused_path_and_the_oracle(full_models, monkeypatch):
+    """Round 6 (models/med.py:228-239,291-317,333-383): decoder sessions run their post-LN stack without
+    LayerNorm launches (DecoderSession.fused_ln -> BertModel._run_layers_fused with the KV arena: LN-folded Q|K|V with the arena
+    epilogue, cross query and fc1; the residual LayerNorm formed inside the next residual GEMM).  Same function as the unfused
+    launches up to the rounding point of the GEMM operands (raw sums instead of LN(sums) are rounded to 16 bits): all 16
+    teacher-forced passes of a beam search agree with the unfused path to a fraction of the plain-mode tolerance, both stay
+    within that tolerance of the fp32 oracle, and the choice is a property of the session, not of its size."""
+    from oracle import beam_ref, clip_ref, med_ref, vit_ref
+    from vidil_amd.blip import DecoderSession
+
+    fm = full_models
+    cap, sd = fm["cap"], fm["sd_cap"]
+    B, nb = 3, 3
+    u8 = synthetic_frames(1, B, first_video=7)[0]
+    with torch.no_grad():
+        y_ref = vit_ref.vit_forward(sd, clip_ref.preprocess_u8(u8))
+    _, y16 = cap.visual_encoder.forward_u8(torch.from_numpy(u8).to(DEV), clip_ref.CLIP_MEAN, clip_ref.CLIP_STD)
+    enc3 = y_ref.repeat_interleave(nb, dim=0)
+    state, otrace, calls = {}, [], []
+
+    def step(ids, beam_idx):
+        calls.append((ids.copy(), None if beam_idx is None else beam_idx.copy()))
+        with torch.no_grad():
+            past = None if beam_idx is None else med_ref.reorder_cache(state["cache"], torch.from_numpy(beam_idx))
+            lg, state["cache"] = med_ref.decoder_logits(sd, torch.from_numpy(ids), enc3, past)
+        return lg.numpy()
+
+    prompt = cap.prompt_ids(B, "cpu").long().numpy()
+    beam_ref.beam_search(step, prompt, num_beams=nb, max_length=20, min_length=5, eos_token_id=102, pad_token_id=0, trace=otrace)
+
+    def teacher_forced(fused, tiled):
+        monkeypatch.setenv("VIDIL_DECODE_FUSE_LN", "1" if fused else "0")
+        sess = DecoderSession(cap.text_decoder, y16, B, nb, 20, tiled_cross=tiled)
+        assert sess.fused_ln == fused
+        out = []
+        for s_, (ids, beam_idx) in enumerate(calls):
+            if s_ == 0:
+                lg = sess.prefill(torch.from_numpy(ids).to(torch.int32).reshape(-1).to(DEV), ids.shape[1])
+            else:
+                lg = sess.step(torch.from_numpy(ids[:, -1].copy()).to(torch.int32).to(DEV),
+                               torch.from_numpy(beam_idx).to(torch.int32).to(DEV), ids.shape[1] - 1)
+            out.append(lg.float().cpu().clone())
+        return out
+
+    plain = teacher_forced(False, True)
+    fused = teacher_forced(True, True)
+    fused_rm = teacher_forced(True, False)                 # (row-major cross K / V^T: the other attention kernels, same folds)
+    worst = 0.0
+    for s_ in range(len(calls)):
+        ref = torch.from_numpy(otrace[s_]["logits"])
+        logits_close(plain[s_], ref, label=f"unfused step {s_}")
+        logits_close(fused[s_], ref, label=f"LN-folded step {s_}")
+        logits_close(fused_rm[s_], ref, label=f"LN-folded step {s_} (row-major cross K/V)")
+        scale = max(1.0, ref.abs().max().item())
+        worst = max(worst, (fused[s_] - plain[s_]).abs().max().item() / scale)
+    print(f"\nLN-folded decoder vs the unfused launches: max |d logit| = {worst:.2e} of the logit scale over 16 passes")
+    assert worst < PLAIN_F16_REL                          # (the two differ by operand roundings only, like either from the oracle)
+    # the shared prompt pass (one row per image) writes the same arena as the per-row one reads back: first decode step equal
+    monkeypatch.setenv("VIDIL_DECODE_FUSE_LN", "1")
+    sa = DecoderSession(cap.text_decoder, y16, B, nb, 20, tiled_cross=True)
+    ids0 = torch.from_numpy(calls[0][0]).to(torch.int32)
+    lg_shared = sa.prefill(ids0[::nb].reshape(-1).to(DEV), ids0.shape[1], shared=True)
+    assert torch.equal(lg_shared.cpu(), fused[0][::nb])
+    ids1, bi1 = calls[1]
+    lg1 = sa.step(torch.from_numpy(ids1[:, -1].copy()).to(torch.int32).to(DEV), torch.from_numpy(bi1).to(torch.int32).to(DEV), ids1.shape[1] - 1)
+    assert torch.equal(lg1.cpu(), fused[1])
+    # batch independence: the same images inside a larger search give the same logits bit for bit
+    y16_big = torch.cat([y16, y16, y16])                    # 9 images: the same three, three times
+    sb = DecoderSession(cap.text_decoder, y16_big, 3 * B, nb, 20, tiled_cross=True)
+    big = sb.prefill(ids0[::nb].repeat(3, 1).reshape(-1).to(DEV), ids0.shape[1], shared=True)
+    assert torch.equal(big[:B].cpu(), lg_shared.cpu()) and torch.equal(big[2 * B:].cpu(), lg_shared.cpu())
+    cap.__dict__.pop("_decode_state", None)
+
+
 def test_captured_decode_graphs_replay_the_eager_result(full_models):
     """generate_ids reuses its session per shape: call 1 runs eagerly, call 2 captures one HIP graph per decode step,
     call 3+ replays them.  All must produce the tokens of a fresh eager search — also on a DIFFERENT batch, which

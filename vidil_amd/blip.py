@@ -107,6 +107,11 @@ class DecoderSession:
         self.arena = BeamArena(self.L, self.Tcap, self.R, cfg.hidden_size, dev, dtype=arena_dtype)
         self.ws_prefill, self.ws_step = {}, {}
         self.logits = None
+        # round 6: the decoder's post-LN stack without LayerNorm launches (BertModel._run_layers_fused: raw sums + row partials
+        # between the GEMMs, the LayerNorms folded into the consuming / residual GEMMs) — a property of the SESSION, never of its
+        # size: a caption must not depend on how many images share its search ($VIDIL_DECODE_FUSE_LN=0: the unfused launches)
+        self.fused_ln = (os.environ.get("VIDIL_DECODE_FUSE_LN", "1") != "0" and not self.bert.parity
+                         and self.bert._text_fold_ok(enc16.dtype) and cfg.add_cross_attention)
 
     @classmethod
     def like(cls, parent, B):
@@ -125,6 +130,7 @@ class DecoderSession:
         self.arena = BeamArena(pa.L, pa.Tcap, self.R, pa.k.shape[-1], pa.k.device, dtype=pa.k.dtype)
         self.ws_prefill, self.ws_step = {}, {}
         self.logits = None
+        self.fused_ln = parent.fused_ln
         return self
 
     def adopt(self, parent, images, n_pos):
@@ -167,7 +173,7 @@ class DecoderSession:
         self.arena.init_prompt(P, self.nb if shared else 1)
         self.bert.run_layers(h32, h16, rows=rows, T=P, self_k=sk, self_vt=sv, t_off=0, Tk_cap=P, NPs=NPp, causal=True,
                              kv_len=None, cross=self.cross, cross_group=1 if shared else self.nb, ws=self.ws_prefill,
-                             arena=self.arena, arena_slot_stride=self.nb if shared else 1)
+                             arena=self.arena, arena_slot_stride=self.nb if shared else 1, fused=self.fused_ln)
         return self.dec.lm_logits(h16, rows, P, h32=h32)
 
     def step(self, next_tok_i32, beam_idx_i32, past_len):
@@ -178,7 +184,7 @@ class DecoderSession:
         h32, h16 = self.bert.embed(next_tok_i32, 1, past_len)
         self.bert.run_layers(h32, h16, rows=self.R, T=1, self_k=None, self_vt=None, t_off=past_len, Tk_cap=self.Tcap,
                              NPs=0, causal=False, kv_len=None, cross=self.cross, cross_group=self.nb, ws=self.ws_step,
-                             arena=self.arena)
+                             arena=self.arena, fused=self.fused_ln)
         self.logits = self.dec.lm_logits(h16, self.R, 1, out=self.logits, h32=h32)
         return self.logits
 

@@ -384,7 +384,8 @@ int check_args(const vidil_gemm_args& a) {
   VIDIL_REQUIRE(a.lda == 0 || (a.lda >= a.K && a.lda % 8 == 0), "gemm: lda=%d must be 0 or >= K and a multiple of 8", a.lda);
   VIDIL_REQUIRE(((uintptr_t)a.A & 15) == 0 && ((uintptr_t)a.W & 15) == 0, "gemm: operands must be 16-B aligned");
   if (a.ln_fold) {
-    VIDIL_REQUIRE(a.epi == VIDIL_EPI_F16 || a.epi == VIDIL_EPI_HEADS, "gemm/ln_fold: only EPI_F16 / EPI_HEADS consume a folded LayerNorm");
+    VIDIL_REQUIRE(a.epi == VIDIL_EPI_F16 || a.epi == VIDIL_EPI_HEADS || a.epi == VIDIL_EPI_ARENA,
+                  "gemm/ln_fold: only EPI_F16 / EPI_HEADS / EPI_ARENA consume a folded LayerNorm");
     VIDIL_REQUIRE(a.ln_colsum != nullptr && a.ln_stats != nullptr && a.ln_eps >= 0.f, "gemm/ln_fold: null ln_colsum / ln_stats");
     VIDIL_REQUIRE(a.lda == 0 || a.lda == a.K, "gemm/ln_fold: A rows must be dense (K = the LayerNorm width)");
     VIDIL_REQUIRE(a.K <= 1024, "gemm/ln_fold: LayerNorm widths up to 1024 (K=%d)", a.K);

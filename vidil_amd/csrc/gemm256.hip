@@ -420,6 +420,7 @@ template <typename T>
 static int launch256_dispatch(const vidil_gemm_args& a, hipStream_t s) {
   if (a.ln_fold) {
     if (a.epi == VIDIL_EPI_HEADS) return launch256<T, VIDIL_EPI_HEADS, VIDIL_ACT_NONE, true>(a, s);
+    if (a.epi == VIDIL_EPI_ARENA) return launch256<T, VIDIL_EPI_ARENA, VIDIL_ACT_NONE, true>(a, s);   // (round 6: the decode steps' Q|K|V)
     if (a.act == VIDIL_ACT_NONE) return launch256<T, VIDIL_EPI_F16, VIDIL_ACT_NONE, true>(a, s);
     if (a.act == VIDIL_ACT_GELU_ERF) return launch256<T, VIDIL_EPI_F16, VIDIL_ACT_GELU_ERF, true>(a, s);
     return launch256<T, VIDIL_EPI_F16, VIDIL_ACT_QUICK_GELU, true>(a, s);

@@ -607,6 +607,7 @@ int launch4w_dispatch(const vidil_gemm_args& a, hipStream_t s) {
 #else
   if (a.ln_fold) {
     if (a.epi == VIDIL_EPI_HEADS) return launch4w<T, VIDIL_EPI_HEADS, VIDIL_ACT_NONE, true>(a, s);
+    if (a.epi == VIDIL_EPI_ARENA) return launch4w<T, VIDIL_EPI_ARENA, VIDIL_ACT_NONE, true>(a, s);     // (round 6: the decode steps' Q|K|V)
     if (a.act == VIDIL_ACT_NONE) return launch4w<T, VIDIL_EPI_F16, VIDIL_ACT_NONE, true>(a, s);
     if (a.act == VIDIL_ACT_GELU_ERF) return launch4w<T, VIDIL_EPI_F16, VIDIL_ACT_GELU_ERF, true>(a, s);
     return launch4w<T, VIDIL_EPI_F16, VIDIL_ACT_QUICK_GELU, true>(a, s);

@@ -362,14 +362,19 @@ class BertModel(PackedCache, nn.Module):
         if fused is None:
             # encoder batches with cross-attention (the ITM pairs) run without LayerNorm launches, WHATEVER their size: a
             # pair's logits must not depend on how many other pairs share its batch (ranks / tail batches of different
-            # sizes write the same JSON), so the choice cannot depend on M ($VIDIL_FUSE_LN_MIN_ROWS is for experiments)
+            # sizes write the same JSON), so the choice cannot depend on M ($VIDIL_FUSE_LN_MIN_ROWS is for experiments).
+            # Decoder sessions (arena) state their choice themselves (DecoderSession.fused_ln), for the same reason.
             fused = (self._text_fold_ok(cdt) and cross is not None and arena is None and not stop_after_self
                      and M >= int(os.environ.get("VIDIL_FUSE_LN_MIN_ROWS", 0)))
+        elif fused and not (self._text_fold_ok(cdt) and cross is not None and not stop_after_self):
+            raise K.VidilHipError("run_layers(fused=True): the LN-folded text stack needs cross-attention layers, 16-bit operands and "
+                                  "hidden_size % 64 == 0, <= 1024")
         if fused:
             return self._run_layers_fused(h32, h16, rows=rows, T=T, self_k=self_k, self_vt=self_vt, t_off=t_off, Tk_cap=Tk_cap,
                                           NPs=NPs, causal=causal, kv_len=kv_len, cross=cross, cross_index=cross_index,
                                           cross_group=cross_group, cross_groups=cross_groups, cross_max_group=cross_max_group,
-                                          n_layers=n_layers, self_done_first=self_done_first)
+                                          n_layers=n_layers, self_done_first=self_done_first, arena=arena,
+                                          arena_slot_stride=arena_slot_stride)
         if ws is None:
             ws = {}
         q = ws.get("q")
@@ -413,7 +418,7 @@ class BertModel(PackedCache, nn.Module):
                 # frame) is served by one fetch of that image's K/V: see vidil_attention's grouping forms
                 K.gemm(h16, d["cq_w"], d["cq_b"], heads=dict(q=q, T=T, H=H, part0=0, Tq_cap=T, q_scale=0.125))
                 for b0, b1 in self._cross_blocks(cross, cross_index, cross_groups):
-                    r0, r1 = b0 * cross_group, min(rows, b1 * cross_group)
+                    r0, r1 = (0, rows) if (b0, b1) == (0, cross.B) else (b0 * cross_group, b1 * cross_group)
                     K.attention(q[r0:r1], cross.k[i][b0:b1], cross.vt[i][b0:b1], o[r0 * T:r1 * T], Bq=r1 - r0, H=H, Nq=T, Nk=cross.Te,
                                 Tq_cap=T, Tk_cap=cross.Tk_cap, NP=cross.NP, kv_group=cross_group, kv_index=cross_index,
                                 group_start=cross_groups, max_group=cross_max_group, kv_tiled=cross.tiled)
@@ -430,7 +435,7 @@ class BertModel(PackedCache, nn.Module):
         blocks of that many images, each a launch over contiguous slices of Q, K, V and the output rows."""
         B, n = cross.B, self.MAX_IMAGES_PER_LAUNCH
         if cross_index is not None or cross_groups is not None or B <= n:
-            return [(0, B)]
+            return [(0, B)]                           # (one launch over every query row, whatever maps rows to images)
         return [(b0, min(B, b0 + n)) for b0 in range(0, B, n)]
 
     def _run_layers_parity(self, p, h32, h3, *, rows, T, self_k, self_vt, t_off, Tk_cap, NPs, causal, kv_len, cross, cross_index,
@@ -532,7 +537,7 @@ class BertModel(PackedCache, nn.Module):
                 K.gemm(h3, d["cq_w3"], d["cq_b"], out=q32, split_k=True, a_planes=planes_h)
                 if kv16:
                     for b0, b1 in self._cross_blocks(cross, cross_index, cross_groups):
-                        r0, r1 = b0 * cross_group * T, min(rows, b1 * cross_group) * T
+                        r0, r1 = (0, M) if (b0, b1) == (0, cross.B) else (b0 * cross_group * T, b1 * cross_group * T)
                         K.attention_f32(q32[r0:r1], cross.k[i][b0:b1], cross.vt[i][b0:b1], o3[r0:r1], Bq=(r1 - r0) // T, H=H, Nq=T, Nk=cross.Te,
                                         kv_rows=cross.Tk_cap, kv_group=cross_group, kv_index=cross_index, group_start=cross_groups,
                                         max_group=cross_max_group, arith=1, kv16=True, planes=planes_h)
@@ -564,7 +569,7 @@ class BertModel(PackedCache, nn.Module):
 
     def _run_layers_fused(self, h32, h16, *, rows, T, self_k, self_vt, t_off, Tk_cap, NPs, causal, kv_len, cross, cross_index=None,
                           cross_group=1, cross_groups=None, cross_max_group=0, n_layers=None, self_done_first=False,
-                          stop_after_self=False, state_in=None):
+                          stop_after_self=False, state_in=None, arena: "BeamArena" = None, arena_slot_stride=1):
         """run_layers for encoder batches with cross-attention, WITHOUT LayerNorm launches between the GEMMs
         (models/med.py:236-239,306-317 are post-LN: h = LN(x + dense(.)) is the next dense's input AND the next residual).
         The stream is kept as the RAW sums u (f32 in h32's storage, a 16-bit copy in h16's) plus per-row (sum, sum of
@@ -576,7 +581,11 @@ class BertModel(PackedCache, nn.Module):
         stop_after_self: run layer 0's self-attention block only and return the RAW state (h32, h16, partials, (gamma,
         beta)) — what encode_cls computes once per distinct text; state_in = (partials, (gamma, beta)): start from such
         a state (h32 / h16 hold raw sums), so the per-text front and the per-pair rest are the same arithmetic as one
-        pass over the expanded batch."""
+        pass over the expanded batch.
+        arena (round 6, the caption decoder: models/med.py:228-239,291-317,333-383 through the same folds): as run_layers — with
+        T == 1 the new key / value of row r go to arena[position t_off][slot r] straight from the (LN-folded) Q|K|V GEMM's epilogue
+        and attention follows the ancestry table; the prompt block (T > 1, t_off == 0) attends to itself and its K / V are also
+        written to the arena at slots r * arena_slot_stride by a second, equally folded, K|V GEMM."""
         p = self.packed()
         fw = self._folded(p)
         cfg = self.config
@@ -611,9 +620,32 @@ class BertModel(PackedCache, nn.Module):
             wf, bf, cs = fw[i][name]
             return K.gemm(h16, wf, bf, ln=(cs, eps, stats[cur]), **kw)
 
+        if arena is not None and T > 1 and t_off != 0:
+            raise K.VidilHipError("run_layers: a multi-token block can only be appended to a beam arena at position 0")
+
+        def arena_kv(i, d):
+            """the prompt block's K | V once more, in the arena layout (a prompt is a few tokens): the K|V rows of the same
+            (folded) weights — same values as the per-head K / V the block attends to"""
+            kw = dict(arena=dict(k=arena.k[i], v=arena.v[i], T=T, H=H, part0=1, t_off=0, Tcap=arena.Tcap, arena_rows=arena.rows,
+                                 slot_stride=arena_slot_stride))
+            if pend is None:
+                return K.gemm(h16, d["qkv_w"][C:], d["qkv_b"][C:], **kw)
+            wf, bf, cs = fw[i]["qkv"]
+            return K.gemm(h16, wf[C:], bf[C:], ln=(cs[C:], eps, stats[cur]), **kw)
+
         layers = p["layers"][:n_layers]
         for i, d in enumerate(layers):
-            if not (self_done_first and i == 0):
+            if self_done_first and i == 0:
+                pass
+            elif arena is not None and T == 1:
+                consumer("qkv", i, d["qkv_w"], d["qkv_b"],
+                         arena=dict(q=q, k=arena.k[i], v=arena.v[i], T=1, H=H, part0=0, t_off=t_off, Tcap=arena.Tcap,
+                                    arena_rows=arena.rows, slot_stride=1, q_scale=0.125))
+                K.beam_attention(q, arena.k[i], arena.v[i], arena.anc, o, rows=rows, H=H, n_keys=Nk)
+                residual_gemm(o, d["ao_w"], d["ao_b"], d["ao_g"], d["ao_bt"])
+            else:
+                if arena is not None:
+                    arena_kv(i, d)                     # (before the residual GEMM below replaces the stream it reads)
                 consumer("qkv", i, d["qkv_w"], d["qkv_b"],
                          heads=dict(q=q, k=self_k[i], vt=self_vt[i], T=T, H=H, part0=0, t_off=t_off, Tq_cap=T, Tk_cap=Tk_cap,
                                     NP=NPs, q_scale=0.125))
@@ -623,9 +655,11 @@ class BertModel(PackedCache, nn.Module):
             if stop_after_self:
                 return h32, h16, stats[cur], pend
             consumer("cq", i, d["cq_w"], d["cq_b"], heads=dict(q=q, T=T, H=H, part0=0, Tq_cap=T, q_scale=0.125))
-            K.attention(q, cross.k[i], cross.vt[i], o, Bq=rows, H=H, Nq=T, Nk=cross.Te, Tq_cap=T, Tk_cap=cross.Tk_cap,
-                        NP=cross.NP, kv_group=cross_group, kv_index=cross_index, group_start=cross_groups,
-                        max_group=cross_max_group, kv_tiled=cross.tiled)
+            for b0, b1 in self._cross_blocks(cross, cross_index, cross_groups):
+                r0, r1 = (0, rows) if (b0, b1) == (0, cross.B) else (b0 * cross_group, b1 * cross_group)
+                K.attention(q[r0:r1], cross.k[i][b0:b1], cross.vt[i][b0:b1], o[r0 * T:r1 * T], Bq=r1 - r0, H=H, Nq=T, Nk=cross.Te,
+                            Tq_cap=T, Tk_cap=cross.Tk_cap, NP=cross.NP, kv_group=cross_group, kv_index=cross_index,
+                            group_start=cross_groups, max_group=cross_max_group, kv_tiled=cross.tiled)
             residual_gemm(o, d["co_w"], d["co_b"], d["co_g"], d["co_bt"])
             consumer("fc1", i, d["i_w"], d["i_b"], out=inter, act=K.ACT_GELU_ERF)
             residual_gemm(inter, d["o_w"], d["o_b"], d["o_g"], d["o_bt"])
