@@ -15,6 +15,9 @@ os.environ.setdefault("VIDIL_DEV_ENV", "1")
 
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+    config.addinivalue_line("markers", "slow: the wide parameter sweeps of a GPU test family (one representative of each stays in "
+                                       "`-m gpu`); DESELECTED unless $VIDIL_RUN_SLOW=1 or the -m expression names `slow` — the driver's "
+                                       "GPU step is 1,200 s and the suite is kept under 600 s (VERDICT r5 #7)")
 
 
 def pytest_sessionstart(session):
@@ -30,6 +33,12 @@ def pytest_sessionstart(session):
 
 def pytest_collection_modifyitems(config, items):
     import torch
+
+    if os.environ.get("VIDIL_RUN_SLOW") != "1" and "slow" not in (config.getoption("-m") or ""):
+        slow = [it for it in items if "slow" in it.keywords]
+        if slow:
+            config.hook.pytest_deselected(items=slow)
+            items[:] = [it for it in items if "slow" not in it.keywords]
 
     if torch.cuda.is_available():
         return
