@@ -161,6 +161,7 @@ def test_bench_refuses_more_ranks_than_gpus():
     assert r.returncode != 0 and "one rank per GPU" in (r.stderr + r.stdout)
 
 
+@pytest.mark.slow      # (test_bench_launches_itself_for_gpus_1_and_gpus_2 runs the same two ranks through the launcher)
 def test_bench_gpus_2_one_device_smoke(tmp_path):
     """`bench.py --gpus 2` as the driver launches it (torch.distributed.run, one JSON line from rank 0), with both
     ranks on the box's single GPU (VIDIL_BENCH_SMOKE_ONE_DEVICE=1 -> Gloo).  The log is kept under gpurun_out/."""

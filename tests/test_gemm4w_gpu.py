@@ -45,7 +45,10 @@ def _row_partials(x32):
     return torch.stack([xs.sum(-1), (xs * xs).sum(-1)], dim=-1).contiguous()
 
 
-SHAPES = [(256 * 300, 768, 128), (256 * 8 + 5, 256 * 8, 192), (197 * 130 + 37, 768, 768), (197 * 40 + 3, 3072, 768), (197 * 130, 768, 3072), (256 * 90, 832, 512), (197 * 70, 2304, 2304)]
+_SLOW = pytest.mark.slow      # (the wide sweeps run under $VIDIL_RUN_SLOW=1 / -m "gpu and slow"; two shapes stay in -m gpu)
+SHAPES = [pytest.param(256 * 300, 768, 128, marks=_SLOW), (256 * 8 + 5, 256 * 8, 192), pytest.param(197 * 130 + 37, 768, 768, marks=_SLOW),
+          pytest.param(197 * 40 + 3, 3072, 768, marks=_SLOW), (197 * 130, 768, 3072), pytest.param(256 * 90, 832, 512, marks=_SLOW),
+          pytest.param(197 * 70, 2304, 2304, marks=_SLOW)]
 
 
 @pytest.mark.parametrize("dtype", [torch.float16, torch.bfloat16])
@@ -219,7 +222,7 @@ def test_gemm4w_rows_times_k_beyond_2_to_the_31(monkeypatch):
     assert torch.equal(k.gemm(a, w, bias), out)
 
 
-@pytest.mark.parametrize("D,N", [(1024, 4096), (512, 2048), (320, 1280)])
+@pytest.mark.parametrize("D,N", [(1024, 4096), pytest.param(512, 2048, marks=_SLOW), pytest.param(320, 1280, marks=_SLOW)])
 def test_gemm4w_layernorm_fold_at_other_widths_equals_gemm256(D, N):
     """ViT-L (1024: 16 row partials per row — every part slot of a half-wave in use), 512 and a width whose partial count
     (5) is not a multiple of 4 (the masked slots of the statistics exchange)."""
@@ -242,7 +245,7 @@ def test_gemm4w_layernorm_fold_at_other_widths_equals_gemm256(D, N):
 
 
 @pytest.mark.parametrize("dtype", [torch.float16, torch.bfloat16])
-@pytest.mark.parametrize("M,N,K", [(10752, 768, 768), (10752, 768, 3072), (128 * 70 + 5, 768, 192), (9999, 832, 512)])
+@pytest.mark.parametrize("M,N,K", [(10752, 768, 768), pytest.param(10752, 768, 3072, marks=_SLOW), pytest.param(128 * 70 + 5, 768, 192, marks=_SLOW), (9999, 832, 512)])
 def test_gemm4w_128_row_tile_form_equals_the_other_kernels(monkeypatch, dtype, M, N, K):
     """The 128 x 256-tile form of gemm4w (mid-size grids: the decode steps' projections and FFN at ~10^4 beam rows) against
     whatever serves the problem without it (the small-tile kernel or gemm256 — themselves bit-identical): f32 + residual,

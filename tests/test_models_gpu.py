@@ -1004,7 +1004,7 @@ def test_end_to_end_three_videos_vs_oracle_pipeline_at_the_vg_ontology_size(full
     from vidil_amd.visual_tokenization import CATEGORIES, VisualTokenizer
 
     fm = full_models
-    Nv, F = 3, 8
+    Nv, F = 2, 8      # (round 6: two videos — the fp32 CPU oracle of a third costs 24 s of the suite and adds no new case)
     u8 = synthetic_frames(Nv, F, first_video=7)
     cfg = dict(caption=True, filter=True, filter_generated_only=True, keep_original_caption=False, threshold=0.4,
                filter_mode="max_filter", generation_mode="beam", image_size=224, vit="base", topk_visualize=5)
@@ -1063,12 +1063,12 @@ def test_end_to_end_three_videos_vs_oracle_pipeline_at_the_vg_ontology_size(full
         assert got["aggregated_tokens"] == agg and set(agg.keys()) == set(CATEGORIES)
     print(f"e2e: {checked}/{Nv * F} free-running captions equal the fp32 oracle's; visual-token ranks compared exactly "
           f"{ranks - masked}/{ranks} (the rest lie within {GAP} of a neighbour in the oracle's own scores)")
-    # measured: 24 of 24 free-running captions equal the fp32 oracle's (every decisive frame is asserted above; two
+    # measured (three videos): 24 of 24 free-running captions equal the fp32 oracle's (every decisive frame is asserted above; two
     # near-tie flips of 24 are allowed), 199 of 480 ranks undecided by the oracle's own score gaps
     assert checked >= Nv * F - 2, checked
     assert masked <= 0.45 * ranks, (masked, ranks)
     f_out, u_out = collect_outputs(items)
-    assert list(u_out.keys()) == ["video0", "video1", "video2"]
+    assert list(u_out.keys()) == [f"video{v}" for v in range(Nv)]
 
 
 def test_results_do_not_depend_on_batch_composition(full_models):

@@ -553,7 +553,8 @@ def test_attention_f32_arena_form_follows_the_ancestry_table():
 
 
 # ------------------------------------------------------------------------------- out16_split3 (round 5)
-@pytest.mark.parametrize("M,N,K,act", [(300, 192, 384, 1), (4096, 3072, 2304, 1), (99000, 768, 1536, 0), (33000, 3072, 1536, 2), (10752, 3072, 2304, 1)])
+@pytest.mark.parametrize("M,N,K,act", [(300, 192, 384, 1), pytest.param(4096, 3072, 2304, 1, marks=pytest.mark.slow), pytest.param(99000, 768, 1536, 0, marks=pytest.mark.slow),
+                                           (33000, 3072, 1536, 2), pytest.param(10752, 3072, 2304, 1, marks=pytest.mark.slow)])
 def test_gemm_f32_epilogue_writes_split3_operand_rows_itself(M, N, K, act):
     """vidil_gemm_args.out16_split3: the f32 epilogue (bias + activation in f32) hands its result over as [hi | lo | hi] rows —
     bit for bit what vidil_split3_f32 makes of the same GEMM's f32 output, on the 8-wave kernel (small grids) and the 4-wave one;
