@@ -373,8 +373,10 @@ def secondary_measurements(args, cap, flt, clip, step, frames, dev, parity_file,
     mean, std = (0.48145466, 0.4578275, 0.40821073), (0.26862954, 0.26130258, 0.27577711)
 
     def free_sessions():
+        import gc
         cap.__dict__.pop("_decode_state", None)
-        torch.cuda.empty_cache()
+        gc.collect()               # (a session's step closures and captured graphs sit in reference cycles: 150 GB of K/V at 14,336 images
+        torch.cuda.empty_cache()   #  must be gone before the next operand type builds its own)
 
     def prompt_logits():
         """caption logits of the prompt pass for the first two frames of video 0 (what the CPU leg computed in fp32)"""
