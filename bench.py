@@ -958,8 +958,14 @@ def main():
         result["config"]["executed_gflop_breakdown"] = {"gemm": round(sum(v[1] for v in agg.values()) / (Nv * F) / 1e9, 2),
                                                         **{k: round(v / (Nv * F) / 1e9, 3) for k, v in timer.other_flops.items()}}
         peak = mfma_peak_for(key)
+        dom = split[0] if split else None         # (the instantiation's shape with the most time: flat, driver-visible)
         result["roofline"] = {"bound": "mfma", "kernel": key, "achieved": round(ach, 1), "peak": peak,
                               "unit": "TFLOP/s", "frac": round(ach / peak, 4), "traffic": traffic, "traffic_source": traffic_source,
+                              "flop_basis": ("executed: a compensated GEMM (`..., true>`) is counted with its three MFMA products, i.e. 3 x the "
+                                             "algorithmic 2 M N K of the product it forms" if key.rstrip().endswith("true>") else "algorithmic 2 M N K"),
+                              "dominant_shape": None if dom is None else f"N={dom['N']} K={dom['K']} ({dom['launches']} launches, {dom['ms']} ms)",
+                              "dominant_shape_bound": None if dom is None else dom["bound"],
+                              "dominant_shape_frac": None if dom is None else dom["frac"],
                               "by_shape": split,
                               "algorithmic_flop_per_launch": round(flops / n),
                               "launches_per_step": n, "avg_launch_us": round(secs / n * 1e6, 2),
