@@ -1023,7 +1023,7 @@ def test_end_to_end_three_videos_vs_oracle_pipeline_at_the_vg_ontology_size(full
     for v in range(Nv):
         x = clip_ref.preprocess_u8(u8[v])
         otrace = []
-        caps_frames = pipeline_ref.caption_video(fm["sd_cap"], x, prompt, fm["tok"], fm["cap"].prompt, trace=otrace)
+        caps_frames = pipeline_ref.caption_video(fm["sd_cap"], x, prompt, fm["tok"], fm["cap"].prompt, trace=otrace, dedup=True)
         # a frame's caption must match when every beam decision of the oracle had a margin above the tolerance;
         # otherwise a near-tie may legitimately flip (random-init weights give an almost flat distribution)
         gaps = np.stack([np.min(t["cand_scores"][:, :-1] - t["cand_scores"][:, 1:], axis=1) for t in otrace])   # [steps,F]
@@ -1035,7 +1035,7 @@ def test_end_to_end_three_videos_vs_oracle_pipeline_at_the_vg_ontology_size(full
                 assert dev_caps[f] == caps_frames[f], (v, f)
         # the filter, on the captions the device produced (so this check does not depend on beam near-ties)
         caps = items[v]["unfiltered_text"]
-        kept, probs = pipeline_ref.filter_video(fm["sd_itm"], x, caps, fm["tok"], 0.4, return_probs=True)
+        kept, probs = pipeline_ref.filter_video(fm["sd_itm"], x, caps, fm["tok"], 0.4, return_probs=True, dedup=True)      # (same results as the per-caption ViT schedule: tests/test_oracle_cpu.py::test_deduplicated_cpu_schedule...)
         if all(abs(float(np.max(p)) - 0.4) > 2e-3 for p in probs):
             assert items[v]["text"] == kept
         # visual tokens: the reference form (fp32 embeds @ text.T, argsort, run_visual_tokenization.py:276,298-308)

@@ -316,9 +316,9 @@ def test_parity_mode_itm_logits_and_capfilt_decisions_vs_oracle():
     prompt = cap.prompt_ids(1, "cpu")[0].long().numpy()
     for v in range(Nv):
         xv = clip_ref.preprocess_u8(frames[v])
-        caps_ref = pipeline_ref.caption_video(sd_cap, xv, prompt, tok, cap.prompt)
+        caps_ref = pipeline_ref.caption_video(sd_cap, xv, prompt, tok, cap.prompt, dedup=True)
         assert eng.last_frame_captions[v * Fv:(v + 1) * Fv] == caps_ref, v
-        kept, probs = pipeline_ref.filter_video(sd_itm, xv, items[v]["unfiltered_text"], tok, 0.4, return_probs=True)
+        kept, probs = pipeline_ref.filter_video(sd_itm, xv, items[v]["unfiltered_text"], tok, 0.4, return_probs=True, dedup=True)      # (same results as the per-caption ViT schedule: tests/test_oracle_cpu.py::test_deduplicated_cpu_schedule...)
         if all(abs(float(np.max(p)) - 0.4) > 1e-4 for p in probs):
             assert items[v]["text"] == kept, v
 
