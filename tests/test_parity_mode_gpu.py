@@ -809,3 +809,28 @@ def test_tiny_image_parity_captioner_has_no_unwritten_plane_on_its_path(monkeypa
     b = logits()
     assert torch.isfinite(a).all() and torch.isfinite(b).all()
     assert torch.equal(a, b)
+
+
+def test_split_attention_session_refuses_more_than_32_query_rows_per_image_with_a_clear_message():
+    """ADVICE r5 (attention.hip kv16 form: at most 32 query rows per image): a decoder session on 16-bit cross K / V tiles whose
+    prompt pass runs every beam row (P tokens x nb beams > 32 rows per image) is refused by the host with the remedy in the message
+    instead of an EINVAL from the launch; the shared prompt pass (P rows per image) and tiled_cross=False both work."""
+    from vidil_amd import kernels as K
+    from vidil_amd.blip import BLIP_Decoder, DecoderSession
+    from vidil_amd.packing import set_compute_dtype, set_parity_mode
+    from vidil_amd.tokenizer import SyntheticBertTokenizer
+
+    torch.manual_seed(0)
+    cap = BLIP_Decoder(image_size=32, vit="base", tokenizer=SyntheticBertTokenizer()).eval().to(DEV)
+    set_compute_dtype("f16", cap)
+    set_parity_mode(True, cap)
+    B, nb, P = 2, 3, 12                                    # 36 query rows per image in an unshared prompt pass
+    _, y3 = cap.visual_encoder.forward_both(torch.randn(B, 3, 32, 32, device=DEV))
+    ids = torch.randint(1000, 2000, (B * nb, P), dtype=torch.int32, device=DEV)
+    sess = DecoderSession(cap.text_decoder, y3, B, nb, 20, tiled_cross=True)
+    with pytest.raises(K.VidilHipError, match="tiled_cross=False"):
+        sess.prefill(ids.reshape(-1), P)
+    lg_shared = DecoderSession(cap.text_decoder, y3, B, nb, 20, tiled_cross=True).prefill(ids[::nb].reshape(-1).contiguous(), P, shared=True)
+    lg_rows = DecoderSession(cap.text_decoder, y3, B, nb, 20, tiled_cross=False).prefill(ids[::nb].repeat_interleave(nb, 0).reshape(-1).contiguous(), P)
+    torch.cuda.synchronize()
+    assert torch.isfinite(lg_shared).all() and (lg_rows[::nb] - lg_shared).abs().max().item() < 1e-3
