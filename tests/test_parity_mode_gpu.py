@@ -834,3 +834,26 @@ def test_split_attention_session_refuses_more_than_32_query_rows_per_image_with_
     lg_rows = DecoderSession(cap.text_decoder, y3, B, nb, 20, tiled_cross=False).prefill(ids[::nb].repeat_interleave(nb, 0).reshape(-1).contiguous(), P)
     torch.cuda.synchronize()
     assert torch.isfinite(lg_shared).all() and (lg_rows[::nb] - lg_shared).abs().max().item() < 1e-3
+
+
+def test_clip_last_layer_on_class_token_rows_gives_the_full_layers_embeddings(parity_clip, monkeypatch):
+    """Round 6: in the parity precision mode the CLIP vision tower runs its LAST layer for the class-token rows only (K | V for
+    every token; query, attention output, out-proj, LayerNorm 2 and the MLP for one row per image — the pooled output reads nothing
+    else, HF CLIPVisionTransformer.forward: `pooled_output = last_hidden_state[:, 0, :]`).  Same function: embeddings equal the
+    full-layer run's to f32 rounding (the class token's attention runs in plain f32 arithmetic instead of the split-operand form)
+    and stay within the mode's bound of the fp32 oracle; a frame's embedding does not depend on the batch around it."""
+    from oracle import clip_ref
+
+    clip, sd = parity_clip
+    u8 = torch.from_numpy(synthetic_frames(1, 6, first_video=77)[0]).to(DEV)
+    clip.cls_only_last_layer = False
+    full = clip.encode_image_u8(u8).float().cpu()
+    clip.cls_only_last_layer = True
+    fast = clip.encode_image_u8(u8).float().cpu()
+    alone = clip.encode_image_u8(u8[2:3].contiguous()).float().cpu()
+    with torch.no_grad():
+        ref = clip_ref.image_embeds(sd, clip_ref.preprocess_u8(u8.cpu().numpy()))
+    d_ff, d_ref = (fast - full).abs().max().item(), (fast - ref).abs().max().item()
+    print(f"\nCLS-only last layer vs full layer: max |d| {d_ff:.2e}; vs fp32 oracle {d_ref:.2e} (full layer: {(full - ref).abs().max().item():.2e})")
+    assert d_ff < 2e-6 and d_ref < 3e-6
+    assert torch.equal(alone[0], fast[2])

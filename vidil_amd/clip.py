@@ -154,8 +154,13 @@ def _pack_layers(encoder, c, fuse=False, fp8=False, parity=False):
     return out
 
 
-def _run_layers(layers, x, B, T, H, eps, *, causal=False, kv_len=None, f32_attn=True, arith=0):
-    """Pre-LN CLIP encoder layers on the f32 residual stream x [B*T, D] (in place)."""
+def _run_layers(layers, x, B, T, H, eps, *, causal=False, kv_len=None, f32_attn=True, arith=0, cls_last=False):
+    """Pre-LN CLIP encoder layers on the f32 residual stream x [B*T, D] (in place).
+    cls_last (the vision tower in the parity precision mode with the f32-row attention kinds, round 6): the caller reads token 0
+    of every image only (pooled output = post_layernorm(CLS), HF CLIPVisionTransformer), so the LAST layer computes K | V for all
+    rows and everything else — the query, the attention output, out-proj, LayerNorm 2, fc1, fc2 — for the B class-token rows alone
+    (10/12 of that layer's GEMM rows are not computed: ~7 % of the tower); returns the f32 CLS rows [B, D] instead of x.
+    Per class-token row the arithmetic is the full layer's (its attention in plain f32 arithmetic instead of the split form)."""
     dev = x.device
     M, D = x.shape
     cdt = layers[0]["qkv_w"].dtype
@@ -193,8 +198,26 @@ def _run_layers(layers, x, B, T, H, eps, *, causal=False, kv_len=None, f32_attn=
         if planes == 2 and os.environ.get("VIDIL_POISON_SPLIT3") == "1":       # (developer: NaNs in the unwritten third planes —
             for _b in (a3, o3, hid3,):                               #  any consumer that reads one shows up at once)
                 _b[:, 2 * (_b.shape[1] // 3):] = float("nan")
-        for l in layers:
+        cls_last = cls_last and f32_attn and not causal and kv_len is None and T > 1
+        for li, l in enumerate(layers):
             K.layernorm(x, l["n1g"], l["n1b"], eps, out16=a3, split3=True, planes=planes)
+            if cls_last and li == n - 1:
+                # ---- last layer, class-token rows only (K | V still for every token)
+                kv32 = qkv32.view(-1)[:M * 2 * D].view(M, 2 * D)               # (the layers' scratch, re-shaped: [M, 2D] keys | values)
+                K.gemm(a3, l["qkv_w3"][D:], l["qkv_b"][D:], out=kv32, split_k=True, a_planes=planes)
+                a3c = a3.view(B, T, 3 * D)[:, 0].contiguous()                  # [B, 3D] operand rows of the class tokens
+                if planes == 2:
+                    a3c[:, 2 * D:] = a3c[:, :D]                                # (three valid planes: the small launches below may be plain)
+                q32c = K.gemm(a3c, l["qkv_w3"][:D], l["qkv_b"][:D], out_dtype=torch.float32, split_k=True)
+                o3c = torch.empty((B, 3 * D), dtype=cdt, device=dev)
+                K.attention_f32(q32c, kv32[:, :D], kv32[:, D:], o3c, Bq=B, H=H, Nq=1, Nk=T, kv_rows=T, arith=0, planes=3)
+                xc = x.view(B, T, D)[:, 0].contiguous()                        # [B, D] f32 residual rows of the class tokens
+                K.gemm(o3c, l["o_w3"], l["o_b"], out=xc, resid=xc, split_k=True)
+                K.layernorm(xc, l["n2g"], l["n2b"], eps, out16=a3c, split3=True, planes=3)
+                h3c = K.gemm(a3c, l["fc1_w3"], l["fc1_b"], split3_out=torch.empty((B, 3 * Dh), dtype=cdt, device=dev), act=K.ACT_QUICK_GELU,
+                             split_k=True, split3_planes=3)
+                K.gemm(h3c, l["fc2_w3"], l["fc2_b"], out=xc, resid=xc, split_k=True)
+                return xc
             if f32_attn:    # (Q | K | V stay f32 and row-major: vidil_attention_f32 reads them in place)
                 K.gemm(a3, l["qkv_w3"], l["qkv_b"], out=qkv32, split_k=True, a_planes=planes)
                 K.attention_f32(qkv32[:, :D], qkv32[:, D:2 * D], qkv32[:, 2 * D:], o3, Bq=B, H=H, Nq=T, Nk=T, causal=causal, kv_len=kv_len,
@@ -259,6 +282,8 @@ class CLIPModel(PackedCache, nn.Module):
         self.logit_scale = nn.Parameter(torch.tensor(2.6592))
         import os
         self.fuse_layernorm = os.environ.get("VIDIL_FUSE_LN", "1") != "0"   # vision tower only (the text tower runs once per ontology)
+        # (parity precision mode: the vision tower's last layer on the class-token rows only — _run_layers(cls_last=True); A/B switch)
+        self.cls_only_last_layer = os.environ.get("VIDIL_CLIP_CLS_LAST", "1") != "0"
         self.apply(self._init)
 
     @classmethod
@@ -349,11 +374,14 @@ class CLIPModel(PackedCache, nn.Module):
         K.gemm(patches16, p["pe_w3"] if par else p["pe_w"], None, patch=dict(out=x, pos=p["pos"], tpi=P), split_k=par)
         K.set_cls_row(x, p["cls"], p["pos"], B, T, D)
         K.layernorm(x, p["pre_g"], p["pre_b"], vc.layer_norm_eps, out32=x)
-        _run_layers(p["vlayers"], x, B, T, H, vc.layer_norm_eps, f32_attn=parity_attention_f32(self), arith=parity_attention_arith(self))
+        cls_last = par and self.cls_only_last_layer
+        xo = _run_layers(p["vlayers"], x, B, T, H, vc.layer_norm_eps, f32_attn=parity_attention_f32(self), arith=parity_attention_arith(self),
+                         cls_last=cls_last)
+        cls_rows = xo.shape[0] == B and T > 1          # (the layers handed back the class-token rows [B, D] instead of the stream)
         pooled16 = torch.empty((B, (3 if par else 1) * D), dtype=cdt, device=dev)
         pooled32 = torch.empty((B, D), dtype=torch.float32, device=dev) if pooled else None
-        K.layernorm(x, p["post_g"], p["post_b"], vc.layer_norm_eps, M=B, D=D, x_stride=T * D, out16=pooled16,
-                    out32=pooled32, split3=par)
+        K.layernorm(xo if cls_rows else x, p["post_g"], p["post_b"], vc.layer_norm_eps, M=B, D=D, x_stride=D if cls_rows else T * D,
+                    out16=pooled16, out32=pooled32, split3=par)
         if pooled:
             return pooled32
         emb = K.gemm(pooled16, p["vproj3"] if par else p["vproj"], None, out_dtype=torch.float32, split_k=par)
