@@ -719,6 +719,8 @@ def main():
     ap.add_argument("--videos-per-step", type=int, default=1792)
     ap.add_argument("--tower-chunk-videos", type=int, default=448,
                     help="videos per tower / ITM pass inside a step (CapFiltEngine config `tower_chunk_videos`; 0 = the whole step at once)")
+    ap.add_argument("--itm-chunk-videos", type=int, default=0,
+                    help="videos per ITM pass (CapFiltEngine config `itm_chunk_videos`; 0 = the tower chunk)")
     ap.add_argument("--frames", type=int, default=8, help="frames per video (config 4: 16)")
     ap.add_argument("--dtype", choices=["f16", "bf16", "fp8"], default="bf16",
                     help="MFMA operand type. Default bf16: the type BASELINE.json's configs[1] ('1xMI355X bf16') and north_star "
@@ -806,7 +808,8 @@ def main():
     config = dict(caption=True, filter=True, filter_generated_only=True, keep_original_caption=False,
                   threshold=0.4, filter_mode="max_filter", generation_mode="beam", do_sentence_tokenization=False,
                   image_size=args.size, vit=args.vit, topk_visualize=5, itm_short_circuit=args.itm_short_circuit,
-                  decode_streams=args.decode_streams, tower_chunk_videos=args.tower_chunk_videos)
+                  decode_streams=args.decode_streams, tower_chunk_videos=args.tower_chunk_videos,
+                  itm_chunk_videos=args.itm_chunk_videos)
     engine = CapFiltEngine(config, dev, captioner=cap, filterer=flt)
     vtok = VisualTokenizer(config, clip, onto_texts, onto_embeds, dev)
 

@@ -80,3 +80,46 @@ def test_itm_logits_of_a_pair_do_not_depend_on_the_batch_around_it():
     for n in (8, 1):
         small = flt.itm_pairs(y16, 256, ids, lens, image_index=image[:n].to(torch.int32), pair_text=text[:n])
         assert torch.equal(big[:n], small), n
+
+
+@pytest.mark.slow      # (45 s and 225 GiB: run with $VIDIL_RUN_SLOW=1 / -m "gpu and slow" on a box with nothing else resident)
+def test_bench_step_shape_results_do_not_depend_on_the_tower_chunking():
+    """The bench's step shape (round 6): 1,792 videos, ONE beam search over 14,336 images (43,008 beam rows, cross K/V and
+    cross-attention launched per 4,096 images), towers / CLIP / ITM per `tower_chunk_videos`.  Tower chunks of 448 and of 896 videos
+    (1.41 M ViT rows per GEMM launch, activations past 2^32 bytes) must give identical items and visual tokens, and the first 448
+    videos those of a 448-video batch run by itself — every per-unit offset of every kernel at sizes twice the largest the rest of the
+    suite exercises."""
+    sys.path.insert(0, ROOT)
+    import bench
+    from vidil_amd.capfilt import CapFiltEngine
+    from vidil_amd.packing import set_compute_dtype, set_parity_mode
+    from vidil_amd.pipeline import FramePipeline
+    from vidil_amd.visual_tokenization import VisualTokenizer
+
+    Nv, F = 1792, 8
+    cap, flt, clip, tok = bench.build_models(DEV, 224, "b32", "base", "bf16")
+    set_compute_dtype("f16", clip)
+    set_parity_mode(True, clip)                              # (the bench's default: CLIP tower compensated)
+    onto_embeds, onto_texts = bench.synthetic_ontology(dim=clip.config.projection_dim)
+    frames = torch.from_numpy(bench.synthetic_frames(Nv, F, 224, 0)).to(DEV)
+
+    def run(chunk, n):
+        cfg = dict(caption=True, filter=True, filter_generated_only=True, keep_original_caption=False, threshold=0.4,
+                   filter_mode="max_filter", generation_mode="beam", do_sentence_tokenization=False, image_size=224, vit="base",
+                   topk_visualize=5, tower_chunk_videos=chunk)
+        eng = CapFiltEngine(cfg, DEV, captioner=cap, filterer=flt)
+        vt = VisualTokenizer(cfg, clip, onto_texts, onto_embeds, DEV)
+        items = [dict(video_id=f"video{i}", text=[]) for i in range(n)]
+        out = FramePipeline(eng, vt).process(items, frames[:n])
+        torch.cuda.synchronize()
+        return out
+
+    a_items, a_toks = run(448, Nv)
+    b_items, b_toks = run(896, Nv)
+    assert a_items == b_items
+    assert a_toks == b_toks
+    cap.__dict__.pop("_decode_state", None)
+    torch.cuda.empty_cache()
+    s_items, s_toks = run(0, 448)
+    assert s_items == a_items[:448]
+    assert all(s_toks[it["video_id"]] == a_toks[it["video_id"]] for it in s_items)

@@ -128,7 +128,8 @@ class CapFiltEngine:
     do_sentence_tokenization, image_size, vit, caption_model_ckpt, filterer_model_ckpt.
     Own keys: tower_chunk_videos (round 6: the ViTs, the CLIP tower and the ITM run over at most this many videos at a time while
     ONE beam search runs over every image of the batch — the decode steps' GEMMs have 3 rows per image, so a search over the
-    images of several tower chunks runs them at 4x the rows per launch; 0 / absent = no chunking); decode_streams (parts of the batch whose beam searches run side by side on their own streams; default 1:
+    images of several tower chunks runs them at 4x the rows per launch; 0 / absent = no chunking); itm_chunk_videos (the ITM passes
+    over at most this many videos — default: the tower chunk; their per-image cross K/V are sized by it); decode_streams (parts of the batch whose beam searches run side by side on their own streams; default 1:
     measured +0.2 % with 2, -4 % with 4 at 3,072 frames — a decode step already occupies the chip); itm_short_circuit (default False = score every (frame, caption) pair like the reference; True = the
     any()-short-circuit of ``_filter_enqueue``, same kept lists with a fraction of the ITM work).
     """
@@ -250,13 +251,19 @@ class CapFiltEngine:
             # the ITM pairs of one tower chunk at a time (a video's pairs only meet that video's frames): the per-image cross K/V of
             # the filter are sized by the chunk and released behind the chunk's last launch
             home = st.get("home")
-            st["itm"] = []
-            for (a, b), fy in zip(st["spans"], st["fy16"]):
-                pend = self._filter_enqueue(fy, b - a, F, to_filter[a:b], None if home is None else home[a:b],
-                                            tag=f"{a}:" if len(st["spans"]) > 1 else "")
-                if pend is not None and not pend["short"] and len(st["spans"]) > 1:
-                    pend["cross"] = pend["y16"] = None         # (every launch that reads them is queued: stream-ordered reuse)
-                st["itm"].append(pend)
+            st["itm"], st["itm_spans"] = [], []
+            c_itm = int(cfg.get("itm_chunk_videos") or 0)     # (own key: ITM passes over fewer videos than a tower chunk — the filter's
+            for (a, b), fy in zip(st["spans"], st["fy16"]):   #  per-image cross K/V, 8.3 MB per frame, are sized by THIS chunk)
+                Te_rows = fy.shape[0] // (b - a)              # rows of the filter ViT's output per video (F x tokens per frame)
+                subs = [(a, b)] if c_itm <= 0 or b - a <= c_itm else [(x, min(x + c_itm, b)) for x in range(a, b, c_itm)]
+                for a2, b2 in subs:
+                    many = len(st["spans"]) > 1 or len(subs) > 1
+                    pend = self._filter_enqueue(fy[(a2 - a) * Te_rows:(b2 - a) * Te_rows], b2 - a2, F, to_filter[a2:b2],
+                                                None if home is None else home[a2:b2], tag=f"{a2}:" if many else "")
+                    if pend is not None and not pend["short"] and many:
+                        pend["cross"] = pend["y16"] = None     # (every launch that reads them is queued: stream-ordered reuse)
+                    st["itm"].append(pend)
+                    st["itm_spans"].append((a2, b2))
             st["fy16"] = None
 
     @torch.no_grad()
@@ -266,7 +273,7 @@ class CapFiltEngine:
         n_pairs = 0
         if cfg["filter"]:
             kept = []
-            for (a, b), pend in zip(st["spans"], st["itm"]):
+            for (a, b), pend in zip(st["itm_spans"], st["itm"]):
                 kept.extend(self._filter_finish(pend, b - a, F, st["to_filter"][a:b]))
                 n_pairs += pend["n_pairs"] if pend is not None else 0
             for v, item in enumerate(items):
