@@ -260,8 +260,10 @@ class CapFiltEngine:
                     many = len(st["spans"]) > 1 or len(subs) > 1
                     pend = self._filter_enqueue(fy[(a2 - a) * Te_rows:(b2 - a) * Te_rows], b2 - a2, F, to_filter[a2:b2],
                                                 None if home is None else home[a2:b2], tag=f"{a2}:" if many else "")
-                    if pend is not None and not pend["short"] and many:
-                        pend["cross"] = pend["y16"] = None     # (every launch that reads them is queued: stream-ordered reuse)
+                    if pend is not None and many:
+                        pend["cross"] = None                   # (every launch that reads them is queued: stream-ordered reuse;
+                        if not pend["short"]:                  #  the short circuit's second phase projects them again, _cross_of)
+                            pend["y16"] = None
                     st["itm"].append(pend)
                     st["itm_spans"].append((a2, b2))
             st["fy16"] = None
@@ -276,6 +278,8 @@ class CapFiltEngine:
             for (a, b), pend in zip(st["itm_spans"], st["itm"]):
                 kept.extend(self._filter_finish(pend, b - a, F, st["to_filter"][a:b]))
                 n_pairs += pend["n_pairs"] if pend is not None else 0
+                if pend is not None and len(st["itm"]) > 1:
+                    pend["cross"] = pend["y16"] = None
             for v, item in enumerate(items):
                 if cfg["filter_generated_only"]:
                     item["text"] = list(item.get("text", [])) + kept[v]
@@ -328,6 +332,13 @@ class CapFiltEngine:
                 buckets.append(np.sort(np.asarray(cur)))   # (itm_pairs falls back to its small-call layout for a thin call: min_rows)
         return buckets
 
+    def _cross_of(self, pend):
+        """The filter's per-image cross K/V of this chunk — projected again if they were released after the chunk's first phase
+        (the short circuit over several chunks: 8.3 MB per frame are not kept for every chunk of the batch until the second phase)."""
+        if pend["cross"] is None:
+            pend["cross"] = self.filterer.project_image_kv(pend["y16"], pend["n_images"], pend["min_rows"])
+        return pend["cross"]
+
     def _score(self, pend, cap_idx, frame_of=None):
         """Queue the ITM of captions ``cap_idx`` (global indices, ascending) against the frames of their videos — all
         F, or only ``frame_of[c]`` when given (int array aligned with cap_idx).  Pair order is IMAGE-major (video, frame,
@@ -341,7 +352,7 @@ class CapFiltEngine:
         if frame_of is not None:                      # one pair per caption: pair -> image map
             image = (vid * F + frame_of).astype(np.int32)
             logits = flt.itm_pairs(pend["y16"], pend["n_images"], ids, lens, image_index=torch.from_numpy(image),
-                                   pair_text=torch.from_numpy(local), cross=pend["cross"])
+                                   pair_text=torch.from_numpy(local), cross=self._cross_of(pend))
             pair_c, pair_f = cap_idx, np.asarray(frame_of, dtype=np.int64)
         else:
             skip = pend.get("skip")
@@ -364,7 +375,7 @@ class CapFiltEngine:
             group_start = torch.zeros(pend["n_images"] + 1, dtype=torch.int32)
             group_start[1:] = torch.from_numpy(np.cumsum(counts).astype(np.int32))
             logits = flt.itm_pairs(pend["y16"], pend["n_images"], ids, lens, group_start=group_start,
-                                   max_group=int(counts.max()), pair_text=torch.from_numpy(pair_l), cross=pend["cross"])
+                                   max_group=int(counts.max()), pair_text=torch.from_numpy(pair_l), cross=self._cross_of(pend))
         prob = torch.nn.functional.softmax(logits, dim=1)[:, 1].contiguous()
         pend["calls"].append((self._to_host(f"itm{pend.get('tag', '')}{len(pend['calls'])}", prob), pair_c, pair_f))
         pend["n_pairs"] += len(pair_c)
@@ -405,6 +416,7 @@ class CapFiltEngine:
         if not short:
             min_rows = min(min(int(ids.shape[1]), int(lens_np[b].max())) * int(np.bincount(pend["cap_video"][b], minlength=Nv).max())
                            for b in buckets)
+        pend["min_rows"] = min_rows
         pend["cross"] = flt.project_image_kv(y16, Nv * F, min_rows)
         if not short:
             for b in buckets:
