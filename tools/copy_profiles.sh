@@ -3,7 +3,7 @@
 # usage: bash tools/copy_profiles.sh <tag> [name prefix, default r3]      e.g. copy_profiles.sh r3bf16 r3_bf16
 P=gpurun_out/prof_$1
 N=${2:-r4}
-{ echo "# rocprofv3 --kernel-trace --stats of \`python bench.py $(head -1 $P/cmdline.txt 2>/dev/null) --no-roofline\` (1,792 videos x 8 frames per step in tower chunks of 448 unless the arguments say otherwise, 1 x MI355X)"; echo
+{ echo "# rocprofv3 --kernel-trace --stats of \`python bench.py $(head -1 $P/cmdline.txt 2>/dev/null) --no-roofline\` (1,792 videos x 8 frames per step in tower chunks of 896 unless the arguments say otherwise, 1 x MI355X)"; echo
   echo "Bench line of the traced run (tracing costs a few %): \`$(cut -c1-260 $P/bench_traced.json)...\`"; echo
   cat $P/kernel_summary.md; echo; echo "## rocprofv3 --stats (t_kernel_stats.csv, top 25)"; echo; echo '```'; head -26 $P/trace/t_kernel_stats.csv | cut -c1-200; echo '```'; } > profiles/${N}_bench_kernel_trace.md
 { echo "# rocprofv3 --pmc passes (FETCH_SIZE / WRITE_SIZE / SQ_* in separate runs, each with --kernel-trace only) of the same bench command"; echo; cat $P/pmc_summary.md; } > profiles/${N}_bench_pmc.md
