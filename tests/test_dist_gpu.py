@@ -58,6 +58,9 @@ if e > s:
 f, u = capfilt.collect_outputs(items)
 capfilt.write_outputs({out!r}, f, u)
 vt.write_outputs({out!r}, toks)
+seen = vdist.ranks_seen()
+# (gloo: one identity per process; nccl: one per DEVICE — equal to the world size exactly when every rank has its own GPU)
+assert seen == (world if {backend!r} == "gloo" else len({{torch.cuda.get_device_properties(i).uuid for i in range(world)}})), seen
 vdist.barrier()
 """
 
@@ -122,6 +125,9 @@ assert (rank, world) == (0, 1) and torch.distributed.get_backend() == "nccl"
 assert vdist._comm_device().type == "cuda"
 assert vdist.gather_json({"a": [1, 2, 3]}) == [{"a": [1, 2, 3]}]
 assert vdist.max_over_ranks(1.25) == 1.25
+assert vdist.ranks_seen() == 1          # (round 6: the device identity — GPU UUID — all_gather'ed as a DEVICE buffer over RCCL)
+os.environ["VIDIL_GATHER"] = "allgather"
+assert vdist.gather_json({"b": 2}) == [{"b": 2}]          # (the other collective form, chosen before it is issued)
 vdist.barrier()
 print("nccl-single-rank-ok")
 """ % ROOT
