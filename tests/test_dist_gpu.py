@@ -60,7 +60,7 @@ capfilt.write_outputs({out!r}, f, u)
 vt.write_outputs({out!r}, toks)
 seen = vdist.ranks_seen()
 # (gloo: one identity per process; nccl: one per DEVICE — equal to the world size exactly when every rank has its own GPU)
-assert seen == (world if {backend!r} == "gloo" else len({{torch.cuda.get_device_properties(i).uuid for i in range(world)}})), seen
+assert seen == (world if {backend!r} == "gloo" else len({{str(getattr(torch.cuda.get_device_properties(i), 'uuid', i)) for i in range(world)}})), seen
 vdist.barrier()
 """
 
