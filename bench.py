@@ -338,6 +338,7 @@ def cpu_baseline(args, budget_s=240, parity_file=None):
     dt, dt2 = max(r["reference"] for r in res), max(r["dedup"] for r in res)
     n_caps = sum(r["n_caps"] for r in res)
     return dict(base, value=round(workers * args.frames / dt, 4), dedup_value=round(workers * args.frames / dt2, 4),
+                spread_note="a reported baseline, never credit: rounds 1-6 measured 0.61-0.92 frames/s (reference schedule) across the pool's boxes",
                 sample=f"{workers} videos x {args.frames} frames, one per worker process ({workers} x {t_per} threads = "
                        f"{workers * t_per} of the host's {ncpu} hardware threads), oracle (PyTorch fp32) at the same time: reference "
                        f"schedule incl. {n_caps} ITM caption passes {dt:.1f} s (slowest worker); de-duplicated schedule (filter ViT "
