@@ -92,9 +92,16 @@ def _run(world, out, backend="gloo"):
             raise AssertionError("\n".join(bad))
 
 
-def test_two_ranks_on_one_gpu_through_the_engines_equal_single_process(tmp_path):
-    out1, out2 = str(tmp_path / "w1"), str(tmp_path / "w2")
-    _run(1, out1)
+@pytest.fixture(scope="module")
+def single_process_out(tmp_path_factory):
+    """The un-distributed run's three files, once per module (every comparison below is against them)."""
+    out = str(tmp_path_factory.mktemp("single") / "w1")
+    _run(1, out)
+    return out
+
+
+def test_two_ranks_on_one_gpu_through_the_engines_equal_single_process(tmp_path, single_process_out):
+    out1, out2 = single_process_out, str(tmp_path / "w2")
     _run(2, out2)
     for name in ("video_text_CapFilt.json", "video_text_Cap.json", "visual_tokens.json"):
         a = open(os.path.join(out1, name)).read()
@@ -106,13 +113,12 @@ def test_two_ranks_on_one_gpu_through_the_engines_equal_single_process(tmp_path)
     assert list(toks.keys()) == [f"video{i}" for i in range(5)] and len(toks["video4"]["frame_tokens"]) == 4
 
 
-def test_rccl_backend_with_a_single_rank_runs_the_device_side_collectives(tmp_path):
+def test_rccl_backend_with_a_single_rank_runs_the_device_side_collectives(tmp_path, single_process_out):
     """What a one-GPU box CAN execute of the RCCL branch: backend "nccl" with world size 1 — process-group creation on the
     device, `barrier(device_ids=...)`, BOTH all_gathers of gather_json (sizes, then the padded payload bytes: since round 4
     the gather has no peer-to-peer half, so the code an 8-GPU job takes is exactly the code that runs here) and the
     max-reduce of `vidil_amd.dist` on DEVICE buffers.  Outputs equal the un-distributed run's."""
-    out0, out1 = str(tmp_path / "plain"), str(tmp_path / "nccl1")
-    _run(1, out0)
+    out0, out1 = single_process_out, str(tmp_path / "nccl1")
     _run(1, out1, backend="nccl")
     for name in ("video_text_CapFilt.json", "video_text_Cap.json", "visual_tokens.json"):
         assert open(os.path.join(out0, name)).read() == open(os.path.join(out1, name)).read(), name
@@ -137,7 +143,7 @@ print("nccl-single-rank-ok")
     assert r.returncode == 0 and "nccl-single-rank-ok" in r.stdout, (r.stdout[-1000:], r.stderr[-3000:])
 
 
-def test_one_rank_per_gpu_over_rccl_equals_single_process(tmp_path):
+def test_one_rank_per_gpu_over_rccl_equals_single_process(tmp_path, single_process_out):
     """The RCCL branch of vidil_amd.dist (backend "nccl": sizes, then the padded JSON bytes all_gather'ed as DEVICE
     buffers over xGMI, barrier pinned to the rank's device): 2 ranks (4 when the node has them), one per GPU, through both
     engines and both writers; the merged files equal the single-process ones byte for byte."""
@@ -146,8 +152,7 @@ def test_one_rank_per_gpu_over_rccl_equals_single_process(tmp_path):
     n = torch.cuda.device_count()
     if n < 2:
         pytest.skip(f"needs >= 2 GPUs for one rank per device over RCCL (this node has {n})")
-    out1 = str(tmp_path / "w1")
-    _run(1, out1)
+    out1 = single_process_out
     for world in sorted({2, min(n, 4)}):
         outn = str(tmp_path / f"w{world}_nccl")
         _run(world, outn, backend="nccl")

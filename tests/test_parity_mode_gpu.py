@@ -403,6 +403,7 @@ def test_parity_mode_visual_token_indices_end_to_end_equal_the_reference_form(pa
     assert masked <= 0.05 * ranks, (masked, ranks)
 
 
+@pytest.mark.slow      # (round 4's mix, superseded by the qualified configuration: bench.py `secondary.parity_mix_full_step` only)
 def test_parity_mix_plain_vit_with_compensated_decoder_keeps_caption_logits_within_1e_3(parity_captioner):
     """VERDICT r3 #2c — the CHEAPEST mix that still meets "caption logits within 1e-3" as an absolute bound
     (tests/probes/probe_parity_mix.py swept it: ViT blocks compensated k = 0 .. 12 -> worst pass 7.6e-4 .. 4.3e-4 at x1.34 ..
