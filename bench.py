@@ -908,7 +908,7 @@ def main():
         step()
         for st in states:
             st["graphs_ok"] = True
-        del states, st             # (no reference to a session may outlive it here: secondary_measurements frees them between modes)
+        states = st = None         # (no reference to a session may outlive it here: secondary_measurements frees them between modes)
         timer.remove()
         agg = timer.summary()
         if args.gemm_shapes:
